@@ -1,0 +1,150 @@
+/* libneraf_hip -- C ABI of the MI355X-native NeRAF field-query engine.
+ *
+ * The reference (AmandineBtto/NeRAF) is pure Python and has no FFI of its own; the
+ * entry points below are what a nerfstudio-side binding for the hot path would
+ * bind.  Each function cites the reference interface it
+ * replaces (paths relative to the reference's NeRAF/ package).
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless
+ *    a parameter is documented "host".
+ *  - the caller owns every buffer (PyTorch's caching allocator in our host layer);
+ *    the library allocates nothing persistent except the opaque neraf_ctx.
+ *  - every launch is asynchronous on the hipStream_t passed in; no hidden syncs.
+ *  - return 0 on success or a negative NERAF_E* code; never throws across the ABI;
+ *    neraf_last_error(ctx) returns a description of the last failure on that ctx.
+ *  - layouts: row-major contiguous, point-major [N,.]; voxel grid [7,X,Y,Z] as in
+ *    NeRAF_model.py:271-277.
+ */
+#ifndef NERAF_HIP_H
+#define NERAF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct neraf_ctx neraf_ctx;
+typedef void* neraf_stream_t; /* hipStream_t */
+
+enum {
+  NERAF_OK = 0,
+  NERAF_EINVAL = -1, /* bad argument / unsupported shape */
+  NERAF_EHIP = -2,   /* a HIP runtime call failed */
+  NERAF_ENOGPU = -3  /* no gfx950 device */
+};
+
+#define NERAF_ABI_VERSION 1
+
+int neraf_abi_version(void);
+int neraf_ctx_create(neraf_ctx** out, int device);
+void neraf_ctx_destroy(neraf_ctx* ctx);
+const char* neraf_last_error(neraf_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------
+ * Per-kernel timing (measurement only; off by default).  When enabled, every launch of a
+ * tracked kernel family is bracketed by a hipEvent pair on the launch stream and its
+ * algorithmic work (FLOPs or bytes, logical un-padded extents) is recorded.
+ * neraf_prof_summary synchronises those events and returns totals since the last enable.
+ * kernel ids: 0 = gemm_f16 128x128 tile, 1 = gemm_f16 64x64 tile (more are appended as
+ * kernels are added; neraf_prof_kernel_name(id) returns NULL past the end).
+ * ---------------------------------------------------------------------------------- */
+int neraf_prof_enable(neraf_ctx* ctx, int on);
+int neraf_prof_summary(neraf_ctx* ctx, int kernel_id, double* total_ms, int* launches, double* work);
+const char* neraf_prof_kernel_name(int kernel_id);
+
+/* ------------------------------------------------------------------------------------
+ * Generic fp16 MFMA GEMM with fused epilogue:  C = epi(alpha * A[M,K] . B[N,K]^T)
+ * (replaces the cuBLAS nn.Linear GEMMs behind NeRAF_field.py:49-58; exported for tests
+ * and for callers that want the raw contraction).  A/B are fp16, K-contiguous; rows are
+ * padded to Mpad/Npad (multiples of 128) and K is a multiple of 64.  act: 0 none,
+ * 1 LeakyReLU(0.1), 2 tanh*10, 3 ReLU.
+ * ---------------------------------------------------------------------------------- */
+int neraf_gemm_f16(neraf_ctx* ctx, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                   int Mpad, int Npad, float alpha, const float* bias, int act,
+                   void* C16, int ldc16, void* C16T, int ldc16t, float* C32, int ldc32,
+                   neraf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * NAcF -- neural acoustic field MLP (NeRAFAudioSoundField, NeRAF_field.py:37-65) with the
+ * query prologue of NeRAFAudioModel.get_outputs (NeRAF_model.py:531-564) fused in front
+ * and the tanh*10 heads behind.
+ * ---------------------------------------------------------------------------------- */
+typedef struct neraf_nacf_desc {
+  int n_feat;  /* grid feature width (1024, NeRAF_config.py:103); 0 = no grid (NeRAF_model.py:207) */
+  int n_query; /* per-row encoded query width: 21+63+63+16 = 163 (NeRAF_model.py:169-171,560) */
+  int W;       /* trunk output width W_field (512, NeRAF_config.py:106) */
+  int C;       /* sound_rez: 1 RAF / 2 SoundSpaces (NeRAF_model.py:129,133) */
+  int F;       /* N_frequencies: 513 RAF / 257 SoundSpaces */
+  int dense_l0; /* also pack layer 0 for the dense h[B,n_feat+n_query] entry points (fwd_dense/bwd_dense) */
+} neraf_nacf_desc;
+
+/* Bytes of the packed fp16 weight blob (both orientations of every layer + fp32 biases). */
+size_t neraf_nacf_packed_bytes(const neraf_nacf_desc* d);
+/* Bytes of the activation workspace for a batch of B rows (saved for backward if training). */
+size_t neraf_nacf_workspace_bytes(const neraf_nacf_desc* d, int B, int training);
+
+/* Pack fp32 master weights (state-dict order: soundfield.{0..4}.{weight,bias}, then
+ * STFT_linear.{c}.{weight,bias} for c<C; each a device pointer to the nn.Linear tensor,
+ * NeRAF_field.py:41-45) into the fp16 MFMA layout.  `weights` is a HOST array of
+ * 2*(5+C) device pointers. */
+int neraf_nacf_pack_weights(neraf_ctx* ctx, const neraf_nacf_desc* d, const float* const* weights,
+                            void* packed, neraf_stream_t stream);
+
+/* Query prologue (NeRAF_model.py:533-551): time/(T-1), AABB-normalise + in-box selector,
+ * NeRF encodings, SH deg-4 -> q fp16 [Bpad,192] (+ transposed copy for backward) inside
+ * the workspace.  aabb is a HOST array of 6 floats (min xyz, max xyz). */
+int neraf_nacf_encode_queries(neraf_ctx* ctx, const neraf_nacf_desc* d, const int64_t* time_query,
+                              const double* mic_pose, const double* source_pose, const double* rot,
+                              const float* aabb_host, int max_len, int B, void* workspace, int training,
+                              neraf_stream_t stream);
+
+/* Forward with the layer-0 split: feat [n_feat] fp32 is the ResNet3D feature shared by all
+ * rows (NeRAF_model.py:557-558); queries must have been encoded into the workspace.
+ * out: fp32 [B, C, F] (NeRAF_field.py:63).  fp32 master weights are read for the
+ * feature half of layer 0 (pointer array as in pack_weights). */
+int neraf_nacf_fwd(neraf_ctx* ctx, const neraf_nacf_desc* d, const void* packed, const float* const* weights,
+                   const float* feat, int B, float* out, void* workspace, int training, neraf_stream_t stream);
+
+/* Dense forward on an explicit h [B, n_feat+n_query] fp32 -- exactly the signature of
+ * NeRAFAudioSoundField.forward(h) (NeRAF_field.py:47). */
+int neraf_nacf_fwd_dense(neraf_ctx* ctx, const neraf_nacf_desc* d, const void* packed, const float* h, int B,
+                         float* out, void* workspace, int training, neraf_stream_t stream);
+
+/* Backward of neraf_nacf_fwd: dout fp32 [B,C,F] -> grads (HOST array of 2*(5+C) device
+ * pointers, same order/shapes as `weights`, overwritten) and dfeat [n_feat] (may be null). */
+int neraf_nacf_bwd(neraf_ctx* ctx, const neraf_nacf_desc* d, const void* packed, const float* const* weights,
+                   const float* feat, int B, const float* out, const float* dout, float* const* grads,
+                   float* dfeat, void* workspace, neraf_stream_t stream);
+
+/* Backward of neraf_nacf_fwd_dense; dh fp32 [B, n_feat+n_query] may be null. */
+int neraf_nacf_bwd_dense(neraf_ctx* ctx, const neraf_nacf_desc* d, const void* packed, int B, const float* out,
+                         const float* dout, float* const* grads, float* dh, void* workspace,
+                         neraf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * STFT loss (STFTLoss.forward, NeRAF_evaluator.py:88-108; scaling NeRAF_model.py:584-600).
+ * loss_type: 0 = 'mse' (SC+SLMSE), 1 = 'l1' (SC+SLL1).  sums (fp32[4], device, zeroed by the
+ * call): sum (ymag-xmag)^2, sum ymag^2, sum |x-y|^p, unused.  losses (fp32[2], device):
+ * {sc, mag} unscaled.  The *_bwd writes d(w[0]*sc + w[1]*mag)/dpred into dpred; w is a DEVICE
+ * pointer to the two upstream gradients (loss weights x grad-scaler scale) so that no host
+ * synchronisation is needed between forward and backward.
+ * ---------------------------------------------------------------------------------- */
+int neraf_stft_loss_fwd(neraf_ctx* ctx, const float* pred, const float* gt, size_t n, int loss_type,
+                        float* sums, float* losses, neraf_stream_t stream);
+/* The same in two steps for data-parallel training: the spectral-convergence ratio is over the
+ * GLOBAL batch (NeRAF_evaluator.py:26), so ranks compute local sums, all-reduce the 4 floats
+ * (RCCL), then finalize with the global element count n_total. */
+int neraf_stft_loss_sums(neraf_ctx* ctx, const float* pred, const float* gt, size_t n, int loss_type,
+                         float* sums, neraf_stream_t stream);
+int neraf_stft_loss_finalize(neraf_ctx* ctx, const float* sums, size_t n_total, float* losses,
+                             neraf_stream_t stream);
+int neraf_stft_loss_bwd(neraf_ctx* ctx, const float* pred, const float* gt, size_t n, size_t n_total,
+                        int loss_type, const float* sums, const float* w, float* dpred, neraf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERAF_HIP_H */

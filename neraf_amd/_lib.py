@@ -1,0 +1,107 @@
+"""ctypes binding of libneraf_hip.so (C ABI declared in include/neraf_hip.h).
+
+The HIP library is the product path.  There is NO fallback: if the shared object is
+missing, or no gfx950 GPU is visible, every op raises.  PyTorch is used only for device
+memory (caching allocator) and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libneraf_hip.so")
+
+_lib: Optional[C.CDLL] = None
+_ctxs: Dict[int, C.c_void_p] = {}
+
+c_fpp = C.POINTER(C.c_void_p)
+
+
+class NacfDesc(C.Structure):
+    _fields_ = [("n_feat", C.c_int), ("n_query", C.c_int), ("W", C.c_int), ("C", C.c_int), ("F", C.c_int),
+                ("dense_l0", C.c_int)]
+
+
+# name -> (restype, argtypes).  Mirrors include/neraf_hip.h one to one; tests check that every
+# symbol declared in the header is exported and listed here.
+SIGNATURES = {
+    "neraf_abi_version": (C.c_int, []),
+    "neraf_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "neraf_ctx_destroy": (None, [C.c_void_p]),
+    "neraf_last_error": (C.c_char_p, [C.c_void_p]),
+    "neraf_gemm_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "neraf_nacf_packed_bytes": (C.c_size_t, [C.POINTER(NacfDesc)]),
+    "neraf_nacf_workspace_bytes": (C.c_size_t, [C.POINTER(NacfDesc), C.c_int, C.c_int]),
+    "neraf_nacf_pack_weights": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), c_fpp, C.c_void_p, C.c_void_p]),
+    "neraf_nacf_encode_queries": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                            C.c_void_p]),
+    "neraf_nacf_fwd": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), C.c_void_p, c_fpp, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_int, C.c_void_p]),
+    "neraf_nacf_fwd_dense": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p]),
+    "neraf_nacf_bwd": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), C.c_void_p, c_fpp, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_void_p, c_fpp, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_nacf_bwd_dense": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                       c_fpp, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_stft_loss_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "neraf_stft_loss_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "neraf_stft_loss_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "neraf_stft_loss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "neraf_prof_summary": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "neraf_prof_kernel_name": (C.c_char_p, [C.c_int]),
+}
+
+
+def load() -> C.CDLL:
+    """Load libneraf_hip.so and attach the signatures.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C neraf_amd/csrc`).  neraf_amd has no CPU / eager fallback by design.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.neraf_abi_version() != 1:
+        raise RuntimeError("libneraf_hip ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def ctx(device_index: int = 0) -> C.c_void_p:
+    """Per-device neraf_ctx (created on first use).  Raises without a GPU."""
+    if device_index in _ctxs:
+        return _ctxs[device_index]
+    lib = load()
+    h = C.c_void_p()
+    rc = lib.neraf_ctx_create(C.byref(h), device_index)
+    if rc != 0:
+        raise RuntimeError(f"neraf_ctx_create(device={device_index}) failed with {rc}: no MI355X/gfx950 GPU visible; "
+                           "the NeRAF hot path only runs on the HIP library (no fallback).")
+    _ctxs[device_index] = h
+    return h
+
+
+def check(rc: int, device_index: int = 0) -> None:
+    if rc != 0:
+        msg = load().neraf_last_error(_ctxs.get(device_index)) if device_index in _ctxs else b""
+        raise RuntimeError(f"libneraf_hip call failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr_array(tensors) -> "C.Array":
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr

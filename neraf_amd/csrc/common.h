@@ -1,0 +1,86 @@
+// Internal shared declarations for libneraf_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/neraf_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_NUM_KERNELS = 2 };
+
+struct ProfRec { hipEvent_t a, b; int kid; double work; };
+
+struct neraf_ctx {
+  int device;
+  int num_cus;
+  std::string last_error;
+  bool prof = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> free_events;
+};
+
+// RAII bracket: records an event pair around a launch when profiling is on.
+struct ProfScope {
+  neraf_ctx* ctx; hipStream_t st; ProfRec r; bool on;
+  ProfScope(neraf_ctx* c, hipStream_t s, int kid, double work) : ctx(c), st(s), on(c && c->prof) {
+    if (!on) return;
+    auto get = [&]() { hipEvent_t e; if (!c->free_events.empty()) { e = c->free_events.back(); c->free_events.pop_back(); }
+                       else (void)hipEventCreate(&e); return e; };
+    r.a = get(); r.b = get(); r.kid = kid; r.work = work;
+    (void)hipEventRecord(r.a, st);
+  }
+  ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); ctx->recs.push_back(r); } }
+};
+
+static inline int neraf_fail(neraf_ctx* ctx, int code, const char* what) {
+  if (ctx) ctx->last_error = what;
+  return code;
+}
+
+#define NERAF_HIP_CHECK(ctx, expr)                                                  \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      char _b[512];                                                                 \
+      snprintf(_b, sizeof(_b), "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return neraf_fail(ctx, NERAF_EHIP, _b);                                       \
+    }                                                                               \
+  } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+// ---- fp16 MFMA GEMM with fused epilogue (gemm_f16.hip) ----------------------------------
+// C = epi(alpha * A[M,K] . B[N,K]^T) ; A and B are fp16, K-contiguous ("NT" form).
+// Buffers are tile-padded: A has >= Mpad rows, B has >= Npad rows, K % 64 == 0.  Loads are
+// unguarded; every fp16 output tile is written in full with zeros outside the logical MxN
+// extent so padded buffers are always valid K-/M-padding for the next GEMM.
+enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_TANH10 = 2, ACT_RELU = 3 };
+
+struct GemmParams {
+  const half_t* A; int lda;
+  const half_t* B; int ldb;
+  int M, N, K;          // logical extents (K multiple of 64)
+  int Mpad, Npad;       // tile-padded extents; multiples of the chosen tile
+  float alpha;
+  const float* bias;    // [Npad] fp32 or null (added before act)
+  int act;
+  const half_t* lmask; int ldmask;   // optional: v *= (lmask[m][n] > 0 ? 1 : slope)  (leaky/relu backward)
+  float mask_slope;
+  half_t* C16; int ldc16;            // optional row-major fp16 out [Mpad, >=Npad]
+  half_t* C16T; int ldc16t;          // optional transposed fp16 out [Npad, >=Mpad]
+  float* C32; int ldc32;             // optional fp32 out, masked to M x N
+  float* colsum;                     // optional [Npad] fp32: atomically += column sums of the final values
+};
+
+int launch_gemm_f16(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream);

@@ -1,0 +1,188 @@
+"""Host-side mirror of ``NeRAF/NeRAF_field.py`` for the MI355X engine.
+
+``NeRAFAudioSoundField`` keeps the reference's constructor signature, sub-module names and
+therefore its state-dict keys (``soundfield.{0-4}.{weight,bias}``, ``STFT_linear.{c}.{weight,bias}``;
+NeRAF_field.py:39-45), so reference checkpoints load with ``load_state_dict``.  The arithmetic is
+not PyTorch: ``forward`` runs the fused fp16-MFMA MLP of libneraf_hip through the C ABI
+(include/neraf_hip.h) and there is no fallback when the library or the GPU is missing.
+
+Two entry points:
+  * ``forward(h)``            -- exactly NeRAF_field.py:47 (dense ``h [B, in_size]``).
+  * ``forward_queries(...)``  -- what NeRAFAudioModel.get_outputs needs (NeRAF_model.py:531-564):
+    raw batch fields + the shared 1024-d grid feature; the query encodings are computed on the GPU
+    and the feature half of layer 0 is folded into its bias (layer-0 split).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+N_QUERY = 163  # 21 (time) + 63 (mic) + 63 (source) + 16 (SH rot)  NeRAF_model.py:169-171
+
+
+def _stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_index(t: torch.Tensor) -> int:
+    if not t.is_cuda:
+        raise RuntimeError("neraf_amd ops need CUDA(HIP) tensors: the NeRAF hot path has no CPU fallback")
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+class _NacfSplitFn(torch.autograd.Function):
+    """out = NAcF(feat, encoded queries) ; grads for feat and the 2*(5+C) parameters."""
+
+    @staticmethod
+    def forward(ctx, field: "NeRAFAudioSoundField", feat: torch.Tensor, ws: torch.Tensor, B: int, training: bool,
+                *params: torch.Tensor):
+        lib = _lib.load()
+        dev = _dev_index(feat)
+        h = _lib.ctx(dev)
+        packed = field._packed(params)
+        out = torch.empty((B, field.sound_rez, field.N_frequencies), dtype=torch.float32, device=feat.device)
+        wptr = _lib.ptr_array(params)
+        _lib.check(lib.neraf_nacf_fwd(h, C.byref(field._desc), packed.data_ptr(), wptr, feat.data_ptr(), B,
+                                      out.data_ptr(), ws.data_ptr(), int(training), _stream_ptr()), dev)
+        ctx.field, ctx.B, ctx.dev = field, B, dev
+        ctx.save_for_backward(feat, ws, out, packed, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: torch.Tensor):
+        feat, ws, out, packed, *params = ctx.saved_tensors
+        field: NeRAFAudioSoundField = ctx.field
+        lib = _lib.load()
+        dout = dout.contiguous().float()
+        grads = [torch.empty_like(p) for p in params]
+        dfeat = torch.empty_like(feat)
+        _lib.check(lib.neraf_nacf_bwd(_lib.ctx(ctx.dev), C.byref(field._desc), packed.data_ptr(), _lib.ptr_array(params),
+                                      feat.data_ptr(), ctx.B, out.data_ptr(), dout.data_ptr(), _lib.ptr_array(grads),
+                                      dfeat.data_ptr(), ws.data_ptr(), _stream_ptr()), ctx.dev)
+        return (None, dfeat, None, None, None, *grads)
+
+
+class _NacfDenseFn(torch.autograd.Function):
+    """out = NeRAFAudioSoundField.forward(h) with h dense [B, in_size]."""
+
+    @staticmethod
+    def forward(ctx, field: "NeRAFAudioSoundField", h_in: torch.Tensor, training: bool, *params: torch.Tensor):
+        lib = _lib.load()
+        dev = _dev_index(h_in)
+        B = h_in.shape[0]
+        packed = field._packed(params)
+        ws = field._workspace(B, training, h_in.device)
+        out = torch.empty((B, field.sound_rez, field.N_frequencies), dtype=torch.float32, device=h_in.device)
+        _lib.check(lib.neraf_nacf_fwd_dense(_lib.ctx(dev), C.byref(field._desc), packed.data_ptr(), h_in.data_ptr(), B,
+                                            out.data_ptr(), ws.data_ptr(), int(training), _stream_ptr()), dev)
+        ctx.field, ctx.B, ctx.dev = field, B, dev
+        ctx.need_dh = h_in.requires_grad
+        ctx.save_for_backward(ws, out, packed, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: torch.Tensor):
+        ws, out, packed, *params = ctx.saved_tensors
+        field: NeRAFAudioSoundField = ctx.field
+        lib = _lib.load()
+        dout = dout.contiguous().float()
+        grads = [torch.empty_like(p) for p in params]
+        dh = torch.empty((ctx.B, field.in_size), dtype=torch.float32, device=dout.device) if ctx.need_dh else None
+        _lib.check(lib.neraf_nacf_bwd_dense(_lib.ctx(ctx.dev), C.byref(field._desc), packed.data_ptr(), ctx.B,
+                                            out.data_ptr(), dout.data_ptr(), _lib.ptr_array(grads),
+                                            dh.data_ptr() if dh is not None else None, ws.data_ptr(), _stream_ptr()),
+                   ctx.dev)
+        return (None, dh, None, *grads)
+
+
+class NeRAFAudioSoundField(nn.Module):
+    """Drop-in for ``NeRAFAudioSoundField`` (NeRAF_field.py:37-65) running on libneraf_hip."""
+
+    def __init__(self, in_size: int, W: int, sound_rez: int = 2, N_frequencies: int = 257):
+        super().__init__()
+        # Parameter containers identical to the reference (NeRAF_field.py:41-45) -> same state-dict keys/init.
+        self.soundfield = nn.ModuleList(
+            [nn.Linear(in_size, 5096), nn.Linear(5096, 2048), nn.Linear(2048, 1024), nn.Linear(1024, 1024), nn.Linear(1024, W)])
+        self.STFT_linear = nn.ModuleList([nn.Linear(W, N_frequencies) for _ in range(sound_rez)])
+        if in_size < N_QUERY:
+            raise ValueError(f"in_size must be >= {N_QUERY} (grid features + {N_QUERY} encoded query dims)")
+        self.in_size, self.W, self.sound_rez, self.N_frequencies = in_size, W, sound_rez, N_frequencies
+        self._desc = _lib.NacfDesc(in_size - N_QUERY, N_QUERY, W, sound_rez, N_frequencies, 1)
+        self._packed_buf: Optional[torch.Tensor] = None
+        self._packed_key = None
+
+    # -- parameters in the C-ABI order (state-dict order) -------------------------------------
+    def flat_params(self) -> List[torch.Tensor]:
+        ps: List[torch.Tensor] = []
+        for lin in list(self.soundfield) + list(self.STFT_linear):
+            ps += [lin.weight, lin.bias]
+        return ps
+
+    def _packed(self, params: Sequence[torch.Tensor]) -> torch.Tensor:
+        """fp16 MFMA-layout copy of the fp32 master weights; re-packed when any parameter changed."""
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        dev = params[0].device
+        if self._packed_buf is None or self._packed_buf.device != dev or key != self._packed_key:
+            lib = _lib.load()
+            d = _dev_index(params[0])
+            nbytes = lib.neraf_nacf_packed_bytes(C.byref(self._desc))
+            # a fresh buffer each re-pack: earlier ones may still be referenced by a pending backward
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            for p in params:
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("NAcF parameters must be contiguous float32")
+            _lib.check(lib.neraf_nacf_pack_weights(_lib.ctx(d), C.byref(self._desc), _lib.ptr_array(params),
+                                                   buf.data_ptr(), _stream_ptr()), d)
+            self._packed_buf, self._packed_key = buf, key
+        return self._packed_buf
+
+    def _workspace(self, B: int, training: bool, device) -> torch.Tensor:
+        nbytes = _lib.load().neraf_nacf_workspace_bytes(C.byref(self._desc), B, int(training))
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    # -- NeRAF_field.py:47 -----------------------------------------------------------------------
+    def forward(self, h: torch.Tensor) -> torch.Tensor:
+        if h.dim() != 2 or h.shape[1] != self.in_size:
+            raise ValueError(f"h must be [B, {self.in_size}]")
+        h = h.contiguous().float()
+        training = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in self.parameters()))
+        return _NacfDenseFn.apply(self, h, training, *self.flat_params())
+
+    # -- NeRAF_model.py:531-564 ------------------------------------------------------------------
+    def forward_queries(self, feat: torch.Tensor, time_query: torch.Tensor, mic_pose: torch.Tensor,
+                        source_pose: torch.Tensor, rot: torch.Tensor, aabb: torch.Tensor, max_len: int) -> torch.Tensor:
+        """feat [n_feat] fp32 (ResNet3D output, flattened); batch fields as produced by the audio
+        datamanager (NeRAF_dataset.py:129-130): time_query int64 [B], poses / rot float64 [B,3]."""
+        lib = _lib.load()
+        dev = _dev_index(mic_pose)
+        B = int(time_query.shape[0])
+        feat = feat.reshape(-1).float().contiguous()
+        if feat.numel() != self._desc.n_feat:
+            raise ValueError(f"feat must have {self._desc.n_feat} elements")
+        tq = time_query.to(torch.int64).contiguous()
+        mic = mic_pose.to(torch.float64).contiguous()
+        src = source_pose.to(torch.float64).contiguous()
+        r = rot.to(torch.float64).contiguous()
+        training = torch.is_grad_enabled() and (feat.requires_grad or any(p.requires_grad for p in self.parameters()))
+        ws = self._workspace(B, training, mic.device)
+        ab = (C.c_float * 6)(*[float(v) for v in aabb.detach().reshape(-1).cpu().tolist()])
+        _lib.check(lib.neraf_nacf_encode_queries(_lib.ctx(dev), C.byref(self._desc), tq.data_ptr(), mic.data_ptr(),
+                                                 src.data_ptr(), r.data_ptr(), ab, int(max_len), B, ws.data_ptr(),
+                                                 int(training), _stream_ptr()), dev)
+        return _NacfSplitFn.apply(self, feat, ws, B, training, *self.flat_params())
+
+
+class NeRAFVisionFieldValue(nn.Module):
+    """Pass-through wrapper that provides the ``.module`` attribute path (NeRAF_field.py:27-34)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, ray_samples, compute_normals=False):
+        return self.module(ray_samples, compute_normals=compute_normals)

@@ -1,0 +1,94 @@
+"""Host-side mirror of the training loss in ``NeRAF/NeRAF_evaluator.py`` (STFTLoss :76-108,
+SpectralConvergenceLoss :8-26, LogSTFTMagnitudeLoss :29-53) on libneraf_hip.
+
+``STFTLoss(loss_type)(x_log, y_log)`` returns ``{'audio_sc_loss', 'audio_mag_loss'}`` exactly
+like the reference; both reductions run in one fused HIP kernel and the backward is one
+element-wise kernel.  No fallback without the HIP library / GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .field import _dev_index, _stream_ptr
+
+
+class _StftLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_log: torch.Tensor, y_log: torch.Tensor, loss_type: int, group=None):
+        lib = _lib.load()
+        dev = _dev_index(x_log)
+        x = x_log.contiguous().float()
+        y = y_log.contiguous().float()
+        if x.shape != y.shape:
+            raise ValueError("STFTLoss: prediction / target shape mismatch")
+        sums = torch.empty(4, dtype=torch.float32, device=x.device)
+        losses = torch.empty(2, dtype=torch.float32, device=x.device)
+        n_total = x.numel()
+        _lib.check(lib.neraf_stft_loss_sums(_lib.ctx(dev), x.data_ptr(), y.data_ptr(), x.numel(), loss_type,
+                                            sums.data_ptr(), _stream_ptr()), dev)
+        if group is not None:
+            # data parallel: the Frobenius ratio / mean are over the GLOBAL batch (NeRAF_evaluator.py:26)
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=group if group is not True else None)
+            n_total = x.numel() * dist.get_world_size(group if group is not True else None)
+        _lib.check(lib.neraf_stft_loss_finalize(_lib.ctx(dev), sums.data_ptr(), n_total, losses.data_ptr(),
+                                                _stream_ptr()), dev)
+        ctx.save_for_backward(x, y, sums)
+        ctx.loss_type, ctx.dev, ctx.n_total = loss_type, dev, n_total
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g_sc: torch.Tensor, g_mag: torch.Tensor):
+        x, y, sums = ctx.saved_tensors
+        lib = _lib.load()
+        dx = torch.empty_like(x)
+        # upstream scalars (loss weights x GradScaler scale) stay on the device: no host sync
+        zero = torch.zeros((), dtype=torch.float32, device=x.device)
+        w = torch.stack([(g_sc if g_sc is not None else zero).float().reshape(()),
+                         (g_mag if g_mag is not None else zero).float().reshape(())]).contiguous()
+        _lib.check(lib.neraf_stft_loss_bwd(_lib.ctx(ctx.dev), x.data_ptr(), y.data_ptr(), x.numel(), ctx.n_total,
+                                           ctx.loss_type, sums.data_ptr(), w.data_ptr(), dx.data_ptr(), _stream_ptr()),
+                   ctx.dev)
+        return dx, None, None, None
+
+
+class SpectralConvergenceLoss(nn.Module):
+    """NeRAF_evaluator.py:8-26 (takes magnitudes).  Kept for API parity; STFTLoss uses the fused kernel."""
+
+    def forward(self, x_mag, y_mag):
+        sc, _ = _StftLossFn.apply(torch.log(x_mag + 1e-3), torch.log(y_mag + 1e-3), 0)
+        return sc
+
+
+class LogSTFTMagnitudeLoss(nn.Module):
+    """NeRAF_evaluator.py:29-53."""
+
+    def __init__(self, loss_type="l1"):
+        super().__init__()
+        self.loss_type = loss_type
+
+    def forward(self, x_log, y_log):
+        _, mag = _StftLossFn.apply(x_log, y_log, 1 if self.loss_type == "l1" else 0)
+        return mag
+
+
+class STFTLoss(nn.Module):
+    """NeRAF_evaluator.py:76-108."""
+
+    def __init__(self, loss_type="l1", process_group=None):
+        """``process_group``: None = single process; True = default group; or a group handle.  With a
+        group, per-rank Frobenius sums are all-reduced (RCCL) so the loss equals the reference's on the
+        concatenated global batch."""
+        super().__init__()
+        if loss_type not in ("l1", "mse"):
+            raise ValueError("loss_type must be 'l1' or 'mse'")
+        self.loss_type = loss_type
+        self.process_group = process_group
+
+    def forward(self, x_log, y_log):
+        sc, mag = _StftLossFn.apply(x_log, y_log, 1 if self.loss_type == "l1" else 0, self.process_group)
+        return {"audio_sc_loss": sc, "audio_mag_loss": mag}

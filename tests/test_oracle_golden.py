@@ -154,7 +154,8 @@ def test_nerf_encoding_properties():
     assert O.nerf_encoding(torch.rand(5, 1)).shape == (5, 21)
     # frequency k of dim 0 is sin(2 pi x 2^(8k/9))
     k = 4
-    np.testing.assert_allclose(e[:, k].numpy(), np.sin(2 * np.pi * x[:, 0].numpy() * 2 ** (8 * k / 9)), atol=1e-9)
+    # (frequencies are float32-rounded as in nerfstudio -> phase error <= 2*pi*2^8*6e-8)
+    np.testing.assert_allclose(e[:, k].numpy(), np.sin(2 * np.pi * x[:, 0].numpy() * 2 ** (8 * k / 9)), atol=2e-4)
 
 
 def test_sh4_orthonormal_on_sphere():
