@@ -73,6 +73,7 @@ struct GemmParams {
   int M, N, K;          // logical extents (K multiple of 64)
   int Mpad, Npad;       // tile-padded extents; multiples of the chosen tile
   float alpha;
+  const float* alpha_dev; // optional device scalar multiplied into alpha (backward un-scaling)
   const float* bias;    // [Npad] fp32 or null (added before act)
   int act;
   const half_t* lmask; int ldmask;   // optional: v *= (lmask[m][n] > 0 ? 1 : slope)  (leaky/relu backward)

@@ -69,6 +69,7 @@ struct WsLayout {
   size_t bias0;            // fp32 [np0] effective layer-0 bias
   size_t dz[2], dzT[2];    // backward ping-pong fp16 [Mpad][5120] / [5120+128][Mpad]
   size_t colsum[6];        // fp32 [np]
+  size_t scale;            // fp32 [4]: {S, 1/S, amax bits, -} backward auto-scale
   size_t total;
 };
 
@@ -97,6 +98,7 @@ WsLayout make_ws_layout(const neraf_nacf_desc* d, const Dims& D, int B, int trai
       L.dzT[i] = take((size_t)(maxw + 128) * M * 2);
     }
     for (int l = 0; l < 6; ++l) L.colsum[l] = take((size_t)D.np[l] * 4);
+    L.scale = take(256);
   }
   L.total = off;
   return L;
@@ -108,12 +110,13 @@ WsLayout make_ws_layout(const neraf_nacf_desc* d, const Dims& D, int B, int trai
 // mode 1: value = src * (10 - aux^2/10) (tanh*10 backward, aux = forward output, same layout as src).
 // Optional colsum (fp32 [>=Cpad]) of the written values.
 __global__ __launch_bounds__(256) void cvt_pad_transpose_kernel(
-    const float* __restrict__ src, const float* __restrict__ aux, int ld, int R, int Cc, int mode,
-    half_t* __restrict__ dst, int ld_dst, int Rpad, int Cpad,
+    const float* __restrict__ src, const float* __restrict__ aux, const float* __restrict__ scale, int ld, int R, int Cc,
+    int mode, half_t* __restrict__ dst, int ld_dst, int Rpad, int Cpad,
     half_t* __restrict__ dstT, int ld_dstT, int RpadT, int CpadT, float* __restrict__ colsum) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const float sc = scale ? scale[0] : 1.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + ty + i * 8, c = c0 + tx;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void cvt_pad_transpose_kernel(
       v = src[(size_t)r * ld + c];
       if (mode == 1) {
         const float o = aux[(size_t)r * ld + c];
-        v *= (10.f - o * o * 0.1f);
+        v *= (10.f - o * o * 0.1f) * sc;
       }
     }
     tile[ty + i * 8][tx] = v;
@@ -269,6 +272,41 @@ __global__ __launch_bounds__(256) void encode_queries_kernel(EncodeArgs a, int t
   else a.q[(size_t)row * KQ_PAD + col] = (half_t)v;
 }
 
+// Backward auto-scaling.  The gradient chain dz_l is carried in fp16; to keep it inside fp16's range for ANY
+// upstream loss scale (with or without a GradScaler) the head gradient is multiplied by a power of two S chosen
+// so that max|dz_5| lands in [256, 512); every fp32 output (dW, db, dfeat, dh) is multiplied back by 1/S.
+__global__ __launch_bounds__(256) void amax_dz5_kernel(const float* __restrict__ dout, const float* __restrict__ out, size_t n,
+                                                      unsigned* __restrict__ amax_bits) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float o = out[i];
+    const float v = fabsf(dout[i] * (10.f - o * o * 0.1f));
+    m = (v == v && v > m) ? v : m;   // NaNs are ignored here; they still propagate through the data path
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
+}
+
+__global__ void make_scale_kernel(float* __restrict__ scale) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float amax = __uint_as_float(reinterpret_cast<unsigned*>(scale)[2]);
+    float S = 1.f;
+    if (amax > 0.f && amax < 3.0e38f) {
+      int e = 8 - (int)floorf(log2f(amax));
+      e = e > 100 ? 100 : (e < -100 ? -100 : e);
+      S = exp2f((float)e);
+    }
+    scale[0] = S;
+    scale[1] = 1.f / S;
+  }
+}
+
+__global__ void scale_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, int n, const float* __restrict__ mul) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] * mul[0];
+}
+
 // ---- STFT loss -------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stft_loss_sums_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             size_t n, int l1, float* __restrict__ sums) {
@@ -314,14 +352,15 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
 }
 
 // ---- helpers ---------------------------------------------------------------------------------
-int cvt_pad_transpose(neraf_ctx* ctx, hipStream_t st, const float* src, const float* aux, int ld, int R, int Cc, int mode,
+int cvt_pad_transpose(neraf_ctx* ctx, hipStream_t st, const float* src, const float* aux, const float* scale, int ld, int R,
+                      int Cc, int mode,
                       half_t* dst, int ld_dst, int Rpad, int Cpad, half_t* dstT, int ld_dstT, int RpadT, int CpadT,
                       float* colsum) {
   int rmax = Rpad, cmax = Cpad;
   if (dstT) { rmax = RpadT > rmax ? RpadT : rmax; cmax = CpadT > cmax ? CpadT : cmax; }
   if (!dst) { rmax = RpadT; cmax = CpadT; }
   dim3 grid((cmax + 31) / 32, (rmax + 31) / 32);
-  hipLaunchKernelGGL(cvt_pad_transpose_kernel, grid, dim3(256), 0, st, src, aux, ld, R, Cc, mode, dst, ld_dst,
+  hipLaunchKernelGGL(cvt_pad_transpose_kernel, grid, dim3(256), 0, st, src, aux, scale, ld, R, Cc, mode, dst, ld_dst,
                      dst ? Rpad : 0, dst ? Cpad : 0, dstT, ld_dstT, RpadT, CpadT, colsum);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
@@ -358,16 +397,16 @@ extern "C" int neraf_nacf_pack_weights(neraf_ctx* ctx, const neraf_nacf_desc* d,
   char* P = (char*)packed;
   const int ld0 = D.kdense;
   // layer 0, query half: columns [n_feat, n_feat+163) of W0
-  if (int e = cvt_pad_transpose(ctx, st, Wptr(w, 0) + d->n_feat, nullptr, ld0, D.n[0], D.k[0], 0, (half_t*)(P + L.w[0]),
+  if (int e = cvt_pad_transpose(ctx, st, Wptr(w, 0) + d->n_feat, nullptr, nullptr, ld0, D.n[0], D.k[0], 0, (half_t*)(P + L.w[0]),
                                 D.kp[0], D.np[0], D.kp[0], nullptr, 0, 0, 0, nullptr))
     return e;
   if (d->dense_l0) {
-    if (int e = cvt_pad_transpose(ctx, st, Wptr(w, 0), nullptr, ld0, D.n[0], D.kdense, 0, (half_t*)(P + L.w0d), D.kdense_p,
+    if (int e = cvt_pad_transpose(ctx, st, Wptr(w, 0), nullptr, nullptr, ld0, D.n[0], D.kdense, 0, (half_t*)(P + L.w0d), D.kdense_p,
                                   D.np[0], D.kdense_p, (half_t*)(P + L.w0dt), D.np[0], D.np[0], D.kdense_p, nullptr))
       return e;
   }
   for (int l = 1; l < 5; ++l) {
-    if (int e = cvt_pad_transpose(ctx, st, Wptr(w, l), nullptr, D.k[l], D.n[l], D.k[l], 0, (half_t*)(P + L.w[l]), D.kp[l],
+    if (int e = cvt_pad_transpose(ctx, st, Wptr(w, l), nullptr, nullptr, D.k[l], D.n[l], D.k[l], 0, (half_t*)(P + L.w[l]), D.kp[l],
                                   D.np[l], D.kp[l], (half_t*)(P + L.wt[l]), D.np[l], D.np[l], round_up(D.kp[l], 128), nullptr))
       return e;
   }
@@ -380,7 +419,7 @@ extern "C" int neraf_nacf_pack_weights(neraf_ctx* ctx, const neraf_nacf_desc* d,
     const float* bh = w[2 * (5 + c) + 1];
     half_t* dst = (half_t*)(P + L.w[5]) + (size_t)c * d->F * D.kp[5];
     half_t* dstT = (half_t*)(P + L.wt[5]) + (size_t)c * d->F;
-    if (int e = cvt_pad_transpose(ctx, st, Wh, nullptr, d->W, d->F, d->W, 0, dst, D.kp[5], d->F, D.kp[5], dstT, D.np[5],
+    if (int e = cvt_pad_transpose(ctx, st, Wh, nullptr, nullptr, d->W, d->F, d->W, 0, dst, D.kp[5], d->F, D.kp[5], dstT, D.np[5],
                                   d->F, D.kp[5], nullptr))
       return e;
     hipLaunchKernelGGL(pad_copy_f32_kernel, dim3((d->F + 255) / 256), dim3(256), 0, st, bh, d->F,
@@ -479,7 +518,7 @@ extern "C" int neraf_nacf_fwd_dense(neraf_ctx* ctx, const neraf_nacf_desc* d, co
   const WsLayout WL = make_ws_layout(d, D, B, training);
   const char* P = (const char*)packed;
   char* ws = (char*)workspace;
-  if (int e = cvt_pad_transpose(ctx, st, h, nullptr, D.kdense, B, D.kdense, 0, (half_t*)(ws + WL.hd), D.kdense_p, WL.Mpad,
+  if (int e = cvt_pad_transpose(ctx, st, h, nullptr, nullptr, D.kdense, B, D.kdense, 0, (half_t*)(ws + WL.hd), D.kdense_p, WL.Mpad,
                                 D.kdense_p, training ? (half_t*)(ws + WL.hdT) : nullptr, WL.Mpad, WL.Mpad, D.kdense_p,
                                 nullptr))
     return e;
@@ -502,10 +541,23 @@ static int nacf_bwd_body(neraf_ctx* ctx, const neraf_nacf_desc* d, const Dims& D
   const int M = WL.Mpad;
   for (int l = 0; l < 6; ++l) NERAF_HIP_CHECK(ctx, hipMemsetAsync(ws + WL.colsum[l], 0, (size_t)D.np[l] * 4, st));
   // heads: dz5 = dout * (10 - out^2/10)  -> fp16 [Mpad][np5] and transposed [np5(+128)][Mpad]
+  float* scale = (float*)(ws + WL.scale);
+  const float* inv_scale = scale + 1;
+  NERAF_HIP_CHECK(ctx, hipMemsetAsync(scale, 0, 16, st));
+  {
+    const size_t n = (size_t)B * D.n[5];
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(amax_dz5_kernel, dim3(blocks), dim3(256), 0, st, dout, out, n, reinterpret_cast<unsigned*>(scale) + 2);
+    hipLaunchKernelGGL(make_scale_kernel, dim3(1), dim3(64), 0, st, scale);
+  }
+  auto copy_out = [&](float* dst, const float* src, int n) {
+    hipLaunchKernelGGL(scale_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, src, n, inv_scale);
+  };
   int cur = 0;
   half_t* dz = (half_t*)(ws + WL.dz[cur]);
   half_t* dzT = (half_t*)(ws + WL.dzT[cur]);
-  if (int e = cvt_pad_transpose(ctx, st, dout, out, D.n[5], B, D.n[5], 1, dz, D.np[5], M, D.np[5], dzT, M, M, D.np[5] + 128,
+  if (int e = cvt_pad_transpose(ctx, st, dout, out, scale, D.n[5], B, D.n[5], 1, dz, D.np[5], M, D.np[5], dzT, M, M, D.np[5] + 128,
                                 (float*)(ws + WL.colsum[5])))
     return e;
   for (int c = 0; c < d->C; ++c) {
@@ -514,10 +566,10 @@ static int nacf_bwd_body(neraf_ctx* ctx, const neraf_nacf_desc* d, const Dims& D
     g.A = dzT + (size_t)c * d->F * M; g.lda = M;
     g.B = (const half_t*)(ws + WL.hT[4]); g.ldb = M;
     g.M = d->F; g.N = D.n[4]; g.K = M; g.Mpad = round_up(d->F, 128); g.Npad = D.np[4]; g.alpha = 1.f;
+    g.alpha_dev = inv_scale;
     g.C32 = grads[2 * (5 + c)]; g.ldc32 = D.n[4];
     if (int e = launch_gemm_f16(ctx, g, st)) return e;
-    NERAF_HIP_CHECK(ctx, hipMemcpyAsync(grads[2 * (5 + c) + 1], (float*)(ws + WL.colsum[5]) + (size_t)c * d->F,
-                                        (size_t)d->F * 4, hipMemcpyDeviceToDevice, st));
+    copy_out(grads[2 * (5 + c) + 1], (const float*)(ws + WL.colsum[5]) + (size_t)c * d->F, d->F);
   }
   for (int l = 5; l >= 1; --l) {
     // dz_{l-1} = (dz_l . W_l) * leaky'(h_{l-1})   [Mpad, np_{l-1}]
@@ -540,13 +592,14 @@ static int nacf_bwd_body(neraf_ctx* ctx, const neraf_nacf_desc* d, const Dims& D
       w.A = dznT; w.lda = M;
       w.B = (const half_t*)(ws + WL.hT[l - 2]); w.ldb = M;
       w.M = D.n[l - 1]; w.N = D.k[l - 1]; w.K = M; w.Mpad = D.np[l - 1]; w.Npad = D.kp[l - 1]; w.alpha = 1.f;
+      w.alpha_dev = inv_scale;
       w.C32 = grads[2 * (l - 1)]; w.ldc32 = D.k[l - 1];
       if (int e = launch_gemm_f16(ctx, w, st)) return e;
-      NERAF_HIP_CHECK(ctx, hipMemcpyAsync(grads[2 * (l - 1) + 1], ws + WL.colsum[l - 1], (size_t)D.n[l - 1] * 4,
-                                          hipMemcpyDeviceToDevice, st));
+      copy_out(grads[2 * (l - 1) + 1], (const float*)(ws + WL.colsum[l - 1]), D.n[l - 1]);
     }
   }
-  NERAF_HIP_CHECK(ctx, hipMemcpyAsync(grads[1], ws + WL.colsum[0], (size_t)D.n[0] * 4, hipMemcpyDeviceToDevice, st));
+  copy_out(grads[1], (const float*)(ws + WL.colsum[0]), D.n[0]);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
   *slot0 = cur;
   return NERAF_OK;
 }
@@ -570,9 +623,10 @@ extern "C" int neraf_nacf_bwd(neraf_ctx* ctx, const neraf_nacf_desc* d, const vo
   g.A = (const half_t*)(ws + WL.dzT[s0]); g.lda = M;
   g.B = (const half_t*)(ws + WL.qT); g.ldb = M;
   g.M = D.n[0]; g.N = D.k[0]; g.K = M; g.Mpad = D.np[0]; g.Npad = QT_ROWS; g.alpha = 1.f;
+  g.alpha_dev = (const float*)(ws + WL.scale) + 1;
   g.C32 = grads[0] + d->n_feat; g.ldc32 = D.kdense;
   if (int e = launch_gemm_f16(ctx, g, st)) return e;
-  const float* db0 = (const float*)(ws + WL.colsum[0]);
+  const float* db0 = grads[1];   // un-scaled layer-0 bias gradient
   if (d->n_feat > 0) {
     hipLaunchKernelGGL(outer_kernel, dim3((d->n_feat + 255) / 256, D.n[0]), dim3(256), 0, st, db0, feat, D.n[0], d->n_feat,
                        grads[0], D.kdense);
@@ -605,6 +659,7 @@ extern "C" int neraf_nacf_bwd_dense(neraf_ctx* ctx, const neraf_nacf_desc* d, co
   g.A = (const half_t*)(ws + WL.dzT[s0]); g.lda = M;
   g.B = (const half_t*)(ws + WL.hdT); g.ldb = M;
   g.M = D.n[0]; g.N = D.kdense; g.K = M; g.Mpad = D.np[0]; g.Npad = D.kdense_p; g.alpha = 1.f;
+  g.alpha_dev = (const float*)(ws + WL.scale) + 1;
   g.C32 = grads[0]; g.ldc32 = D.kdense;
   if (int e = launch_gemm_f16(ctx, g, st)) return e;
   if (dh) {
@@ -612,6 +667,7 @@ extern "C" int neraf_nacf_bwd_dense(neraf_ctx* ctx, const neraf_nacf_desc* d, co
     x.A = (const half_t*)(ws + WL.dz[s0]); x.lda = D.np[0];
     x.B = (const half_t*)(P + PL.w0dt); x.ldb = D.np[0];
     x.M = B; x.N = D.kdense; x.K = D.np[0]; x.Mpad = M; x.Npad = D.kdense_p; x.alpha = 1.f;
+    x.alpha_dev = (const float*)(ws + WL.scale) + 1;
     x.C32 = dh; x.ldc32 = D.kdense;
     if (int e = launch_gemm_f16(ctx, x, st)) return e;
   }

@@ -44,7 +44,7 @@ class _NacfSplitFn(torch.autograd.Function):
         lib = _lib.load()
         dev = _dev_index(feat)
         h = _lib.ctx(dev)
-        packed = field._packed(params)
+        packed = field._packed(params, training)
         out = torch.empty((B, field.sound_rez, field.N_frequencies), dtype=torch.float32, device=feat.device)
         wptr = _lib.ptr_array(params)
         _lib.check(lib.neraf_nacf_fwd(h, C.byref(field._desc), packed.data_ptr(), wptr, feat.data_ptr(), B,
@@ -75,10 +75,10 @@ class _NacfDenseFn(torch.autograd.Function):
         lib = _lib.load()
         dev = _dev_index(h_in)
         B = h_in.shape[0]
-        packed = field._packed(params)
-        ws = field._workspace(B, training, h_in.device)
+        packed = field._packed(params, training, dense=True)
+        ws = field._workspace(B, training, h_in.device, dense=True)
         out = torch.empty((B, field.sound_rez, field.N_frequencies), dtype=torch.float32, device=h_in.device)
-        _lib.check(lib.neraf_nacf_fwd_dense(_lib.ctx(dev), C.byref(field._desc), packed.data_ptr(), h_in.data_ptr(), B,
+        _lib.check(lib.neraf_nacf_fwd_dense(_lib.ctx(dev), C.byref(field._desc_dense), packed.data_ptr(), h_in.data_ptr(), B,
                                             out.data_ptr(), ws.data_ptr(), int(training), _stream_ptr()), dev)
         ctx.field, ctx.B, ctx.dev = field, B, dev
         ctx.need_dh = h_in.requires_grad
@@ -93,7 +93,7 @@ class _NacfDenseFn(torch.autograd.Function):
         dout = dout.contiguous().float()
         grads = [torch.empty_like(p) for p in params]
         dh = torch.empty((ctx.B, field.in_size), dtype=torch.float32, device=dout.device) if ctx.need_dh else None
-        _lib.check(lib.neraf_nacf_bwd_dense(_lib.ctx(ctx.dev), C.byref(field._desc), packed.data_ptr(), ctx.B,
+        _lib.check(lib.neraf_nacf_bwd_dense(_lib.ctx(ctx.dev), C.byref(field._desc_dense), packed.data_ptr(), ctx.B,
                                             out.data_ptr(), dout.data_ptr(), _lib.ptr_array(grads),
                                             dh.data_ptr() if dh is not None else None, ws.data_ptr(), _stream_ptr()),
                    ctx.dev)
@@ -112,9 +112,11 @@ class NeRAFAudioSoundField(nn.Module):
         if in_size < N_QUERY:
             raise ValueError(f"in_size must be >= {N_QUERY} (grid features + {N_QUERY} encoded query dims)")
         self.in_size, self.W, self.sound_rez, self.N_frequencies = in_size, W, sound_rez, N_frequencies
-        self._desc = _lib.NacfDesc(in_size - N_QUERY, N_QUERY, W, sound_rez, N_frequencies, 1)
-        self._packed_buf: Optional[torch.Tensor] = None
-        self._packed_key = None
+        # two layouts: split (layer-0 feature half folded into the bias) and dense (full K=in_size layer 0)
+        self._desc = _lib.NacfDesc(in_size - N_QUERY, N_QUERY, W, sound_rez, N_frequencies, 0)
+        self._desc_dense = _lib.NacfDesc(in_size - N_QUERY, N_QUERY, W, sound_rez, N_frequencies, 1)
+        self._packed_buf = {False: None, True: None}
+        self._packed_key = {False: None, True: None}
 
     # -- parameters in the C-ABI order (state-dict order) -------------------------------------
     def flat_params(self) -> List[torch.Tensor]:
@@ -123,26 +125,38 @@ class NeRAFAudioSoundField(nn.Module):
             ps += [lin.weight, lin.bias]
         return ps
 
-    def _packed(self, params: Sequence[torch.Tensor]) -> torch.Tensor:
-        """fp16 MFMA-layout copy of the fp32 master weights; re-packed when any parameter changed."""
+    def _packed(self, params: Sequence[torch.Tensor], training: bool = True, dense: bool = False) -> torch.Tensor:
+        """fp16 MFMA-layout copy of the fp32 master weights.
+
+        Training forwards ALWAYS re-pack: fused optimizers (torch.optim.Adam(fused=True)) update the
+        parameters in place without bumping ``_version``, so a version-keyed cache would silently go
+        stale.  Inference re-packs only when a parameter's (data_ptr, _version) changed; call
+        ``invalidate_packed()`` after out-of-band weight edits."""
         key = tuple((p.data_ptr(), p._version) for p in params)
         dev = params[0].device
-        if self._packed_buf is None or self._packed_buf.device != dev or key != self._packed_key:
+        desc = self._desc_dense if dense else self._desc
+        cur = self._packed_buf[dense]
+        if training or cur is None or cur.device != dev or key != self._packed_key[dense]:
             lib = _lib.load()
             d = _dev_index(params[0])
-            nbytes = lib.neraf_nacf_packed_bytes(C.byref(self._desc))
+            nbytes = lib.neraf_nacf_packed_bytes(C.byref(desc))
             # a fresh buffer each re-pack: earlier ones may still be referenced by a pending backward
             buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             for p in params:
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("NAcF parameters must be contiguous float32")
-            _lib.check(lib.neraf_nacf_pack_weights(_lib.ctx(d), C.byref(self._desc), _lib.ptr_array(params),
+            _lib.check(lib.neraf_nacf_pack_weights(_lib.ctx(d), C.byref(desc), _lib.ptr_array(params),
                                                    buf.data_ptr(), _stream_ptr()), d)
-            self._packed_buf, self._packed_key = buf, key
-        return self._packed_buf
+            self._packed_buf[dense], self._packed_key[dense] = buf, key
+        return self._packed_buf[dense]
 
-    def _workspace(self, B: int, training: bool, device) -> torch.Tensor:
-        nbytes = _lib.load().neraf_nacf_workspace_bytes(C.byref(self._desc), B, int(training))
+    def invalidate_packed(self) -> None:
+        self._packed_buf = {False: None, True: None}
+        self._packed_key = {False: None, True: None}
+
+    def _workspace(self, B: int, training: bool, device, dense: bool = False) -> torch.Tensor:
+        desc = self._desc_dense if dense else self._desc
+        nbytes = _lib.load().neraf_nacf_workspace_bytes(C.byref(desc), B, int(training))
         return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
     # -- NeRAF_field.py:47 -----------------------------------------------------------------------
