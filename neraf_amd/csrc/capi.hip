@@ -47,6 +47,6 @@ extern "C" int neraf_prof_summary(neraf_ctx* ctx, int kernel_id, double* total_m
 }
 
 extern "C" const char* neraf_prof_kernel_name(int kernel_id) {
-  static const char* names[PROF_NUM_KERNELS] = {"gemm_f16_nt_kernel<128,128>", "gemm_f16_nt_kernel<64,64>"};
+  static const char* names[PROF_NUM_KERNELS] = {"gemm_f16_nt_pipe_kernel<128, 128, 4>", "gemm_f16_nt_pipe_kernel<64, 64, 4>"};
   return (kernel_id >= 0 && kernel_id < PROF_NUM_KERNELS) ? names[kernel_id] : nullptr;
 }

@@ -285,7 +285,11 @@ __global__ __launch_bounds__(256) void amax_dz5_kernel(const float* __restrict__
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // one same-address atomic per block (same-address atomics serialise at ~12 ns each)
+  if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]))));
 }
 
 __global__ void make_scale_kernel(float* __restrict__ scale) {
@@ -546,8 +550,8 @@ static int nacf_bwd_body(neraf_ctx* ctx, const neraf_nacf_desc* d, const Dims& D
   NERAF_HIP_CHECK(ctx, hipMemsetAsync(scale, 0, 16, st));
   {
     const size_t n = (size_t)B * D.n[5];
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
+    int blocks = (int)((n + 1023) / 1024);
+    if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(amax_dz5_kernel, dim3(blocks), dim3(256), 0, st, dout, out, n, reinterpret_cast<unsigned*>(scale) + 2);
     hipLaunchKernelGGL(make_scale_kernel, dim3(1), dim3(64), 0, st, scale);
   }
@@ -632,7 +636,7 @@ extern "C" int neraf_nacf_bwd(neraf_ctx* ctx, const neraf_nacf_desc* d, const vo
                        grads[0], D.kdense);
     if (dfeat) {
       NERAF_HIP_CHECK(ctx, hipMemsetAsync(dfeat, 0, (size_t)d->n_feat * 4, st));
-      hipLaunchKernelGGL(dfeat_kernel, dim3((d->n_feat + 255) / 256, 64), dim3(256), 0, st, Wptr(w, 0), D.kdense, db0,
+      hipLaunchKernelGGL(dfeat_kernel, dim3((d->n_feat + 255) / 256, 512), dim3(256), 0, st, Wptr(w, 0), D.kdense, db0,
                          D.n[0], d->n_feat, dfeat);
     }
   }
@@ -679,8 +683,8 @@ extern "C" int neraf_stft_loss_sums(neraf_ctx* ctx, const float* pred, const flo
   if (!pred || !gt || !sums || n == 0) return neraf_fail(ctx, NERAF_EINVAL, "stft_loss_sums: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   NERAF_HIP_CHECK(ctx, hipMemsetAsync(sums, 0, 16, st));
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  int blocks = (int)((n + 1023) / 1024);
+  if (blocks > 256) blocks = 256;   // 3 same-address atomics per block: keep the count low
   hipLaunchKernelGGL(stft_loss_sums_kernel, dim3(blocks), dim3(256), 0, st, pred, gt, n, loss_type, sums);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
