@@ -48,8 +48,9 @@ const char* neraf_last_error(neraf_ctx* ctx);
  * tracked kernel family is bracketed by a hipEvent pair on the launch stream and its
  * algorithmic work (FLOPs or bytes, logical un-padded extents) is recorded.
  * neraf_prof_summary synchronises those events and returns totals since the last enable.
- * kernel ids: 0 = gemm_f16 128x128 tile, 1 = gemm_f16 64x64 tile (more are appended as
- * kernels are added; neraf_prof_kernel_name(id) returns NULL past the end).
+ * kernel ids: 0 = gemm_f16 128x128 tile (work = FLOPs), 1 = gemm_f16 64x64 tile (FLOPs),
+ * 2 = proposal_density (work = gathered hash-table bytes), 3 = field_query (gathered bytes);
+ * neraf_prof_kernel_name(id) returns NULL past the end.
  * ---------------------------------------------------------------------------------- */
 int neraf_prof_enable(neraf_ctx* ctx, int on);
 int neraf_prof_summary(neraf_ctx* ctx, int kernel_id, double* total_ms, int* launches, double* work);
@@ -143,6 +144,61 @@ int neraf_stft_loss_finalize(neraf_ctx* ctx, const float* sums, size_t n_total, 
                              neraf_stream_t stream);
 int neraf_stft_loss_bwd(neraf_ctx* ctx, const float* pred, const float* gt, size_t n, size_t n_total,
                         int loss_type, const float* sums, const float* w, float* dpred, neraf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Radiance half (forward).  Replaces what NeRAFVisionModel (NeRAF_model.py:54-79) inherits from
+ * nerfstudio's NerfactoModel and executes through tiny-cuda-nn: ProposalNetworkSampler
+ * (UniformLinDispPiecewiseSampler + PDFSampler), HashMLPDensityField, NerfactoField (reached via
+ * NeRAFVisionFieldValue.forward, NeRAF_field.py:33-34, and from the grid refresh
+ * NeRAF_model.py:333-350), RaySamples.get_weights and the RGB/Depth/Accumulation renderers.
+ * Samples of a ray are described by their S+1 bin edges: s_bins (normalised spacing) and
+ * e_bins (euclidean), both fp32 [R, S+1]; sample position = o + d * (e[i]+e[i+1])/2.
+ * ---------------------------------------------------------------------------------- */
+typedef struct neraf_grid_desc {
+  int n_levels;          /* 16 main field / 5 proposal nets            */
+  int base_res;          /* 16                                         */
+  int max_res;           /* 2048 main / 128, 256 proposal              */
+  int log2_hashmap_size; /* 19 main / 17 proposal                      */
+  int n_features;        /* features per level: 2                      */
+} neraf_grid_desc;
+
+/* Level table of a tiny-cuda-nn style multiresolution hash grid (host helper so every layer of
+ * the stack agrees): scales/resolutions/sizes [n_levels], offsets [n_levels+1] in table rows. */
+int neraf_grid_layout(const neraf_grid_desc* g, float* scales, int* resolutions, uint32_t* sizes, uint32_t* offsets);
+
+/* Initial samples: S bins uniform in piecewise lin-disp spacing between near and far, optional
+ * single jitter per ray (jitter [R] in [0,1), NULL = deterministic / eval). */
+int neraf_sample_uniform(neraf_ctx* ctx, int R, int S, float near, float far, const float* jitter,
+                         float* s_bins, float* e_bins, neraf_stream_t stream);
+
+/* Proposal density: contraction -> hash grid -> MLP(2L -> 16 -> 1) -> avg_density * exp.
+ * table_f16: fp16 [rows, 2]; mlp_f16: fp16 [16*16 + 16] = layer-0 [hidden][input] then layer-1 row.
+ * density: fp32 [R, S]. */
+int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
+                           const float* origins, const float* dirs, const float* e_bins, int R, int S,
+                           float avg_density, float* density, neraf_stream_t stream);
+
+/* get_weights + PDF resampling of n_new bins (n_new+1 edges) from annealed weights; weights
+ * (fp32 [R,S], may be NULL) are the un-annealed volume-rendering weights of the S input bins. */
+int neraf_pdf_resample(neraf_ctx* ctx, const float* density, const float* s_bins, const float* e_bins, int R, int S,
+                       float anneal, const float* jitter, int n_new, float near, float far, float* weights,
+                       float* s_new, float* e_new, neraf_stream_t stream);
+
+/* Fused nerfacto field query: position map (mode 0: L-inf scene contraction, mode 1: AABB
+ * normalisation with aabb_host[6]) -> 16-level hash grid -> base MLP -> density; SH(dir) +
+ * appearance embedding -> colour MLP -> sigmoid.  wfrag_f16: 24 MFMA weight fragments (24 KB)
+ * packed by the host layer; emb_f16: fp16 [rows,32]; avg_row >= 0 selects one row for every
+ * sample (eval: the mean embedding), else cam_idx[R] is used.  rgb fp32 [R,S,3], density [R,S]. */
+int neraf_field_query(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                      const void* emb_f16, const float* origins, const float* dirs, const float* e_bins,
+                      const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host, float avg_density,
+                      int avg_row, float* rgb, float* density, neraf_stream_t stream);
+
+/* Weights + composite for S <= 64 samples per ray: rgb = sum w c + c_last (1 - sum w) (clipped to
+ * [0,1], NeRAF_model.py:67), median depth, expected depth (needs scratch8: 8 bytes), accumulation. */
+int neraf_composite(neraf_ctx* ctx, const float* density, const float* rgb, const float* e_bins, int R, int S,
+                    int training, float* weights, float* rgb_out, float* depth, float* expected, float* acc,
+                    void* scratch8, neraf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,11 @@ _ctxs: Dict[int, C.c_void_p] = {}
 c_fpp = C.POINTER(C.c_void_p)
 
 
+class GridDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_int), ("base_res", C.c_int), ("max_res", C.c_int), ("log2_hashmap_size", C.c_int),
+                ("n_features", C.c_int)]
+
+
 class NacfDesc(C.Structure):
     _fields_ = [("n_feat", C.c_int), ("n_query", C.c_int), ("W", C.c_int), ("C", C.c_int), ("F", C.c_int),
                 ("dense_l0", C.c_int)]
@@ -57,6 +62,20 @@ SIGNATURES = {
     "neraf_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "neraf_prof_summary": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "neraf_prof_kernel_name": (C.c_char_p, [C.c_int]),
+    "neraf_grid_layout": (C.c_int, [C.POINTER(GridDesc), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_uint32)]),
+    "neraf_sample_uniform": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "neraf_proposal_density": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "neraf_pdf_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                     C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    "neraf_field_query": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                    C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 

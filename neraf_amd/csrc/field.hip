@@ -1,0 +1,549 @@
+// Radiance half of the hot path (forward): piecewise sampler, proposal density (hash grid + 16-wide MLP),
+// PDF resampling, the fused nerfacto field query (16-level hash grid -> base MLP -> SH/appearance -> colour
+// MLP on MFMA, entirely in registers), and the volume-render composite.
+//
+// Replaces, for NeRAFVisionModel (NeRAF_model.py:54-79) / NeRAFVisionFieldValue.forward (NeRAF_field.py:33-34)
+// and the refresh query (NeRAF_model.py:333-350), what nerfstudio + tiny-cuda-nn execute: ProposalNetworkSampler,
+// HashMLPDensityField, NerfactoField, RaySamples.get_weights, RGB/Depth/AccumulationRenderer.  Those sources are
+// not in the reference tree; formulas follow oracle/vision.py (parity unpinned).
+//
+// MI355X mapping of the field query: one wavefront owns 16 sample points per step.  Lane l = (p = l & 15,
+// q = l >> 4): the four lanes that share p split the 16 hash levels of point p (4 levels x 8 corners each,
+// half2 gathers from the fp16 table, which is L2/Infinity-Cache resident), and their 8 interpolated
+// features ARE the v_mfma_f32_16x16x32_f16 B-operand fragment of the first layer.  Every layer computes
+// D[out][point] = W[out][k] . X[k][point], so a lane's 4 accumulator registers are 4 consecutive outputs of
+// its own point; two accumulator blocks converted to fp16 form the next layer's B fragment directly (the
+// k-order permutation this implies is baked into the packed weight fragments), so activations never touch
+// LDS or HBM.  All 24 weight fragments (24 KB fp16) live in registers for the whole kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_LEVELS = 16;
+
+struct GridLayout {
+  int n_levels;
+  float scale[MAX_LEVELS];
+  int res[MAX_LEVELS];
+  unsigned size[MAX_LEVELS];
+  unsigned offset[MAX_LEVELS + 1];
+  int hashed[MAX_LEVELS];
+};
+
+int make_grid_layout(const neraf_grid_desc* g, GridLayout* L) {
+  if (!g || g->n_levels < 1 || g->n_levels > MAX_LEVELS || g->n_features != 2 || g->log2_hashmap_size < 4 ||
+      g->log2_hashmap_size > 24 || g->base_res < 2 || g->max_res < g->base_res)
+    return NERAF_EINVAL;
+  L->n_levels = g->n_levels;
+  const double growth = g->n_levels > 1 ? exp(log((double)g->max_res / g->base_res) / (g->n_levels - 1)) : 1.0;
+  const float log2g = (float)log2(growth);
+  const unsigned T = 1u << g->log2_hashmap_size;
+  unsigned off = 0;
+  for (int l = 0; l < g->n_levels; ++l) {
+    const float scale = exp2f((float)l * log2g) * (float)g->base_res - 1.0f;   // tcnn grid_scale()
+    const int res = (int)ceilf(scale) + 1;                                      // tcnn grid_resolution()
+    unsigned long long n = (unsigned long long)res * res * res;
+    n = (n + 7ull) / 8ull * 8ull;
+    const unsigned sz = n > T ? T : (unsigned)n;
+    L->scale[l] = scale; L->res[l] = res; L->size[l] = sz; L->offset[l] = off;
+    L->hashed[l] = ((unsigned long long)res * res * res) > sz;
+    off += sz;
+  }
+  L->offset[g->n_levels] = off;
+  return NERAF_OK;
+}
+
+__device__ __forceinline__ float spacing_fn(float x) { return x < 1.f ? 0.5f * x : 1.f - 1.f / (2.f * x); }
+__device__ __forceinline__ float spacing_inv(float x) { return x < 0.5f ? 2.f * x : 1.f / (2.f - 2.f * x); }
+
+// ---- sampler level 0: UniformLinDispPiecewiseSampler with single jitter -----------------------------------
+__global__ __launch_bounds__(256) void sample_uniform_kernel(int R, int S, float near, float far, const float* __restrict__ jitter,
+                                                            float* __restrict__ s_bins, float* __restrict__ e_bins) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)R * (S + 1)) return;
+  const int ray = (int)(idx / (S + 1)), i = (int)(idx % (S + 1));
+  const float step = 1.0f / (float)S;
+  float b = (float)i * step;
+  if (i == S) b = 1.0f;
+  if (jitter) {
+    // bins = lower + (upper-lower)*u ; lower/upper = neighbouring bin centres (ends clamp to 0 / 1)
+    const float cl = i > 0 ? ((float)(i - 1) * step + b) * 0.5f : 0.f;      // centre below (or bins[0])
+    const float bn = (i + 1 == S) ? 1.0f : (float)(i + 1) * step;
+    const float cu = i < S ? (b + bn) * 0.5f : 1.0f;                         // centre above (or bins[-1])
+    const float lower = i == 0 ? 0.f : cl;
+    const float upper = i == S ? 1.f : cu;
+    b = lower + (upper - lower) * jitter[ray];
+  }
+  const float sn = spacing_fn(near), sf = spacing_fn(far);
+  s_bins[idx] = b;
+  e_bins[idx] = spacing_inv(b * sf + (1.f - b) * sn);
+}
+
+// ---- shared point helpers ---------------------------------------------------------------------------------
+__device__ __forceinline__ bool map_position(float& x, float& y, float& z, int mode, const float* aabb) {
+  if (mode == 0) {   // SceneContraction(L-inf) then (x+2)/4
+    const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    if (mag >= 1.f) {
+      const float k = (2.f - 1.f / mag) / mag;
+      x *= k; y *= k; z *= k;
+    }
+    x = (x + 2.f) * 0.25f; y = (y + 2.f) * 0.25f; z = (z + 2.f) * 0.25f;
+  } else {           // SceneBox normalisation (spatial_distortion = None)
+    x = (x - aabb[0]) / (aabb[3] - aabb[0]);
+    y = (y - aabb[1]) / (aabb[4] - aabb[1]);
+    z = (z - aabb[2]) / (aabb[5] - aabb[2]);
+  }
+  const bool sel = x > 0.f && x < 1.f && y > 0.f && y < 1.f && z > 0.f && z < 1.f;
+  if (!sel) { x = 0.f; y = 0.f; z = 0.f; }
+  return sel;
+}
+
+// one hash-grid level, trilinear; table entries are half2 (2 features)
+__device__ __forceinline__ void encode_level(const unsigned* __restrict__ table, float x, float y, float z, float scale, int res,
+                                             unsigned size, unsigned offset, int hashed, float& f0, float& f1) {
+  const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+  const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+  const float wx = px - flx, wy = py - fly, wz = pz - flz;
+  const unsigned ix = (unsigned)(int)flx, iy = (unsigned)(int)fly, iz = (unsigned)(int)flz;
+  f0 = 0.f; f1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned cx = ix + (c & 1), cy = iy + ((c >> 1) & 1), cz = iz + ((c >> 2) & 1);
+    const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+    unsigned idx;
+    if (hashed) idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1u);   // hashed levels have size = 2^log2_T
+    else {
+      // dense level: tcnn's `index % size`; corners of the last cell reach res, so idx < res^3+res^2+res < 2*size
+      idx = cx + cy * (unsigned)res + cz * (unsigned)res * (unsigned)res;
+      if (idx >= size) idx -= size;
+    }
+    const unsigned raw = table[offset + idx];
+    const half2v v = *reinterpret_cast<const half2v*>(&raw);
+    f0 = fmaf(w, (float)v[0], f0);
+    f1 = fmaf(w, (float)v[1], f1);
+  }
+}
+
+// ---- proposal density: hash grid (<= 8 levels) + MLP 2L->16->1, VALU ----------------------------------------
+struct PropArgs {
+  GridLayout g;
+  const unsigned* table;        // fp16x2 entries
+  const half_t* w;              // [16][16] layer 0 (row = hidden unit, col = input; cols >= 2L ignored) then [16] layer 1 row 0
+  const float* origins; const float* dirs; const float* e_bins;
+  int R, S; float avg_density;
+  float* density;
+};
+
+__global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
+  __shared__ float w0[16][16];
+  __shared__ float w1[16];
+  for (int i = threadIdx.x; i < 256; i += 256) w0[i >> 4][i & 15] = (float)a.w[i];
+  if (threadIdx.x < 16) w1[threadIdx.x] = (float)a.w[256 + threadIdx.x];
+  __syncthreads();
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)a.R * a.S) return;
+  const int ray = (int)(idx / a.S), s = (int)(idx % a.S);
+  const float t = 0.5f * (a.e_bins[(size_t)ray * (a.S + 1) + s] + a.e_bins[(size_t)ray * (a.S + 1) + s + 1]);
+  float x = fmaf(a.dirs[ray * 3 + 0], t, a.origins[ray * 3 + 0]);
+  float y = fmaf(a.dirs[ray * 3 + 1], t, a.origins[ray * 3 + 1]);
+  float z = fmaf(a.dirs[ray * 3 + 2], t, a.origins[ray * 3 + 2]);
+  const bool sel = map_position(x, y, z, 0, nullptr);
+  float enc[2 * 8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    enc[2 * l] = 0.f; enc[2 * l + 1] = 0.f;
+    if (l < a.g.n_levels) {
+      float f0, f1;
+      encode_level(a.table, x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.offset[l], a.g.hashed[l], f0, f1);
+      enc[2 * l] = (float)(half_t)f0; enc[2 * l + 1] = (float)(half_t)f1;   // tcnn hands fp16 features to the MLP
+    }
+  }
+  float out = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    float h = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) h = fmaf(w0[j][k], enc[k], h);
+    h = fmaxf(h, 0.f);
+    out = fmaf(w1[j], h, out);
+  }
+  a.density[idx] = sel ? a.avg_density * __expf(out) : 0.f;
+}
+
+// ---- weights + PDF resampling, one wavefront per ray ------------------------------------------------------
+// RaySamples.get_weights then PDFSampler.generate_ray_samples (single jitter, include_original=False).
+struct PdfArgs {
+  const float* density; const float* s_bins; const float* e_bins;
+  int R, S; float anneal; const float* jitter; int n_new; float near, far;
+  float* weights; float* s_new; float* e_new;
+};
+
+constexpr int PDF_MAX_S = 256;
+
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float n = __shfl_up(v, o);
+    if (lane >= o) v += n;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void pdf_resample_kernel(PdfArgs a) {
+  __shared__ float cdf_s[4][PDF_MAX_S + 1];
+  __shared__ float bins_s[4][PDF_MAX_S + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int ray = blockIdx.x * 4 + wv;
+  const bool active = ray < a.R;                 // tail waves run on the last ray and store nothing
+  if (!active) ray = a.R - 1;
+  const int S = a.S;
+  const int per = (S + 63) / 64;                 // samples per lane, contiguous chunk [lane*per, ...)
+  const float* dens = a.density + (size_t)ray * S;
+  const float* eb = a.e_bins + (size_t)ray * (S + 1);
+  const float* sb = a.s_bins + (size_t)ray * (S + 1);
+  float* cdf = cdf_s[wv];
+  float* bins = bins_s[wv];
+  for (int i = lane; i <= S; i += 64) bins[i] = sb[i];
+  // --- weights: w_i = (1 - exp(-dd_i)) * exp(-sum_{j<i} dd_j)
+  float dd[4], loc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane * per + k;
+    dd[k] = (k < per && i < S) ? (eb[i + 1] - eb[i]) * dens[i] : 0.f;
+    loc += dd[k];
+  }
+  const float incl = wave_incl_scan(loc, lane);
+  float run = incl - loc;                         // exclusive prefix of this lane's chunk
+  float wts[4], wl = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane * per + k;
+    float w = (1.f - __expf(-dd[k])) * __expf(-run);
+    if (!(w == w) ) w = 0.f;                       // nan_to_num
+    run += dd[k];
+    wts[k] = w;
+    if (k < per && i < S) {
+      if (a.weights && active) a.weights[(size_t)ray * S + i] = w;
+      // annealed weight + histogram padding 0.01
+      const float wa = (a.anneal == 1.f ? w : __powf(w, a.anneal)) + 0.01f;
+      wts[k] = wa; wl += wa;
+    } else wts[k] = 0.f;
+  }
+  // --- pdf / cdf
+  float tot = wl;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+  const float padding = fmaxf(1e-5f - tot, 0.f);
+  const float addw = padding / (float)S;
+  const float wsum = tot + padding;
+  float loc2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane * per + k;
+    if (k < per && i < S) { wts[k] = (wts[k] + addw) / wsum; loc2 += wts[k]; }
+  }
+  const float incl2 = wave_incl_scan(loc2, lane);
+  float c = incl2 - loc2;
+  if (lane == 0) cdf[0] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane * per + k;
+    if (k < per && i < S) { c += wts[k]; cdf[i + 1] = fminf(1.f, c); }
+  }
+  __syncthreads();   // uniform: every wave of the block reaches it
+  // --- inverse-CDF sampling of n_new+1 bin edges
+  const int nb = a.n_new + 1;
+  const float sn = spacing_fn(a.near), sf = spacing_fn(a.far);
+  for (int j = lane; j < nb; j += 64) {
+    float u = (float)j * ((1.f - 1.f / (float)nb) / (float)(nb - 1));    // linspace(0, 1-1/nb, nb)
+    if (j == nb - 1) u = 1.f - 1.f / (float)nb;
+    u += a.jitter ? a.jitter[ray] / (float)nb : 1.f / (2.f * (float)nb);
+    // searchsorted(cdf, u, side='right'): first index with cdf[idx] > u, over S+1 entries
+    int lo = 0, hi = S + 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] > u) hi = mid; else lo = mid + 1; }
+    const int below = min(max(lo - 1, 0), S), above = min(max(lo, 0), S);
+    const float c0 = cdf[below], c1 = cdf[above], b0 = bins[below], b1 = bins[above];
+    float t = (u - c0) / (c1 - c0);
+    if (!(t == t)) t = 0.f;                      // nan_to_num(nan=0); +-inf are absorbed by the clip
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    const float b = b0 + t * (b1 - b0);
+    if (active) {
+      a.s_new[(size_t)ray * nb + j] = b;
+      a.e_new[(size_t)ray * nb + j] = spacing_inv(b * sf + (1.f - b) * sn);
+    }
+  }
+}
+
+// ---- fused nerfacto field query -----------------------------------------------------------------------------
+struct FieldArgs {
+  GridLayout g;                  // 16 levels
+  const unsigned* table;         // fp16x2
+  const half8* wfrag;            // 24 fragments x 64 lanes (packed by the host layer, see neraf_amd/vision.py)
+  const half_t* emb;             // fp16 [n_emb][32]; row used = cam_idx (training) or row `avg_row` (eval mean)
+  const float* origins; const float* dirs; const float* e_bins; const int* cam_idx;
+  int R, S; int mode; float aabb[6]; float avg_density; int avg_row;
+  float* rgb; float* density;
+};
+
+constexpr int NFRAG = 24;   // base0: 0-3, base1: 4-5, head0: 6-13 (ob*2+s), head1: 14-21, head2: 22-23
+
+__device__ __forceinline__ half8 pack_relu(const f32x4& a, const f32x4& b, bool relu) {
+  half8 h;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    h[r] = (half_t)(relu ? fmaxf(a[r], 0.f) : a[r]);
+    h[4 + r] = (half_t)(relu ? fmaxf(b[r], 0.f) : b[r]);
+  }
+  return h;
+}
+
+__global__ __launch_bounds__(256) void field_query_kernel(FieldArgs a) {
+  __shared__ float l_scale[MAX_LEVELS];
+  __shared__ int l_res[MAX_LEVELS];
+  __shared__ unsigned l_size[MAX_LEVELS], l_off[MAX_LEVELS];
+  __shared__ int l_hash[MAX_LEVELS];
+  if (threadIdx.x < MAX_LEVELS) {
+    const int l = threadIdx.x;
+    l_scale[l] = a.g.scale[l]; l_res[l] = a.g.res[l]; l_size[l] = a.g.size[l]; l_off[l] = a.g.offset[l]; l_hash[l] = a.g.hashed[l];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int p = lane & 15, q = lane >> 4;
+  half8 wf[NFRAG];
+#pragma unroll
+  for (int f = 0; f < NFRAG; ++f) wf[f] = a.wfrag[f * 64 + lane];
+
+  const long N = (long)a.R * a.S;
+  const long ngroups = (N + 15) / 16;
+  const long gstride = (long)gridDim.x * 4;
+  for (long grp = (long)blockIdx.x * 4 + (threadIdx.x >> 6); grp < ngroups; grp += gstride) {
+    long n = grp * 16 + p;
+    const bool valid = n < N;
+    if (!valid) n = N - 1;                       // MFMA needs every lane: clamp, compute, do not store
+    const int ray = (int)(n / a.S), s = (int)(n % a.S);
+    const float t = 0.5f * (a.e_bins[(size_t)ray * (a.S + 1) + s] + a.e_bins[(size_t)ray * (a.S + 1) + s + 1]);
+    const float dx = a.dirs[ray * 3 + 0], dy = a.dirs[ray * 3 + 1], dz = a.dirs[ray * 3 + 2];
+    float x = fmaf(dx, t, a.origins[ray * 3 + 0]);
+    float y = fmaf(dy, t, a.origins[ray * 3 + 1]);
+    float z = fmaf(dz, t, a.origins[ray * 3 + 2]);
+    const bool sel = map_position(x, y, z, a.mode, a.aabb);
+    // --- hash encode: this lane's 4 levels -> B fragment of the first layer (k = 8q + 2*li + f)
+    half8 xin;
+#pragma unroll
+    for (int li = 0; li < 4; ++li) {
+      const int l = 4 * q + li;
+      float f0, f1;
+      encode_level(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1);
+      xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // --- base MLP 32 -> 64 (ReLU) -> 16
+    f32x4 d1[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) d1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ob], xin, zero, 0, 0, 0);
+    f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[4], pack_relu(d1[0], d1[1], true), zero, 0, 0, 0);
+    d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[5], pack_relu(d1[2], d1[3], true), d2, 0, 0, 0);
+    // density = avg * trunc_exp(logit) * selector ; logit = base output 0 -> lane q == 0, register 0
+    if (q == 0 && valid) a.density[n] = sel ? a.avg_density * __expf(d2[0]) : 0.f;
+    // --- colour head input: k-step 0 = [base out 4q..4q+3 | SH 4q..4q+3], k-step 1 = appearance embedding 8q..8q+7
+    float sh[4];
+    {
+      const float xy = dx * dy, xz = dx * dz, yz = dy * dz, x2 = dx * dx, y2 = dy * dy, z2 = dz * dz;
+      if (q == 0) {
+        sh[0] = 0.28209479177387814f; sh[1] = -0.48860251190291987f * dy;
+        sh[2] = 0.48860251190291987f * dz; sh[3] = -0.48860251190291987f * dx;
+      } else if (q == 1) {
+        sh[0] = 1.0925484305920792f * xy; sh[1] = -1.0925484305920792f * yz;
+        sh[2] = 0.94617469575755997f * z2 - 0.31539156525251999f; sh[3] = -1.0925484305920792f * xz;
+      } else if (q == 2) {
+        sh[0] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2; sh[1] = 0.59004358992664352f * dy * (-3.0f * x2 + y2);
+        sh[2] = 2.8906114426405538f * xy * dz; sh[3] = 0.45704579946446572f * dy * (1.0f - 5.0f * z2);
+      } else {
+        sh[0] = 0.3731763325901154f * dz * (5.0f * z2 - 3.0f); sh[1] = 0.45704579946446572f * dx * (1.0f - 5.0f * z2);
+        sh[2] = 1.4453057213202769f * dz * (x2 - y2); sh[3] = 0.59004358992664352f * dx * (-x2 + 3.0f * y2);
+      }
+    }
+    half8 h0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { h0[r] = (half_t)d2[r]; h0[4 + r] = (half_t)sh[r]; }
+    if (q == 0) h0[0] = (half_t)0.f;              // the density logit is not an input of the head (weight column is 0 too)
+    const int erow = a.avg_row >= 0 ? a.avg_row : a.cam_idx[ray];
+    const half8 h1 = *reinterpret_cast<const half8*>(a.emb + (size_t)erow * 32 + 8 * q);
+    f32x4 d3[4], d4[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[6 + ob * 2], h0, zero, 0, 0, 0);
+      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[7 + ob * 2], h1, d3[ob], 0, 0, 0);
+    }
+    const half8 a0 = pack_relu(d3[0], d3[1], true), a1 = pack_relu(d3[2], d3[3], true);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[14 + ob * 2], a0, zero, 0, 0, 0);
+      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[15 + ob * 2], a1, d4[ob], 0, 0, 0);
+    }
+    f32x4 d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[22], pack_relu(d4[0], d4[1], true), zero, 0, 0, 0);
+    d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[23], pack_relu(d4[2], d4[3], true), d5, 0, 0, 0);
+    if (q == 0 && valid) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.rgb[(size_t)n * 3 + c] = 1.f / (1.f + __expf(-d5[c]));
+    }
+  }
+}
+
+// ---- weights + composite, one wavefront per ray (S <= 64) ---------------------------------------------------
+struct CompArgs {
+  const float* density; const float* rgb; const float* e_bins;
+  int R, S, training;
+  float* weights; float* rgb_out; float* depth; float* expected; float* acc;
+  const unsigned* minmax;        // {bits(min step), bits(max step)} over the whole batch (expected-depth clip range)
+};
+
+// global min / max of the sample mid-points (positive floats order like their bit patterns)
+__global__ __launch_bounds__(256) void steps_minmax_kernel(const float* __restrict__ e_bins, int R, int S, unsigned* __restrict__ mm) {
+  const int ray = blockIdx.x * 256 + threadIdx.x;
+  float lo = 3.0e38f, hi = 0.f;
+  if (ray < R) {
+    const float* eb = e_bins + (size_t)ray * (S + 1);
+    lo = 0.5f * (eb[0] + eb[1]); hi = 0.5f * (eb[S - 1] + eb[S]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+  if ((threadIdx.x & 63) == 0) { atomicMin(mm, __float_as_uint(lo)); atomicMax(mm + 1, __float_as_uint(hi)); }
+}
+
+__global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.R) return;
+  const int S = a.S;
+  const bool on = lane < S;
+  const float* eb = a.e_bins + (size_t)ray * (S + 1);
+  const float e0 = on ? eb[lane] : 0.f, e1 = on ? eb[lane + 1] : 0.f;
+  const float dd = on ? (e1 - e0) * a.density[(size_t)ray * S + lane] : 0.f;
+  const float incl = wave_incl_scan(dd, lane);
+  float w = (1.f - __expf(-dd)) * __expf(-(incl - dd));
+  if (!(w == w)) w = 0.f;
+  if (!on) w = 0.f;
+  if (on && a.weights) a.weights[(size_t)ray * S + lane] = w;
+  const float step = 0.5f * (e0 + e1);
+  float r = 0.f, g = 0.f, b = 0.f;
+  if (on) { const float* c = a.rgb + ((size_t)ray * S + lane) * 3; r = c[0]; g = c[1]; b = c[2]; }
+  const float cum = wave_incl_scan(w, lane);
+  float sr = w * r, sg = w * g, sb = w * b, sw = w, sd = w * step;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sr += __shfl_xor(sr, o); sg += __shfl_xor(sg, o); sb += __shfl_xor(sb, o); sw += __shfl_xor(sw, o); sd += __shfl_xor(sd, o);
+  }
+  // background = last sample's colour
+  const float lr = __shfl(r, S - 1), lg = __shfl(g, S - 1), lb = __shfl(b, S - 1);
+  // median depth: first index with cumulative weight >= 0.5 (searchsorted side='left'), clamped to S-1
+  const unsigned long long ge = __ballot(on && cum >= 0.5f);
+  const int mi = ge ? (int)__ffsll((long long)ge) - 1 : S - 1;
+  const float med = __shfl(step, mi);
+  if (lane == 0) {
+    float cr = sr + lr * (1.f - sw), cg = sg + lg * (1.f - sw), cb = sb + lb * (1.f - sw);
+    if (!a.training) { cr = fminf(fmaxf(cr, 0.f), 1.f); cg = fminf(fmaxf(cg, 0.f), 1.f); cb = fminf(fmaxf(cb, 0.f), 1.f); }
+    // NeRAFVisionModel.get_outputs clips rgb to [0,1] (NeRAF_model.py:67)
+    a.rgb_out[ray * 3 + 0] = fminf(fmaxf(cr, 0.f), 1.f);
+    a.rgb_out[ray * 3 + 1] = fminf(fmaxf(cg, 0.f), 1.f);
+    a.rgb_out[ray * 3 + 2] = fminf(fmaxf(cb, 0.f), 1.f);
+    if (a.depth) a.depth[ray] = med;
+    if (a.expected) a.expected[ray] = fminf(fmaxf(sd / (sw + 1e-10f), __uint_as_float(a.minmax[0])), __uint_as_float(a.minmax[1]));
+    if (a.acc) a.acc[ray] = sw;
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" int neraf_grid_layout(const neraf_grid_desc* g, float* scales, int* resolutions, uint32_t* sizes,
+                                 uint32_t* offsets) {
+  GridLayout L;
+  if (int e = make_grid_layout(g, &L)) return e;
+  for (int l = 0; l < L.n_levels; ++l) {
+    if (scales) scales[l] = L.scale[l];
+    if (resolutions) resolutions[l] = L.res[l];
+    if (sizes) sizes[l] = L.size[l];
+    if (offsets) offsets[l] = L.offset[l];
+  }
+  if (offsets) offsets[L.n_levels] = L.offset[L.n_levels];
+  return NERAF_OK;
+}
+
+extern "C" int neraf_sample_uniform(neraf_ctx* ctx, int R, int S, float near, float far, const float* jitter,
+                                    float* s_bins, float* e_bins, neraf_stream_t stream) {
+  if (R <= 0 || S <= 0 || !s_bins || !e_bins) return neraf_fail(ctx, NERAF_EINVAL, "sample_uniform: bad arguments");
+  const long n = (long)R * (S + 1);
+  hipLaunchKernelGGL(sample_uniform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, R, S, near, far,
+                     jitter, s_bins, e_bins);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
+                                      const float* origins, const float* dirs, const float* e_bins, int R, int S,
+                                      float avg_density, float* density, neraf_stream_t stream) {
+  PropArgs a{};
+  if (make_grid_layout(g, &a.g) || a.g.n_levels > 8) return neraf_fail(ctx, NERAF_EINVAL, "proposal_density: bad grid (<= 8 levels)");
+  if (R <= 0 || S <= 0 || !table_f16 || !mlp_f16 || !origins || !dirs || !e_bins || !density)
+    return neraf_fail(ctx, NERAF_EINVAL, "proposal_density: bad arguments");
+  a.table = (const unsigned*)table_f16; a.w = (const half_t*)mlp_f16; a.origins = origins; a.dirs = dirs; a.e_bins = e_bins;
+  a.R = R; a.S = S; a.avg_density = avg_density; a.density = density;
+  const long n = (long)R * S;
+  ProfScope prof(ctx, (hipStream_t)stream, PROF_PROP_DENSITY, (double)n * a.g.n_levels * 8 * 4);   // gathered table bytes
+  hipLaunchKernelGGL(proposal_density_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" int neraf_pdf_resample(neraf_ctx* ctx, const float* density, const float* s_bins, const float* e_bins, int R, int S,
+                                  float anneal, const float* jitter, int n_new, float near, float far, float* weights,
+                                  float* s_new, float* e_new, neraf_stream_t stream) {
+  if (R <= 0 || S <= 0 || S > PDF_MAX_S || n_new <= 0 || !density || !s_bins || !e_bins || !s_new || !e_new)
+    return neraf_fail(ctx, NERAF_EINVAL, "pdf_resample: bad arguments (S <= 256)");
+  PdfArgs a{density, s_bins, e_bins, R, S, anneal, jitter, n_new, near, far, weights, s_new, e_new};
+  hipLaunchKernelGGL(pdf_resample_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" int neraf_field_query(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                                 const void* emb_f16, const float* origins, const float* dirs, const float* e_bins,
+                                 const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host, float avg_density,
+                                 int avg_row, float* rgb, float* density, neraf_stream_t stream) {
+  FieldArgs a{};
+  if (make_grid_layout(g, &a.g) || a.g.n_levels != 16) return neraf_fail(ctx, NERAF_EINVAL, "field_query: grid must have 16 levels");
+  if (R <= 0 || S <= 0 || !table_f16 || !wfrag_f16 || !emb_f16 || !origins || !dirs || !e_bins || !rgb || !density ||
+      (avg_row < 0 && !cam_idx) || (mode != 0 && !aabb_host))
+    return neraf_fail(ctx, NERAF_EINVAL, "field_query: bad arguments");
+  a.table = (const unsigned*)table_f16; a.wfrag = (const half8*)wfrag_f16; a.emb = (const half_t*)emb_f16;
+  a.origins = origins; a.dirs = dirs; a.e_bins = e_bins; a.cam_idx = cam_idx; a.R = R; a.S = S; a.mode = mode;
+  for (int i = 0; i < 6; ++i) a.aabb[i] = aabb_host ? aabb_host[i] : 0.f;
+  a.avg_density = avg_density; a.avg_row = avg_row; a.rgb = rgb; a.density = density;
+  const long n = (long)R * S;
+  const long groups = (n + 15) / 16;
+  long blocks = (groups + 3) / 4;
+  const long cap = (long)(ctx ? ctx->num_cus : 256) * 8;
+  if (blocks > cap) blocks = cap;
+  ProfScope prof(ctx, (hipStream_t)stream, PROF_FIELD_QUERY, (double)n * 16 * 8 * 4);   // gathered table bytes
+  hipLaunchKernelGGL(field_query_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" int neraf_composite(neraf_ctx* ctx, const float* density, const float* rgb, const float* e_bins, int R, int S,
+                               int training, float* weights, float* rgb_out, float* depth, float* expected, float* acc,
+                               void* scratch8, neraf_stream_t stream) {
+  if (R <= 0 || S <= 0 || S > 64 || !density || !rgb || !e_bins || !rgb_out || (expected && !scratch8))
+    return neraf_fail(ctx, NERAF_EINVAL, "composite: bad arguments (S <= 64; scratch8 needed for expected depth)");
+  unsigned* mm = (unsigned*)scratch8;
+  if (expected) {
+    const unsigned init[2] = {0x7f7fffffu, 0u};
+    NERAF_HIP_CHECK(ctx, hipMemcpyAsync(mm, init, 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+    hipLaunchKernelGGL(steps_minmax_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, e_bins, R, S, mm);
+  }
+  CompArgs a{density, rgb, e_bins, R, S, training, weights, rgb_out, depth, expected, acc, mm};
+  hipLaunchKernelGGL(composite_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}

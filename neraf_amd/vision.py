@@ -1,0 +1,329 @@
+"""Host-side mirror of the radiance half of the reference (``NeRAFVisionModel``, NeRAF_model.py:54-79,
+and the field it wraps, NeRAF_field.py:27-34) on libneraf_hip.
+
+The reference inherits this half from nerfstudio's ``NerfactoModel`` and runs it on tiny-cuda-nn; here
+the same stages are hand-written HIP kernels behind the C ABI (include/neraf_hip.h, "Radiance half"):
+piecewise sampler -> proposal density x2 -> PDF resampling x2 -> fused field query -> composite.
+
+Status (round 1): FORWARD ONLY.  ``get_outputs`` / ``get_outputs_for_camera`` / ``field.forward`` are
+complete for inference and for producing the quantities the losses need (``weights_list``,
+``ray_samples_list``); the backward kernels (hash-grid gradient scatter, MLP weight gradients, loss
+gradients) are the next row of the build plan, so outputs carry no autograd graph yet.
+
+No fallback: every method raises if the HIP library or the GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .field import _dev_index, _stream_ptr
+
+
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class RayBundle:
+    """The fields of nerfstudio's RayBundle that the hot path reads."""
+    origins: torch.Tensor            # [R,3] fp32
+    directions: torch.Tensor         # [R,3] fp32 (unit)
+    camera_indices: Optional[torch.Tensor] = None   # [R] or [R,1] int
+    nears: Optional[torch.Tensor] = None
+    fars: Optional[torch.Tensor] = None
+
+    def __len__(self):
+        return self.origins.shape[0]
+
+
+@dataclass
+class Frustums:
+    origins: torch.Tensor
+    directions: torch.Tensor
+    starts: torch.Tensor
+    ends: torch.Tensor
+    pixel_area: Optional[torch.Tensor] = None
+
+    def get_positions(self):
+        return self.origins + self.directions * (self.starts + self.ends) / 2
+
+
+@dataclass
+class RaySamples:
+    """Structured samples of R rays: S+1 bin edges per ray in normalised spacing and euclidean distance."""
+    frustums: Optional[Frustums]
+    camera_indices: Optional[torch.Tensor] = None
+    s_bins: Optional[torch.Tensor] = None     # [R,S+1]
+    e_bins: Optional[torch.Tensor] = None     # [R,S+1]
+
+    def to(self, device):
+        return self
+
+
+class FieldHeadNames:
+    RGB = "rgb"
+    DENSITY = "density"
+
+
+def grid_layout(desc: _lib.GridDesc):
+    lib = _lib.load()
+    L = desc.n_levels
+    sc, rs = (C.c_float * L)(), (C.c_int * L)()
+    sz, off = (C.c_uint32 * L)(), (C.c_uint32 * (L + 1))()
+    rc = lib.neraf_grid_layout(C.byref(desc), sc, rs, sz, off)
+    if rc != 0:
+        raise ValueError("unsupported hash-grid descriptor")
+    return list(sc), list(rs), list(sz), list(off)
+
+
+# ---- MFMA weight-fragment packing of the field MLPs ----------------------------------------------------
+def _dperm(s: int, q: int, j: int) -> int:
+    """k index held by (lane quarter q, element j) of k-step s when the B operand is built from two
+    accumulator blocks of the previous layer (see csrc/field.hip header)."""
+    return 16 * (2 * s) + 4 * q + j if j < 4 else 16 * (2 * s + 1) + 4 * q + (j - 4)
+
+
+def _build_frag_index() -> np.ndarray:
+    sizes = {"b0": (64, 32), "b1": (16, 64), "h0": (64, 64), "h1": (64, 64), "h2": (16, 64)}
+    base, off = {}, 0
+    for k, (o, i) in sizes.items():
+        base[k] = off
+        off += o * i
+    ZERO = off
+    idx = np.full((24, 64, 8), ZERO, np.int64)
+
+    def put(f, l, j, name, out, col):
+        idx[f, l, j] = base[name] + out * sizes[name][1] + col
+
+    for l in range(64):
+        row, q = l & 15, l >> 4
+        for j in range(8):
+            for ob in range(4):
+                put(ob, l, j, "b0", 16 * ob + row, 8 * q + j)
+            for s in range(2):
+                put(4 + s, l, j, "b1", row, _dperm(s, q, j))
+                put(22 + s, l, j, "h2", row, _dperm(s, q, j))
+                for ob in range(4):
+                    put(14 + ob * 2 + s, l, j, "h1", 16 * ob + row, _dperm(s, q, j))
+            for ob in range(4):
+                out = 16 * ob + row
+                # k-step 0: [base output 4q+j (geo feature 4q+j-1; the density logit has no weight) | SH 4q+j-4]
+                if j < 4:
+                    t = 4 * q + j
+                    if t >= 1:
+                        put(6 + ob * 2, l, j, "h0", out, 16 + (t - 1))
+                else:
+                    put(6 + ob * 2, l, j, "h0", out, 4 * q + (j - 4))
+                # k-step 1: appearance embedding 8q+j -> column 31 + 8q + j of [SH16 | geo15 | emb32]
+                put(7 + ob * 2, l, j, "h0", out, 31 + 8 * q + j)
+    return idx.reshape(-1)
+
+
+_FRAG_INDEX = _build_frag_index()
+
+
+class HashMLPDensityField(nn.Module):
+    """Proposal network: 5-level hash grid + MLP(10 -> 16 -> 1), tcnn layout (bias-free, padded to 16)."""
+
+    def __init__(self, max_res: int, log2_hashmap_size: int = 17, num_levels: int = 5, base_res: int = 16,
+                 average_init_density: float = 0.01):
+        super().__init__()
+        self.desc = _lib.GridDesc(num_levels, base_res, max_res, log2_hashmap_size, 2)
+        _, _, _, off = grid_layout(self.desc)
+        self.table = nn.Parameter(torch.empty(off[-1], 2).uniform_(-1e-4, 1e-4))
+        self.w0 = nn.Parameter(torch.empty(16, 16).uniform_(-0.43, 0.43))
+        self.w1 = nn.Parameter(torch.empty(16, 16).uniform_(-0.43, 0.43))
+        self.average_init_density = average_init_density
+
+    def packed(self):
+        return self.table.detach().half().contiguous(), torch.cat([self.w0.detach().reshape(-1), self.w1.detach()[0]]).half().contiguous()
+
+    def density(self, origins, directions, e_bins):
+        lib = _lib.load()
+        dev = _dev_index(origins)
+        R, S = e_bins.shape[0], e_bins.shape[1] - 1
+        tab, w = self.packed()
+        out = torch.empty((R, S), dtype=torch.float32, device=origins.device)
+        _lib.check(lib.neraf_proposal_density(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), w.data_ptr(),
+                                              origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(), R, S,
+                                              self.average_init_density, out.data_ptr(), _stream_ptr()), dev)
+        return out
+
+
+class NerfactoField(nn.Module):
+    """The nerfacto radiance field: 16-level hash grid -> MLP(32->64->16) -> density / geo features;
+    SH(dir) + geo + appearance embedding -> MLP(63->64->64->3) -> sigmoid.  ``forward`` keeps the
+    ``Field`` signature the reference calls (NeRAF_model.py:339-342)."""
+
+    def __init__(self, aabb: torch.Tensor, num_images: int, average_init_density: float = 0.01, spatial_distortion="linf"):
+        super().__init__()
+        self.register_buffer("aabb", aabb.float())
+        self.spatial_distortion = spatial_distortion          # "linf" scene contraction, or None (NeRAF_model.py:302)
+        self.desc = _lib.GridDesc(16, 16, 2048, 19, 2)
+        _, _, _, off = grid_layout(self.desc)
+        self.table = nn.Parameter(torch.empty(off[-1], 2).uniform_(-1e-4, 1e-4))
+
+        def xav(o, i):
+            b = (6.0 / (o + i)) ** 0.5
+            return nn.Parameter(torch.empty(o, i).uniform_(-b, b))
+        self.base_w0, self.base_w1 = xav(64, 32), xav(16, 64)
+        self.head_w0, self.head_w1, self.head_w2 = xav(64, 64), xav(64, 64), xav(16, 64)
+        self.embedding = nn.Parameter(torch.randn(num_images, 32))
+        self.average_init_density = average_init_density
+        self.register_buffer("_frag_index", torch.from_numpy(_FRAG_INDEX), persistent=False)
+
+    def packed(self):
+        flat = torch.cat([self.base_w0.detach().reshape(-1), self.base_w1.detach().reshape(-1), self.head_w0.detach().reshape(-1),
+                          self.head_w1.detach().reshape(-1), self.head_w2.detach().reshape(-1),
+                          torch.zeros(1, device=self.table.device)])
+        wfrag = flat[self._frag_index].half().contiguous()
+        emb = torch.cat([self.embedding.detach(), self.embedding.detach().mean(0, keepdim=True)], 0).half().contiguous()
+        return self.table.detach().half().contiguous(), wfrag, emb
+
+    def query(self, origins, directions, e_bins, camera_indices=None, use_average_embedding: bool = False):
+        """Structured query: R rays x S samples.  Returns (rgb [R,S,3], density [R,S])."""
+        lib = _lib.load()
+        dev = _dev_index(origins)
+        R, S = e_bins.shape[0], e_bins.shape[1] - 1
+        tab, wfrag, emb = self.packed()
+        rgb = torch.empty((R, S, 3), dtype=torch.float32, device=origins.device)
+        den = torch.empty((R, S), dtype=torch.float32, device=origins.device)
+        avg_row = self.embedding.shape[0] if (use_average_embedding or camera_indices is None) else -1
+        cam = camera_indices.reshape(-1).to(torch.int32).contiguous() if camera_indices is not None else None
+        mode = 0 if self.spatial_distortion is not None else 1
+        ab = (C.c_float * 6)(*[float(v) for v in self.aabb.reshape(-1).cpu().tolist()])
+        _lib.check(lib.neraf_field_query(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), wfrag.data_ptr(), emb.data_ptr(),
+                                         origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(),
+                                         cam.data_ptr() if cam is not None else None, R, S, mode, ab,
+                                         self.average_init_density, avg_row, rgb.data_ptr(), den.data_ptr(), _stream_ptr()), dev)
+        return rgb, den
+
+    def forward(self, ray_samples: RaySamples, compute_normals: bool = False) -> Dict[str, torch.Tensor]:
+        """Generic frustum query (one sample per frustum), e.g. the refresh call NeRAF_model.py:339."""
+        f = ray_samples.frustums
+        o = f.origins.reshape(-1, 3).float().contiguous()
+        d = f.directions.reshape(-1, 3).float().contiguous()
+        e = torch.cat([f.starts.reshape(-1, 1), f.ends.reshape(-1, 1)], dim=-1).float().contiguous()
+        cam = ray_samples.camera_indices
+        rgb, den = self.query(o, d, e, cam, use_average_embedding=not self.training)
+        shp = f.origins.shape[:-1]
+        return {FieldHeadNames.RGB: rgb.reshape(*shp, 3), FieldHeadNames.DENSITY: den.reshape(*shp, 1)}
+
+
+class RGBRenderer:
+    """``renderer_rgb`` as used by the refresh (NeRAF_model.py:344-350): background = last sample."""
+
+    def __call__(self, rgb: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+        comp = torch.sum(weights * rgb, dim=-2)
+        acc = torch.sum(weights, dim=-2)
+        return comp + rgb[..., -1, :] * (1.0 - acc)
+
+
+class NeRAFVisionModel(nn.Module):
+    """Drop-in surface of ``NeRAFVisionModel`` (NeRAF_model.py:54-79) with nerfacto defaults and the NeRAF
+    overrides (NeRAF_config.py:94-98)."""
+
+    num_proposal_samples_per_ray = (256, 96)
+    num_nerf_samples_per_ray = 48
+    near_plane, far_plane = 0.05, 1000.0
+    eval_num_rays_per_chunk = 1 << 15
+    proposal_weights_anneal_slope, proposal_weights_anneal_max_num_iters = 10.0, 1000
+
+    def __init__(self, aabb: torch.Tensor, num_train_data: int, average_init_density: float = 0.01):
+        super().__init__()
+        from .field import NeRAFVisionFieldValue
+        self.field = NeRAFVisionFieldValue(NerfactoField(aabb, num_train_data, average_init_density))   # NeRAF_model.py:61
+        self.proposal_networks = nn.ModuleList([HashMLPDensityField(128, average_init_density=average_init_density),
+                                                HashMLPDensityField(256, average_init_density=average_init_density)])
+        self.renderer_rgb = RGBRenderer()
+        self.audio_model = None
+        self.step = 0
+
+    @property
+    def device(self):
+        return self.field.module.table.device
+
+    def update_to_step(self, step: int):
+        self.step = step
+
+    def _anneal(self) -> float:
+        if not self.training:
+            return 1.0
+        x = min(max(self.step / self.proposal_weights_anneal_max_num_iters, 0.0), 1.0)
+        b = self.proposal_weights_anneal_slope
+        return (b * x) / ((b - 1) * x + 1)
+
+    def get_outputs(self, ray_bundle: RayBundle, jitters: Optional[List[torch.Tensor]] = None):
+        """NerfactoModel.get_outputs + rgb clip (NeRAF_model.py:65-68).  ``jitters`` (3 tensors [R]) override the
+        training-time single jitter of the three sampling stages (tests pass the oracle's values)."""
+        lib = _lib.load()
+        o = ray_bundle.origins.float().contiguous()
+        d = ray_bundle.directions.float().contiguous()
+        dev = _dev_index(o)
+        h, st = _lib.ctx(dev), _stream_ptr()
+        R = o.shape[0]
+        near, far = self.near_plane, self.far_plane
+        if self.training and jitters is None:
+            jitters = [torch.rand(R, device=o.device) for _ in range(3)]
+        jit = [j.reshape(-1).float().contiguous() if j is not None else None for j in (jitters or [None] * 3)]
+        jp = [j.data_ptr() if j is not None else None for j in jit]
+        S0, S1 = self.num_proposal_samples_per_ray
+        S2 = self.num_nerf_samples_per_ray
+        f32 = dict(dtype=torch.float32, device=o.device)
+        s0, e0 = torch.empty((R, S0 + 1), **f32), torch.empty((R, S0 + 1), **f32)
+        _lib.check(lib.neraf_sample_uniform(h, R, S0, near, far, jp[0], s0.data_ptr(), e0.data_ptr(), st), dev)
+        anneal = self._anneal()
+        weights_list, samples_list = [], []
+        s_prev, e_prev = s0, e0
+        for i, S_next in enumerate((S1, S2)):
+            dens = self.proposal_networks[i].density(o, d, e_prev)
+            S_cur = e_prev.shape[1] - 1
+            w = torch.empty((R, S_cur), **f32)
+            s_n, e_n = torch.empty((R, S_next + 1), **f32), torch.empty((R, S_next + 1), **f32)
+            _lib.check(lib.neraf_pdf_resample(h, dens.data_ptr(), s_prev.data_ptr(), e_prev.data_ptr(), R, S_cur, anneal,
+                                              jp[i + 1], S_next, near, far, w.data_ptr(), s_n.data_ptr(), e_n.data_ptr(), st), dev)
+            weights_list.append(w)
+            samples_list.append(RaySamples(None, ray_bundle.camera_indices, s_prev, e_prev))
+            s_prev, e_prev = s_n, e_n
+        field = self.field.module
+        rgb_s, dens = field.query(o, d, e_prev, ray_bundle.camera_indices, use_average_embedding=not self.training)
+        w = torch.empty((R, S2), **f32)
+        rgb, depth = torch.empty((R, 3), **f32), torch.empty((R, 1), **f32)
+        expd, acc = torch.empty((R, 1), **f32), torch.empty((R, 1), **f32)
+        scratch = torch.empty(2, dtype=torch.int32, device=o.device)
+        _lib.check(lib.neraf_composite(h, dens.data_ptr(), rgb_s.data_ptr(), e_prev.data_ptr(), R, S2, int(self.training),
+                                       w.data_ptr(), rgb.data_ptr(), depth.data_ptr(), expd.data_ptr(), acc.data_ptr(),
+                                       scratch.data_ptr(), st), dev)
+        weights_list.append(w)
+        samples_list.append(RaySamples(None, ray_bundle.camera_indices, s_prev, e_prev))
+        out = {"rgb": rgb, "accumulation": acc, "depth": depth, "expected_depth": expd}
+        if self.training:
+            out["weights_list"] = weights_list
+            out["ray_samples_list"] = samples_list
+        out["rgb_samples"], out["density"] = rgb_s, dens
+        return out
+
+    forward = get_outputs
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, ray_bundle: RayBundle):
+        """Full-image render in chunks of eval_num_rays_per_chunk rays (NeRAF_config.py:95), as nerfstudio's
+        Model.get_outputs_for_camera_ray_bundle does; NeRAFVisionModel.get_outputs_for_camera (NeRAF_model.py:70-79)
+        then clips rgb (already applied by the composite kernel)."""
+        R = len(ray_bundle)
+        outs: Dict[str, List[torch.Tensor]] = {}
+        was = self.training
+        self.eval()
+        for i in range(0, R, self.eval_num_rays_per_chunk):
+            sl = slice(i, min(R, i + self.eval_num_rays_per_chunk))
+            rb = RayBundle(ray_bundle.origins[sl], ray_bundle.directions[sl],
+                           ray_bundle.camera_indices[sl] if ray_bundle.camera_indices is not None else None)
+            o = self.get_outputs(rb)
+            for k in ("rgb", "accumulation", "depth", "expected_depth"):
+                outs.setdefault(k, []).append(o[k])
+        self.train(was)
+        return {k: torch.cat(v, 0) for k, v in outs.items()}
