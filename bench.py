@@ -87,13 +87,8 @@ class AudioBranchStep:
         loss = d["audio_sc_loss"] * 1e-1 * 1e-3 + d["audio_mag_loss"] * 1.0 * 1e-3   # NeRAF_model.py:597-598
         self.scaler.scale(loss).backward()
         if self.world > 1:
-            import torch.distributed as dist
-            grads = [p.grad for p in self.params]
-            flat = torch._utils._flatten_dense_tensors(grads)
-            dist.all_reduce(flat)
-            flat.div_(self.world)
-            for g, s in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-                g.copy_(s)
+            from neraf_amd.parallel import allreduce_gradients
+            allreduce_gradients(self.params, self.world)
         self.scaler.step(self.opt)
         self.scaler.update()
         return loss

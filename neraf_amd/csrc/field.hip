@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void pdf_resample_kernel(PdfArgs a) {
     if (k < per && i < S) {
       if (a.weights && active) a.weights[(size_t)ray * S + i] = w;
       // annealed weight + histogram padding 0.01
-      const float wa = (a.anneal == 1.f ? w : __powf(w, a.anneal)) + 0.01f;
+      const float wa = (a.anneal == 1.f ? w : powf(w, a.anneal)) + 0.01f;
       wts[k] = wa; wl += wa;
     } else wts[k] = 0.f;
   }

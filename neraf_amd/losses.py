@@ -32,9 +32,8 @@ class _StftLossFn(torch.autograd.Function):
                                             sums.data_ptr(), _stream_ptr()), dev)
         if group is not None:
             # data parallel: the Frobenius ratio / mean are over the GLOBAL batch (NeRAF_evaluator.py:26)
-            import torch.distributed as dist
-            dist.all_reduce(sums, group=group if group is not True else None)
-            n_total = x.numel() * dist.get_world_size(group if group is not True else None)
+            from .parallel import allreduce_loss_sums
+            n_total = allreduce_loss_sums(sums, x.numel(), group=group if group is not True else None, uniform_shards=True)
         _lib.check(lib.neraf_stft_loss_finalize(_lib.ctx(dev), sums.data_ptr(), n_total, losses.data_ptr(),
                                                 _stream_ptr()), dev)
         ctx.save_for_backward(x, y, sums)
