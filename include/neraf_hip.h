@@ -200,6 +200,33 @@ int neraf_composite(neraf_ctx* ctx, const float* density, const float* rgb, cons
                     int training, float* weights, float* rgb_out, float* depth, float* expected, float* acc,
                     void* scratch8, neraf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * ResNet3D scene encoder (ResNet3D_helper / ResNet3D.forward, NeRAF_resnet3d.py:116-201,266-285;
+ * backbone 'resnet50' truncated after layer3, N_features = 1024; called at NeRAF_model.py:554-558
+ * and :680-684): voxel grid fp32 [7,S,S,S] (S = 128 for grid_step 1/128, 64 for 1/64) -> feat fp32
+ * [1024].  conv_w: HOST array of the Conv3d weights (device pointers) in state-dict order (conv1,
+ * then per Bottleneck conv1, conv2, conv3, [downsample.0]); bn: HOST array of 4 device pointers per
+ * BatchNorm3d in the same order {weight, bias, running_mean, running_var}.  use_batch_stats = 1 is
+ * nn.Module.train() behaviour (statistics over the voxels of the single sample), 0 uses the running
+ * statistics.  Forward only in round 1.
+ * ---------------------------------------------------------------------------------- */
+typedef struct neraf_resnet3d_desc {
+  int grid_size;   /* 128 or 64 */
+  int in_channels; /* 7: rgb, alpha, xyz (NeRAF_model.py:185) */
+  int n_features;  /* 1024 */
+} neraf_resnet3d_desc;
+
+int neraf_resnet3d_num_convs(const neraf_resnet3d_desc* d); /* 43 */
+size_t neraf_resnet3d_packed_bytes(const neraf_resnet3d_desc* d);
+size_t neraf_resnet3d_workspace_bytes(const neraf_resnet3d_desc* d);
+int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const float* const* conv_w, void* packed,
+                                neraf_stream_t stream);
+int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed, const float* const* bn,
+                       const float* grid, void* workspace, float* feat, int use_batch_stats, neraf_stream_t stream);
+/* After a train-mode forward: running_mean/var <- (1-m) running + m batch (unbiased var), as nn.BatchNorm3d. */
+int neraf_resnet3d_update_running_stats(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* workspace,
+                                        float* const* bn, float momentum, neraf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

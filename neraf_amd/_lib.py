@@ -24,6 +24,10 @@ class GridDesc(C.Structure):
                 ("n_features", C.c_int)]
 
 
+class ResnetDesc(C.Structure):
+    _fields_ = [("grid_size", C.c_int), ("in_channels", C.c_int), ("n_features", C.c_int)]
+
+
 class NacfDesc(C.Structure):
     _fields_ = [("n_feat", C.c_int), ("n_query", C.c_int), ("W", C.c_int), ("C", C.c_int), ("F", C.c_int),
                 ("dense_l0", C.c_int)]
@@ -74,6 +78,14 @@ SIGNATURES = {
     "neraf_field_query": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                     C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_resnet3d_num_convs": (C.c_int, [C.POINTER(ResnetDesc)]),
+    "neraf_resnet3d_packed_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),
+    "neraf_resnet3d_workspace_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),
+    "neraf_resnet3d_pack_weights": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), c_fpp, C.c_void_p, C.c_void_p]),
+    "neraf_resnet3d_fwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int, C.c_void_p]),
+    "neraf_resnet3d_update_running_stats": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, C.c_float,
+                                                      C.c_void_p]),
     "neraf_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -67,6 +67,15 @@ static inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * 
 // extent so padded buffers are always valid K-/M-padding for the next GEMM.
 enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_TANH10 = 2, ACT_RELU = 3 };
 
+// Implicit-GEMM convolution geometry (cubic volumes, channels-last activations [D^3][cin] fp16).
+// loader 0: plain GEMM (A is a matrix);  1: cin % 64 == 0, one filter tap per 64-wide K-step;
+// 2: cin == 8, one filter tap per 16-byte chunk (the 7->64 channel stem, NeRAF_resnet3d.py:120).
+struct ConvGeom {
+  int loader;
+  int din, dout, stride, pad, ksize, cin;
+  const half_t* zero_page;   // >= 16 bytes of zeros: source of every out-of-bounds / padding-tap chunk
+};
+
 struct GemmParams {
   const half_t* A; int lda;
   const half_t* B; int ldb;
@@ -82,6 +91,10 @@ struct GemmParams {
   half_t* C16T; int ldc16t;          // optional transposed fp16 out [Npad, >=Mpad]
   float* C32; int ldc32;             // optional fp32 out, masked to M x N
   float* colsum;                     // optional [Npad] fp32: atomically += column sums of the final values
+  float* colsumsq;                   // optional [Npad] fp32: atomically += column sums of squares (BatchNorm statistics)
+  ConvGeom conv;                     // conv.loader == 0 for a plain GEMM
+  float* splitk_ws; size_t splitk_ws_bytes;   // optional fp32 scratch enabling split-K for under-filled grids
+  int tile_n;                        // 0 = auto; 64 forces the 128x64 tile (Cout = 64 layers)
 };
 
 int launch_gemm_f16(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream);

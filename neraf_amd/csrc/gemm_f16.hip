@@ -1,18 +1,22 @@
-// fp16 MFMA GEMM (NT form) with fused epilogue for gfx950 -- the contraction behind the NAcF
-// MLP (NeRAF_field.py:49-58) and the 1x1x1 convolutions of the ResNet3D (NeRAF_resnet3d.py:81,86).
+// fp16 MFMA GEMM / implicit-GEMM convolution (NT form) with fused epilogue for gfx950 -- the contraction
+// behind the NAcF MLP (NeRAF_field.py:49-58, forward, dX and dW) and the Conv3d layers of the ResNet3D scene
+// encoder (NeRAF_resnet3d.py:81-86,120).
 //
 //   C[m][n] = epi( alpha * sum_k A[m][k] * B[n][k] )
 //
-// Design (MI355X): 256-thread workgroup = 4 waves (2x2), block tile BM x BN x 64, each wave a
-// (BM/2)x(BN/2) sub-tile of v_mfma_f32_16x16x32_f16 fragments.  Global->LDS staging goes through
-// registers (issue the next tile's 16-B loads before the MFMA phase, write them to the other LDS
-// stage after it: one barrier per K-step).  The LDS image is [row][8 x 16-B chunk] with the chunk
-// index XOR-swizzled by (row & 7) so that the ds_read_b128 fragment reads (16 rows x one chunk per
-// lane group) are bank-conflict free, while the image stays lane-linear per staging instruction.
-// MFMA operand order is (W-fragment, X-fragment) so each lane's 4 accumulator registers run along
-// n: the epilogue packs them into one 8-byte LDS write and the tile leaves the CU as whole 128-B
-// rows.  Workgroup ids are remapped so that each XCD (blockIdx % 8) owns a compact 2-D patch of
-// tiles and re-uses its A/B panels out of its private 4 MiB L2.
+// Design (MI355X): 256-thread workgroup = 4 waves (2x2), block tile BM x BN x 64, each wave a (BM/2)x(BN/2)
+// sub-tile of v_mfma_f32_16x16x32_f16 fragments.  An NST-stage LDS ring is filled by LDS-DMA
+// (global_load_lds_dwordx4, 16 B per lane, no VGPR round trip); NST-1 tiles stay in flight across the ONE raw
+// s_barrier per K-step behind a counted s_waitcnt vmcnt(N) -- with one workgroup per CU this is what hides the
+// load latency (the register-staged double buffer it replaced ran 3.1x slower, profiles/r01_a_gemm_*.log).
+// The LDS image is [row][8 x 16-B chunk] with the chunk index XOR-swizzled by (row & 7): ds_read_b128 fragment
+// reads are bank-conflict free while each DMA instruction still writes 1 KiB linearly (the swizzle is applied
+// to the per-lane SOURCE address).  MFMA operand order is (W-fragment, X-fragment) so a lane's 4 accumulator
+// registers run along n and the tile leaves the CU as whole 128-B rows through an LDS-staged epilogue.
+// Workgroup ids are remapped so each XCD (blockIdx % 8) owns a compact patch of tiles (L2 re-use of panels).
+// Implicit-GEMM convolution only changes where an A chunk comes from (a filter tap of an input voxel, or a
+// zero page for padding).  Under-filled grids (few tiles, long K) are split along K into fp32 partial slabs that
+// a second kernel reduces and finishes.
 #include "common.h"
 #include <stdlib.h>
 
@@ -33,15 +37,14 @@ struct Tile {
   static constexpr int FM = WM / 16, FN = WN / 16;
   static constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
   static constexpr int STAGE_BYTES = (BM + BN) * 128;
-  // epilogue images, per wave
   static constexpr int IMG16_LD = WN + 8;    // halfs
   static constexpr int IMG16T_LD = WM + 8;   // halfs
   static constexpr int IMG32_LD = WN + 4;    // floats
   static constexpr int EPI_BYTES_WAVE = WM * IMG32_LD * 4;
-  static constexpr int LDS_BYTES =
-      (2 * STAGE_BYTES > 4 * EPI_BYTES_WAVE) ? 2 * STAGE_BYTES : 4 * EPI_BYTES_WAVE;
 };
 
+// ------------------------------------------------------------------------------------------------------
+// Epilogue of the GEMM kernel (the split-K reducer applies the same operations element-wise).
 template <int BM, int BN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[Tile<BM, BN>::FM][Tile<BM, BN>::FN],
                                               char* smem, int bm, int bn, int lane, int wave) {
@@ -49,7 +52,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   constexpr int WM = T::WM, WN = T::WN, FM = T::FM, FN = T::FN;
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fq = lane >> 4;
-  // ------------------------------- epilogue -------------------------------------------------
   // lane holds, for fragment (i,j): m = wm*WM + i*16 + (lane&15), n = wn*WN + j*16 + (lane>>4)*4 + r
   const int m_tile0 = bm * BM, n_tile0 = bn * BN;
   const float alpha = p.alpha_dev ? p.alpha * (*p.alpha_dev) : p.alpha;
@@ -83,21 +85,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   char* img = smem + wave * T::EPI_BYTES_WAVE;
   const int m_w0 = m_tile0 + wm * WM, n_w0 = n_tile0 + wn * WN;
 
-  if (p.colsum) {
+  if (p.colsum || p.colsumsq) {
     // column sums over this wave's WM rows: reduce over i and over the 16 lanes (lane&15) that share a column
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < FM; ++i) s += acc[i][j];
+      for (int i = 0; i < FM; ++i) { s += acc[i][j]; s2 += acc[i][j] * acc[i][j]; }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x = s[r];
-        x += __shfl_xor(x, 1);
-        x += __shfl_xor(x, 2);
-        x += __shfl_xor(x, 4);
-        x += __shfl_xor(x, 8);
-        if (frow == 0) atomicAdd(p.colsum + n_w0 + j * 16 + n_l + r, x);
+        float x = s[r], y = s2[r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { x += __shfl_xor(x, o); y += __shfl_xor(y, o); }
+        if (frow == 0) {
+          if (p.colsum) atomicAdd(p.colsum + n_w0 + j * 16 + n_l + r, x);
+          if (p.colsumsq) atomicAdd(p.colsumsq + n_w0 + j * 16 + n_l + r, y);
+        }
       }
     }
   }
@@ -155,7 +158,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         *reinterpret_cast<f32x4*>(im + (i * 16 + m_l) * T::IMG32_LD + j * 16 + n_l) = acc[i][j];
     __syncthreads();
     // one float per lane, 64 consecutive columns per wave-instruction (256-B segments)
-    constexpr int RPI = 64 / WN > 0 ? 64 / WN : 1;   // rows per instruction when WN < 64
     if (WN >= 64) {
 #pragma unroll 4
       for (int row = 0; row < WM; ++row) {
@@ -168,6 +170,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
       }
     } else {
+      constexpr int RPI = 64 / WN;
       for (int r0 = 0; r0 < WM; r0 += RPI) {
         const int row = r0 + lane / WN, col = lane % WN;
         const int m = m_w0 + row, n = n_w0 + col;
@@ -177,140 +180,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   }
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_f16_nt_kernel(GemmParams p) {
-  using T = Tile<BM, BN>;
-  constexpr int WM = T::WM, WN = T::WN, FM = T::FM, FN = T::FN;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // ---- XCD-aware tile mapping: consecutive hardware block ids round-robin over the 8 XCDs, so
-  // give XCD x the contiguous logical range [x*per, (x+1)*per) and walk that range in GROUP_M-row
-  // column-major groups (compact 2-D patch -> few distinct A/B panels per L2).
-  const int tiles_m = p.Mpad / BM, tiles_n = p.Npad / BN;
-  const int ntiles = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = ntiles >> 3, r = ntiles & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective for any ntiles
-  }
-  constexpr int GROUP_M = 4;
-  const int group = bid / (GROUP_M * tiles_n);
-  const int first_m = group * GROUP_M;
-  const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
-  const int in_group = bid - group * GROUP_M * tiles_n;
-  const int bm = first_m + in_group % gsz;
-  const int bn = in_group / gsz;
-
-  const half_t* Ag = p.A + (size_t)bm * BM * p.lda;
-  const half_t* Bg = p.B + (size_t)bn * BN * p.ldb;
-
-  // ---- per-thread staging descriptors: chunk c = i*256 + tid -> LDS byte c*16 (lane-linear);
-  // physical chunk slot pc = c & 7 holds logical chunk pc ^ (row & 7).
-  const half_t* a_src[T::A_CH];
-  const half_t* b_src[T::B_CH];
-#pragma unroll
-  for (int i = 0; i < T::A_CH; ++i) {
-    const int c = i * 256 + tid, row = c >> 3, lc = (c & 7) ^ (row & 7);
-    a_src[i] = Ag + (size_t)row * p.lda + lc * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < T::B_CH; ++i) {
-    const int c = i * 256 + tid, row = c >> 3, lc = (c & 7) ^ (row & 7);
-    b_src[i] = Bg + (size_t)row * p.ldb + lc * 8;
-  }
-  uint4 ra[T::A_CH], rb[T::B_CH];
-
-  auto g_load = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < T::A_CH; ++i) ra[i] = *reinterpret_cast<const uint4*>(a_src[i] + (size_t)kt * BK);
-#pragma unroll
-    for (int i = 0; i < T::B_CH; ++i) rb[i] = *reinterpret_cast<const uint4*>(b_src[i] + (size_t)kt * BK);
-  };
-  auto s_store = [&](int stage) {
-    char* sa = smem + stage * T::STAGE_BYTES;
-    char* sb = sa + BM * 128;
-#pragma unroll
-    for (int i = 0; i < T::A_CH; ++i) *reinterpret_cast<uint4*>(sa + (i * 256 + tid) * 16) = ra[i];
-#pragma unroll
-    for (int i = 0; i < T::B_CH; ++i) *reinterpret_cast<uint4*>(sb + (i * 256 + tid) * 16) = rb[i];
-  };
-
-  // fragment read offsets (bytes): row = sub-tile base + (lane & 15); chunk = ks*4 + (lane >> 4)
-  const int frow = lane & 15, fq = lane >> 4;
-  const int a_row_off = (wm * WM + frow) * 128;
-  const int b_row_off = (wn * WN + frow) * 128;
-  int ch_off[2];
-  ch_off[0] = ((0 + fq) ^ (frow & 7)) * 16;
-  ch_off[1] = ((4 + fq) ^ (frow & 7)) * 16;
-
-  f32x4 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / BK;
-  g_load(0);
-  s_store(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1) < nk;
-    if (more) g_load(kt + 1);
-    const char* sa = smem + (kt & 1) * T::STAGE_BYTES;
-    const char* sb = sa + BM * 128;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8 xa[FM], wb[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-        xa[i] = *reinterpret_cast<const half8*>(sa + a_row_off + i * 16 * 128 + ch_off[ks]);
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-        wb[j] = *reinterpret_cast<const half8*>(sb + b_row_off + j * 16 * 128 + ch_off[ks]);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          // D[r = n][c = m] : W fragment is the MFMA "A" operand, X fragment the "B" operand
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
-    }
-    if (more) s_store((kt + 1) & 1);
-    __syncthreads();
-  }
-
-  gemm_epilogue<BM, BN>(p, acc, smem, bm, bn, lane, wave);
-}
-
-template <int BM, int BN>
-int launch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
-  using T = Tile<BM, BN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_nt_kernel<BM, BN>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
-    attr_set = true;
-  }
-  const int ntiles = (p.Mpad / BM) * (p.Npad / BN);
-  ProfScope prof(ctx, stream, BM == 128 ? PROF_GEMM128 : PROF_GEMM64, 2.0 * p.M * p.N * p.K);
-  hipLaunchKernelGGL((gemm_f16_nt_kernel<BM, BN>), dim3(ntiles), dim3(256), T::LDS_BYTES, stream, p);
-  NERAF_HIP_CHECK(ctx, hipGetLastError());
-  return NERAF_OK;
-}
-
-
-// ---- v2: NST-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4), counted vmcnt ------------
-// The v1 structure keeps one tile (32 KB) in flight per CU and is load-latency bound (~2.5 us per
-// K-step measured).  Here NST-1 tiles stay in flight across the single raw s_barrier per K-step, which
-// is what saturates the per-CU load path (MI355X guide: >= 64-72 KB in flight per CU).
-//   iteration kt:  s_waitcnt vmcnt(tiles issued after kt) ; s_barrier ; issue tile kt+NST-1 ; MFMA tile kt
-// The barrier at the top of iteration kt is also what frees stage (kt-1)%NST for the new DMA.
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
 template <int BM, int BN, int NST>
@@ -320,8 +189,9 @@ struct PipeTile {
       (NST * T::STAGE_BYTES > 4 * T::EPI_BYTES_WAVE) ? NST * T::STAGE_BYTES : 4 * T::EPI_BYTES_WAVE;
 };
 
-template <int BM, int BN, int NST>
-__global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p) {
+// LOADER: 0 plain GEMM, 1 conv tap-per-K-step (cin % 64 == 0), 2 conv tap-per-chunk (cin == 8).  KS = filter size.
+template <int BM, int BN, int NST, int LOADER, int KS>
+__global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int splits) {
   using T = Tile<BM, BN>;
   constexpr int WM = T::WM, WN = T::WN, FM = T::FM, FN = T::FN;
   constexpr int LOADS = T::A_CH + T::B_CH;
@@ -332,14 +202,18 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
+  // ---- XCD-aware tile mapping (bijective for any tile count) + split-K slice
   const int tiles_m = p.Mpad / BM, tiles_n = p.Npad / BN;
   const int ntiles = tiles_m * tiles_n;
+  const int nblocks = ntiles * splits;
   int bid = blockIdx.x;
   {
-    const int q = ntiles >> 3, r = ntiles & 7;
+    const int q = nblocks >> 3, r = nblocks & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  const int split = bid % splits;      // the slices of one tile are neighbours -> same XCD, shared panels
+  bid /= splits;
   constexpr int GROUP_M = 4;
   const int group = bid / (GROUP_M * tiles_n);
   const int first_m = group * GROUP_M;
@@ -348,20 +222,36 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p) {
   const int bm = first_m + in_group % gsz;
   const int bn = in_group / gsz;
 
-  const half_t* Ag = p.A + (size_t)bm * BM * p.lda;
-  const half_t* Bg = p.B + (size_t)bn * BN * p.ldb;
+  const int nk_total = p.K / BK;
+  const int per = (nk_total + splits - 1) / splits;
+  const int k_begin = split * per;
+  const int k_end = (k_begin + per) < nk_total ? (k_begin + per) : nk_total;
+  const int nk = k_end > k_begin ? k_end - k_begin : 0;
 
-  const half_t* a_src[T::A_CH];
+  const half_t* Bg = p.B + (size_t)bn * BN * p.ldb;
   const half_t* b_src[T::B_CH];
-#pragma unroll
-  for (int i = 0; i < T::A_CH; ++i) {
-    const int c = i * 256 + tid, row = c >> 3, lc = (c & 7) ^ (row & 7);
-    a_src[i] = Ag + (size_t)row * p.lda + lc * 8;
-  }
 #pragma unroll
   for (int i = 0; i < T::B_CH; ++i) {
     const int c = i * 256 + tid, row = c >> 3, lc = (c & 7) ^ (row & 7);
     b_src[i] = Bg + (size_t)row * p.ldb + lc * 8;
+  }
+  // A side: plain rows, or output-voxel coordinates for the convolution loaders
+  const half_t* a_src[T::A_CH];
+  int az[T::A_CH], ay[T::A_CH], ax[T::A_CH], alc[T::A_CH];
+#pragma unroll
+  for (int i = 0; i < T::A_CH; ++i) {
+    const int c = i * 256 + tid, row = c >> 3, lc = (c & 7) ^ (row & 7);
+    alc[i] = lc;
+    az[i] = ay[i] = ax[i] = 0;
+    a_src[i] = nullptr;
+    if (LOADER == 0) {
+      a_src[i] = p.A + (size_t)(bm * BM + row) * p.lda + lc * 8;
+    } else {
+      const int m = bm * BM + row;
+      const int d = p.conv.dout;
+      const int x = m % d, y = (m / d) % d, z = m / (d * d);
+      az[i] = z * p.conv.stride - p.conv.pad; ay[i] = y * p.conv.stride - p.conv.pad; ax[i] = x * p.conv.stride - p.conv.pad;
+    }
   }
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -369,9 +259,34 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p) {
   auto issue = [&](int kt, int stage) {
     char* sa = smem + stage * T::STAGE_BYTES + wave * 1024;   // wave-uniform base; HW adds lane*16
     char* sb = sa + BM * 128;
+    if (LOADER == 0) {
 #pragma unroll
-    for (int i = 0; i < T::A_CH; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + (size_t)kt * BK), (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
+      for (int i = 0; i < T::A_CH; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + (size_t)kt * BK), (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
+    } else if (LOADER == 1) {
+      const int cpb = p.conv.cin >> 6;
+      const int tap = kt / cpb, cb = kt - tap * cpb;
+      const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+      const int din = p.conv.din;
+#pragma unroll
+      for (int i = 0; i < T::A_CH; ++i) {
+        const int iz = az[i] + dz, iy = ay[i] + dy, ix = ax[i] + dx;
+        const bool ok = (unsigned)iz < (unsigned)din && (unsigned)iy < (unsigned)din && (unsigned)ix < (unsigned)din;
+        const half_t* src = ok ? p.A + ((size_t)(iz * din + iy) * din + ix) * p.conv.cin + cb * 64 + alc[i] * 8 : p.conv.zero_page;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
+      }
+    } else {
+      const int din = p.conv.din;
+#pragma unroll
+      for (int i = 0; i < T::A_CH; ++i) {
+        const int tap = kt * 8 + alc[i];
+        const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+        const int iz = az[i] + dz, iy = ay[i] + dy, ix = ax[i] + dx;
+        const bool ok = tap < KS * KS * KS && (unsigned)iz < (unsigned)din && (unsigned)iy < (unsigned)din && (unsigned)ix < (unsigned)din;
+        const half_t* src = ok ? p.A + ((size_t)(iz * din + iy) * din + ix) * 8 : p.conv.zero_page;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < T::B_CH; ++i)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[i] + (size_t)kt * BK), (lds_ptr_t)(sb + i * 4096), 16, 0, 0);
@@ -390,26 +305,21 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
-    if (s0 < nk) issue(s0, s0);
+    if (s0 < nk) issue(k_begin + s0, s0);
 
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int after = nk - 1 - kt;   // tiles issued after tile kt that may still be in flight
-    if (NST >= 4 && after >= 2) {
-      if (NST == 4) wait_vmcnt<2 * LOADS>(); else wait_vmcnt<(NST - 2) * LOADS>();
-    } else if (after >= 1 && NST >= 3) {
-      // (for NST > 4 the tail over-waits, which is only slower, never wrong)
-      wait_vmcnt<LOADS>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
+    // iteration kt:  s_waitcnt vmcnt(loads of the tiles issued after kt) ; s_barrier ; issue tile kt+NST-1 ; MFMA
+    const int after = nk - 1 - kt;
+    if (NST >= 4 && after >= 2) wait_vmcnt<2 * LOADS>();
+    else if (NST >= 3 && after >= 1) wait_vmcnt<LOADS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();     // also frees stage (kt-1)%NST for the DMA issued below
     if (kt + NST - 1 < nk) {
       int st2 = stage + NST - 1; if (st2 >= NST) st2 -= NST;
-      issue(kt + NST - 1, st2);
+      issue(k_begin + kt + NST - 1, st2);
     }
     const char* sa = smem + stage * T::STAGE_BYTES;
     const char* sb = sa + BM * 128;
@@ -426,54 +336,133 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
+          // D[r = n][c = m] : W fragment is the MFMA "A" operand, X fragment the "B" operand
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
     }
     if (++stage == NST) stage = 0;
   }
   __syncthreads();
+
+  if (splits > 1) {
+    // raw fp32 partial slab [split][Mpad][Npad]; finished by splitk_reduce_kernel
+    float* slab = p.splitk_ws + (size_t)split * p.Mpad * p.Npad;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int m = bm * BM + wm * WM + i * 16 + frow;
+        const int n0 = bn * BN + wn * WN + j * 16 + fq * 4;
+        *reinterpret_cast<f32x4*>(slab + (size_t)m * p.Npad + n0) = acc[i][j];
+      }
+    return;
+  }
   gemm_epilogue<BM, BN>(p, acc, smem, bm, bn, lane, wave);
 }
 
-template <int BM, int BN, int NST>
-int launch_pipe(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
+// Split-K reducer: sums the partial slabs and applies the same epilogue element-wise on 32x32 tiles.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int splits) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const float alpha = p.alpha_dev ? p.alpha * (*p.alpha_dev) : p.alpha;
+  const size_t slab = (size_t)p.Mpad * p.Npad;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty + i * 8, n = n0 + tx;
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += p.splitk_ws[s * slab + (size_t)m * p.Npad + n];
+    v *= alpha;
+    if (p.bias) v += p.bias[n];
+    v = act_apply(v, p.act);
+    if (p.lmask) v *= ((float)p.lmask[(size_t)m * p.ldmask + n] > 0.f) ? 1.f : p.mask_slope;
+    if (m >= p.M || n >= p.N) v = 0.f;
+    tile[ty + i * 8][tx] = v;
+    if (p.C16) p.C16[(size_t)m * p.ldc16 + n] = (half_t)v;
+    if (p.C32 && m < p.M && n < p.N) p.C32[(size_t)m * p.ldc32 + n] = v;
+  }
+  __syncthreads();
+  if (p.C16T) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + ty + i * 8, m = m0 + tx;
+      p.C16T[(size_t)n * p.ldc16t + m] = (half_t)tile[tx][ty + i * 8];
+    }
+  }
+  if ((p.colsum || p.colsumsq) && ty == 0) {
+    float cs = 0.f, cs2 = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) { const float v = tile[i][tx]; cs += v; cs2 += v * v; }
+    if (p.colsum) atomicAdd(p.colsum + n0 + tx, cs);
+    if (p.colsumsq) atomicAdd(p.colsumsq + n0 + tx, cs2);
+  }
+}
+
+template <int BM, int BN, int NST, int LOADER, int KS>
+int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t stream) {
   using PT = PipeTile<BM, BN, NST>;
   static bool attr_set = false;
   if (!attr_set) {
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_nt_pipe_kernel<BM, BN, NST>),
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, PT::LDS_BYTES));
     attr_set = true;
   }
   const int ntiles = (p.Mpad / BM) * (p.Npad / BN);
-  ProfScope prof(ctx, stream, BM == 128 ? PROF_GEMM128 : PROF_GEMM64, 2.0 * p.M * p.N * p.K);
-  hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST>), dim3(ntiles), dim3(256), PT::LDS_BYTES, stream, p);
+  ProfScope prof(ctx, stream, BM * BN == 128 * 128 ? PROF_GEMM128 : PROF_GEMM64, 2.0 * p.M * p.N * p.K);
+  hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS>), dim3(ntiles * splits), dim3(256), PT::LDS_BYTES,
+                     stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
+  if (splits > 1) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(p.Npad / 32, p.Mpad / 32), dim3(256), 0, stream, p, splits);
+    NERAF_HIP_CHECK(ctx, hipGetLastError());
+  }
   return NERAF_OK;
+}
+
+template <int LOADER, int KS>
+int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
+  const int cus = ctx ? ctx->num_cus : 256;
+  const int nk = p.K / BK;
+  // tile choice: 128x128 when it fills the chip; 128x64 for 64-wide outputs; otherwise 64x64 (4x the workgroups)
+  int bm = 128, bn = 128;
+  if (p.tile_n == 64 && (p.Mpad % 128) == 0 && (p.Npad % 64) == 0) { bm = 128; bn = 64; }
+  else if ((p.Mpad / 128) * (p.Npad / 128) < cus) { bm = 64; bn = 64; }
+  const int ntiles = (p.Mpad / bm) * (p.Npad / bn);
+  // split-K: only with scratch, when the grid under-fills the chip and every slice keeps >= 4 K-steps
+  int splits = 1;
+  if (p.splitk_ws && ntiles * 2 <= cus && nk >= 8) {
+    splits = cus / ntiles;
+    if (splits > nk / 4) splits = nk / 4;
+    if (splits > 16) splits = 16;
+    const size_t need = (size_t)splits * p.Mpad * p.Npad * 4;
+    if (splits < 2 || need > p.splitk_ws_bytes) splits = 1;
+  }
+  if (bm == 128 && bn == 128) return launch_pipe<128, 128, 4, LOADER, KS>(ctx, p, splits, stream);
+  if (bm == 128 && bn == 64) return launch_pipe<128, 64, 4, LOADER, KS>(ctx, p, splits, stream);
+  return launch_pipe<64, 64, 4, LOADER, KS>(ctx, p, splits, stream);
 }
 
 }  // namespace
 
 int launch_gemm_f16(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   if (p.K <= 0 || (p.K % BK) != 0) return neraf_fail(ctx, NERAF_EINVAL, "gemm: K must be a positive multiple of 64");
-  if ((p.Mpad % 128) != 0 || (p.Npad % 128) != 0 || p.M > p.Mpad || p.N > p.Npad || p.M <= 0 || p.N <= 0)
-    return neraf_fail(ctx, NERAF_EINVAL, "gemm: Mpad/Npad must be multiples of 128 covering M/N");
-  if ((p.lda % 8) || (p.ldb % 8) || (p.C16 && (p.ldc16 % 8)) || (p.C16T && (p.ldc16t % 8)) || (p.lmask && (p.ldmask % 4)))
+  const int nmult = p.tile_n == 64 ? 64 : 128;
+  if ((p.Mpad % 128) != 0 || (p.Npad % nmult) != 0 || p.M > p.Mpad || p.N > p.Npad || p.M <= 0 || p.N <= 0)
+    return neraf_fail(ctx, NERAF_EINVAL, "gemm: Mpad/Npad must be tile multiples covering M/N");
+  if ((p.conv.loader == 0 && (p.lda % 8)) || (p.ldb % 8) || (p.C16 && (p.ldc16 % 8)) || (p.C16T && (p.ldc16t % 8)) ||
+      (p.lmask && (p.ldmask % 4)))
     return neraf_fail(ctx, NERAF_EINVAL, "gemm: leading dimensions must keep 16-byte alignment");
-  // Tile choice: 128x128 when it fills the chip, otherwise 64x64 tiles (4x the workgroups) so that
-  // the narrow layers of the MLP (N = 512..1024 at B = 2048) still cover all 256 CUs.
-  const int cus = ctx ? ctx->num_cus : 256;
-  const int tiles128 = (p.Mpad / 128) * (p.Npad / 128);
-  // NERAF_GEMM_VARIANT (A/B switch, read once): 1 = v1 register-staged double buffer; 3/4 = LDS-DMA ring depth.
-  static const int variant = [] { const char* e = getenv("NERAF_GEMM_VARIANT"); return e ? atoi(e) : 4; }();
-  if (variant == 1) {
-    if (tiles128 >= cus) return launch_tile<128, 128>(ctx, p, stream);
-    return launch_tile<64, 64>(ctx, p, stream);
+  switch (p.conv.loader) {
+    case 0: return dispatch_tile<0, 1>(ctx, p, stream);
+    case 1:
+      if ((p.conv.cin % 64) || !p.conv.zero_page) return neraf_fail(ctx, NERAF_EINVAL, "conv loader 1: cin % 64 and zero page");
+      if (p.conv.ksize == 3) return dispatch_tile<1, 3>(ctx, p, stream);
+      if (p.conv.ksize == 1) return dispatch_tile<1, 1>(ctx, p, stream);
+      return neraf_fail(ctx, NERAF_EINVAL, "conv loader 1: ksize must be 1 or 3");
+    case 2:
+      if (p.conv.cin != 8 || p.conv.ksize != 5 || !p.conv.zero_page) return neraf_fail(ctx, NERAF_EINVAL, "conv loader 2: cin 8, ksize 5");
+      return dispatch_tile<2, 5>(ctx, p, stream);
   }
-  if (variant == 3) {
-    if (tiles128 >= cus) return launch_pipe<128, 128, 3>(ctx, p, stream);
-    return launch_pipe<64, 64, 3>(ctx, p, stream);
-  }
-  if (tiles128 >= cus) return launch_pipe<128, 128, 4>(ctx, p, stream);
-  return launch_pipe<64, 64, 4>(ctx, p, stream);
+  return neraf_fail(ctx, NERAF_EINVAL, "gemm: unknown loader");
 }
 
 extern "C" int neraf_gemm_f16(neraf_ctx* ctx, const void* A, int lda, const void* B, int ldb, int M, int N, int K,

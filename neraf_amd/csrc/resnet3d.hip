@@ -1,0 +1,398 @@
+// ResNet3D scene encoder (NeRAF_resnet3d.py:116-201; 'resnet50' truncated after layer3, N_features = 1024):
+// voxel grid fp32 [7,S,S,S] -> 1024-vector.  Forward (train-mode batch statistics or eval-mode running
+// statistics).  Activations are channels-last fp16 [D*H*W, C]; every Conv3d is the implicit-GEMM form of
+// gemm_f16.hip (1x1x1 convs are plain GEMMs), whose epilogue also accumulates the per-channel sum and sum of
+// squares that BatchNorm3d needs (batch = 1: statistics over the voxels, NeRAF_resnet3d.py:82-87 / SURVEY A4),
+// so BN costs one element-wise pass that is fused with ReLU, the residual add and (stem) the 3^3 max-pool.
+#include "common.h"
+
+namespace {
+
+struct ConvSpec { int cin, cout, k, stride, pad, din, dout; };
+struct BlockSpec { int conv[3]; int ds; int planes; };   // indices into the conv list (state-dict order); ds = -1 if none
+
+struct Arch {
+  int S;                       // input grid edge
+  int nconv;
+  ConvSpec conv[64];
+  int nblock;
+  BlockSpec block[16];
+  int pooled;                  // edge after the stem max-pool
+  int final_edge;              // edge of layer3's output
+};
+
+int make_arch(const neraf_resnet3d_desc* d, Arch* A) {
+  if (!d || d->in_channels != 7 || d->n_features != 1024 || (d->grid_size != 128 && d->grid_size != 64)) return NERAF_EINVAL;
+  A->S = d->grid_size;
+  int n = 0;
+  A->conv[n++] = ConvSpec{8, 64, 5, 2, 2, A->S, A->S / 2};             // stem: 7 (padded to 8) -> 64, NeRAF_resnet3d.py:120
+  A->pooled = A->S / 4;                                                  // MaxPool3d(3, 2, 1), :123
+  int edge = A->pooled, in_planes = 64, nb = 0;
+  const int planes_l[3] = {64, 128, 256}, blocks_l[3] = {3, 4, 6}, stride_l[3] = {1, 2, 2};   // :124-126, resnet50 :237
+  for (int li = 0; li < 3; ++li) {
+    for (int b = 0; b < blocks_l[li]; ++b) {
+      const int s = b == 0 ? stride_l[li] : 1, p = planes_l[li];
+      BlockSpec B{};
+      B.planes = p;
+      B.conv[0] = n; A->conv[n++] = ConvSpec{in_planes, p, 1, 1, 0, edge, edge};             // :81
+      B.conv[1] = n; A->conv[n++] = ConvSpec{p, p, 3, s, 1, edge, edge / s};                  // :83-84
+      B.conv[2] = n; A->conv[n++] = ConvSpec{p, p * 4, 1, 1, 0, edge / s, edge / s};          // :86
+      B.ds = -1;
+      if (b == 0 && (s != 1 || in_planes != p * 4)) { B.ds = n; A->conv[n++] = ConvSpec{in_planes, p * 4, 1, s, 0, edge, edge / s}; }  // :169-174
+      A->block[nb++] = B;
+      in_planes = p * 4;
+      edge /= s;
+    }
+  }
+  A->nconv = n; A->nblock = nb; A->final_edge = edge;
+  return NERAF_OK;
+}
+
+inline int conv_kpad(const ConvSpec& c) { return round_up(c.k * c.k * c.k * c.cin, 64); }
+inline int conv_npad(const ConvSpec& c) { return c.cout == 64 ? 64 : round_up(c.cout, 128); }
+__host__ __device__ inline size_t cube(int e) { return (size_t)e * e * e; }
+inline size_t rows_pad(int e) { return round_up_sz(cube(e), 128); }
+
+struct Layout {
+  size_t w[64];                 // packed fp16 weights [npad][kpad]
+  size_t packed_total;
+  // workspace
+  size_t zero_page, x0;         // zero page, NDHWC8 input
+  size_t pre[64], stat[64];     // per conv: pre-BN output fp16 [rows_pad][cout], stats fp32 [2][cout]
+  size_t act_pool;              // stem: pooled activation
+  size_t a1[16], a2[16], out[16];   // per block post-activation tensors
+  size_t splitk; size_t splitk_bytes;
+  size_t stats_begin, stats_bytes;
+  size_t total;
+};
+
+void make_layout(const Arch& A, Layout* L) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += round_up_sz(bytes, 256); return o; };
+  for (int i = 0; i < A.nconv; ++i) L->w[i] = take((size_t)conv_npad(A.conv[i]) * conv_kpad(A.conv[i]) * 2);
+  L->packed_total = off;
+  off = 0;
+  L->zero_page = take(256);
+  L->x0 = take(cube(A.S) * 8 * 2);
+  L->stats_begin = off;
+  for (int i = 0; i < A.nconv; ++i) L->stat[i] = take((size_t)2 * round_up(A.conv[i].cout, 128) * 4);
+  L->stats_bytes = off - L->stats_begin;
+  for (int i = 0; i < A.nconv; ++i) L->pre[i] = take(rows_pad(A.conv[i].dout) * A.conv[i].cout * 2);
+  L->act_pool = take(rows_pad(A.pooled) * 64 * 2);
+  for (int b = 0; b < A.nblock; ++b) {
+    const ConvSpec& c0 = A.conv[A.block[b].conv[0]]; const ConvSpec& c1 = A.conv[A.block[b].conv[1]];
+    const ConvSpec& c2 = A.conv[A.block[b].conv[2]];
+    L->a1[b] = take(rows_pad(c0.dout) * c0.cout * 2);
+    L->a2[b] = take(rows_pad(c1.dout) * c1.cout * 2);
+    L->out[b] = take(rows_pad(c2.dout) * c2.cout * 2);
+  }
+  L->splitk_bytes = (size_t)64 << 20;
+  L->splitk = take(L->splitk_bytes);
+  L->total = off;
+}
+
+// ---- kernels ---------------------------------------------------------------------------------------------
+// fp32 grid [7][S^3] (NeRAF_model.py:271-277) -> fp16 channels-last [S^3][8] (channel 7 = 0)
+__global__ __launch_bounds__(256) void grid_to_ndhwc8_kernel(const float* __restrict__ grid, size_t nvox, half_t* __restrict__ out) {
+  const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= nvox) return;
+  half8 h;
+#pragma unroll
+  for (int c = 0; c < 7; ++c) h[c] = (half_t)grid[c * nvox + v];
+  h[7] = (half_t)0.f;
+  reinterpret_cast<half8*>(out)[v] = h;
+}
+
+// W fp32 [cout][cin_real][k^3] -> fp16 [npad][kpad], k index = tap * cin + c (tap-major, channel-minor)
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ W, int cout, int cin_real, int cin, int taps,
+                                                              int npad, int kpad, half_t* __restrict__ out) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)npad * kpad) return;
+  const int n = (int)(idx / kpad), k = (int)(idx % kpad);
+  const int tap = k / cin, c = k % cin;
+  float v = 0.f;
+  if (n < cout && tap < taps && c < cin_real) v = W[((size_t)n * cin_real + c) * taps + tap];
+  out[idx] = (half_t)v;
+}
+
+struct BnSrc {
+  const half_t* x;          // pre-BN conv output [rows][C]
+  const float* stats;       // [2][Cpad]: sum, sum of squares (batch statistics) -- or null
+  const float* gamma; const float* beta; const float* rmean; const float* rvar;
+  int cpad;
+};
+
+__device__ __forceinline__ void bn_scale_shift(const BnSrc& s, int c, float inv_m, float& scale, float& shift) {
+  float mean, var;
+  if (s.stats) {
+    mean = s.stats[c] * inv_m;
+    var = fmaxf(s.stats[s.cpad + c] * inv_m - mean * mean, 0.f);    // biased variance, as nn.BatchNorm3d normalises with
+  } else {
+    mean = s.rmean[c]; var = s.rvar[c];
+  }
+  const float rstd = rsqrtf(var + 1e-5f);
+  scale = s.gamma[c] * rstd;
+  shift = s.beta[c] - mean * scale;
+}
+
+// out = [relu]( bn(x) [+ residual | + bn_r(xr)] ) ; 8 channels (16 B) per thread; rows >= M are written as zeros
+struct BnApplyArgs {
+  BnSrc a; BnSrc r; const half_t* res;   // r.x != null: residual is bn_r(r.x); else res (may be null)
+  int M, Mpad, C; int relu;
+  half_t* out;
+};
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
+  extern __shared__ float sm[];            // scale[C] shift[C] (+ scale_r[C] shift_r[C])
+  float* sc = sm; float* sh = sm + p.C; float* scr = sm + 2 * p.C; float* shr = sm + 3 * p.C;
+  const float inv_m = 1.f / (float)p.M;
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    bn_scale_shift(p.a, c, inv_m, sc[c], sh[c]);
+    if (p.r.x) bn_scale_shift(p.r, c, inv_m, scr[c], shr[c]);
+  }
+  __syncthreads();
+  const int cpr = p.C >> 3;                 // 16-B chunks per row
+  const size_t total = (size_t)p.Mpad * cpr;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const size_t row = idx / cpr; const int c0 = (int)(idx % cpr) * 8;
+    half8 o;
+    if (row < (size_t)p.M) {
+      const half8 x = *reinterpret_cast<const half8*>(p.a.x + row * p.C + c0);
+      half8 rr;
+      if (p.r.x) rr = *reinterpret_cast<const half8*>(p.r.x + row * p.C + c0);
+      else if (p.res) rr = *reinterpret_cast<const half8*>(p.res + row * p.C + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = fmaf((float)x[j], sc[c0 + j], sh[c0 + j]);
+        if (p.r.x) v += fmaf((float)rr[j], scr[c0 + j], shr[c0 + j]);
+        else if (p.res) v += (float)rr[j];
+        if (p.relu) v = fmaxf(v, 0.f);
+        o[j] = (half_t)v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (half_t)0.f;
+    }
+    *reinterpret_cast<half8*>(p.out + row * p.C + c0) = o;
+  }
+}
+
+// stem: out[32^3-like][64] = maxpool3(s2,p1)( relu(bn(x)) ), x pre-BN [din^3][64]
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnSrc s, int din, int dout, size_t m_in, half_t* __restrict__ out) {
+  __shared__ float sc[64], sh[64];
+  if (threadIdx.x < 64) bn_scale_shift(s, threadIdx.x, 1.f / (float)m_in, sc[threadIdx.x], sh[threadIdx.x]);
+  __syncthreads();
+  const size_t total = cube(dout) * 8;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t vox = idx >> 3; const int c0 = (int)(idx & 7) * 8;
+  const int x = (int)(vox % dout), y = (int)((vox / dout) % dout), z = (int)(vox / ((size_t)dout * dout));
+  float best[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) best[j] = -3.0e38f;
+  for (int dz = -1; dz <= 1; ++dz) {
+    const int iz = 2 * z + dz; if ((unsigned)iz >= (unsigned)din) continue;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int iy = 2 * y + dy; if ((unsigned)iy >= (unsigned)din) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int ix = 2 * x + dx; if ((unsigned)ix >= (unsigned)din) continue;
+        const half8 v = *reinterpret_cast<const half8*>(s.x + (((size_t)iz * din + iy) * din + ix) * 64 + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], fmaxf(fmaf((float)v[j], sc[c0 + j], sh[c0 + j]), 0.f));
+      }
+    }
+  }
+  half8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (half_t)best[j];
+  *reinterpret_cast<half8*>(out + vox * 64 + c0) = o;
+}
+
+// AvgPool3d over all remaining voxels (NeRAF_resnet3d.py:143/:149): feat[c] = mean_rows x[row][c]; feat pre-zeroed
+__global__ __launch_bounds__(256) void avgpool_kernel(const half_t* __restrict__ x, int M, int C, int rows_per, float* __restrict__ feat) {
+  const int cpr = C >> 3;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int chunk = idx % cpr, grp = idx / cpr;
+  const int r0 = grp * rows_per;
+  if (r0 >= M) return;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < min(M, r0 + rows_per); ++r) {
+    const half8 v = *reinterpret_cast<const half8*>(x + (size_t)r * C + chunk * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+  }
+  const float inv = 1.f / (float)M;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) atomicAdd(feat + chunk * 8 + j, s[j] * inv);
+}
+
+// running_mean / running_var update of nn.BatchNorm3d in training mode (momentum m, unbiased variance)
+__global__ void bn_update_running_kernel(const float* __restrict__ stats, int cpad, int C, float inv_m, float unbias, float mom,
+                                         float* __restrict__ rmean, float* __restrict__ rvar) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = stats[c] * inv_m;
+  const float var = fmaxf(stats[cpad + c] * inv_m - mean * mean, 0.f);
+  rmean[c] = (1.f - mom) * rmean[c] + mom * mean;
+  rvar[c] = (1.f - mom) * rvar[c] + mom * var * unbias;
+}
+
+int run_conv(neraf_ctx* ctx, hipStream_t st, const Arch& A, const Layout& L, int ci, const char* packed, char* ws,
+             const half_t* input) {
+  const ConvSpec& c = A.conv[ci];
+  GemmParams g{};
+  const int M = (int)cube(c.dout);
+  g.A = input; g.lda = c.cin;
+  g.B = (const half_t*)(packed + L.w[ci]); g.ldb = conv_kpad(c);
+  g.M = M; g.N = c.cout; g.K = conv_kpad(c); g.Mpad = (int)rows_pad(c.dout); g.Npad = conv_npad(c); g.alpha = 1.f;
+  g.tile_n = c.cout == 64 ? 64 : 0;
+  g.C16 = (half_t*)(ws + L.pre[ci]); g.ldc16 = c.cout;
+  float* stats = (float*)(ws + L.stat[ci]);
+  g.colsum = stats; g.colsumsq = stats + round_up(c.cout, 128);
+  g.splitk_ws = (float*)(ws + L.splitk); g.splitk_ws_bytes = L.splitk_bytes;
+  if (c.k == 1 && c.stride == 1) {
+    g.conv.loader = 0;
+  } else {
+    g.conv.loader = c.cin == 8 ? 2 : 1;
+    g.conv.din = c.din; g.conv.dout = c.dout; g.conv.stride = c.stride; g.conv.pad = c.pad; g.conv.ksize = c.k; g.conv.cin = c.cin;
+    g.conv.zero_page = (const half_t*)(ws + L.zero_page);
+  }
+  return launch_gemm_f16(ctx, g, st);
+}
+
+BnSrc bn_src(const half_t* x, const float* stats, const float* const* bn, int ci, int cout, int use_batch) {
+  BnSrc s{};
+  s.x = x; s.stats = use_batch ? stats : nullptr;
+  s.gamma = bn[4 * ci + 0]; s.beta = bn[4 * ci + 1]; s.rmean = bn[4 * ci + 2]; s.rvar = bn[4 * ci + 3];
+  s.cpad = round_up(cout, 128);
+  return s;
+}
+
+int run_bn_apply(neraf_ctx* ctx, hipStream_t st, const BnApplyArgs& a) {
+  const size_t total = (size_t)a.Mpad * (a.C >> 3);
+  long blocks = (long)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * a.C * sizeof(float), st, a);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" int neraf_resnet3d_num_convs(const neraf_resnet3d_desc* d) {
+  Arch A;
+  if (make_arch(d, &A)) return -1;
+  return A.nconv;
+}
+
+extern "C" size_t neraf_resnet3d_packed_bytes(const neraf_resnet3d_desc* d) {
+  Arch A; Layout L;
+  if (make_arch(d, &A)) return 0;
+  make_layout(A, &L);
+  return L.packed_total;
+}
+
+extern "C" size_t neraf_resnet3d_workspace_bytes(const neraf_resnet3d_desc* d) {
+  Arch A; Layout L;
+  if (make_arch(d, &A)) return 0;
+  make_layout(A, &L);
+  return L.total;
+}
+
+extern "C" int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const float* const* conv_w, void* packed,
+                                           neraf_stream_t stream) {
+  Arch A; Layout L;
+  if (make_arch(d, &A) || !conv_w || !packed) return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_pack_weights: bad arguments");
+  make_layout(A, &L);
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < A.nconv; ++i) {
+    const ConvSpec& c = A.conv[i];
+    const int npad = conv_npad(c), kpad = conv_kpad(c), taps = c.k * c.k * c.k;
+    const size_t n = (size_t)npad * kpad;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, conv_w[i], c.cout,
+                       i == 0 ? d->in_channels : c.cin, c.cin, taps, npad, kpad, (half_t*)((char*)packed + L.w[i]));
+  }
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed_, const float* const* bn,
+                                  const float* grid, void* workspace, float* feat, int use_batch_stats,
+                                  neraf_stream_t stream) {
+  Arch A; Layout L;
+  if (make_arch(d, &A) || !packed_ || !bn || !grid || !workspace || !feat)
+    return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_fwd: bad arguments (grid_size 64|128, in_channels 7, n_features 1024)");
+  make_layout(A, &L);
+  hipStream_t st = (hipStream_t)stream;
+  const char* packed = (const char*)packed_;
+  char* ws = (char*)workspace;
+  NERAF_HIP_CHECK(ctx, hipMemsetAsync(ws + L.zero_page, 0, 256, st));
+  NERAF_HIP_CHECK(ctx, hipMemsetAsync(ws + L.stats_begin, 0, L.stats_bytes, st));
+  NERAF_HIP_CHECK(ctx, hipMemsetAsync(feat, 0, 1024 * sizeof(float), st));
+  const size_t nvox = cube(A.S);
+  hipLaunchKernelGGL(grid_to_ndhwc8_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, grid, nvox, (half_t*)(ws + L.x0));
+  // stem: conv1 -> bn1 -> relu -> maxpool (NeRAF_resnet3d.py:185-188)
+  if (int e = run_conv(ctx, st, A, L, 0, packed, ws, (const half_t*)(ws + L.x0))) return e;
+  {
+    const ConvSpec& c = A.conv[0];
+    BnSrc s = bn_src((const half_t*)(ws + L.pre[0]), (const float*)(ws + L.stat[0]), bn, 0, 64, use_batch_stats);
+    const size_t total = cube(A.pooled) * 8;
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, c.dout, A.pooled,
+                       cube(c.dout), (half_t*)(ws + L.act_pool));
+    NERAF_HIP_CHECK(ctx, hipGetLastError());
+  }
+  const half_t* x = (const half_t*)(ws + L.act_pool);
+  for (int b = 0; b < A.nblock; ++b) {                                        // Bottleneck.forward, :92-113
+    const BlockSpec& B = A.block[b];
+    const int i0 = B.conv[0], i1 = B.conv[1], i2 = B.conv[2];
+    const ConvSpec &c0 = A.conv[i0], &c1 = A.conv[i1], &c2 = A.conv[i2];
+    if (int e = run_conv(ctx, st, A, L, i0, packed, ws, x)) return e;
+    BnApplyArgs a{};
+    a.a = bn_src((const half_t*)(ws + L.pre[i0]), (const float*)(ws + L.stat[i0]), bn, i0, c0.cout, use_batch_stats);
+    a.M = (int)cube(c0.dout); a.Mpad = (int)rows_pad(c0.dout); a.C = c0.cout; a.relu = 1; a.out = (half_t*)(ws + L.a1[b]);
+    if (int e = run_bn_apply(ctx, st, a)) return e;
+    if (int e = run_conv(ctx, st, A, L, i1, packed, ws, (const half_t*)(ws + L.a1[b]))) return e;
+    BnApplyArgs a2{};
+    a2.a = bn_src((const half_t*)(ws + L.pre[i1]), (const float*)(ws + L.stat[i1]), bn, i1, c1.cout, use_batch_stats);
+    a2.M = (int)cube(c1.dout); a2.Mpad = (int)rows_pad(c1.dout); a2.C = c1.cout; a2.relu = 1; a2.out = (half_t*)(ws + L.a2[b]);
+    if (int e = run_bn_apply(ctx, st, a2)) return e;
+    if (int e = run_conv(ctx, st, A, L, i2, packed, ws, (const half_t*)(ws + L.a2[b]))) return e;
+    BnApplyArgs a3{};
+    a3.a = bn_src((const half_t*)(ws + L.pre[i2]), (const float*)(ws + L.stat[i2]), bn, i2, c2.cout, use_batch_stats);
+    if (B.ds >= 0) {
+      if (int e = run_conv(ctx, st, A, L, B.ds, packed, ws, x)) return e;
+      a3.r = bn_src((const half_t*)(ws + L.pre[B.ds]), (const float*)(ws + L.stat[B.ds]), bn, B.ds, c2.cout, use_batch_stats);
+    } else {
+      a3.res = x;
+    }
+    a3.M = (int)cube(c2.dout); a3.Mpad = (int)rows_pad(c2.dout); a3.C = c2.cout; a3.relu = 1; a3.out = (half_t*)(ws + L.out[b]);
+    if (int e = run_bn_apply(ctx, st, a3)) return e;
+    x = (const half_t*)(ws + L.out[b]);
+  }
+  {
+    const int M = (int)cube(A.final_edge), C = 1024, rows_per = 16;
+    const int groups = (M + rows_per - 1) / rows_per;
+    const int threads = groups * (C >> 3);
+    hipLaunchKernelGGL(avgpool_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, x, M, C, rows_per, feat);
+    NERAF_HIP_CHECK(ctx, hipGetLastError());
+  }
+  return NERAF_OK;
+}
+
+extern "C" int neraf_resnet3d_update_running_stats(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* workspace,
+                                                   float* const* bn, float momentum, neraf_stream_t stream) {
+  Arch A; Layout L;
+  if (make_arch(d, &A) || !workspace || !bn) return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_update_running_stats: bad arguments");
+  make_layout(A, &L);
+  const char* ws = (const char*)workspace;
+  for (int i = 0; i < A.nconv; ++i) {
+    const ConvSpec& c = A.conv[i];
+    const float m = (float)cube(c.dout);
+    hipLaunchKernelGGL(bn_update_running_kernel, dim3((c.cout + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)(ws + L.stat[i]), round_up(c.cout, 128), c.cout, 1.f / m, m / (m - 1.f), momentum,
+                       bn[4 * i + 2], bn[4 * i + 3]);
+  }
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}

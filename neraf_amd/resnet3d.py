@@ -1,0 +1,131 @@
+"""Host-side mirror of ``NeRAF/NeRAF_resnet3d.py`` (``ResNet3D_helper`` :266-285, ``ResNet3D`` :116-201,
+``Bottleneck`` :76-113) on libneraf_hip.
+
+The module tree only holds parameters: it reproduces the reference's sub-module names so that state-dict
+keys are identical (``backbone_net.conv1.weight``, ``backbone_net.layer2.0.downsample.1.running_var`` ...)
+and reference checkpoints load with ``load_state_dict``.  ``forward`` never calls a torch conv: it hands
+the 43 Conv3d weights and 43 BatchNorm3d parameter sets to ``neraf_resnet3d_fwd`` (implicit-GEMM MFMA
+convolutions with fused BN statistics, include/neraf_hip.h).  Forward only in round 1: the returned
+feature carries no autograd graph (the backward kernels are the next build row).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .field import _dev_index, _stream_ptr
+
+
+class _Bottleneck(nn.Module):
+    """Parameter container with the attribute names of the reference Bottleneck (NeRAF_resnet3d.py:79-90)."""
+    expansion = 4
+
+    def __init__(self, in_planes: int, planes: int, stride: int, with_downsample: bool):
+        super().__init__()
+        self.conv1 = nn.Conv3d(in_planes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm3d(planes)
+        self.conv2 = nn.Conv3d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm3d(planes)
+        self.conv3 = nn.Conv3d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm3d(planes * 4)
+        self.downsample = None
+        if with_downsample:
+            self.downsample = nn.Sequential(nn.Conv3d(in_planes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                                            nn.BatchNorm3d(planes * 4))
+
+    def conv_bn_pairs(self):
+        pairs = [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+        if self.downsample is not None:
+            pairs.append((self.downsample[0], self.downsample[1]))
+        return pairs
+
+
+class ResNet3D(nn.Module):
+    """'resnet50' layout truncated after layer3 (N_features = 1024), NeRAF_resnet3d.py:116-165."""
+
+    def __init__(self, in_channels: int = 7, layers=(3, 4, 6), grid_step: float = 1 / 128, N_features: int = 1024):
+        super().__init__()
+        if N_features != 1024 or in_channels != 7 or tuple(layers) != (3, 4, 6):
+            raise NotImplementedError("the HIP scene encoder implements the configuration NeRAF uses: "
+                                      "in_channels=7, resnet50[3,4,6], N_features=1024 (NeRAF_model.py:185)")
+        if grid_step >= 1 / 64 - 1 / 512:
+            self.grid_size = 64
+        elif grid_step >= 1 / 128 - 1 / 512:
+            self.grid_size = 128
+        else:
+            raise NotImplementedError("grid_step 1/256 is not supported by the HIP scene encoder yet")
+        self.conv1 = nn.Conv3d(in_channels, 64, kernel_size=5, stride=2, padding=2, bias=False)
+        self.bn1 = nn.BatchNorm3d(64)
+        in_planes = 64
+        for li, (planes, nblocks, stride) in enumerate(zip((64, 128, 256), layers, (1, 2, 2)), start=1):
+            blocks = []
+            for b in range(nblocks):
+                s = stride if b == 0 else 1
+                blocks.append(_Bottleneck(in_planes, planes, s, b == 0 and (s != 1 or in_planes != planes * 4)))
+                in_planes = planes * 4
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        self.N_features = N_features
+        for m in self.modules():                                   # NeRAF_resnet3d.py:160-165
+            if isinstance(m, nn.Conv3d):
+                nn.init.xavier_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm3d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+        self._desc = _lib.ResnetDesc(self.grid_size, in_channels, N_features)
+        self._ws = None
+
+    def conv_bn_pairs(self):
+        pairs = [(self.conv1, self.bn1)]
+        for li in (1, 2, 3):
+            for blk in getattr(self, f"layer{li}"):
+                pairs += blk.conv_bn_pairs()
+        return pairs
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x fp32 [1,7,S,S,S] -> [1,1024,1,1,1] (NeRAF_resnet3d.py:184-198)."""
+        lib = _lib.load()
+        S = self.grid_size
+        if tuple(x.shape) != (1, 7, S, S, S):
+            raise ValueError(f"expected a [1,7,{S},{S},{S}] grid, got {tuple(x.shape)}")
+        dev = _dev_index(x)
+        h, st = _lib.ctx(dev), _stream_ptr()
+        grid = x.detach().float().contiguous()
+        pairs = self.conv_bn_pairs()
+        assert len(pairs) == lib.neraf_resnet3d_num_convs(C.byref(self._desc))
+        conv_w: List[torch.Tensor] = [c.weight.detach().contiguous() for c, _ in pairs]
+        bn: List[torch.Tensor] = []
+        for _, b in pairs:
+            bn += [b.weight.detach(), b.bias.detach(), b.running_mean, b.running_var]
+        packed = torch.empty(lib.neraf_resnet3d_packed_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.neraf_resnet3d_pack_weights(h, C.byref(self._desc), _lib.ptr_array(conv_w), packed.data_ptr(), st), dev)
+        if self._ws is None or self._ws.device != x.device:
+            self._ws = torch.empty(lib.neraf_resnet3d_workspace_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
+        feat = torch.empty(1024, dtype=torch.float32, device=x.device)
+        _lib.check(lib.neraf_resnet3d_fwd(h, C.byref(self._desc), packed.data_ptr(), _lib.ptr_array(bn), grid.data_ptr(),
+                                          self._ws.data_ptr(), feat.data_ptr(), int(self.training), st), dev)
+        if self.training:
+            mom = pairs[0][1].momentum if pairs[0][1].momentum is not None else 0.1
+            if mom > 0:
+                _lib.check(lib.neraf_resnet3d_update_running_stats(h, C.byref(self._desc), self._ws.data_ptr(),
+                                                                   _lib.ptr_array(bn), float(mom), st), dev)
+                for _, b in pairs:
+                    b.num_batches_tracked += 1
+        return feat.reshape(1, 1024, 1, 1, 1)
+
+
+class ResNet3D_helper(nn.Module):
+    """Same constructor and attribute (``backbone_net``) as the reference helper (NeRAF_resnet3d.py:266-285)."""
+
+    def __init__(self, in_channels: int = 3, backbone: str = "resnet50", pretrained: bool = False, grid_step=None,
+                 N_features: int = 1024):
+        super().__init__()
+        if backbone != "resnet50" or pretrained:
+            raise NotImplementedError("only backbone='resnet50', pretrained=False (what NeRAF instantiates, NeRAF_model.py:185)")
+        self.backbone_net = ResNet3D(in_channels, (3, 4, 6), grid_step if grid_step is not None else 1 / 128, N_features)
+
+    def forward(self, x):
+        return self.backbone_net(x)
