@@ -200,6 +200,12 @@ int neraf_composite(neraf_ctx* ctx, const float* density, const float* rgb, cons
                     int training, float* weights, float* rgb_out, float* depth, float* expected, float* acc,
                     void* scratch8, neraf_stream_t stream);
 
+/* Grid refresh epilogue of query_grid_one_batch (NeRAF_model.py:352-357,386,395-400): mean over the ndirs
+ * view directions of rgb [ndirs*n,3] / density [ndirs*n] (direction-major), alpha = clip(1-exp(-delta d)),
+ * written to channels 0..3 of grid fp32 [7, nvox] at flat cells [start, start+n). */
+int neraf_grid_refresh_write(neraf_ctx* ctx, const float* rgb, const float* density, int n, int ndirs, float delta,
+                             float* grid, size_t nvox, size_t start, neraf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * ResNet3D scene encoder (ResNet3D_helper / ResNet3D.forward, NeRAF_resnet3d.py:116-201,266-285;
  * backbone 'resnet50' truncated after layer3, N_features = 1024; called at NeRAF_model.py:554-558

@@ -453,9 +453,42 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
   }
 }
 
+// ---- grid refresh epilogue (NeRAF_model.py:352-357, :386, :395-400) ---------------------------------------
+// rgb [ndirs*n,3], density [ndirs*n] (direction-major, as the reference concatenates them :327-333) -> per-cell mean
+// over the view directions, alpha = clip(1 - exp(-delta * density), 0, 1), written into channels 0..3 of the
+// [7,S,S,S] grid at flat cells [start, start+n).  The refresh window is contiguous in the grid's x-major order
+// (coordinates_to_render, :200-202), so the four index_put scatters are four contiguous slab writes.
+__global__ __launch_bounds__(256) void grid_refresh_write_kernel(const float* __restrict__ rgb, const float* __restrict__ density,
+                                                                int n, int ndirs, float delta, float* __restrict__ grid,
+                                                                size_t nvox, size_t start) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float r = 0.f, g = 0.f, b = 0.f, d = 0.f;
+  for (int j = 0; j < ndirs; ++j) {
+    const size_t k = (size_t)j * n + i;
+    r += rgb[k * 3 + 0]; g += rgb[k * 3 + 1]; b += rgb[k * 3 + 2]; d += density[k];
+  }
+  const float inv = 1.f / (float)ndirs;
+  const float alpha = fminf(fmaxf(1.f - __expf(-delta * d * inv), 0.f), 1.f);
+  grid[0 * nvox + start + i] = r * inv;
+  grid[1 * nvox + start + i] = g * inv;
+  grid[2 * nvox + start + i] = b * inv;
+  grid[3 * nvox + start + i] = alpha;
+}
+
 }  // namespace
 
 // =================================================================================================
+extern "C" int neraf_grid_refresh_write(neraf_ctx* ctx, const float* rgb, const float* density, int n, int ndirs, float delta,
+                                        float* grid, size_t nvox, size_t start, neraf_stream_t stream) {
+  if (!rgb || !density || !grid || n <= 0 || ndirs <= 0 || start + (size_t)n > nvox)
+    return neraf_fail(ctx, NERAF_EINVAL, "grid_refresh_write: bad arguments");
+  hipLaunchKernelGGL(grid_refresh_write_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rgb, density, n, ndirs,
+                     delta, grid, nvox, start);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
 extern "C" int neraf_grid_layout(const neraf_grid_desc* g, float* scales, int* resolutions, uint32_t* sizes,
                                  uint32_t* offsets) {
   GridLayout L;

@@ -1,0 +1,236 @@
+"""Host-side mirror of ``NeRAFAudioModel`` (NeRAF_model.py:104-805) on libneraf_hip.
+
+Keeps the reference's config fields (``NeRAFAudioModelConfig`` :83-101), method names and state-dict key
+prefixes (``field.soundfield.*``, ``field.STFT_linear.*``, ``resnet3d.backbone_net.*``, ``grid``), so that
+``NeRAFPipeline`` (NeRAF_pipeline.py:135-222) can drive it unchanged:
+
+    query_grid_one_batch(step, vision_field, renderer_rgb, batch_size)   :294-407
+    get_outputs(batch_audio) -> Tensor [B,C,F]                           :531-566
+    get_loss_dict(outputs, batch)                                        :584-600
+    get_outputs_for_camera(None, None, batch_audio) -> dict              :610-728  (eval branch, camera=None)
+    get_param_groups() -> {"audio_fields": [...]}                        :730-737
+
+Everything numeric runs in HIP kernels through the C ABI; there is no fallback without the GPU library.
+Differences from the reference that are deliberate (and cheaper):
+  * the voxel grid and the refresh frustums live on the device (the reference builds them on the CPU and
+    copies 73,728 frustums per step, :311-337);
+  * the ResNet3D feature is cached between calls while the grid and the encoder weights are unchanged
+    (the reference recomputes it for every eval RIR, :680-684, although the grid is static).
+Round-1 limits: the refresh does not yet carry the autograd edge from the grid into the radiance field
+(NeRAF_model.py:395-400 keeps it), and the ResNet3D is forward-only, so the audio loss trains the NAcF MLP.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .field import NeRAFAudioSoundField, _dev_index, _stream_ptr
+from .losses import STFTLoss
+from .resnet3d import ResNet3D_helper
+from .vision import FieldHeadNames, Frustums, RaySamples
+
+
+@dataclass
+class NeRAFAudioModelConfig:
+    """Fields and defaults of the reference config (NeRAF_model.py:88-101)."""
+    dataset: str = "SoundSpaces"
+    use_grid: bool = True
+    grid_step: float = 1 / 128
+    N_features: int = 1024
+    use_multiple_viewing_directions: bool = True
+    loss_factor: float = 1e-3
+    max_len: float = 76
+    W_field: int = 512
+    fs: int = 22050
+    criterion: str = "SC+SLMSE"
+    N_freq_stft: int = 257
+    hop_len: int = 128
+    win_len: int = 512
+
+
+class NeRAFAudioModel(nn.Module):
+    def __init__(self, config: NeRAFAudioModelConfig, aabb: torch.Tensor, process_group=None):
+        """``aabb`` [2,3] is the audio scene box (mic bounding box +- 1 m, NeRAF_dataparser.py:155-161)."""
+        super().__init__()
+        self.config = config
+        self.register_buffer("aabb", aabb.float())
+        self.dataset = config.dataset
+        if self.dataset == "RAF":                                   # default_RAF_config, :109-119, :126-129
+            config.fs, config.max_len = 48000, 0.32
+            config.N_freq_stft, config.hop_len, config.win_len = 513, 256, 512
+            self.max_len = int(config.max_len * config.fs) // config.hop_len
+            self.mic_ch = 1
+        else:                                                       # :131-133
+            self.max_len = int(config.max_len)
+            self.mic_ch = 2
+        self.use_grid = config.use_grid
+        self.loss_factor = config.loss_factor
+        self.criterion_name = config.criterion
+        if self.criterion_name == "MSE":                            # :141-149
+            self.criterion = None
+        else:
+            self.criterion = STFTLoss(loss_type="mse" if "MSE" in self.criterion_name else "l1", process_group=process_group)
+        self.spatial_distortion = None                              # :155, set by the pipeline (NeRAF_pipeline.py:143)
+        n_query = 21 + 63 + 63 + 16                                 # :169-171
+        if self.use_grid:
+            self.grid_size = np.array([0, 1, 0, 1, 0, 1])
+            self.grid_step = config.grid_step
+            self.N_features = config.N_features
+            self.resnet3d = ResNet3D_helper(in_channels=7, backbone="resnet50", pretrained=False, grid_step=self.grid_step,
+                                            N_features=self.N_features)                                    # :185
+            self.field = NeRAFAudioSoundField(self.N_features + n_query, config.W_field, sound_rez=self.mic_ch,
+                                              N_frequencies=config.N_freq_stft)                            # :189
+            self._delta = 1e-2                                                                             # :191
+            self.view_dirs = self._generate_fixed_viewing_directions() if config.use_multiple_viewing_directions else None
+            S = self.resnet3d.backbone_net.grid_size
+            ax = torch.arange(0 + self.grid_step / 2, 1, self.grid_step)                                   # :200
+            coords = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).view(-1, 3)
+            self.register_buffer("coordinates_to_render", coords, persistent=False)                       # :202
+            self.grid_batch_i = 0                                                                          # :203
+            self.register_buffer("grid", self._fresh_grid(S, ax), persistent=True)   # the pipeline checkpoints it (NeRAF_pipeline.py:492-497)
+        else:
+            self.field = NeRAFAudioSoundField(n_query, config.W_field, sound_rez=self.mic_ch, N_frequencies=config.N_freq_stft)  # :207
+        self._feat_cache = None
+        self._feat_key = None
+        self.eval_source_pose = self.eval_mic_pose = self.eval_rot = self.eval_gt = None
+
+    # ---- A2: grid --------------------------------------------------------------------------------
+    @staticmethod
+    def _fresh_grid(S: int, ax: torch.Tensor) -> torch.Tensor:
+        g = torch.zeros((7, S, S, S), dtype=torch.float32)
+        g[4:] = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=0)          # :275-277
+        return g
+
+    def reset_grid(self, device=None):                                                  # :269-277
+        S = self.grid.shape[1]
+        ax = torch.arange(0 + self.grid_step / 2, 1, self.grid_step)
+        self.grid.copy_(self._fresh_grid(S, ax).to(self.grid.device))
+        self._feat_key = None
+
+    def _generate_fixed_viewing_directions(self) -> torch.Tensor:                       # :279-292, reproduced literally
+        phis = [math.pi / 3, 0, -math.pi]
+        thetas = [k * math.pi / 3 for k in range(0, 6)]
+        v = [torch.Tensor([math.cos(p) * math.sin(t), math.cos(p) * math.sin(t), math.sin(t)]) for p in phis for t in thetas]
+        return torch.stack(v, dim=0)
+
+    # ---- A3: refresh -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def query_grid_one_batch(self, step, vision_field, renderer_rgb=None, batch_size=4096):
+        if not self.use_grid:
+            return
+        lib = _lib.load()
+        module = vision_field.module
+        saved = module.spatial_distortion
+        module.spatial_distortion = None                                                # :302
+        try:
+            aabb = module.aabb
+            lengths = aabb[1] - aabb[0]
+            n_cells = self.coordinates_to_render.shape[0]
+            i = self.grid_batch_i
+            if i + batch_size > n_cells:                                                # :308-309
+                batch_size = n_cells - i
+            coords = self.coordinates_to_render[i:i + batch_size]
+            ori = coords * lengths + aabb[0]                                            # :315
+            dirs = self.view_dirs.to(ori.device) if self.view_dirs is not None else torch.tensor([[1.0, 0.0, 0.0]], device=ori.device)
+            nd = dirs.shape[0]
+            oris = ori.repeat(nd, 1)                                                    # direction-major concat, :327-333
+            dd = dirs.repeat_interleave(batch_size, dim=0)
+            z = torch.zeros((oris.shape[0], 1), device=ori.device)
+            rs = RaySamples(Frustums(oris, dd, z, z), torch.zeros((oris.shape[0], 1), dtype=torch.int32, device=ori.device))
+            was = module.training
+            module.train(True)           # the reference queries with camera index 0's appearance embedding (:334)
+            out = vision_field.forward(rs)                                              # :339
+            module.train(was)
+            rgb = out[FieldHeadNames.RGB].contiguous()
+            den = out[FieldHeadNames.DENSITY].reshape(-1).contiguous()
+            # renderer_rgb with weights == 1 on a single sample returns rgb unchanged (:344-350); without a renderer the
+            # reference applies a sigmoid to the (already sigmoid) colour (:390)
+            if renderer_rgb is None:
+                rgb = torch.sigmoid(rgb)
+            dev = _dev_index(rgb)
+            nvox = self.grid.shape[1] * self.grid.shape[2] * self.grid.shape[3]
+            _lib.check(lib.neraf_grid_refresh_write(_lib.ctx(dev), rgb.data_ptr(), den.data_ptr(), batch_size, nd, self._delta,
+                                                    self.grid.data_ptr(), nvox, i, _stream_ptr()), dev)
+            self.grid_batch_i += batch_size                                             # :402-404
+            if self.grid_batch_i >= n_cells:
+                self.grid_batch_i = 0
+            self._feat_key = None
+        finally:
+            module.spatial_distortion = saved                                           # :407
+
+    # ---- A4: scene feature -----------------------------------------------------------------------
+    def scene_feature(self) -> torch.Tensor:
+        """ResNet3D(grid) -> [1024].  Cached in eval mode while the grid is untouched."""
+        if not self.training and self._feat_key is not None and self._feat_cache is not None:
+            return self._feat_cache
+        feat = self.resnet3d(self.grid.unsqueeze(0)).flatten()                          # :554-557
+        if not self.training:
+            self._feat_cache, self._feat_key = feat, True
+        return feat
+
+    # ---- A1 + A5 ---------------------------------------------------------------------------------
+    def get_outputs(self, batch_audio: Dict[str, torch.Tensor]) -> torch.Tensor:        # :531-566
+        dev = self.aabb.device
+        feat = self.scene_feature() if self.use_grid else torch.zeros(0, device=dev)
+        if self.training and self.use_grid:
+            feat = feat.detach().requires_grad_(True)       # d loss / d feature is produced (ResNet3D backward: next round)
+        return self.field.forward_queries(feat, batch_audio["time_query"].to(dev), batch_audio["mic_pose"].to(dev),
+                                          batch_audio["source_pose"].to(dev), batch_audio["rot"].to(dev), self.aabb, self.max_len)
+
+    def get_metrics_dict(self, outputs, batch):
+        return {}
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None):                         # :584-600
+        gt = batch["data"].to(outputs.device).float()
+        pred = outputs.float()
+        if self.criterion_name == "MSE":
+            return {"audio_mse": torch.nn.functional.mse_loss(pred, gt) * self.loss_factor}
+        loss = self.criterion(pred, gt)
+        loss["audio_sc_loss"] = loss["audio_sc_loss"] * 1e-1 * self.loss_factor
+        loss["audio_mag_loss"] = loss["audio_mag_loss"] * 1.0 * self.loss_factor
+        return loss
+
+    def set_eval_data(self, eval_source_pose, eval_mic_pose, eval_rot, eval_gt):        # :602-607
+        self.eval_source_pose, self.eval_mic_pose, self.eval_rot, self.eval_gt = eval_source_pose, eval_mic_pose, eval_rot, eval_gt
+
+    # ---- A7: eval branch -------------------------------------------------------------------------
+    @torch.no_grad()
+    def get_outputs_for_camera(self, camera, obb_box, batch_audio=None):                # :610-728 (camera=None branch)
+        if camera is not None:
+            raise NotImplementedError("viewer camera branch (:611-646) is UI code, out of scope (SURVEY.md row 15)")
+        dev = self.aabb.device
+        T = self.max_len
+        tq = torch.arange(0, T, 1, device=dev)                                          # :649
+        mic = batch_audio["mic_pose"].to(dev).reshape(1, 3).expand(T, -1)
+        src = batch_audio["source_pose"].to(dev).reshape(1, 3).expand(T, -1)
+        rot = batch_audio["rot"].to(dev).reshape(1, 3).expand(T, -1)
+        self.set_eval_data(mic[0], src[0], rot[0], batch_audio["data"])                 # :653 (argument order as written there)
+        feat = self.scene_feature() if self.use_grid else torch.zeros(0, device=dev)
+        out = self.field.forward_queries(feat, tq, mic, src, rot, self.aabb, T)         # [T,C,F]
+        stft: Dict[str, torch.Tensor] = {}
+        for ch in range(out.shape[1]):                                                  # :695-700
+            v = out[:, ch, :].transpose(0, 1).unsqueeze(-1).cpu()
+            stft["stft_ch_" + str(ch)] = torch.flip(v, [0])
+        gt = self.eval_gt.to(dev)
+        for ch in range(gt.shape[0]):                                                   # :703-714
+            stft["gt_ch_" + str(ch)] = torch.flip(gt[ch, :, :].unsqueeze(-1).cpu(), [0])
+        for ch in range(gt.shape[0]):
+            stft["comparison_ch_" + str(ch)] = torch.cat([stft["stft_ch_" + str(ch)], stft["gt_ch_" + str(ch)]], dim=1)
+        if self.use_grid:                                                               # :716-723
+            stft["grid"] = self.grid[0:3].mean(dim=3).permute(1, 2, 0)
+            stft["grid_density"] = self.grid[3].mean(dim=2).unsqueeze(-1)
+        stft["raw_output"] = out                                                        # :725-726
+        return stft
+
+    def get_param_groups(self):                                                         # :730-737
+        params = list(self.field.parameters())
+        if self.use_grid:
+            params += list(self.resnet3d.parameters())
+        return {"audio_fields": params}

@@ -1,0 +1,120 @@
+"""GPU tests of the NeRAFAudioModel mirror (neraf_amd/model.py): grid refresh (A3), end-to-end get_outputs (A1+A4+A5),
+loss dict (A6), eval branch (A7), against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from neraf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture(scope="module")
+def models():
+    from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
+    from neraf_amd.vision import NeRAFVisionModel
+    from oracle import vision as V
+    dev = torch.device("cuda:0")
+    spec = V.NerfactoSpec()
+    tot = (spec.prop_grids[0].total, spec.prop_grids[1].total, spec.main_grid.total)
+    P = {k: T(v) for k, v in synth.vision_params(tot, num_train_data=210, table_scale=0.5).items()}
+    vaabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    vm = NeRAFVisionModel(vaabb, 210)
+    with torch.no_grad():
+        f = vm.field.module
+        f.table.copy_(P["field.table"])
+        for k in ("base_w0", "base_w1", "head_w0", "head_w1", "head_w2", "embedding"):
+            getattr(f, k).copy_(P["field." + k])
+    cfg = NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 64)
+    am = NeRAFAudioModel(cfg, T(synth.audio_aabb()))
+    am.field.load_state_dict({k: T(v) for k, v in synth.nacf_state_dict(1187, 512, 1, 513).items()})
+    am.resnet3d.backbone_net.load_state_dict({k: T(v) for k, v in synth.resnet3d_state_dict(7).items()})
+    return vm.to(dev), am.to(dev), {k: v.half().float() for k, v in P.items()}, spec, V, dev
+
+
+def test_state_dict_keys_match_reference_prefixes(models):
+    _, am, *_ = models
+    keys = set(am.state_dict().keys())
+    for k in ("field.soundfield.0.weight", "field.STFT_linear.0.bias", "resnet3d.backbone_net.conv1.weight",
+              "resnet3d.backbone_net.layer3.5.bn3.running_var", "resnet3d.backbone_net.layer2.0.downsample.1.weight", "grid"):
+        assert k in keys, k
+    assert am.max_len == 60 and am.mic_ch == 1 and am.field.in_size == 1187      # RAF: int(0.32*48000)//256 (NeRAF_model.py:128)
+
+
+def test_grid_refresh_vs_oracle(models):
+    """query_grid_one_batch (NeRAF_model.py:294-407): window walk incl. the partial last batch + wrap, 18-direction mean,
+    alpha, slab writes -- against oracle.grid_refresh_scatter (pinned by G4) fed by the oracle field."""
+    from oracle import audio as O
+    vm, am, P16, spec, V, dev = models
+    am.reset_grid()
+    am.grid_batch_i = 64 ** 3 - 4096 - 1000
+    gs = 1 / 64
+    grid_o = O.reset_grid(gs)
+    coords = O.coordinates_to_render(gs)
+    dirs = O.fixed_viewing_directions()
+    aabb = vm.field.module.aabb.cpu()
+    cursor = am.grid_batch_i
+    for _ in range(2):
+        am.query_grid_one_batch(0, vm.field, renderer_rgb=vm.renderer_rgb, batch_size=4096)
+        s, n, cursor = O.refresh_window(cursor, 4096, coords.shape[0])
+        c01 = coords[s:s + n]
+        ori = O.refresh_world_positions(c01, aabb)
+        rgbs, dens = [], []
+        for j in range(18):
+            r, d = V.field_forward(ori, dirs[j].expand(n, -1), torch.zeros(n, dtype=torch.long), P16, spec, contract=False, aabb=aabb)
+            rgbs.append(r); dens.append(d[:, None])
+        grid_o = O.grid_refresh_scatter(grid_o, c01, torch.stack(rgbs).mean(0), torch.stack(dens).mean(0), gs)
+        assert am.grid_batch_i == cursor
+    assert vm.field.module.spatial_distortion == "linf"          # restored (NeRAF_model.py:407)
+    g = am.grid.cpu()
+    np.testing.assert_array_equal(g[4:].numpy(), grid_o[4:].numpy())
+    assert float((g[:3] - grid_o[:3]).abs().max()) <= 4e-3
+    np.testing.assert_allclose(g[3].numpy(), grid_o[3].numpy(), rtol=2e-2, atol=1e-7)
+    assert int((g[3] != 0).sum()) == int((grid_o[3] != 0).sum()) == 5096
+
+
+def test_get_outputs_loss_and_eval_branch(models):
+    from oracle import audio as O
+    vm, am, P16, spec, V, dev = models
+    am.train()
+    for m in am.resnet3d.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.momentum = 0.0
+    B = 256
+    b = {k: T(v) for k, v in synth.audio_batch(B, 1, 513, 60, tag="t.model").items()}
+    y = am.get_outputs({k: v.to(dev) for k, v in b.items()})
+    assert y.shape == (B, 1, 513)
+    # oracle: ResNet3D (train-mode BN) on the same grid -> NAcF
+    sdr = {k: T(v) for k, v in synth.resnet3d_state_dict(7).items()}
+    sdn = {k: T(v) for k, v in synth.nacf_state_dict(1187, 512, 1, 513).items()}
+    with torch.no_grad():
+        feat = O.resnet3d_forward(am.grid.cpu().unsqueeze(0), sdr, train=True).flatten()
+        yo = O.audio_get_outputs(b, feat, sdn, T(synth.audio_aabb()), 60)
+    rel = float((y.detach().cpu() - yo).norm() / yo.norm())
+    assert rel <= 1e-2, rel
+    ld = am.get_loss_dict(y, {k: v.to(dev) for k, v in b.items()})
+    lo = O.audio_loss_dict(yo, b["data"])
+    np.testing.assert_allclose(ld["audio_sc_loss"].item(), lo["audio_sc_loss"].item(), rtol=2e-2)
+    np.testing.assert_allclose(ld["audio_mag_loss"].item(), lo["audio_mag_loss"].item(), rtol=2e-2)
+    (ld["audio_sc_loss"] + ld["audio_mag_loss"]).backward()
+    assert am.field.soundfield[0].weight.grad is not None and bool(torch.isfinite(am.field.soundfield[0].weight.grad).all())
+    # eval branch: T = 60 slices of one RIR
+    am.eval()
+    item = {"mic_pose": b["mic_pose"][5], "source_pose": b["source_pose"][5], "rot": b["rot"][5],
+            "data": T(synth.uniform("t.model.gt", (1, 513, 60), -6.0, 1.0))}
+    out = am.get_outputs_for_camera(None, None, batch_audio=item)
+    assert out["raw_output"].shape == (60, 1, 513) and out["stft_ch_0"].shape == (513, 60, 1)
+    assert out["comparison_ch_0"].shape == (513, 120, 1) and out["grid"].shape == (64, 64, 3) and out["grid_density"].shape == (64, 64, 1)
+    with torch.no_grad():
+        feat_e = O.resnet3d_forward(am.grid.cpu().unsqueeze(0), sdr, train=False).flatten()
+        be = {"time_query": torch.arange(60), "mic_pose": item["mic_pose"].reshape(1, 3).expand(60, -1),
+              "source_pose": item["source_pose"].reshape(1, 3).expand(60, -1), "rot": item["rot"].reshape(1, 3).expand(60, -1)}
+        ye = O.audio_get_outputs(be, feat_e, sdn, T(synth.audio_aabb()), 60)
+    rel = float((out["raw_output"].cpu() - ye).norm() / ye.norm())
+    assert rel <= 1e-2, rel
+    np.testing.assert_array_equal(out["stft_ch_0"][:, :, 0].numpy(), np.flip(out["raw_output"][:, 0, :].cpu().numpy().T, 0))
+    am.train()
