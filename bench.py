@@ -4,14 +4,15 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-A *step* is one training pass of the hot path over one synthetic batch (already resident in HBM):
-``config.workload`` names exactly which stages are inside the timed region.  One process per GPU;
-for N > 1 each rank owns its own shard of RIR slices (weak scaling: per-GPU batch fixed) and the
-gradients are all-reduced over RCCL before the optimizer step.
+A *step* is one pass of NeRAFPipeline.get_train_loss_dict (NeRAF_pipeline.py:166-222) over one synthetic
+batch already resident in HBM, at the RAF FurnishedRoom training shape (4096 rays + 2048 RIR STFT slices of
+513 bins, NeRAF_config.py:57,87); ``config.workload`` states exactly which stages are inside the timed region.
+One process per GPU; for N > 1 every rank owns its own shard of rays and slices (weak scaling) and gradients
+and loss sums are all-reduced over RCCL.
 
-Rank 0 prints ONE JSON line: whole-job field-samples/s (+ ``roofline`` for the dominant kernel,
-measured with HIP events inside the library over an instrumented replay of the same steps, and
-``cpu_baseline`` = the CPU oracle timed on this host on a bounded sample of the same workload).
+Rank 0 prints ONE JSON line: whole-job field-samples/s, plus ``roofline`` for the dominant kernel family
+(HIP-event durations recorded inside the library over an instrumented replay of the same steps) and
+``cpu_baseline`` (the CPU oracle on this host, bounded sample of the same workload).
 """
 import argparse
 import ctypes as C
@@ -28,7 +29,10 @@ import numpy as np
 import torch
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+HBM_PEAK_GBS = 8000.0       # HBM3E spec, same guide
 NACF_DENSE_FLOP_PER_SLICE_FWD = 40_836_464  # SURVEY.md 8(d), RAF head (C*F = 513)
+RESNET_FWD_GFLOP = 94.72
+C_, F_, T_ = 1, 513, 60
 
 
 def parse():
@@ -36,99 +40,133 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (NeRAF_config.py:87)")
     ap.add_argument("--slices", type=int, default=2048, help="RIR STFT slices per GPU per step (NeRAF_config.py:57)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
 
-class AudioBranchStep:
-    """RAF FurnishedRoom audio branch of NeRAFPipeline.get_train_loss_dict (NeRAF_pipeline.py:186-199):
-    next audio batch (synthetic, resident) -> NeRAFAudioModel.get_outputs (query prologue + NAcF MLP,
-    NeRAF_model.py:531-566) -> STFTLoss + scaling (:584-600) -> backward (all NAcF parameter grads +
-    d/d(grid feature)) -> [RCCL grad all-reduce] -> GradScaler + Adam step (NeRAF_config.py:124-127)."""
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
 
-    C_, F_, T_ = 1, 513, 60
 
-    def __init__(self, dev, B, world):
+class JointStep:
+    """cfg3 (RAF FurnishedRoom joint) step with the stages that exist in HIP today:
+       1. NeRAFVisionModel.get_outputs on the ray batch (sampler, 2 proposal nets, 2 PDF resamplings, fused field
+          query, composite)                                            -- FORWARD ONLY (vision backward: next round)
+       2. audio_model.query_grid_one_batch: 4096 cells x 18 directions through the field, mean, slab write
+       3. ResNet3D(7x128^3 grid) -> 1024 feature (train-mode BatchNorm)  -- FORWARD ONLY
+       4. audio get_outputs (GPU prologue + NAcF MLP) -> STFT loss -> backward (all NAcF grads + d/d feature)
+          -> [RCCL all-reduce] -> GradScaler + fused Adam on the NAcF parameters."""
+
+    def __init__(self, dev, R, B, world):
         from neraf_amd import synth
-        from neraf_amd.field import NeRAFAudioSoundField
-        from neraf_amd.losses import STFTLoss
-        self.dev, self.B, self.world = dev, B, world
+        from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
+        from neraf_amd.vision import NeRAFVisionModel, RayBundle
+        self.dev, self.R, self.B, self.world = dev, R, B, world
         rank = int(os.environ.get("RANK", "0"))
-        sd = {k: torch.from_numpy(v) for k, v in synth.nacf_state_dict(1187, 512, self.C_, self.F_).items()}
-        self.field = NeRAFAudioSoundField(1187, 512, sound_rez=self.C_, N_frequencies=self.F_)
-        self.field.load_state_dict(sd)
-        self.field.to(dev)
-        b = synth.audio_batch(B, self.C_, self.F_, self.T_, tag=f"bench.r{rank}")
-        self.batch = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in b.items()}
-        self.aabb = torch.from_numpy(synth.audio_aabb())
-        # stand-in for the ResNet3D scene feature until that stage is inside the step (requires grad: dfeat is computed)
-        self.feat = torch.from_numpy(synth.uniform("bench.feat", (1024,), 0.0, 2.0)).to(dev).requires_grad_(True)
-        self.crit = STFTLoss("mse", process_group=True if world > 1 else None)
-        self.params = list(self.field.parameters())
+        self.vm = NeRAFVisionModel(torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]), 210).to(dev)
+        with torch.no_grad():      # trained-like table magnitudes (synthetic, same on every rank)
+            g = torch.Generator(device="cpu").manual_seed(0)
+            for p in [self.vm.field.module.table] + [pn.table for pn in self.vm.proposal_networks]:
+                p.copy_((torch.rand(p.shape, generator=g) - 0.5).to(dev))
+        self.am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 128), T(synth.audio_aabb()),
+                                  process_group=True if world > 1 else None)
+        self.am.field.load_state_dict({k: T(v) for k, v in synth.nacf_state_dict(1187, 512, C_, F_).items()})
+        self.am.resnet3d.backbone_net.load_state_dict({k: T(v) for k, v in synth.resnet3d_state_dict(7).items()})
+        self.am.to(dev)
+        self.vm.train(); self.am.train()
+        rb = synth.ray_batch(R, tag=f"bench.rays.r{rank}")
+        self.bundle = RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev))
+        self.batch = {k: T(v).to(dev) for k, v in synth.audio_batch(B, C_, F_, T_, tag=f"bench.r{rank}").items()}
+        self.params = list(self.am.field.parameters())
         try:
             self.opt = torch.optim.Adam(self.params, lr=1e-4, eps=1e-15, fused=True)
         except Exception:
             self.opt = torch.optim.Adam(self.params, lr=1e-4, eps=1e-15, foreach=True)
         self.scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
-        self.flat = None
+        self.i = 0
 
     def samples_per_step(self):
-        return self.B * self.C_ * self.F_
+        return self.R + self.B * C_ * F_
 
     def step(self):
-        bt = self.batch
+        self.i += 1
+        self.vm.update_to_step(self.i)
+        out_v = self.vm.get_outputs(self.bundle)                                                   # NeRAF_pipeline.py:176
+        self.am.query_grid_one_batch(self.i, self.vm.field, renderer_rgb=self.vm.renderer_rgb, batch_size=self.R)  # :181-184
         self.opt.zero_grad(set_to_none=True)
-        self.feat.grad = None
-        y = self.field.forward_queries(self.feat, bt["time_query"], bt["mic_pose"], bt["source_pose"], bt["rot"],
-                                       self.aabb, self.T_)
-        d = self.crit(y, bt["data"])
-        loss = d["audio_sc_loss"] * 1e-1 * 1e-3 + d["audio_mag_loss"] * 1.0 * 1e-3   # NeRAF_model.py:597-598
+        y = self.am.get_outputs(self.batch)                                                        # :188
+        d = self.am.get_loss_dict(y, self.batch)                                                   # :191
+        loss = d["audio_sc_loss"] + d["audio_mag_loss"]
         self.scaler.scale(loss).backward()
         if self.world > 1:
             from neraf_amd.parallel import allreduce_gradients
             allreduce_gradients(self.params, self.world)
         self.scaler.step(self.opt)
         self.scaler.update()
-        return loss
+        return out_v["rgb"], loss
 
 
-def cpu_baseline(B, seconds):
-    """The oracle (torch-CPU restatement, pinned to the reference on G1-G5) on the same workload:
-    prologue + NAcF fwd + STFT loss + backward + Adam, all host cores."""
+def cpu_baseline(R, B):
+    """The CPU oracle (torch fp32; audio half pinned to the reference on G1-G5, radiance half unpinned) timed on this
+    host for the SAME stages.  A full step costs ~1 min of CPU, so the ray/slice-proportional stages are timed on a
+    1/8 sample and scaled by 8 while the per-step-constant ResNet3D forward is timed in full; the figure reported is
+    samples_per_step / extrapolated step time."""
     from neraf_amd import synth
     from oracle import audio as O
-    ncores = os.cpu_count() or 1
+    from oracle import vision as V
+    ncores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(ncores)
-    C_, F_, T_ = AudioBranchStep.C_, AudioBranchStep.F_, AudioBranchStep.T_
-    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.nacf_state_dict(1187, 512, C_, F_).items()}
-    b = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.audio_batch(B, C_, F_, T_, tag="bench.r0").items()}
-    aabb = torch.from_numpy(synth.audio_aabb())
-    feat = torch.from_numpy(synth.uniform("bench.feat", (1024,), 0.0, 2.0)).requires_grad_(True)
-    opt = torch.optim.Adam(list(sd.values()), lr=1e-4, eps=1e-15)
+    frac = 8
+    r, b = R // frac, B // frac
+    spec = V.NerfactoSpec()
+    tot = (spec.prop_grids[0].total, spec.prop_grids[1].total, spec.main_grid.total)
+    P = {k: T(v) for k, v in synth.vision_params(tot, num_train_data=210, table_scale=0.5).items()}
+    rb = synth.ray_batch(r, tag="bench.rays.r0")
+    sdn = {k: T(v).requires_grad_(True) for k, v in synth.nacf_state_dict(1187, 512, C_, F_).items()}
+    sdr = {k: T(v) for k, v in synth.resnet3d_state_dict(7).items()}
+    ab = {k: T(v) for k, v in synth.audio_batch(b, C_, F_, T_, tag="bench.r0").items()}
+    aabb = T(synth.audio_aabb())
+    grid = O.reset_grid(1 / 128)
+    coords = O.coordinates_to_render(1 / 128)[:r]
+    dirs = O.fixed_viewing_directions()
+    vaabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    opt = torch.optim.Adam(list(sdn.values()), lr=1e-4, eps=1e-15)
+    t = {}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        V.nerfacto_forward(T(rb["origins"]), T(rb["directions"]), T(rb["camera_indices"]), P, spec, training=True,
+                           jitters=[T(j) for j in rb["jitters"]])
+        t["vision_fwd"] = (time.perf_counter() - t0) * frac
+        t0 = time.perf_counter()
+        ori = O.refresh_world_positions(coords, vaabb)
+        rg, dn = [], []
+        for j in range(18):
+            a, d_ = V.field_forward(ori, dirs[j].expand(r, -1), torch.zeros(r, dtype=torch.long), P, spec, contract=False, aabb=vaabb)
+            rg.append(a); dn.append(d_[:, None])
+        grid = O.grid_refresh_scatter(grid, coords, torch.stack(rg).mean(0), torch.stack(dn).mean(0), 1 / 128)
+        t["refresh"] = (time.perf_counter() - t0) * frac
+        O.resnet3d_forward(grid.unsqueeze(0), sdr, train=True)   # warm-up
+        t0 = time.perf_counter()
+        feat = O.resnet3d_forward(grid.unsqueeze(0), sdr, train=True).flatten()
+        t["resnet3d_fwd"] = time.perf_counter() - t0
 
-    def one():
+    def audio():
         opt.zero_grad(set_to_none=True)
-        feat.grad = None
-        y = O.audio_get_outputs(b, feat, sd, aabb, T_)
-        l = O.audio_loss_dict(y, b["data"])
+        f = feat.clone().requires_grad_(True)
+        y = O.audio_get_outputs(ab, f, sdn, aabb, T_)
+        l = O.audio_loss_dict(y, ab["data"])
         (l["audio_sc_loss"] + l["audio_mag_loss"]).backward()
         opt.step()
-
-    one()  # warm-up
+    audio()
     t0 = time.perf_counter()
-    one()
-    t1 = time.perf_counter() - t0
-    n = max(2, min(12, int(seconds / max(t1, 1e-3))))
-    ts = []
-    for _ in range(n):
-        t0 = time.perf_counter()
-        one()
-        ts.append(time.perf_counter() - t0)
-    med = float(np.median(ts))
-    return {"value": B * C_ * F_ / med, "unit": "field-samples/s", "cores": ncores, "kind": "port",
-            "sample": f"{n} steps of the same {B}-slice audio-branch step (median {med*1e3:.0f} ms/step), torch-CPU fp32 oracle"}
+    audio()
+    t["audio_train"] = (time.perf_counter() - t0) * frac
+    step_s = sum(t.values())
+    return {"value": (R + B * C_ * F_) / step_s, "unit": "field-samples/s", "cores": ncores, "kind": "port",
+            "sample": ("1/8 sample (%d rays, %d refresh cells, %d slices) scaled x8 + one full ResNet3D forward; extrapolated "
+                       "step %.1f s = %s; torch-CPU fp32 oracle") % (r, r, b, step_s, {k: round(v, 2) for k, v in t.items()})}
 
 
 def main():
@@ -147,7 +185,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)   # RCCL
     from neraf_amd import _lib
 
-    st = AudioBranchStep(dev, a.slices, world)
+    st = JointStep(dev, a.rays, a.slices, world)
     for _ in range(a.warmup):
         st.step()
 
@@ -170,7 +208,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- instrumented replay (not timed): per-kernel HIP-event durations of the dominant kernel
+    # ---- instrumented replay (not timed): per-kernel-family HIP-event durations
     lib = _lib.load()
     h = _lib.ctx(local)
     lib.neraf_prof_enable(h, 1)
@@ -178,23 +216,25 @@ def main():
     for _ in range(nprof):
         st.step()
     torch.cuda.synchronize()
-    kernels = []
+    fams = []
     kid = 0
     while lib.neraf_prof_kernel_name(kid):
         ms, n, w = C.c_double(), C.c_int(), C.c_double()
         _lib.check(lib.neraf_prof_summary(h, kid, C.byref(ms), C.byref(n), C.byref(w)), local)
         if n.value:
-            kernels.append({"kernel": lib.neraf_prof_kernel_name(kid).decode(), "launches_per_step": n.value / nprof,
-                            "avg_us": ms.value * 1e3 / n.value, "ms_per_step": ms.value / nprof,
-                            "tflops": w.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
-                            "gflop_per_launch": w.value / n.value / 1e9})
+            is_bytes = kid in (2, 3)
+            rate = w.value / (ms.value * 1e-3) / (1e9 if is_bytes else 1e12) if ms.value > 0 else 0.0
+            fams.append({"kernel": lib.neraf_prof_kernel_name(kid).decode(), "bound": "hbm" if is_bytes else "mfma",
+                         "launches_per_step": n.value / nprof, "avg_us": ms.value * 1e3 / n.value,
+                         "ms_per_step": ms.value / nprof, "achieved": rate, "unit": "GB/s" if is_bytes else "TFLOP/s",
+                         "work_per_launch": w.value / n.value})
         kid += 1
     lib.neraf_prof_enable(h, 0)
     sync()
 
     if rank == 0:
         samples = st.samples_per_step() * world * a.steps
-        dom = max(kernels, key=lambda k: k["ms_per_step"]) if kernels else None
+        dom = max(fams, key=lambda k: k["ms_per_step"]) if fams else None
         out = {
             "metric": "field-samples/sec (rays + RIR STFT bins)",
             "value": samples / elapsed,
@@ -209,22 +249,26 @@ def main():
             "dtype": "f16",
             "data": "synthetic",
             "config": {
-                "workload": ("RAF FurnishedRoom audio-branch training step (cfg3 audio half): %d RIR STFT slices x 513 bins "
-                             "per GPU; GPU query prologue -> NAcF MLP (layer-0 split) -> STFT loss -> backward (all NAcF grads "
-                             "+ d/d grid-feature) -> %sGradScaler+Adam; rays=0 and ResNet3D/grid refresh NOT yet inside the step"
-                             % (a.slices, "RCCL grad all-reduce -> " if world > 1 else "")),
-                "slices_per_gpu": a.slices, "rays_per_gpu": 0, "parallelism": f"dp{world}",
+                "workload": ("RAF FurnishedRoom joint step (BASELINE configs[2] shape: %d rays + %d RIR slices x 513 bins per GPU): "
+                             "radiance forward (sampler, 2 proposal nets, 2 PDF resamplings, fused field query, composite) -> grid "
+                             "refresh (%d cells x 18 dirs) -> ResNet3D forward on the 7x128^3 grid -> audio prologue + NAcF MLP "
+                             "-> STFT loss -> NAcF backward (all grads + d/d feature) -> %sGradScaler + fused Adam.  NOT inside "
+                             "the step yet: backward of the radiance half and of the ResNet3D (forward-only stages)."
+                             % (a.rays, a.slices, a.rays, "RCCL all-reduce -> " if world > 1 else "")),
+                "rays_per_gpu": a.rays, "slices_per_gpu": a.slices, "parallelism": f"dp{world}",
             },
         }
         if dom:
-            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None,
+            peak = HBM_PEAK_GBS if dom["bound"] == "hbm" else MFMA_PEAK_TFLOPS
+            out["roofline"] = {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": peak,
+                               "unit": dom["unit"], "frac": dom["achieved"] / peak, "traffic": None,
                                "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
-                               "gflop_per_launch_executed": dom["gflop_per_launch"],
-                               "dense_equiv_gflop_per_step": 3 * NACF_DENSE_FLOP_PER_SLICE_FWD * a.slices / 1e9,
-                               "all_kernels": kernels}
+                               "algorithmic_work_per_launch": dom["work_per_launch"],
+                               "dense_equiv_gflop_per_step": {"nacf_fwd_bwd": 3 * NACF_DENSE_FLOP_PER_SLICE_FWD * a.slices / 1e9,
+                                                              "resnet3d_fwd": RESNET_FWD_GFLOP},
+                               "all_kernel_families": fams}
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.slices, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(a.rays, a.slices)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

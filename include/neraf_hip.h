@@ -49,7 +49,8 @@ const char* neraf_last_error(neraf_ctx* ctx);
  * algorithmic work (FLOPs or bytes, logical un-padded extents) is recorded.
  * neraf_prof_summary synchronises those events and returns totals since the last enable.
  * kernel ids: 0 = gemm_f16 128x128 tile (work = FLOPs), 1 = gemm_f16 64x64 tile (FLOPs),
- * 2 = proposal_density (work = gathered hash-table bytes), 3 = field_query (gathered bytes);
+ * 2 = proposal_density (work = gathered hash-table bytes), 3 = field_query (gathered bytes),
+ * 4 = implicit-GEMM convolution instances of gemm_f16 (FLOPs, zero-padded taps/channels included);
  * neraf_prof_kernel_name(id) returns NULL past the end.
  * ---------------------------------------------------------------------------------- */
 int neraf_prof_enable(neraf_ctx* ctx, int on);

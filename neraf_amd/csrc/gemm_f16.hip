@@ -407,7 +407,7 @@ int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
     attr_set = true;
   }
   const int ntiles = (p.Mpad / BM) * (p.Npad / BN);
-  ProfScope prof(ctx, stream, BM * BN == 128 * 128 ? PROF_GEMM128 : PROF_GEMM64, 2.0 * p.M * p.N * p.K);
+  ProfScope prof(ctx, stream, LOADER != 0 ? PROF_CONV : (BM * BN == 128 * 128 ? PROF_GEMM128 : PROF_GEMM64), 2.0 * p.M * p.N * p.K);
   hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS>), dim3(ntiles * splits), dim3(256), PT::LDS_BYTES,
                      stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());

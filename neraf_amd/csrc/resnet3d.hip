@@ -115,6 +115,52 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __re
   out[idx] = (half_t)v;
 }
 
+// one launch for all 43 convolutions: table of per-conv descriptors in the kernel arguments
+struct PackTable {
+  int n;
+  const float* src[48];
+  unsigned long long begin[49];      // prefix of packed element counts
+  unsigned long long dst_off[48];    // byte offset of the conv's packed matrix
+  int cout[48], cin_real[48], cin[48], taps[48], kpad[48];
+};
+
+__global__ __launch_bounds__(256) void pack_all_conv_weights_kernel(PackTable t, char* __restrict__ packed) {
+  const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= t.begin[t.n]) return;
+  int lo = 0, hi = t.n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.begin[mid] <= idx) lo = mid; else hi = mid - 1; }
+  const int i = lo;
+  const unsigned long long e = idx - t.begin[i];
+  const int kpad = t.kpad[i], cin = t.cin[i];
+  const int n = (int)(e / kpad), k = (int)(e % kpad);
+  const int tap = k / cin, c = k % cin;
+  float v = 0.f;
+  if (n < t.cout[i] && tap < t.taps[i] && c < t.cin_real[i]) v = t.src[i][((size_t)n * t.cin_real[i] + c) * t.taps[i] + tap];
+  reinterpret_cast<half_t*>(packed + t.dst_off[i])[e] = (half_t)v;
+}
+
+struct RunTable {
+  int n;
+  int begin[49];                     // prefix of channel counts
+  unsigned long long stat_off[48];
+  int cpad[48];
+  float inv_m[48], unbias[48];
+  float* rmean[48]; float* rvar[48];
+};
+
+__global__ __launch_bounds__(256) void bn_update_running_all_kernel(RunTable t, const char* __restrict__ ws, float mom) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= t.begin[t.n]) return;
+  int lo = 0, hi = t.n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.begin[mid] <= idx) lo = mid; else hi = mid - 1; }
+  const int i = lo, c = idx - t.begin[i];
+  const float* stats = reinterpret_cast<const float*>(ws + t.stat_off[i]);
+  const float mean = stats[c] * t.inv_m[i];
+  const float var = fmaxf(stats[t.cpad[i] + c] * t.inv_m[i] - mean * mean, 0.f);
+  t.rmean[i][c] = (1.f - mom) * t.rmean[i][c] + mom * mean;
+  t.rvar[i][c] = (1.f - mom) * t.rvar[i][c] + mom * var * t.unbias[i];
+}
+
 struct BnSrc {
   const half_t* x;          // pre-BN conv output [rows][C]
   const float* stats;       // [2][Cpad]: sum, sum of squares (batch statistics) -- or null
@@ -306,13 +352,18 @@ extern "C" int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_
   if (make_arch(d, &A) || !conv_w || !packed) return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_pack_weights: bad arguments");
   make_layout(A, &L);
   hipStream_t st = (hipStream_t)stream;
+  PackTable t{};
+  t.n = A.nconv;
+  unsigned long long acc = 0;
   for (int i = 0; i < A.nconv; ++i) {
     const ConvSpec& c = A.conv[i];
-    const int npad = conv_npad(c), kpad = conv_kpad(c), taps = c.k * c.k * c.k;
-    const size_t n = (size_t)npad * kpad;
-    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, conv_w[i], c.cout,
-                       i == 0 ? d->in_channels : c.cin, c.cin, taps, npad, kpad, (half_t*)((char*)packed + L.w[i]));
+    t.src[i] = conv_w[i]; t.begin[i] = acc; t.dst_off[i] = L.w[i];
+    t.cout[i] = c.cout; t.cin_real[i] = i == 0 ? d->in_channels : c.cin; t.cin[i] = c.cin; t.taps[i] = c.k * c.k * c.k;
+    t.kpad[i] = conv_kpad(c);
+    acc += (unsigned long long)conv_npad(c) * conv_kpad(c);
   }
+  t.begin[A.nconv] = acc;
+  hipLaunchKernelGGL(pack_all_conv_weights_kernel, dim3((unsigned)((acc + 255) / 256)), dim3(256), 0, st, t, (char*)packed);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
@@ -386,13 +437,19 @@ extern "C" int neraf_resnet3d_update_running_stats(neraf_ctx* ctx, const neraf_r
   if (make_arch(d, &A) || !workspace || !bn) return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_update_running_stats: bad arguments");
   make_layout(A, &L);
   const char* ws = (const char*)workspace;
+  RunTable t{};
+  t.n = A.nconv;
+  int acc = 0;
   for (int i = 0; i < A.nconv; ++i) {
     const ConvSpec& c = A.conv[i];
     const float m = (float)cube(c.dout);
-    hipLaunchKernelGGL(bn_update_running_kernel, dim3((c.cout + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)(ws + L.stat[i]), round_up(c.cout, 128), c.cout, 1.f / m, m / (m - 1.f), momentum,
-                       bn[4 * i + 2], bn[4 * i + 3]);
+    t.begin[i] = acc; t.stat_off[i] = L.stat[i]; t.cpad[i] = round_up(c.cout, 128);
+    t.inv_m[i] = 1.f / m; t.unbias[i] = m / (m - 1.f);
+    t.rmean[i] = bn[4 * i + 2]; t.rvar[i] = bn[4 * i + 3];
+    acc += c.cout;
   }
+  t.begin[A.nconv] = acc;
+  hipLaunchKernelGGL(bn_update_running_all_kernel, dim3((acc + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, ws, momentum);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }

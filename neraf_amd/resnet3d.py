@@ -112,8 +112,7 @@ class ResNet3D(nn.Module):
             if mom > 0:
                 _lib.check(lib.neraf_resnet3d_update_running_stats(h, C.byref(self._desc), self._ws.data_ptr(),
                                                                    _lib.ptr_array(bn), float(mom), st), dev)
-                for _, b in pairs:
-                    b.num_batches_tracked += 1
+                torch._foreach_add_([b.num_batches_tracked for _, b in pairs], 1)   # one launch for the 43 counters
         return feat.reshape(1, 1024, 1, 1, 1)
 
 
