@@ -77,6 +77,7 @@ class ResNet3D(nn.Module):
                 m.bias.data.zero_()
         self._desc = _lib.ResnetDesc(self.grid_size, in_channels, N_features)
         self._ws = None
+        self._packed, self._packed_key = None, None
 
     def conv_bn_pairs(self):
         pairs = [(self.conv1, self.bn1)]
@@ -100,8 +101,15 @@ class ResNet3D(nn.Module):
         bn: List[torch.Tensor] = []
         for _, b in pairs:
             bn += [b.weight.detach(), b.bias.detach(), b.running_mean, b.running_var]
-        packed = torch.empty(lib.neraf_resnet3d_packed_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
-        _lib.check(lib.neraf_resnet3d_pack_weights(h, C.byref(self._desc), _lib.ptr_array(conv_w), packed.data_ptr(), st), dev)
+        # fp16 implicit-GEMM weight blob: re-packed when a conv weight changed.  (data_ptr, _version) misses in-place
+        # updates by fused optimizers, so any weight that currently holds a gradient is treated as "being trained".
+        key = tuple((w.data_ptr(), w._version) for w in conv_w)
+        being_trained = any(c.weight.grad is not None for c, _ in pairs)
+        if self._packed is None or self._packed.device != x.device or key != self._packed_key or being_trained:
+            packed = torch.empty(lib.neraf_resnet3d_packed_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
+            _lib.check(lib.neraf_resnet3d_pack_weights(h, C.byref(self._desc), _lib.ptr_array(conv_w), packed.data_ptr(), st), dev)
+            self._packed, self._packed_key = packed, key
+        packed = self._packed
         if self._ws is None or self._ws.device != x.device:
             self._ws = torch.empty(lib.neraf_resnet3d_workspace_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
         feat = torch.empty(1024, dtype=torch.float32, device=x.device)
