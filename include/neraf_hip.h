@@ -50,7 +50,8 @@ const char* neraf_last_error(neraf_ctx* ctx);
  * neraf_prof_summary synchronises those events and returns totals since the last enable.
  * kernel ids: 0 = gemm_f16 128x128 tile (work = FLOPs), 1 = gemm_f16 64x64 tile (FLOPs),
  * 2 = proposal_density (work = gathered hash-table bytes), 3 = field_query (gathered bytes),
- * 4 = implicit-GEMM convolution instances of gemm_f16 (FLOPs, zero-padded taps/channels included);
+ * 4 = implicit-GEMM convolution instances of gemm_f16 (FLOPs, zero-padded taps/channels included),
+ * 5 = proposal_backward, 6 = field_backward (work = gathered + atomically added table bytes);
  * neraf_prof_kernel_name(id) returns NULL past the end.
  * ---------------------------------------------------------------------------------- */
 int neraf_prof_enable(neraf_ctx* ctx, int on);
@@ -200,6 +201,39 @@ int neraf_field_query(neraf_ctx* ctx, const neraf_grid_desc* g, const void* tabl
 int neraf_composite(neraf_ctx* ctx, const float* density, const float* rgb, const float* e_bins, int R, int S,
                     int training, float* weights, float* rgb_out, float* depth, float* expected, float* acc,
                     void* scratch8, neraf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Radiance half, training: losses (V4) and backward.  These replace autograd through nerfstudio's
+ * NerfactoModel.get_loss_dict (rgb MSE on the clipped colour NeRAF_model.py:67, interlevel_loss x1.0,
+ * distortion_loss x0.002) and tiny-cuda-nn's backward kernels.  `up3` is a DEVICE pointer to the upstream
+ * gradients of {rgb_loss, interlevel_loss, distortion_loss} (NULL = compute loss values only);
+ * `sums` (device, fp32[4], caller zeroes) accumulates {sum (rgb-gt)^2, sum_rays distortion,
+ * sum outer-loss, -}; the host layer divides by 3R / R / (R*S2) and applies the multipliers.
+ * ---------------------------------------------------------------------------------- */
+int neraf_render_loss(neraf_ctx* ctx, const float* density, const float* rgb_s, const float* e_bins, const float* s_bins,
+                      const float* gt_rgb, int R, int S, float distortion_mult, const float* up3, float* d_rgb_s,
+                      float* d_density, float* sums, neraf_stream_t stream);
+int neraf_interlevel_loss(neraf_ctx* ctx, const float* c_bins, const float* w_fine, int S2, const float* p_bins,
+                          const float* p_ebins, const float* p_density, int Sp, int R, float mult, const float* up3,
+                          float* d_density, float* sums, neraf_stream_t stream);
+/* Proposal network backward: d_density [R,S] -> table_grad fp32 [rows,2] and w_grad fp32 [16*16+16]
+ * (layer 0 then layer-1 row), both ACCUMULATED (caller zeroes). */
+int neraf_proposal_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
+                            const float* origins, const float* dirs, const float* e_bins, const float* d_density, int R,
+                            int S, float avg_density, float* table_grad, float* w_grad, neraf_stream_t stream);
+/* Fused field backward.  d_rgb [R,S,3], d_density [R,S] (and the forward density) -> table_grad fp32
+ * [rows,2] and emb_grad fp32 [n_emb,32] (ACCUMULATED, caller zeroes) and the five MLP weight gradients
+ * w_grads (HOST array of device pointers {base_w0 [64,32], base_w1 [16,64], head_w0 [64,64], head_w1
+ * [64,64], head_w2 [16,64]}, overwritten).  wfrag_bwd_f16: 26 transposed-weight MFMA fragments packed by
+ * the host layer.  dump: scratch of neraf_field_backward_dump_bytes(R,S) bytes that the caller ZEROES ONCE
+ * at allocation (its padding rows must stay zero); splitk_ws: >= 8 MB fp32 scratch. */
+size_t neraf_field_backward_dump_bytes(int R, int S);
+int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                         const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
+                         const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
+                         float avg_density, int avg_row, const float* density, const float* d_rgb, const float* d_density,
+                         float* table_grad, float* emb_grad, float* const* w_grads, void* dump, void* splitk_ws,
+                         size_t splitk_bytes, neraf_stream_t stream);
 
 /* Grid refresh epilogue of query_grid_one_batch (NeRAF_model.py:352-357,386,395-400): mean over the ndirs
  * view directions of rgb [ndirs*n,3] / density [ndirs*n] (direction-major), alpha = clip(1-exp(-delta d)),

@@ -1,0 +1,656 @@
+// Radiance half, training: losses and backward.
+//   render_loss kernel      : rgb MSE (on the clipped colour, NeRAF_model.py:67) + distortion loss on the final samples,
+//                             and their gradients w.r.t. per-sample colour and density (through composite + get_weights)
+//   interlevel kernel       : proposal "outer" histogram loss and its gradient w.r.t. the proposal densities
+//   proposal_backward kernel: hash-grid + MLP(2L->16->1) backward (table gradient atomics, block-reduced weight grads)
+//   field_backward kernel   : fused nerfacto field backward on MFMA: recompute forward in registers, chain dX through
+//                             the transposed weight fragments, scatter hash-grid gradients, reduce appearance-embedding
+//                             gradients, and dump per-layer (X, dY) in [feature][point] fp16 so that the five weight
+//                             gradients are NT GEMMs (split-K over the ~2e5 points) on gemm_f16.hip.
+// These replace autograd through nerfstudio's NerfactoModel losses (rgb MSE, interlevel_loss, distortion_loss) and
+// tiny-cuda-nn's backward kernels [NS/TCNN-recall; oracle/vision.py is the unpinned checker].  Gradients do not flow
+// through sample positions (PDFSampler detaches its bins) and the final weights are detached inside interlevel_loss.
+#include "field_common.h"
+
+namespace {
+
+constexpr int NFRAG = 24;     // forward fragments (see field.hip)
+constexpr int NFRAG_B = 26;   // backward: Th2 0-3, Th1 4-11 (ib*2+s), Th0a 12-13, Th0b 14-17 (ib*2+s), Tb1 18-21, Tb0 22-25 (rb*2+s)
+
+// ------------------------------------------------------------------------------------------------------------
+struct RenderLossArgs {
+  const float* density; const float* rgb_s; const float* e_bins; const float* s_bins; const float* gt;
+  int R, S; float dist_mult;
+  const float* up;         // device [3]: upstream gradients of {rgb_loss, interlevel_loss, distortion_loss}; null = values only
+  float* d_rgb_s; float* d_density;     // outputs (may be null when up == null)
+  float* sums;             // device [>=2]: += sum (rgb-gt)^2 , += sum_rays distortion
+};
+
+__global__ __launch_bounds__(256) void render_loss_kernel(RenderLossArgs a) {
+  const int lane = threadIdx.x & 63;
+  int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool active = ray < a.R;
+  if (!active) ray = a.R - 1;
+  const int S = a.S;
+  const bool on = lane < S;
+  const float* eb = a.e_bins + (size_t)ray * (S + 1);
+  const float* sb = a.s_bins + (size_t)ray * (S + 1);
+  const float e0 = on ? eb[lane] : 0.f, e1 = on ? eb[lane + 1] : 0.f;
+  const float s0 = on ? sb[lane] : 0.f, s1 = on ? sb[lane + 1] : 0.f;
+  const float de = e1 - e0;
+  const float dd = on ? de * a.density[(size_t)ray * S + lane] : 0.f;
+  const float incl = wave_incl_scan(dd, lane);
+  const float Ti = __expf(-(incl - dd)), ex = __expf(-dd);
+  float w = (1.f - ex) * Ti;
+  const bool bad = !(w == w);
+  if (bad || !on) w = 0.f;
+  float c[3] = {0.f, 0.f, 0.f};
+  if (on) { const float* p = a.rgb_s + ((size_t)ray * S + lane) * 3; c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; }
+  float sw = w, sc[3] = {w * c[0], w * c[1], w * c[2]};
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sw += __shfl_xor(sw, o);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sc[k] += __shfl_xor(sc[k], o);
+  }
+  float cl[3], out[3], g[3], l_rgb = 0.f;
+  const float inv_n = 1.f / (3.f * (float)a.R);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    cl[k] = __shfl(c[k], S - 1);
+    out[k] = sc[k] + cl[k] * (1.f - sw);
+    const float oc = fminf(fmaxf(out[k], 0.f), 1.f);
+    const float diff = oc - a.gt[ray * 3 + k];
+    l_rgb += diff * diff;
+    g[k] = (out[k] > 0.f && out[k] < 1.f) ? 2.f * diff * inv_n : 0.f;     // d mean((clip(rgb)-gt)^2) / d rgb
+  }
+  // distortion (lossfun_distortion): sum_i w_i sum_j w_j |u_i-u_j| + sum_i w_i^2 (s_{i+1}-s_i)/3
+  const float u = 0.5f * (s0 + s1), ds = s1 - s0;
+  float inner = 0.f;
+  for (int j = 0; j < S; ++j) {
+    const float wj = __shfl(w, j), uj = __shfl(u, j);
+    inner += wj * fabsf(u - uj);
+  }
+  float l_dist = on ? (w * inner + w * w * ds * (1.f / 3.f)) : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) l_dist += __shfl_xor(l_dist, o);
+  if (lane == 0 && active) { atomicAdd(a.sums + 0, l_rgb); atomicAdd(a.sums + 1, l_dist); }
+  if (!a.up) return;
+  const float up_rgb = a.up[0], up_dist = a.up[2] * a.dist_mult / (float)a.R;
+  // d loss / d w_i
+  float gw = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) gw += up_rgb * g[k] * (c[k] - cl[k]);
+  gw += up_dist * (2.f * inner + 2.f * w * ds * (1.f / 3.f));
+  if (!on || bad) gw = 0.f;
+  // d loss / d colour_i
+  if (on && active) {
+    float* o = a.d_rgb_s + ((size_t)ray * S + lane) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = up_rgb * g[k] * (w + (lane == S - 1 ? (1.f - sw) : 0.f));
+  }
+  // get_weights backward: d dd_i = gw_i T_i exp(-dd_i) - sum_{k>i} gw_k w_k ; d sigma_i = delta_i d dd_i
+  const float gww = gw * w;
+  const float incl2 = wave_incl_scan(gww, lane);
+  float tot = gww;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+  const float ddd = gw * Ti * ex - (tot - incl2);
+  if (on && active) a.d_density[(size_t)ray * S + lane] = de * ddd;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+struct InterlevelArgs {
+  const float* c_bins; const float* w_fine; int S2;                      // final samples (detached)
+  const float* p_bins; const float* p_ebins; const float* p_density; int Sp;   // proposal level
+  int R; float mult;
+  const float* up;            // device [3] or null (values only)
+  float* d_density;           // [R,Sp]
+  float* sums;                // sums[2] += sum_i lossfun_outer
+};
+
+constexpr int IL_MAX_SP = 256, IL_MAX_S2 = 64;
+
+__global__ __launch_bounds__(256) void interlevel_kernel(InterlevelArgs a) {
+  __shared__ float sp_s[4][IL_MAX_SP + 1], cy_s[4][IL_MAX_SP + 1], diff_s[4][IL_MAX_SP + 2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int ray = blockIdx.x * 4 + wv;
+  const bool active = ray < a.R;
+  if (!active) ray = a.R - 1;
+  const int Sp = a.Sp, S2 = a.S2;
+  const int per = (Sp + 63) / 64;
+  float* sp = sp_s[wv]; float* cy = cy_s[wv]; float* diff = diff_s[wv];
+  const float* pb = a.p_bins + (size_t)ray * (Sp + 1);
+  const float* pe = a.p_ebins + (size_t)ray * (Sp + 1);
+  const float* pd = a.p_density + (size_t)ray * Sp;
+  for (int i = lane; i <= Sp; i += 64) { sp[i] = pb[i]; diff[i] = 0.f; }
+  if (lane == 0) diff[Sp + 1] = 0.f;
+  // proposal weights (recomputed) and their inclusive cumsum
+  float dd[4], loc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane * per + k;
+    dd[k] = (k < per && i < Sp) ? (pe[i + 1] - pe[i]) * pd[i] : 0.f;
+    loc += dd[k];
+  }
+  const float incl = wave_incl_scan(loc, lane);
+  float run = incl - loc, wp[4], Tk[4], exk[4], wl = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    Tk[k] = __expf(-run); exk[k] = __expf(-dd[k]);
+    float w = (1.f - exk[k]) * Tk[k];
+    if (!(w == w)) w = 0.f;
+    const int i = lane * per + k;
+    if (!(k < per && i < Sp)) w = 0.f;
+    run += dd[k];
+    wp[k] = w; wl += w;
+  }
+  const float inclw = wave_incl_scan(wl, lane);
+  float cw = inclw - wl;
+  if (lane == 0) cy[0] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane * per + k;
+    if (k < per && i < Sp) { cw += wp[k]; cy[i + 1] = cw; }
+  }
+  __syncthreads();
+  // one fine interval per lane
+  float loss = 0.f;
+  if (lane < S2) {
+    const float* cb = a.c_bins + (size_t)ray * (S2 + 1);
+    const float c0 = cb[lane], c1 = cb[lane + 1], w = a.w_fine[(size_t)ray * S2 + lane];
+    // idx_lo = searchsorted(starts = sp[0..Sp-1], c0, right) - 1, clamped to [0, Sp-1]
+    int lo = 0, hi = Sp;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sp[mid] > c0) hi = mid; else lo = mid + 1; }
+    const int ilo = min(max(lo - 1, 0), Sp - 1);
+    // idx_hi = searchsorted(ends = sp[1..Sp], c1, right), clamped to [0, Sp-1]
+    lo = 0; hi = Sp;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sp[mid + 1] > c1) hi = mid; else lo = mid + 1; }
+    const int ihi = min(max(lo, 0), Sp - 1);
+    const float w_outer = cy[ihi + 1] - cy[ilo];
+    const float ex = fmaxf(w - w_outer, 0.f);
+    loss = ex * ex / (w + 1e-7f);
+    if (a.up) {   // (an empty range ihi < ilo yields the same signed contributions as torch's cy[hi+1] - cy[lo])
+      const float h = -2.f * ex / (w + 1e-7f);
+      atomicAdd(&diff[ilo], h);
+      atomicAdd(&diff[ihi + 1], -h);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
+  if (lane == 0 && active) atomicAdd(a.sums + 2, loss);
+  if (!a.up) return;
+  __syncthreads();
+  // d loss / d wp_k = prefix sum of the difference array; then get_weights backward
+  const float scale = a.up[1] * a.mult / ((float)a.R * (float)S2);
+  float dl = 0.f, dv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int i = lane * per + k; dv[k] = (k < per && i < Sp) ? diff[i] : 0.f; dl += dv[k]; }
+  const float incd = wave_incl_scan(dl, lane);
+  float rund = incd - dl, gw[4], gwl = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { rund += dv[k]; gw[k] = rund * scale; gwl += gw[k] * wp[k]; }
+  const float incg = wave_incl_scan(gwl, lane);
+  float tot = gwl;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+  float rung = incg - gwl;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane * per + k;
+    rung += gw[k] * wp[k];
+    const float ddd = gw[k] * Tk[k] * exk[k] - (tot - rung);
+    if (k < per && i < Sp && active) a.d_density[(size_t)ray * Sp + i] = (pe[i + 1] - pe[i]) * ddd;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+struct PropBwdArgs {
+  GridLayout g;
+  const unsigned* table; const half_t* w;
+  const float* origins; const float* dirs; const float* e_bins; const float* d_density;
+  int R, S; float avg_density;
+  float* table_grad;      // fp32 [rows,2], accumulated (caller zeroes)
+  float* w_grad;          // fp32 [16*16 + 16], accumulated
+};
+
+__global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
+  __shared__ float w0[16][16], w1[16];
+  __shared__ float s_dh[4][64][17], s_enc[4][64][17], s_hr[4][64][17];   // per wave: [point][16] (+1 pad)
+  __shared__ float acc[16 * 16 + 16];
+  for (int i = threadIdx.x; i < 256; i += 256) w0[i >> 4][i & 15] = (float)a.w[i];
+  if (threadIdx.x < 16) w1[threadIdx.x] = (float)a.w[256 + threadIdx.x];
+  for (int i = threadIdx.x; i < 272; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long N = (long)a.R * a.S;
+  const long nchunks = (N + 255) / 256;
+  for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const long idx = chunk * 256 + threadIdx.x;
+    const bool valid = idx < N;
+    float enc[16], hpre[16], dh[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { enc[k] = 0.f; dh[k] = 0.f; hpre[k] = 0.f; }
+    float x = 0.f, y = 0.f, z = 0.f, gs = 0.f;
+    if (valid) {
+      const int ray = (int)(idx / a.S), s = (int)(idx % a.S);
+      const float t = 0.5f * (a.e_bins[(size_t)ray * (a.S + 1) + s] + a.e_bins[(size_t)ray * (a.S + 1) + s + 1]);
+      x = fmaf(a.dirs[ray * 3 + 0], t, a.origins[ray * 3 + 0]);
+      y = fmaf(a.dirs[ray * 3 + 1], t, a.origins[ray * 3 + 1]);
+      z = fmaf(a.dirs[ray * 3 + 2], t, a.origins[ray * 3 + 2]);
+      const bool sel = map_position(x, y, z, 0, nullptr);
+#pragma unroll
+      for (int l = 0; l < 8; ++l)
+        if (l < a.g.n_levels) {
+          float f0, f1;
+          encode_level(a.table, x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.offset[l], a.g.hashed[l], f0, f1);
+          enc[2 * l] = (float)(half_t)f0; enc[2 * l + 1] = (float)(half_t)f1;
+        }
+      float out = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float h = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h = fmaf(w0[j][k], enc[k], h);
+        hpre[j] = h;
+        out = fmaf(w1[j], fmaxf(h, 0.f), out);
+      }
+      // sigma = avg * trunc_exp(out) * sel  ->  d out = d sigma * avg * exp(min(out, 15)) * sel
+      gs = sel ? a.d_density[idx] * a.avg_density * __expf(fminf(out, 15.f)) : 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) dh[j] = hpre[j] > 0.f ? gs * w1[j] : 0.f;
+      // table gradients
+#pragma unroll
+      for (int l = 0; l < 8; ++l)
+        if (l < a.g.n_levels) {
+          float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { g0 = fmaf(dh[j], w0[j][2 * l], g0); g1 = fmaf(dh[j], w0[j][2 * l + 1], g1); }
+          if (g0 != 0.f || g1 != 0.f)
+            scatter_level(a.table_grad, x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.offset[l], a.g.hashed[l], g0, g1);
+        }
+    }
+    // weight gradients: dW0[j][k] = sum_p dh[p][j] enc[p][k] ; dW1[j] = sum_p gs[p] relu(h[p][j]) -- per-wave LDS staging
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s_dh[wv][lane][k] = dh[k]; s_enc[wv][lane][k] = enc[k]; s_hr[wv][lane][k] = gs * fmaxf(hpre[k], 0.f); }
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    {
+      const int j = lane >> 2, k0 = (lane & 3) * 4;     // 64 lanes x 4 outputs = the 256 entries of dW0
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int p = 0; p < 64; ++p) {
+        const float d = s_dh[wv][p][j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = fmaf(d, s_enc[wv][p][k0 + q], s[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomicAdd(&acc[j * 16 + k0 + q], s[q]);
+      if (lane < 16) {
+        float t = 0.f;
+        for (int p = 0; p < 64; ++p) t += s_hr[wv][p][lane];
+        atomicAdd(&acc[256 + lane], t);
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < 272; i += 256) atomicAdd(a.w_grad + i, acc[i]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+struct FieldBwdArgs {
+  GridLayout g;
+  const unsigned* table; const half8* wfrag; const half8* wfrag_b; const half_t* emb;
+  const float* origins; const float* dirs; const float* e_bins; const int* cam_idx;
+  int R, S; int mode; float aabb[6]; float avg_density; int avg_row;
+  const float* d_rgb; const float* d_density;      // upstream [N,3], [N]
+  const float* scale;                              // device {S, 1/S}: fp16 chain scaling
+  float* table_grad;                               // fp32 [rows,2], accumulated
+  float* emb_grad;                                 // fp32 [n_emb,32], accumulated (null in avg_row mode)
+  half_t* dump; long npad;                         // fp16 [10][128][npad]: X_b0,dY_b0,X_b1,dY_b1,X_h0,dY_h0,X_h1,dY_h1,X_h2,dY_h2
+};
+
+__device__ __forceinline__ void dump_block(half_t* base, long npad, long n, int row0, const f32x4& v, float m) {
+  // rows row0..row0+3 of a [feat][npad] matrix, column n
+#pragma unroll
+  for (int r = 0; r < 4; ++r) base[(long)(row0 + r) * npad + n] = (half_t)(v[r] * m);
+}
+
+__global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
+  __shared__ float l_scale[MAX_LEVELS];
+  __shared__ int l_res[MAX_LEVELS];
+  __shared__ unsigned l_size[MAX_LEVELS], l_off[MAX_LEVELS];
+  __shared__ int l_hash[MAX_LEVELS];
+  if (threadIdx.x < MAX_LEVELS) {
+    const int l = threadIdx.x;
+    l_scale[l] = a.g.scale[l]; l_res[l] = a.g.res[l]; l_size[l] = a.g.size[l]; l_off[l] = a.g.offset[l]; l_hash[l] = a.g.hashed[l];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int p = lane & 15, q = lane >> 4;
+  half8 wf[NFRAG];
+#pragma unroll
+  for (int f = 0; f < NFRAG; ++f) wf[f] = a.wfrag[f * 64 + lane];
+  const half8* wb = a.wfrag_b + lane;            // fragment f at wb[f * 64]
+  const float gscale = a.scale[0], inv_gscale = a.scale[1];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const long N = (long)a.R * a.S;
+  const long ngroups = a.npad / 16;              // covers the zero padding of the dumps as well
+  const long gstride = (long)gridDim.x * 4;
+  const long MAT = 128 * a.npad;                 // elements per dumped matrix
+  for (long grp = (long)blockIdx.x * 4 + (threadIdx.x >> 6); grp < ngroups; grp += gstride) {
+    const long ncol = grp * 16 + p;              // dump column
+    long n = ncol;
+    const bool valid = n < N;
+    if (!valid) n = N - 1;
+    const float vm = valid ? 1.f : 0.f;
+    const int ray = (int)(n / a.S), s = (int)(n % a.S);
+    const float t = 0.5f * (a.e_bins[(size_t)ray * (a.S + 1) + s] + a.e_bins[(size_t)ray * (a.S + 1) + s + 1]);
+    const float dx = a.dirs[ray * 3 + 0], dy = a.dirs[ray * 3 + 1], dz = a.dirs[ray * 3 + 2];
+    float x = fmaf(dx, t, a.origins[ray * 3 + 0]);
+    float y = fmaf(dy, t, a.origins[ray * 3 + 1]);
+    float z = fmaf(dz, t, a.origins[ray * 3 + 2]);
+    const bool sel = map_position(x, y, z, a.mode, a.aabb);
+    // ---------------- forward recompute (identical to field_query_kernel) ----------------
+    half8 xin;
+#pragma unroll
+    for (int li = 0; li < 4; ++li) {
+      const int l = 4 * q + li;
+      float f0, f1;
+      encode_level(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1);
+      xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
+    }
+    f32x4 d1[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) d1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ob], xin, zero, 0, 0, 0);
+    f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[4], pack_relu(d1[0], d1[1], true), zero, 0, 0, 0);
+    d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[5], pack_relu(d1[2], d1[3], true), d2, 0, 0, 0);
+    float sh[4];
+    sh4_quarter(q, dx, dy, dz, sh);
+    half8 h0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { h0[r] = (half_t)d2[r]; h0[4 + r] = (half_t)sh[r]; }
+    const float logit = d2[0];
+    if (q == 0) h0[0] = (half_t)0.f;
+    const int erow = a.avg_row >= 0 ? a.avg_row : a.cam_idx[ray];
+    const half8 h1 = *reinterpret_cast<const half8*>(a.emb + (size_t)erow * 32 + 8 * q);
+    f32x4 d3[4], d4[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[6 + ob * 2], h0, zero, 0, 0, 0);
+      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[7 + ob * 2], h1, d3[ob], 0, 0, 0);
+    }
+    const half8 a0 = pack_relu(d3[0], d3[1], true), a1 = pack_relu(d3[2], d3[3], true);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[14 + ob * 2], a0, zero, 0, 0, 0);
+      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[15 + ob * 2], a1, d4[ob], 0, 0, 0);
+    }
+    f32x4 d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[22], pack_relu(d4[0], d4[1], true), zero, 0, 0, 0);
+    d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[23], pack_relu(d4[2], d4[3], true), d5, 0, 0, 0);
+    // ---------------- backward ----------------
+    f32x4 dy5 = zero;
+    if (q == 0 && valid) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float o = 1.f / (1.f + __expf(-d5[c]));
+        dy5[c] = a.d_rgb[(size_t)n * 3 + c] * o * (1.f - o) * gscale;
+      }
+    }
+    half_t* D = a.dump;
+    // X_h2 = relu(d4), dY_h2 = dy5
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      f32x4 r4; for (int r = 0; r < 4; ++r) r4[r] = fmaxf(d4[ob][r], 0.f);
+      dump_block(D + 8 * MAT, a.npad, ncol, 16 * ob + 4 * q, r4, vm);
+    }
+    dump_block(D + 9 * MAT, a.npad, ncol, 4 * q, dy5, 1.f);
+    // head2: dX = W_h2^T dy5
+    f32x4 dy4[4];
+    {
+      const half8 b5 = pack_relu(dy5, zero, false);
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib) {
+        dy4[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[(0 + ib) * 64], b5, zero, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dy4[ib][r] = d4[ib][r] > 0.f ? dy4[ib][r] : 0.f;
+      }
+    }
+    // X_h1 = relu(d3), dY_h1 = dy4
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      f32x4 r3; for (int r = 0; r < 4; ++r) r3[r] = fmaxf(d3[ob][r], 0.f);
+      dump_block(D + 6 * MAT, a.npad, ncol, 16 * ob + 4 * q, r3, vm);
+      dump_block(D + 7 * MAT, a.npad, ncol, 16 * ob + 4 * q, dy4[ob], 1.f);
+    }
+    f32x4 dy3[4];
+    {
+      const half8 b0 = pack_relu(dy4[0], dy4[1], false), b1 = pack_relu(dy4[2], dy4[3], false);
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib) {
+        dy3[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[(4 + ib * 2) * 64], b0, zero, 0, 0, 0);
+        dy3[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[(5 + ib * 2) * 64], b1, dy3[ib], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dy3[ib][r] = d3[ib][r] > 0.f ? dy3[ib][r] : 0.f;
+      }
+    }
+    // X_h0 (natural column order SH16 | geo15 | emb32 | 0), dY_h0 = dy3
+    {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        D[4 * MAT + (long)(4 * q + r) * a.npad + ncol] = (half_t)(sh[r] * vm);
+        const int tt = 4 * q + r;
+        if (tt >= 1) D[4 * MAT + (long)(15 + tt) * a.npad + ncol] = (half_t)(d2[r] * vm);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) D[4 * MAT + (long)(31 + 8 * q + j) * a.npad + ncol] = (half_t)((float)h1[j] * vm);
+      if (q == 0) D[4 * MAT + (long)63 * a.npad + ncol] = (half_t)0.f;
+#pragma unroll
+      for (int ob = 0; ob < 4; ++ob) dump_block(D + 5 * MAT, a.npad, ncol, 16 * ob + 4 * q, dy3[ob], 1.f);
+    }
+    f32x4 dbase, demb[2];
+    {
+      const half8 b0 = pack_relu(dy3[0], dy3[1], false), b1 = pack_relu(dy3[2], dy3[3], false);
+      dbase = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[12 * 64], b0, zero, 0, 0, 0);
+      dbase = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[13 * 64], b1, dbase, 0, 0, 0);
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        demb[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[(14 + ib * 2) * 64], b0, zero, 0, 0, 0);
+        demb[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[(15 + ib * 2) * 64], b1, demb[ib], 0, 0, 0);
+      }
+    }
+    // appearance-embedding gradient: reduce over the 16 points of the group when they share the row
+    if (a.emb_grad && a.avg_row < 0) {
+      const int e0 = __shfl(erow, lane & 48);                    // row of point 0 of this group (same q)
+      const bool uniform = __all(e0 == erow || !valid);
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = valid ? demb[ib][r] * inv_gscale : 0.f;
+          if (uniform) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+            if (p == 0 && v != 0.f) atomicAdd(a.emb_grad + (size_t)e0 * 32 + 16 * ib + 4 * q + r, v);
+          } else if (valid && v != 0.f) {
+            atomicAdd(a.emb_grad + (size_t)erow * 32 + 16 * ib + 4 * q + r, v);
+          }
+        }
+    }
+    // base output gradient: geo part from the head, logit part from d sigma (sigma = avg * exp(logit) * sel)
+    f32x4 dy2 = dbase;
+    if (q == 0) dy2[0] = (valid && sel) ? a.d_density[n] * a.avg_density * __expf(fminf(logit, 15.f)) * gscale : 0.f;
+    // X_b1 = relu(d1), dY_b1 = dy2
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      f32x4 r1; for (int r = 0; r < 4; ++r) r1[r] = fmaxf(d1[ob][r], 0.f);
+      dump_block(D + 2 * MAT, a.npad, ncol, 16 * ob + 4 * q, r1, vm);
+    }
+    dump_block(D + 3 * MAT, a.npad, ncol, 4 * q, dy2, vm);
+    f32x4 dy1[4];
+    {
+      const half8 b2 = pack_relu(dy2, zero, false);
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib) {
+        dy1[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[(18 + ib) * 64], b2, zero, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dy1[ib][r] = (d1[ib][r] > 0.f && valid) ? dy1[ib][r] : 0.f;
+      }
+    }
+    // X_b0 = enc, dY_b0 = dy1
+#pragma unroll
+    for (int j = 0; j < 8; ++j) D[0 * MAT + (long)(8 * q + j) * a.npad + ncol] = (half_t)((float)xin[j] * vm);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) dump_block(D + 1 * MAT, a.npad, ncol, 16 * ob + 4 * q, dy1[ob], 1.f);
+    // d enc: rows permuted so that this lane receives features 8q..8q+7
+    f32x4 de[2];
+    {
+      const half8 b0 = pack_relu(dy1[0], dy1[1], false), b1 = pack_relu(dy1[2], dy1[3], false);
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        de[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[(22 + rb * 2) * 64], b0, zero, 0, 0, 0);
+        de[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[(23 + rb * 2) * 64], b1, de[rb], 0, 0, 0);
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int li = 0; li < 4; ++li) {
+        const int l = 4 * q + li;
+        const float g0 = de[li >> 1][2 * (li & 1)] * inv_gscale, g1 = de[li >> 1][2 * (li & 1) + 1] * inv_gscale;
+        if (g0 != 0.f || g1 != 0.f)
+          scatter_level(a.table_grad, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], g0, g1);
+      }
+    }
+  }
+}
+
+// amax of the upstream gradients entering the fp16 chain -> power-of-two scale {S, 1/S}
+__global__ __launch_bounds__(256) void field_amax_kernel(const float* __restrict__ d_rgb, const float* __restrict__ d_density,
+                                                        const float* __restrict__ density, long N, unsigned* __restrict__ amax_bits) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
+    float v = fmaxf(fabsf(d_rgb[i * 3]), fmaxf(fabsf(d_rgb[i * 3 + 1]), fabsf(d_rgb[i * 3 + 2]))) * 0.25f;   // sigmoid' <= 1/4
+    v = fmaxf(v, fabsf(d_density[i] * density[i]));
+    m = (v == v && v > m) ? v : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]))));
+}
+
+__global__ void field_make_scale_kernel(float* __restrict__ scale) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float amax = __uint_as_float(reinterpret_cast<unsigned*>(scale)[2]);
+    float S = 1.f;
+    if (amax > 0.f && amax < 3.0e38f) {
+      int e = 6 - (int)floorf(log2f(amax));       // max |dY| of the last layer -> [64, 128)
+      e = e > 100 ? 100 : (e < -100 ? -100 : e);
+      S = exp2f((float)e);
+    }
+    scale[0] = S; scale[1] = 1.f / S;
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" int neraf_render_loss(neraf_ctx* ctx, const float* density, const float* rgb_s, const float* e_bins,
+                                 const float* s_bins, const float* gt_rgb, int R, int S, float distortion_mult, const float* up3,
+                                 float* d_rgb_s, float* d_density, float* sums, neraf_stream_t stream) {
+  if (R <= 0 || S <= 0 || S > 64 || !density || !rgb_s || !e_bins || !s_bins || !gt_rgb || !sums || (up3 && (!d_rgb_s || !d_density)))
+    return neraf_fail(ctx, NERAF_EINVAL, "render_loss: bad arguments (S <= 64)");
+  RenderLossArgs a{density, rgb_s, e_bins, s_bins, gt_rgb, R, S, distortion_mult, up3, d_rgb_s, d_density, sums};
+  hipLaunchKernelGGL(render_loss_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" int neraf_interlevel_loss(neraf_ctx* ctx, const float* c_bins, const float* w_fine, int S2, const float* p_bins,
+                                     const float* p_ebins, const float* p_density, int Sp, int R, float mult, const float* up3,
+                                     float* d_density, float* sums, neraf_stream_t stream) {
+  if (R <= 0 || S2 <= 0 || S2 > IL_MAX_S2 || Sp <= 0 || Sp > IL_MAX_SP || !c_bins || !w_fine || !p_bins || !p_ebins || !p_density ||
+      !sums || (up3 && !d_density))
+    return neraf_fail(ctx, NERAF_EINVAL, "interlevel_loss: bad arguments (S2 <= 64, Sp <= 256)");
+  InterlevelArgs a{c_bins, w_fine, S2, p_bins, p_ebins, p_density, Sp, R, mult, up3, d_density, sums};
+  hipLaunchKernelGGL(interlevel_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" int neraf_proposal_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
+                                       const float* origins, const float* dirs, const float* e_bins, const float* d_density,
+                                       int R, int S, float avg_density, float* table_grad, float* w_grad, neraf_stream_t stream) {
+  PropBwdArgs a{};
+  if (make_grid_layout(g, &a.g) || a.g.n_levels > 8) return neraf_fail(ctx, NERAF_EINVAL, "proposal_backward: bad grid (<= 8 levels)");
+  if (R <= 0 || S <= 0 || !table_f16 || !mlp_f16 || !origins || !dirs || !e_bins || !d_density || !table_grad || !w_grad)
+    return neraf_fail(ctx, NERAF_EINVAL, "proposal_backward: bad arguments");
+  a.table = (const unsigned*)table_f16; a.w = (const half_t*)mlp_f16; a.origins = origins; a.dirs = dirs; a.e_bins = e_bins;
+  a.d_density = d_density; a.R = R; a.S = S; a.avg_density = avg_density; a.table_grad = table_grad; a.w_grad = w_grad;
+  const long n = (long)R * S;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  ProfScope prof(ctx, (hipStream_t)stream, PROF_PROP_BWD, (double)n * a.g.n_levels * 8 * 8);   // fp32x2 atomically added bytes
+  hipLaunchKernelGGL(proposal_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" size_t neraf_field_backward_dump_bytes(int R, int S) {
+  const long npad = ((long)R * S + 63) / 64 * 64;
+  return (size_t)10 * 128 * npad * 2 + 256;
+}
+
+extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                                    const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
+                                    const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
+                                    float avg_density, int avg_row, const float* density, const float* d_rgb, const float* d_density,
+                                    float* table_grad, float* emb_grad, float* const* w_grads, void* dump, void* splitk_ws,
+                                    size_t splitk_bytes, neraf_stream_t stream) {
+  FieldBwdArgs a{};
+  if (make_grid_layout(g, &a.g) || a.g.n_levels != 16) return neraf_fail(ctx, NERAF_EINVAL, "field_backward: grid must have 16 levels");
+  if (R <= 0 || S <= 0 || !table_f16 || !wfrag_f16 || !wfrag_bwd_f16 || !emb_f16 || !origins || !dirs || !e_bins || !density ||
+      !d_rgb || !d_density || !table_grad || !w_grads || !dump || (avg_row < 0 && !cam_idx) || (mode != 0 && !aabb_host))
+    return neraf_fail(ctx, NERAF_EINVAL, "field_backward: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const long N = (long)R * S;
+  const long npad = (N + 63) / 64 * 64;
+  a.table = (const unsigned*)table_f16; a.wfrag = (const half8*)wfrag_f16; a.wfrag_b = (const half8*)wfrag_bwd_f16;
+  a.emb = (const half_t*)emb_f16; a.origins = origins; a.dirs = dirs; a.e_bins = e_bins; a.cam_idx = cam_idx;
+  a.R = R; a.S = S; a.mode = mode;
+  for (int i = 0; i < 6; ++i) a.aabb[i] = aabb_host ? aabb_host[i] : 0.f;
+  a.avg_density = avg_density; a.avg_row = avg_row; a.d_rgb = d_rgb; a.d_density = d_density;
+  a.table_grad = table_grad; a.emb_grad = emb_grad;
+  a.dump = (half_t*)dump; a.npad = npad;
+  float* scale = (float*)((char*)dump + (size_t)10 * 128 * npad * 2);
+  a.scale = scale;
+  NERAF_HIP_CHECK(ctx, hipMemsetAsync(scale, 0, 16, st));
+  {
+    long blocks = (N + 1023) / 1024; if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(field_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_rgb, d_density, density, N,
+                       reinterpret_cast<unsigned*>(scale) + 2);
+    hipLaunchKernelGGL(field_make_scale_kernel, dim3(1), dim3(64), 0, st, scale);
+  }
+  {
+    const long groups = npad / 16;
+    long blocks = (groups + 3) / 4;
+    const long cap = (long)(ctx ? ctx->num_cus : 256) * 8;
+    if (blocks > cap) blocks = cap;
+    ProfScope prof(ctx, st, PROF_FIELD_BWD, (double)N * 16 * 8 * (4 + 8));   // gathered fp16x2 + atomically added fp32x2 bytes
+    hipLaunchKernelGGL(field_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    NERAF_HIP_CHECK(ctx, hipGetLastError());
+  }
+  // weight gradients: dW_l [out,in] = (1/S) dY_l [out,N] . X_l [in,N]^T   (NT GEMM, K = points, split-K)
+  const int outs[5] = {64, 16, 64, 64, 16}, ins[5] = {32, 64, 64, 64, 64};
+  for (int l = 0; l < 5; ++l) {
+    GemmParams gp{};
+    gp.A = (const half_t*)dump + (size_t)(2 * l + 1) * 128 * npad; gp.lda = (int)npad;
+    gp.B = (const half_t*)dump + (size_t)(2 * l) * 128 * npad; gp.ldb = (int)npad;
+    gp.M = outs[l]; gp.N = ins[l]; gp.K = (int)npad; gp.Mpad = 128; gp.Npad = 128; gp.alpha = 1.f; gp.alpha_dev = scale + 1;
+    gp.C32 = w_grads[l]; gp.ldc32 = ins[l];
+    gp.splitk_ws = (float*)splitk_ws; gp.splitk_ws_bytes = splitk_bytes;
+    if (int e = launch_gemm_f16(ctx, gp, st)) return e;
+  }
+  return NERAF_OK;
+}

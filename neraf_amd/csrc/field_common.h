@@ -1,0 +1,150 @@
+// Device/host helpers shared by the radiance-half kernels (field.hip forward, field_bwd.hip backward).
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_LEVELS = 16;
+
+struct GridLayout {
+  int n_levels;
+  float scale[MAX_LEVELS];
+  int res[MAX_LEVELS];
+  unsigned size[MAX_LEVELS];
+  unsigned offset[MAX_LEVELS + 1];
+  int hashed[MAX_LEVELS];
+};
+
+int make_grid_layout(const neraf_grid_desc* g, GridLayout* L) {
+  if (!g || g->n_levels < 1 || g->n_levels > MAX_LEVELS || g->n_features != 2 || g->log2_hashmap_size < 4 ||
+      g->log2_hashmap_size > 24 || g->base_res < 2 || g->max_res < g->base_res)
+    return NERAF_EINVAL;
+  L->n_levels = g->n_levels;
+  const double growth = g->n_levels > 1 ? exp(log((double)g->max_res / g->base_res) / (g->n_levels - 1)) : 1.0;
+  const float log2g = (float)log2(growth);
+  const unsigned T = 1u << g->log2_hashmap_size;
+  unsigned off = 0;
+  for (int l = 0; l < g->n_levels; ++l) {
+    const float scale = exp2f((float)l * log2g) * (float)g->base_res - 1.0f;   // tcnn grid_scale()
+    const int res = (int)ceilf(scale) + 1;                                      // tcnn grid_resolution()
+    unsigned long long n = (unsigned long long)res * res * res;
+    n = (n + 7ull) / 8ull * 8ull;
+    const unsigned sz = n > T ? T : (unsigned)n;
+    L->scale[l] = scale; L->res[l] = res; L->size[l] = sz; L->offset[l] = off;
+    L->hashed[l] = ((unsigned long long)res * res * res) > sz;
+    off += sz;
+  }
+  L->offset[g->n_levels] = off;
+  return NERAF_OK;
+}
+
+__device__ __forceinline__ float spacing_fn(float x) { return x < 1.f ? 0.5f * x : 1.f - 1.f / (2.f * x); }
+__device__ __forceinline__ float spacing_inv(float x) { return x < 0.5f ? 2.f * x : 1.f / (2.f - 2.f * x); }
+
+// ---- shared point helpers ---------------------------------------------------------------------------------
+__device__ __forceinline__ bool map_position(float& x, float& y, float& z, int mode, const float* aabb) {
+  if (mode == 0) {   // SceneContraction(L-inf) then (x+2)/4
+    const float mag = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    if (mag >= 1.f) {
+      const float k = (2.f - 1.f / mag) / mag;
+      x *= k; y *= k; z *= k;
+    }
+    x = (x + 2.f) * 0.25f; y = (y + 2.f) * 0.25f; z = (z + 2.f) * 0.25f;
+  } else {           // SceneBox normalisation (spatial_distortion = None)
+    x = (x - aabb[0]) / (aabb[3] - aabb[0]);
+    y = (y - aabb[1]) / (aabb[4] - aabb[1]);
+    z = (z - aabb[2]) / (aabb[5] - aabb[2]);
+  }
+  const bool sel = x > 0.f && x < 1.f && y > 0.f && y < 1.f && z > 0.f && z < 1.f;
+  if (!sel) { x = 0.f; y = 0.f; z = 0.f; }
+  return sel;
+}
+
+// one hash-grid level, trilinear; table entries are half2 (2 features)
+__device__ __forceinline__ void encode_level(const unsigned* __restrict__ table, float x, float y, float z, float scale, int res,
+                                             unsigned size, unsigned offset, int hashed, float& f0, float& f1) {
+  const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+  const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+  const float wx = px - flx, wy = py - fly, wz = pz - flz;
+  const unsigned ix = (unsigned)(int)flx, iy = (unsigned)(int)fly, iz = (unsigned)(int)flz;
+  f0 = 0.f; f1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned cx = ix + (c & 1), cy = iy + ((c >> 1) & 1), cz = iz + ((c >> 2) & 1);
+    const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+    unsigned idx;
+    if (hashed) idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1u);   // hashed levels have size = 2^log2_T
+    else {
+      // dense level: tcnn's `index % size`; corners of the last cell reach res, so idx < res^3+res^2+res < 2*size
+      idx = cx + cy * (unsigned)res + cz * (unsigned)res * (unsigned)res;
+      if (idx >= size) idx -= size;
+    }
+    const unsigned raw = table[offset + idx];
+    const half2v v = *reinterpret_cast<const half2v*>(&raw);
+    f0 = fmaf(w, (float)v[0], f0);
+    f1 = fmaf(w, (float)v[1], f1);
+  }
+}
+
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float n = __shfl_up(v, o);
+    if (lane >= o) v += n;
+  }
+  return v;
+}
+
+
+// gradient scatter of one level: table_grad[(offset+idx)*2 + f] += w_corner * g_f  (fp32 atomics, 8 corners)
+__device__ __forceinline__ void scatter_level(float* __restrict__ tgrad, float x, float y, float z, float scale, int res,
+                                              unsigned size, unsigned offset, int hashed, float g0, float g1) {
+  const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+  const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+  const float wx = px - flx, wy = py - fly, wz = pz - flz;
+  const unsigned ix = (unsigned)(int)flx, iy = (unsigned)(int)fly, iz = (unsigned)(int)flz;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned cx = ix + (c & 1), cy = iy + ((c >> 1) & 1), cz = iz + ((c >> 2) & 1);
+    const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+    unsigned idx;
+    if (hashed) idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1u);
+    else {
+      idx = cx + cy * (unsigned)res + cz * (unsigned)res * (unsigned)res;
+      if (idx >= size) idx -= size;
+    }
+    float* t = tgrad + (size_t)(offset + idx) * 2;
+    atomicAdd(t, w * g0);
+    atomicAdd(t + 1, w * g1);
+  }
+}
+
+// SH degree 4 components 4q..4q+3 of direction (dx,dy,dz) (tiny-cuda-nn constants), q = lane >> 4
+__device__ __forceinline__ void sh4_quarter(int q, float dx, float dy, float dz, float (&sh)[4]) {
+  const float xy = dx * dy, xz = dx * dz, yz = dy * dz, x2 = dx * dx, y2 = dy * dy, z2 = dz * dz;
+  if (q == 0) {
+    sh[0] = 0.28209479177387814f; sh[1] = -0.48860251190291987f * dy;
+    sh[2] = 0.48860251190291987f * dz; sh[3] = -0.48860251190291987f * dx;
+  } else if (q == 1) {
+    sh[0] = 1.0925484305920792f * xy; sh[1] = -1.0925484305920792f * yz;
+    sh[2] = 0.94617469575755997f * z2 - 0.31539156525251999f; sh[3] = -1.0925484305920792f * xz;
+  } else if (q == 2) {
+    sh[0] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2; sh[1] = 0.59004358992664352f * dy * (-3.0f * x2 + y2);
+    sh[2] = 2.8906114426405538f * xy * dz; sh[3] = 0.45704579946446572f * dy * (1.0f - 5.0f * z2);
+  } else {
+    sh[0] = 0.3731763325901154f * dz * (5.0f * z2 - 3.0f); sh[1] = 0.45704579946446572f * dx * (1.0f - 5.0f * z2);
+    sh[2] = 1.4453057213202769f * dz * (x2 - y2); sh[3] = 0.59004358992664352f * dx * (-x2 + 3.0f * y2);
+  }
+}
+
+__device__ __forceinline__ half8 pack_relu(const f32x4& a, const f32x4& b, bool relu) {
+  half8 h;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    h[r] = (half_t)(relu ? fmaxf(a[r], 0.f) : a[r]);
+    h[4 + r] = (half_t)(relu ? fmaxf(b[r], 0.f) : b[r]);
+  }
+  return h;
+}
+
+}  // namespace

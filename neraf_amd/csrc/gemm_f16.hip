@@ -432,7 +432,7 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   if (p.splitk_ws && ntiles * 2 <= cus && nk >= 8) {
     splits = cus / ntiles;
     if (splits > nk / 4) splits = nk / 4;
-    if (splits > 16) splits = 16;
+    if (splits > (ntiles <= 8 ? 32 : 16)) splits = ntiles <= 8 ? 32 : 16;
     const size_t need = (size_t)splits * p.Mpad * p.Npad * 4;
     if (splits < 2 || need > p.splitk_ws_bytes) splits = 1;
   }

@@ -5,10 +5,12 @@ The reference inherits this half from nerfstudio's ``NerfactoModel`` and runs it
 the same stages are hand-written HIP kernels behind the C ABI (include/neraf_hip.h, "Radiance half"):
 piecewise sampler -> proposal density x2 -> PDF resampling x2 -> fused field query -> composite.
 
-Status (round 1): FORWARD ONLY.  ``get_outputs`` / ``get_outputs_for_camera`` / ``field.forward`` are
-complete for inference and for producing the quantities the losses need (``weights_list``,
-``ray_samples_list``); the backward kernels (hash-grid gradient scatter, MLP weight gradients, loss
-gradients) are the next row of the build plan, so outputs carry no autograd graph yet.
+Training: ``get_outputs`` (forward) + ``get_loss_dict`` (rgb MSE, interlevel x1.0, distortion x0.002 -- the
+nerfacto loss dict, V4) are differentiable end to end: the three losses come out of one autograd node
+(``_VisionLossFn``) whose backward runs the HIP loss-gradient, proposal-backward and fused field-backward
+kernels and returns gradients for the hash tables, the MLP weights and the appearance embedding.  Not yet
+differentiable: the camera optimizer (pose deltas) and the audio-loss path into the field through the voxel
+grid (NeRAF_model.py:395-400).
 
 No fallback: every method raises if the HIP library or the GPU is missing.
 """
@@ -126,6 +128,43 @@ def _build_frag_index() -> np.ndarray:
 _FRAG_INDEX = _build_frag_index()
 
 
+def _build_frag_index_bwd() -> np.ndarray:
+    """Transposed-weight fragments of the backward chain (csrc/field_bwd.hip): the MFMA A operand is W^T restricted to
+    16 input rows, the B operand is built from accumulator blocks of dY exactly as in the forward."""
+    sizes = {"b0": (64, 32), "b1": (16, 64), "h0": (64, 64), "h1": (64, 64), "h2": (16, 64)}
+    base, off = {}, 0
+    for k, (o, i) in sizes.items():
+        base[k] = off
+        off += o * i
+    ZERO = off
+    idx = np.full((26, 64, 8), ZERO, np.int64)
+
+    def W(name, out, col):
+        return base[name] + out * sizes[name][1] + col
+
+    for l in range(64):
+        rho, q = l & 15, l >> 4
+        for j in range(8):
+            for ib in range(4):
+                if j < 4:                                   # 16-output layers: k = out 4q+j, upper half of the k-step is zero
+                    idx[0 + ib, l, j] = W("h2", 4 * q + j, 16 * ib + rho)
+                    idx[18 + ib, l, j] = W("b1", 4 * q + j, 16 * ib + rho)
+                for s in range(2):
+                    idx[4 + ib * 2 + s, l, j] = W("h1", _dperm(s, q, j), 16 * ib + rho)
+            for s in range(2):
+                if rho >= 1:                                # row t = base output index; t = 0 is the density logit (no weight)
+                    idx[12 + s, l, j] = W("h0", _dperm(s, q, j), 15 + rho)
+                for ib in range(2):
+                    idx[14 + ib * 2 + s, l, j] = W("h0", _dperm(s, q, j), 31 + 16 * ib + rho)
+                for rb in range(2):                          # rows permuted: lane quarter q' = rho>>2 receives features 8q'..8q'+7
+                    feat = 8 * (rho >> 2) + 4 * rb + (rho & 3)
+                    idx[22 + rb * 2 + s, l, j] = W("b0", _dperm(s, q, j), feat)
+    return idx.reshape(-1)
+
+
+_FRAG_INDEX_BWD = _build_frag_index_bwd()
+
+
 class HashMLPDensityField(nn.Module):
     """Proposal network: 5-level hash grid + MLP(10 -> 16 -> 1), tcnn layout (bias-free, padded to 16)."""
 
@@ -142,11 +181,11 @@ class HashMLPDensityField(nn.Module):
     def packed(self):
         return self.table.detach().half().contiguous(), torch.cat([self.w0.detach().reshape(-1), self.w1.detach()[0]]).half().contiguous()
 
-    def density(self, origins, directions, e_bins):
+    def density(self, origins, directions, e_bins, packed=None):
         lib = _lib.load()
         dev = _dev_index(origins)
         R, S = e_bins.shape[0], e_bins.shape[1] - 1
-        tab, w = self.packed()
+        tab, w = packed if packed is not None else self.packed()
         out = torch.empty((R, S), dtype=torch.float32, device=origins.device)
         _lib.check(lib.neraf_proposal_density(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), w.data_ptr(),
                                               origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(), R, S,
@@ -175,21 +214,27 @@ class NerfactoField(nn.Module):
         self.embedding = nn.Parameter(torch.randn(num_images, 32))
         self.average_init_density = average_init_density
         self.register_buffer("_frag_index", torch.from_numpy(_FRAG_INDEX), persistent=False)
+        self.register_buffer("_frag_index_bwd", torch.from_numpy(_FRAG_INDEX_BWD), persistent=False)
 
-    def packed(self):
-        flat = torch.cat([self.base_w0.detach().reshape(-1), self.base_w1.detach().reshape(-1), self.head_w0.detach().reshape(-1),
+    def _flat_weights(self):
+        return torch.cat([self.base_w0.detach().reshape(-1), self.base_w1.detach().reshape(-1), self.head_w0.detach().reshape(-1),
                           self.head_w1.detach().reshape(-1), self.head_w2.detach().reshape(-1),
                           torch.zeros(1, device=self.table.device)])
-        wfrag = flat[self._frag_index].half().contiguous()
+
+    def packed(self):
+        wfrag = self._flat_weights()[self._frag_index].half().contiguous()
         emb = torch.cat([self.embedding.detach(), self.embedding.detach().mean(0, keepdim=True)], 0).half().contiguous()
         return self.table.detach().half().contiguous(), wfrag, emb
 
-    def query(self, origins, directions, e_bins, camera_indices=None, use_average_embedding: bool = False):
+    def packed_bwd(self):
+        return self._flat_weights()[self._frag_index_bwd].half().contiguous()
+
+    def query(self, origins, directions, e_bins, camera_indices=None, use_average_embedding: bool = False, packed=None):
         """Structured query: R rays x S samples.  Returns (rgb [R,S,3], density [R,S])."""
         lib = _lib.load()
         dev = _dev_index(origins)
         R, S = e_bins.shape[0], e_bins.shape[1] - 1
-        tab, wfrag, emb = self.packed()
+        tab, wfrag, emb = packed if packed is not None else self.packed()
         rgb = torch.empty((R, S, 3), dtype=torch.float32, device=origins.device)
         den = torch.empty((R, S), dtype=torch.float32, device=origins.device)
         avg_row = self.embedding.shape[0] if (use_average_embedding or camera_indices is None) else -1
@@ -223,6 +268,90 @@ class RGBRenderer:
         return comp + rgb[..., -1, :] * (1.0 - acc)
 
 
+class _VisionLossFn(torch.autograd.Function):
+    """{rgb_loss, interlevel_loss, distortion_loss} as one autograd node over the radiance parameters."""
+
+    @staticmethod
+    def forward(ctx, model: "NeRAFVisionModel", st: dict, gt: torch.Tensor, *params: torch.Tensor):
+        lib = _lib.load()
+        dev = _dev_index(gt)
+        h, stream = _lib.ctx(dev), _stream_ptr()
+        fine = st["samples"][-1]
+        R, S2 = st["dens"].shape
+        sums = torch.zeros(4, dtype=torch.float32, device=gt.device)
+        _lib.check(lib.neraf_render_loss(h, st["dens"].data_ptr(), st["rgb_s"].data_ptr(), fine.e_bins.data_ptr(),
+                                         fine.s_bins.data_ptr(), gt.data_ptr(), R, S2, model.distortion_loss_mult, None, None, None,
+                                         sums.data_ptr(), stream), dev)
+        for i in range(2):
+            ps = st["samples"][i]
+            Sp = ps.e_bins.shape[1] - 1
+            _lib.check(lib.neraf_interlevel_loss(h, fine.s_bins.data_ptr(), st["w_fine"].data_ptr(), S2, ps.s_bins.data_ptr(),
+                                                 ps.e_bins.data_ptr(), st["prop_dens"][i].data_ptr(), Sp, R, model.interlevel_loss_mult,
+                                                 None, None, sums.data_ptr(), stream), dev)
+        ctx.model, ctx.st, ctx.gt, ctx.dev = model, st, gt, dev
+        ctx.n_params = len(params)
+        rgb_loss = sums[0] / (3.0 * R)
+        dist = sums[1] * (model.distortion_loss_mult / R)
+        inter = sums[2] * (model.interlevel_loss_mult / (R * S2))
+        return rgb_loss, inter, dist
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_inter, g_dist):
+        lib = _lib.load()
+        model, st, gt, dev = ctx.model, ctx.st, ctx.gt, ctx.dev
+        h, stream = _lib.ctx(dev), _stream_ptr()
+        device = gt.device
+        f32 = dict(dtype=torch.float32, device=device)
+        zero = torch.zeros((), **f32)
+        up = torch.stack([(g if g is not None else zero).float().reshape(()) for g in (g_rgb, g_inter, g_dist)]).contiguous()
+        fine = st["samples"][-1]
+        R, S2 = st["dens"].shape
+        field = model.field.module
+        sums = torch.zeros(4, **f32)
+        d_rgb_s = torch.empty((R, S2, 3), **f32)
+        d_dens = torch.empty((R, S2), **f32)
+        _lib.check(lib.neraf_render_loss(h, st["dens"].data_ptr(), st["rgb_s"].data_ptr(), fine.e_bins.data_ptr(),
+                                         fine.s_bins.data_ptr(), gt.data_ptr(), R, S2, model.distortion_loss_mult, up.data_ptr(),
+                                         d_rgb_s.data_ptr(), d_dens.data_ptr(), sums.data_ptr(), stream), dev)
+        # ---- main field
+        tab, wfrag, emb = st["field_packed"]
+        wfrag_b = field.packed_bwd()
+        g_table = torch.zeros_like(field.table)
+        g_emb = torch.zeros_like(field.embedding)
+        g_w = [torch.empty_like(p) for p in (field.base_w0, field.base_w1, field.head_w0, field.head_w1, field.head_w2)]
+        dump = model._dump_buffer(R, S2, device)
+        splitk = model._splitk_buffer(device)
+        cam = st["cam"].reshape(-1).to(torch.int32).contiguous() if st["cam"] is not None else None
+        mode = 0 if field.spatial_distortion is not None else 1
+        ab = (C.c_float * 6)(*[float(v) for v in field.aabb.reshape(-1).cpu().tolist()])
+        _lib.check(lib.neraf_field_backward(h, C.byref(field.desc), tab.data_ptr(), wfrag.data_ptr(), wfrag_b.data_ptr(),
+                                            emb.data_ptr(), st["o"].data_ptr(), st["d"].data_ptr(), fine.e_bins.data_ptr(),
+                                            cam.data_ptr() if cam is not None else None, R, S2, mode, ab, field.average_init_density,
+                                            -1 if cam is not None else field.embedding.shape[0], st["dens"].data_ptr(),
+                                            d_rgb_s.data_ptr(), d_dens.data_ptr(), g_table.data_ptr(),
+                                            g_emb.data_ptr() if cam is not None else None, _lib.ptr_array(g_w), dump.data_ptr(),
+                                            splitk.data_ptr(), splitk.numel() * 4, stream), dev)
+        grads = [g_table] + g_w + [g_emb]
+        # ---- proposal networks (interlevel loss)
+        for i, pn in enumerate(model.proposal_networks):
+            ps = st["samples"][i]
+            Sp = ps.e_bins.shape[1] - 1
+            d_pd = torch.empty((R, Sp), **f32)
+            _lib.check(lib.neraf_interlevel_loss(h, fine.s_bins.data_ptr(), st["w_fine"].data_ptr(), S2, ps.s_bins.data_ptr(),
+                                                 ps.e_bins.data_ptr(), st["prop_dens"][i].data_ptr(), Sp, R, model.interlevel_loss_mult,
+                                                 up.data_ptr(), d_pd.data_ptr(), sums.data_ptr(), stream), dev)
+            ptab, pw = st["prop_packed"][i]
+            g_pt = torch.zeros_like(pn.table)
+            g_pw = torch.zeros(16 * 16 + 16, **f32)
+            _lib.check(lib.neraf_proposal_backward(h, C.byref(pn.desc), ptab.data_ptr(), pw.data_ptr(), st["o"].data_ptr(),
+                                                   st["d"].data_ptr(), ps.e_bins.data_ptr(), d_pd.data_ptr(), R, Sp,
+                                                   pn.average_init_density, g_pt.data_ptr(), g_pw.data_ptr(), stream), dev)
+            g_w1 = torch.zeros_like(pn.w1)
+            g_w1[0] = g_pw[256:]
+            grads += [g_pt, g_pw[:256].reshape(16, 16), g_w1]
+        return (None, None, None, *grads)
+
+
 class NeRAFVisionModel(nn.Module):
     """Drop-in surface of ``NeRAFVisionModel`` (NeRAF_model.py:54-79) with nerfacto defaults and the NeRAF
     overrides (NeRAF_config.py:94-98)."""
@@ -246,6 +375,19 @@ class NeRAFVisionModel(nn.Module):
     @property
     def device(self):
         return self.field.module.table.device
+
+    def _dump_buffer(self, R: int, S: int, device) -> torch.Tensor:
+        """Persistent (X, dY) scratch of the field backward; zeroed ONCE (its padding rows must stay zero)."""
+        key = (R, S, str(device))
+        if getattr(self, "_dump_key", None) != key:
+            n = _lib.load().neraf_field_backward_dump_bytes(R, S)
+            self._dump, self._dump_key = torch.zeros(n, dtype=torch.uint8, device=device), key
+        return self._dump
+
+    def _splitk_buffer(self, device) -> torch.Tensor:
+        if getattr(self, "_splitk", None) is None or self._splitk.device != device:
+            self._splitk = torch.empty(4 << 20, dtype=torch.float32, device=device)
+        return self._splitk
 
     def update_to_step(self, step: int):
         self.step = step
@@ -279,8 +421,11 @@ class NeRAFVisionModel(nn.Module):
         anneal = self._anneal()
         weights_list, samples_list = [], []
         s_prev, e_prev = s0, e0
+        prop_packed = [pn.packed() for pn in self.proposal_networks]
+        prop_dens = []
         for i, S_next in enumerate((S1, S2)):
-            dens = self.proposal_networks[i].density(o, d, e_prev)
+            dens = self.proposal_networks[i].density(o, d, e_prev, packed=prop_packed[i])
+            prop_dens.append(dens)
             S_cur = e_prev.shape[1] - 1
             w = torch.empty((R, S_cur), **f32)
             s_n, e_n = torch.empty((R, S_next + 1), **f32), torch.empty((R, S_next + 1), **f32)
@@ -290,7 +435,9 @@ class NeRAFVisionModel(nn.Module):
             samples_list.append(RaySamples(None, ray_bundle.camera_indices, s_prev, e_prev))
             s_prev, e_prev = s_n, e_n
         field = self.field.module
-        rgb_s, dens = field.query(o, d, e_prev, ray_bundle.camera_indices, use_average_embedding=not self.training)
+        field_packed = field.packed()
+        rgb_s, dens = field.query(o, d, e_prev, ray_bundle.camera_indices, use_average_embedding=not self.training,
+                                  packed=field_packed)
         w = torch.empty((R, S2), **f32)
         rgb, depth = torch.empty((R, 3), **f32), torch.empty((R, 1), **f32)
         expd, acc = torch.empty((R, 1), **f32), torch.empty((R, 1), **f32)
@@ -304,8 +451,32 @@ class NeRAFVisionModel(nn.Module):
         if self.training:
             out["weights_list"] = weights_list
             out["ray_samples_list"] = samples_list
+            # everything the fused loss/backward node needs (same packed fp16 parameter copies as the forward used)
+            out["_state"] = dict(o=o, d=d, cam=ray_bundle.camera_indices, samples=samples_list, prop_dens=prop_dens,
+                                 prop_packed=prop_packed, field_packed=field_packed, rgb_s=rgb_s, dens=dens, w_fine=w)
         out["rgb_samples"], out["density"] = rgb_s, dens
         return out
+
+    # ---- V4: losses + backward ---------------------------------------------------------------------------
+    interlevel_loss_mult, distortion_loss_mult = 1.0, 0.002
+
+    def loss_params(self) -> List[torch.Tensor]:
+        f = self.field.module
+        ps = [f.table, f.base_w0, f.base_w1, f.head_w0, f.head_w1, f.head_w2, f.embedding]
+        for pn in self.proposal_networks:
+            ps += [pn.table, pn.w0, pn.w1]
+        return ps
+
+    def get_metrics_dict(self, outputs, batch):
+        return {}
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
+        """NerfactoModel.get_loss_dict: rgb MSE (on the clipped colour, NeRAF_model.py:67) + interlevel + distortion."""
+        if "_state" not in outputs:
+            raise RuntimeError("get_loss_dict needs the outputs of a training-mode get_outputs call")
+        gt = (batch["image"] if "image" in batch else batch["rgb"]).to(outputs["rgb"].device).float().contiguous()
+        rgb_l, inter, dist = _VisionLossFn.apply(self, outputs["_state"], gt, *self.loss_params())
+        return {"rgb_loss": rgb_l, "interlevel_loss": inter, "distortion_loss": dist}
 
     forward = get_outputs
 

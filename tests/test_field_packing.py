@@ -4,7 +4,7 @@ compare with the plain MLP arithmetic of the oracle.  Exercises neraf_amd.vision
 import numpy as np
 
 from neraf_amd import synth
-from neraf_amd.vision import _FRAG_INDEX
+from neraf_amd.vision import _FRAG_INDEX, _FRAG_INDEX_BWD
 
 
 def mfma(afrag, bfrag, acc=None):
@@ -65,3 +65,79 @@ def test_field_fragment_dataflow_matches_plain_mlp():
     rgb = (x @ W["head_w2"].T)[:, :3]
     np.testing.assert_allclose(logit_k, hb[:, 0], rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(rgb_k, rgb, rtol=1e-10, atol=1e-12)
+
+
+def test_field_backward_fragment_dataflow_matches_autograd():
+    """Same emulation for csrc/field_bwd.hip: dX chain through the transposed-weight fragments."""
+    import torch
+    P = synth.vision_params((8, 8, 8), num_train_data=4, table_scale=0.5)
+    Wn = {k: P["field." + k].astype(np.float64) for k in ("base_w0", "base_w1", "head_w0", "head_w1", "head_w2")}
+    flat = np.concatenate([Wn["base_w0"].ravel(), Wn["base_w1"].ravel(), Wn["head_w0"].ravel(), Wn["head_w1"].ravel(),
+                           Wn["head_w2"].ravel(), np.zeros(1)])
+    wf = flat[_FRAG_INDEX].reshape(24, 64, 8)
+    wb = flat[_FRAG_INDEX_BWD].reshape(26, 64, 8)
+    rng = np.random.default_rng(1)
+    enc = rng.normal(size=(16, 32)); sh = rng.normal(size=(16, 16)); emb = rng.normal(size=(16, 32))
+    g_rgb = rng.normal(size=(16, 3)); g_logit = rng.normal(size=(16,))
+    # ---- autograd reference on the plain MLP
+    t = {k: torch.tensor(v, requires_grad=True) for k, v in Wn.items()}
+    enc_t = torch.tensor(enc, requires_grad=True); emb_t = torch.tensor(emb, requires_grad=True)
+    hb = torch.relu(enc_t @ t["base_w0"].T) @ t["base_w1"].T
+    hin = torch.cat([torch.tensor(sh), hb[:, 1:16], emb_t, torch.zeros(16, 1, dtype=torch.float64)], 1)
+    x = torch.relu(torch.relu(hin @ t["head_w0"].T) @ t["head_w1"].T) @ t["head_w2"].T
+    loss = (x[:, :3] * torch.tensor(g_rgb)).sum() + (hb[:, 0] * torch.tensor(g_logit)).sum()
+    loss.backward()
+    # ---- emulate the kernel: forward
+    xin = np.zeros((64, 8)); h1 = np.zeros((64, 8)); shl = np.zeros((64, 4))
+    for l in range(64):
+        p, q = l & 15, l >> 4
+        xin[l] = enc[p, 8 * q:8 * q + 8]; h1[l] = emb[p, 8 * q:8 * q + 8]; shl[l] = sh[p, 4 * q:4 * q + 4]
+    d1 = [mfma(wf[ob], xin) for ob in range(4)]
+    d2 = mfma(wf[5], pack(d1[2], d1[3]), mfma(wf[4], pack(d1[0], d1[1])))
+    h0 = np.concatenate([d2, shl], axis=1)
+    h0[:16, 0] = 0.0
+    d3 = [mfma(wf[7 + 2 * ob], h1, mfma(wf[6 + 2 * ob], h0)) for ob in range(4)]
+    d4 = [mfma(wf[15 + 2 * ob], pack(d3[2], d3[3]), mfma(wf[14 + 2 * ob], pack(d3[0], d3[1]))) for ob in range(4)]
+    # ---- backward
+    zero = np.zeros((64, 4))
+    dy5 = np.zeros((64, 4))
+    for p in range(16):
+        dy5[p, :3] = g_rgb[p]                       # lanes q == 0
+    dy4 = [mfma(wb[ib], pack(dy5, zero, relu=False)) * (d4[ib] > 0) for ib in range(4)]
+    b0, b1 = pack(dy4[0], dy4[1], relu=False), pack(dy4[2], dy4[3], relu=False)
+    dy3 = [mfma(wb[5 + ib * 2], b1, mfma(wb[4 + ib * 2], b0)) * (d3[ib] > 0) for ib in range(4)]
+    b0, b1 = pack(dy3[0], dy3[1], relu=False), pack(dy3[2], dy3[3], relu=False)
+    dbase = mfma(wb[13], b1, mfma(wb[12], b0))
+    demb = [mfma(wb[15 + ib * 2], b1, mfma(wb[14 + ib * 2], b0)) for ib in range(2)]
+    dy2 = dbase.copy()
+    for p in range(16):
+        dy2[p, 0] = g_logit[p]
+    dy1 = [mfma(wb[18 + ib], pack(dy2, zero, relu=False)) * (d1[ib] > 0) for ib in range(4)]
+    b0, b1 = pack(dy1[0], dy1[1], relu=False), pack(dy1[2], dy1[3], relu=False)
+    de = [mfma(wb[23 + rb * 2], b1, mfma(wb[22 + rb * 2], b0)) for rb in range(2)]
+    denc = np.zeros((16, 32)); demb_k = np.zeros((16, 32))
+    for l in range(64):
+        p, q = l & 15, l >> 4
+        denc[p, 8 * q:8 * q + 4] = de[0][l]; denc[p, 8 * q + 4:8 * q + 8] = de[1][l]
+        for ib in range(2):
+            demb_k[p, 16 * ib + 4 * q:16 * ib + 4 * q + 4] = demb[ib][l]
+    np.testing.assert_allclose(denc, enc_t.grad.numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(demb_k, emb_t.grad.numpy(), rtol=1e-9, atol=1e-12)
+    # weight gradients from the dumped (X, dY) pairs: dW = dY . X^T over points (natural feature order)
+    def nat(blocks):            # D-layout blocks -> [feat, 16 points]
+        out = np.zeros((16 * len(blocks), 16))
+        for ob, b in enumerate(blocks):
+            for l in range(64):
+                p, q = l & 15, l >> 4
+                out[16 * ob + 4 * q:16 * ob + 4 * q + 4, p] = b[l]
+        return out
+    dW_h2 = nat([dy5]) @ np.maximum(nat(d4), 0).T
+    dW_h1 = nat(dy4) @ np.maximum(nat(d3), 0).T
+    dW_b1 = nat([dy2]) @ np.maximum(nat(d1), 0).T
+    dW_b0 = nat(dy1) @ enc
+    np.testing.assert_allclose(dW_h2, t["head_w2"].grad.numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(dW_h1, t["head_w1"].grad.numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(dW_b1, t["base_w1"].grad.numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(dW_b0.T.T, t["base_w0"].grad.numpy(), rtol=1e-9, atol=1e-12)
+    Xh0 = np.concatenate([sh, nat([d2]).T[:, 1:16], emb, np.zeros((16, 1))], axis=1)      # natural column order
+    np.testing.assert_allclose(nat(dy3) @ Xh0, t["head_w0"].grad.numpy(), rtol=1e-9, atol=1e-12)

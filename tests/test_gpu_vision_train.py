@@ -1,0 +1,112 @@
+"""GPU parity of the radiance-half TRAINING path (losses V4 + backward) against autograd through the CPU oracle
+(oracle/vision.py, parity unpinned).
+
+Tolerances: loss values within 2e-3 relative (the forward differs by fp16 activations); gradients within
+relative L2 6e-2 per tensor -- the chain carries fp16 activations/gradients with fp32 accumulation and ReLU masks
+taken from the fp16 forward (same reasoning as tests/test_gpu_nacf.py), and hash-table gradients are sums of
+~1e6 fp32 atomics in arbitrary order."""
+import numpy as np
+import pytest
+import torch
+
+from neraf_amd import synth
+
+pytestmark = pytest.mark.gpu
+GRAD_REL_L2 = 6e-2
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from neraf_amd.vision import NeRAFVisionModel
+    from oracle import vision as V
+    dev = torch.device("cuda:0")
+    spec = V.NerfactoSpec()
+    tot = (spec.prop_grids[0].total, spec.prop_grids[1].total, spec.main_grid.total)
+    P = {k: T(v) for k, v in synth.vision_params(tot, num_train_data=210, table_scale=0.5).items()}
+    m = NeRAFVisionModel(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 210)
+    with torch.no_grad():
+        for i in range(2):
+            m.proposal_networks[i].table.copy_(P[f"prop{i}.table"])
+            m.proposal_networks[i].w0.copy_(P[f"prop{i}.w0"])
+            m.proposal_networks[i].w1.copy_(P[f"prop{i}.w1"])
+        f = m.field.module
+        f.table.copy_(P["field.table"])
+        for k in ("base_w0", "base_w1", "head_w0", "head_w1", "head_w2", "embedding"):
+            getattr(f, k).copy_(P["field." + k])
+    return m.to(dev), {k: v.half().float() for k, v in P.items()}, spec, V, dev
+
+
+def _oracle(P16, spec, V, rb, step, scale):
+    P = {k: v.clone().requires_grad_(True) for k, v in P16.items()}
+    out = V.nerfacto_forward(T(rb["origins"]), T(rb["directions"]), T(rb["camera_indices"]), P, spec, step=step, training=True,
+                             jitters=[T(j) for j in rb["jitters"]])
+    ld = V.vision_loss_dict(out, T(rb["rgb"]), spec)
+    (scale * (ld["rgb_loss"] + ld["interlevel_loss"] + ld["distortion_loss"])).backward()
+    return ld, P
+
+
+@pytest.mark.parametrize("R,scale", [(384, 1.0), (130, 4096.0)])
+def test_losses_and_gradients_vs_oracle(setup, R, scale):
+    from neraf_amd.vision import RayBundle
+    m, P16, spec, V, dev = setup
+    rb = synth.ray_batch(R, tag=f"t.vtrain{R}")
+    ld_o, Po = _oracle(P16, spec, V, rb, 300, scale)
+    m.train()
+    m.update_to_step(300)
+    for p in m.parameters():
+        p.grad = None
+    out = m.get_outputs(RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev)),
+                        jitters=[T(j).to(dev) for j in rb["jitters"]])
+    ld = m.get_loss_dict(out, {"image": T(rb["rgb"]).to(dev)})
+    for k in ("rgb_loss", "interlevel_loss", "distortion_loss"):
+        np.testing.assert_allclose(ld[k].item(), ld_o[k].item(), rtol=2e-3, atol=1e-9), k
+    (scale * (ld["rgb_loss"] + ld["interlevel_loss"] + ld["distortion_loss"])).backward()
+    f = m.field.module
+    pairs = [("field.base_w0", f.base_w0), ("field.base_w1", f.base_w1), ("field.head_w0", f.head_w0), ("field.head_w1", f.head_w1),
+             ("field.head_w2", f.head_w2), ("field.embedding", f.embedding), ("field.table", f.table)]
+    for i, pn in enumerate(m.proposal_networks):
+        pairs += [(f"prop{i}.w0", pn.w0), (f"prop{i}.table", pn.table)]
+    for name, p in pairs:
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+        assert rel_l2(p.grad, Po[name].grad) <= GRAD_REL_L2, (name, rel_l2(p.grad, Po[name].grad))
+    for i, pn in enumerate(m.proposal_networks):          # only the used output row of the padded layer-1 matrix
+        assert rel_l2(pn.w1.grad[0], Po[f"prop{i}.w1"].grad[0]) <= GRAD_REL_L2
+        assert float(pn.w1.grad[1:].abs().max()) == 0.0
+    # padding inputs receive no gradient (tcnn pads 63 -> 64 and 10 -> 16)
+    assert float(f.head_w0.grad[:, 63].abs().max()) == 0.0
+    assert float(m.proposal_networks[0].w0.grad[:, 10:].abs().max()) == 0.0
+
+
+def test_training_step_decreases_loss_full_batch(setup):
+    """BASELINE batch (4096 rays): a few Adam steps on a fixed batch must lower the rgb loss (end-to-end sanity of the
+    gradient direction at full size, where the CPU oracle would take minutes)."""
+    from neraf_amd.vision import RayBundle
+    m, _, _, _, dev = setup
+    import copy
+    m2 = copy.deepcopy(m).to(dev)
+    m2.train()
+    rb = synth.ray_batch(4096, tag="t.vtrain.big")
+    bundle = RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev))
+    gt = {"image": T(rb["rgb"]).to(dev) * 0.2 + 0.4}
+    jit = [T(j).to(dev) for j in rb["jitters"]]
+    opt = torch.optim.Adam(m2.parameters(), lr=1e-2, eps=1e-15)
+    losses = []
+    for it in range(12):
+        m2.update_to_step(2000)
+        opt.zero_grad(set_to_none=True)
+        out = m2.get_outputs(bundle, jitters=jit)
+        ld = m2.get_loss_dict(out, gt)
+        (ld["rgb_loss"] + ld["interlevel_loss"] + ld["distortion_loss"]).backward()
+        opt.step()
+        losses.append(ld["rgb_loss"].item())
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.7 * losses[0], losses
