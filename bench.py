@@ -51,13 +51,15 @@ def T(a):
 
 
 class JointStep:
-    """cfg3 (RAF FurnishedRoom joint) step with the stages that exist in HIP today:
+    """cfg3 (RAF FurnishedRoom joint) training step, NeRAFPipeline.get_train_loss_dict order (NeRAF_pipeline.py:175-199):
        1. NeRAFVisionModel.get_outputs on the ray batch (sampler, 2 proposal nets, 2 PDF resamplings, fused field
-          query, composite)                                            -- FORWARD ONLY (vision backward: next round)
+          query, composite) + get_loss_dict (rgb MSE, interlevel, distortion)
        2. audio_model.query_grid_one_batch: 4096 cells x 18 directions through the field, mean, slab write
-       3. ResNet3D(7x128^3 grid) -> 1024 feature (train-mode BatchNorm)  -- FORWARD ONLY
-       4. audio get_outputs (GPU prologue + NAcF MLP) -> STFT loss -> backward (all NAcF grads + d/d feature)
-          -> [RCCL all-reduce] -> GradScaler + fused Adam on the NAcF parameters."""
+       3. ResNet3D(7x128^3 grid) -> 1024 feature (train-mode BatchNorm)  -- FORWARD ONLY (its backward: next round)
+       4. audio get_outputs (GPU prologue + NAcF MLP) -> STFT loss
+       5. ONE backward over the summed loss dict: radiance half (loss grads, proposal backward, fused field backward,
+          weight-grad GEMMs) + NAcF (all grads + d/d feature) -> [RCCL all-reduce] -> GradScaler + fused Adam on the
+          radiance parameters (hash tables, MLPs, embedding; lr 1e-2) and the NAcF parameters (lr 1e-4)."""
 
     def __init__(self, dev, R, B, world):
         from neraf_amd import synth
@@ -79,11 +81,15 @@ class JointStep:
         rb = synth.ray_batch(R, tag=f"bench.rays.r{rank}")
         self.bundle = RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev))
         self.batch = {k: T(v).to(dev) for k, v in synth.audio_batch(B, C_, F_, T_, tag=f"bench.r{rank}").items()}
+        self.gt = {"image": T(rb["rgb"]).to(dev)}
         self.params = list(self.am.field.parameters())
+        self.vparams = list(self.vm.parameters())
         try:
-            self.opt = torch.optim.Adam(self.params, lr=1e-4, eps=1e-15, fused=True)
+            self.opt = torch.optim.Adam(self.params, lr=1e-4, eps=1e-15, fused=True)       # NeRAF_config.py:124-127
+            self.opt_v = torch.optim.Adam(self.vparams, lr=1e-2, eps=1e-15, fused=True)    # :116-123
         except Exception:
             self.opt = torch.optim.Adam(self.params, lr=1e-4, eps=1e-15, foreach=True)
+            self.opt_v = torch.optim.Adam(self.vparams, lr=1e-2, eps=1e-15, foreach=True)
         self.scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
         self.i = 0
 
@@ -93,16 +99,19 @@ class JointStep:
     def step(self):
         self.i += 1
         self.vm.update_to_step(self.i)
-        out_v = self.vm.get_outputs(self.bundle)                                                   # NeRAF_pipeline.py:176
-        self.am.query_grid_one_batch(self.i, self.vm.field, renderer_rgb=self.vm.renderer_rgb, batch_size=self.R)  # :181-184
         self.opt.zero_grad(set_to_none=True)
+        self.opt_v.zero_grad(set_to_none=True)
+        out_v = self.vm.get_outputs(self.bundle)                                                   # NeRAF_pipeline.py:176
+        lv = self.vm.get_loss_dict(out_v, self.gt)                                                 # :178
+        self.am.query_grid_one_batch(self.i, self.vm.field, renderer_rgb=self.vm.renderer_rgb, batch_size=self.R)  # :181-184
         y = self.am.get_outputs(self.batch)                                                        # :188
         d = self.am.get_loss_dict(y, self.batch)                                                   # :191
-        loss = d["audio_sc_loss"] + d["audio_mag_loss"]
+        loss = lv["rgb_loss"] + lv["interlevel_loss"] + lv["distortion_loss"] + d["audio_sc_loss"] + d["audio_mag_loss"]
         self.scaler.scale(loss).backward()
         if self.world > 1:
             from neraf_amd.parallel import allreduce_gradients
-            allreduce_gradients(self.params, self.world)
+            allreduce_gradients(self.vparams + self.params, self.world)
+        self.scaler.step(self.opt_v)
         self.scaler.step(self.opt)
         self.scaler.update()
         return out_v["rgb"], loss
@@ -134,11 +143,15 @@ def cpu_baseline(R, B):
     vaabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
     opt = torch.optim.Adam(list(sdn.values()), lr=1e-4, eps=1e-15)
     t = {}
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    t0 = time.perf_counter()
+    ov = V.nerfacto_forward(T(rb["origins"]), T(rb["directions"]), T(rb["camera_indices"]), Pg, spec, training=True,
+                            jitters=[T(j) for j in rb["jitters"]])
+    lv = V.vision_loss_dict(ov, T(rb["rgb"]), spec)
+    (lv["rgb_loss"] + lv["interlevel_loss"] + lv["distortion_loss"]).backward()
+    t["vision_train"] = (time.perf_counter() - t0) * frac
+    del Pg, ov, lv
     with torch.no_grad():
-        t0 = time.perf_counter()
-        V.nerfacto_forward(T(rb["origins"]), T(rb["directions"]), T(rb["camera_indices"]), P, spec, training=True,
-                           jitters=[T(j) for j in rb["jitters"]])
-        t["vision_fwd"] = (time.perf_counter() - t0) * frac
         t0 = time.perf_counter()
         ori = O.refresh_world_positions(coords, vaabb)
         rg, dn = [], []
@@ -250,10 +263,12 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": ("RAF FurnishedRoom joint step (BASELINE configs[2] shape: %d rays + %d RIR slices x 513 bins per GPU): "
-                             "radiance forward (sampler, 2 proposal nets, 2 PDF resamplings, fused field query, composite) -> grid "
-                             "refresh (%d cells x 18 dirs) -> ResNet3D forward on the 7x128^3 grid -> audio prologue + NAcF MLP "
-                             "-> STFT loss -> NAcF backward (all grads + d/d feature) -> %sGradScaler + fused Adam.  NOT inside "
-                             "the step yet: backward of the radiance half and of the ResNet3D (forward-only stages)."
+                             "radiance forward (sampler, 2 proposal nets, 2 PDF resamplings, fused field query, composite) + rgb/"
+                             "interlevel/distortion losses -> grid refresh (%d cells x 18 dirs) -> ResNet3D forward on the 7x128^3 "
+                             "grid -> audio prologue + NAcF MLP -> STFT loss -> one backward (radiance half: loss grads, proposal "
+                             "nets, fused field backward, weight-grad GEMMs; NAcF: all grads + d/d feature) -> %sGradScaler + fused "
+                             "Adam on radiance + NAcF parameters.  NOT inside the step yet: ResNet3D backward and the grid->field "
+                             "gradient edge (ResNet3D is forward-only), camera optimizer."
                              % (a.rays, a.slices, a.rays, "RCCL all-reduce -> " if world > 1 else "")),
                 "rays_per_gpu": a.rays, "slices_per_gpu": a.slices, "parallelism": f"dp{world}",
             },
