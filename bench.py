@@ -91,7 +91,7 @@ class JointStep:
             self.opt = torch.optim.Adam(self.params, lr=1e-4, eps=1e-15, foreach=True)
             self.opt_v = torch.optim.Adam(self.vparams, lr=1e-2, eps=1e-15, foreach=True)
         self.scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
-        self.i = 0
+        self.i = 20000      # steady-state regime of the 400k-iteration schedule: anneal done, proposal nets updated every 6th step
 
     def samples_per_step(self):
         return self.R + self.B * C_ * F_

@@ -259,17 +259,16 @@ __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
       gs = sel ? a.d_density[idx] * a.avg_density * __expf(fminf(out, 15.f)) : 0.f;
 #pragma unroll
       for (int j = 0; j < 16; ++j) dh[j] = hpre[j] > 0.f ? gs * w1[j] : 0.f;
-      // table gradients
-#pragma unroll
-      for (int l = 0; l < 8; ++l)
-        if (l < a.g.n_levels) {
-          float g0 = 0.f, g1 = 0.f;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) { g0 = fmaf(dh[j], w0[j][2 * l], g0); g1 = fmaf(dh[j], w0[j][2 * l + 1], g1); }
-          if (g0 != 0.f || g1 != 0.f)
-            scatter_level(a.table_grad, x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.offset[l], a.g.hashed[l], g0, g1);
-        }
     }
+    // table gradients: every lane takes part in the segmented pre-reduction (64 consecutive samples per wave)
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+      if (l < a.g.n_levels) {
+        float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { g0 = fmaf(dh[j], w0[j][2 * l], g0); g1 = fmaf(dh[j], w0[j][2 * l + 1], g1); }
+        scatter_level_seg<64>(a.table_grad, x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.offset[l], a.g.hashed[l], g0, g1, lane);
+      }
     // weight gradients: dW0[j][k] = sum_p dh[p][j] enc[p][k] ; dW1[j] = sum_p gs[p] relu(h[p][j]) -- per-wave LDS staging
 #pragma unroll
     for (int k = 0; k < 16; ++k) { s_dh[wv][lane][k] = dh[k]; s_enc[wv][lane][k] = enc[k]; s_hr[wv][lane][k] = gs * fmaxf(hpre[k], 0.f); }
@@ -511,14 +510,12 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
         de[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[(23 + rb * 2) * 64], b1, de[rb], 0, 0, 0);
       }
     }
-    if (valid) {
 #pragma unroll
-      for (int li = 0; li < 4; ++li) {
-        const int l = 4 * q + li;
-        const float g0 = de[li >> 1][2 * (li & 1)] * inv_gscale, g1 = de[li >> 1][2 * (li & 1) + 1] * inv_gscale;
-        if (g0 != 0.f || g1 != 0.f)
-          scatter_level(a.table_grad, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], g0, g1);
-      }
+    for (int li = 0; li < 4; ++li) {
+      const int l = 4 * q + li;
+      const float g0 = valid ? de[li >> 1][2 * (li & 1)] * inv_gscale : 0.f;
+      const float g1 = valid ? de[li >> 1][2 * (li & 1) + 1] * inv_gscale : 0.f;
+      scatter_level_seg<16>(a.table_grad, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], g0, g1, p);
     }
   }
 }

@@ -119,6 +119,50 @@ __device__ __forceinline__ void scatter_level(float* __restrict__ tgrad, float x
   }
 }
 
+// Same scatter with an in-register pre-reduction: the WIDTH consecutive lanes of a group hold consecutive samples of
+// a ray, which at all but the finest levels fall into the same grid cell.  A segmented scan over runs of equal table
+// indices leaves each run's sum in its last lane, and only that lane issues the atomics (global float atomics are the
+// bottleneck of the backward: ~2e10 scattered adds/s chip-wide).  Merging equal indices is valid across rays too.
+// Every lane of the group must call this (zero gradients for lanes without work).
+template <int WIDTH>
+__device__ __forceinline__ void scatter_level_seg(float* __restrict__ tgrad, float x, float y, float z, float scale, int res,
+                                                  unsigned size, unsigned offset, int hashed, float g0, float g1, int pos) {
+  const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+  const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+  const float wx = px - flx, wy = py - fly, wz = pz - flz;
+  const unsigned ix = (unsigned)(int)flx, iy = (unsigned)(int)fly, iz = (unsigned)(int)flz;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned cx = ix + (c & 1), cy = iy + ((c >> 1) & 1), cz = iz + ((c >> 2) & 1);
+    const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+    unsigned idx;
+    if (hashed) idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1u);
+    else {
+      idx = cx + cy * (unsigned)res + cz * (unsigned)res * (unsigned)res;
+      if (idx >= size) idx -= size;
+    }
+    float v0 = w * g0, v1 = w * g1;
+    const unsigned prev = __shfl_up(idx, 1, WIDTH);
+    const unsigned next = __shfl_down(idx, 1, WIDTH);
+    int head = (pos == 0 || prev != idx) ? 1 : 0;
+    const bool tail = (pos == WIDTH - 1) || next != idx;
+#pragma unroll
+    for (int o = 1; o < WIDTH; o <<= 1) {
+      const float a0 = __shfl_up(v0, o, WIDTH), a1 = __shfl_up(v1, o, WIDTH);
+      const int hu = __shfl_up(head, o, WIDTH);
+      if (pos >= o) {
+        if (!head) { v0 += a0; v1 += a1; }
+        head |= hu;
+      }
+    }
+    if (tail && (v0 != 0.f || v1 != 0.f)) {
+      float* t = tgrad + (size_t)(offset + idx) * 2;
+      atomicAdd(t, v0);
+      atomicAdd(t + 1, v1);
+    }
+  }
+}
+
 // SH degree 4 components 4q..4q+3 of direction (dx,dy,dz) (tiny-cuda-nn constants), q = lane >> 4
 __device__ __forceinline__ void sh4_quarter(int q, float dx, float dy, float dz, float (&sh)[4]) {
   const float xy = dx * dy, xz = dx * dz, yz = dy * dz, x2 = dx * dx, y2 = dy * dy, z2 = dz * dz;

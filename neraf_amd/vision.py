@@ -332,7 +332,9 @@ class _VisionLossFn(torch.autograd.Function):
                                             g_emb.data_ptr() if cam is not None else None, _lib.ptr_array(g_w), dump.data_ptr(),
                                             splitk.data_ptr(), splitk.numel() * 4, stream), dev)
         grads = [g_table] + g_w + [g_emb]
-        # ---- proposal networks (interlevel loss)
+        # ---- proposal networks (interlevel loss); densities were computed under no_grad when not `updated`
+        if not st["prop_updated"]:
+            return (None, None, None, *grads, *([None] * (3 * len(model.proposal_networks))))
         for i, pn in enumerate(model.proposal_networks):
             ps = st["samples"][i]
             Sp = ps.e_bins.shape[1] - 1
@@ -361,6 +363,7 @@ class NeRAFVisionModel(nn.Module):
     near_plane, far_plane = 0.05, 1000.0
     eval_num_rays_per_chunk = 1 << 15
     proposal_weights_anneal_slope, proposal_weights_anneal_max_num_iters = 10.0, 1000
+    proposal_update_every, proposal_warmup = 5, 5000          # nerfacto defaults [NS-recall]
 
     def __init__(self, aabb: torch.Tensor, num_train_data: int, average_init_density: float = 0.01):
         super().__init__()
@@ -371,6 +374,7 @@ class NeRAFVisionModel(nn.Module):
         self.renderer_rgb = RGBRenderer()
         self.audio_model = None
         self.step = 0
+        self._steps_since_update = 0
 
     @property
     def device(self):
@@ -390,7 +394,19 @@ class NeRAFVisionModel(nn.Module):
         return self._splitk
 
     def update_to_step(self, step: int):
+        """ProposalNetworkSampler.step_cb [NS-recall]: called once per training iteration."""
         self.step = step
+        self._steps_since_update += 1
+
+    def _proposal_updated(self) -> bool:
+        """ProposalNetworkSampler's schedule [NS-recall]: the proposal networks receive gradients on every step during
+        warm-up and then only when more than ``update_sched(step)`` (-> proposal_update_every) steps have passed."""
+        sched = float(np.clip(np.interp(self.step, [0, self.proposal_warmup], [0, self.proposal_update_every]), 1,
+                              self.proposal_update_every))
+        updated = self._steps_since_update > sched or self.step < 10
+        if updated:
+            self._steps_since_update = 0
+        return updated
 
     def _anneal(self) -> float:
         if not self.training:
@@ -419,6 +435,7 @@ class NeRAFVisionModel(nn.Module):
         s0, e0 = torch.empty((R, S0 + 1), **f32), torch.empty((R, S0 + 1), **f32)
         _lib.check(lib.neraf_sample_uniform(h, R, S0, near, far, jp[0], s0.data_ptr(), e0.data_ptr(), st), dev)
         anneal = self._anneal()
+        prop_updated = self._proposal_updated() if self.training else False
         weights_list, samples_list = [], []
         s_prev, e_prev = s0, e0
         prop_packed = [pn.packed() for pn in self.proposal_networks]
@@ -453,7 +470,8 @@ class NeRAFVisionModel(nn.Module):
             out["ray_samples_list"] = samples_list
             # everything the fused loss/backward node needs (same packed fp16 parameter copies as the forward used)
             out["_state"] = dict(o=o, d=d, cam=ray_bundle.camera_indices, samples=samples_list, prop_dens=prop_dens,
-                                 prop_packed=prop_packed, field_packed=field_packed, rgb_s=rgb_s, dens=dens, w_fine=w)
+                                 prop_packed=prop_packed, field_packed=field_packed, rgb_s=rgb_s, dens=dens, w_fine=w,
+                                 prop_updated=prop_updated)
         out["rgb_samples"], out["density"] = rgb_s, dens
         return out
 

@@ -62,6 +62,7 @@ def test_losses_and_gradients_vs_oracle(setup, R, scale):
     ld_o, Po = _oracle(P16, spec, V, rb, 300, scale)
     m.train()
     m.update_to_step(300)
+    m._steps_since_update = 100            # force an "updated" proposal step (nerfstudio schedule)
     for p in m.parameters():
         p.grad = None
     out = m.get_outputs(RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev)),
@@ -101,7 +102,7 @@ def test_training_step_decreases_loss_full_batch(setup):
     opt = torch.optim.Adam(m2.parameters(), lr=1e-2, eps=1e-15)
     losses = []
     for it in range(12):
-        m2.update_to_step(2000)
+        m2.update_to_step(it)
         opt.zero_grad(set_to_none=True)
         out = m2.get_outputs(bundle, jitters=jit)
         ld = m2.get_loss_dict(out, gt)
@@ -110,3 +111,24 @@ def test_training_step_decreases_loss_full_batch(setup):
         losses.append(ld["rgb_loss"].item())
     assert all(np.isfinite(losses))
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_proposal_update_schedule(setup):
+    """After warm-up the proposal networks receive gradients only every proposal_update_every+1 steps [NS-recall]."""
+    from neraf_amd.vision import RayBundle
+    m, _, _, _, dev = setup
+    rb = synth.ray_batch(64, tag="t.sched")
+    bundle = RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev))
+    m.train()
+    m._steps_since_update = 0
+    got = []
+    for step in range(20000, 20013):
+        m.update_to_step(step)
+        for p in m.parameters():
+            p.grad = None
+        out = m.get_outputs(bundle)
+        ld = m.get_loss_dict(out, {"image": T(rb["rgb"]).to(dev)})
+        (ld["rgb_loss"] + ld["interlevel_loss"] + ld["distortion_loss"]).backward()
+        got.append(m.proposal_networks[0].table.grad is not None)
+        assert m.field.module.table.grad is not None
+    assert got == [False] * 5 + [True] + [False] * 5 + [True] + [False]
