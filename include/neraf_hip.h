@@ -249,7 +249,7 @@ int neraf_grid_refresh_write(neraf_ctx* ctx, const float* rgb, const float* dens
  * then per Bottleneck conv1, conv2, conv3, [downsample.0]); bn: HOST array of 4 device pointers per
  * BatchNorm3d in the same order {weight, bias, running_mean, running_var}.  use_batch_stats = 1 is
  * nn.Module.train() behaviour (statistics over the voxels of the single sample), 0 uses the running
- * statistics.  Forward only in round 1.
+ * statistics.
  * ---------------------------------------------------------------------------------- */
 typedef struct neraf_resnet3d_desc {
   int grid_size;   /* 128 or 64 */
@@ -267,6 +267,21 @@ int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void*
 /* After a train-mode forward: running_mean/var <- (1-m) running + m batch (unbiased var), as nn.BatchNorm3d. */
 int neraf_resnet3d_update_running_stats(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* workspace,
                                         float* const* bn, float momentum, neraf_stream_t stream);
+
+/* Backward of neraf_resnet3d_fwd (train-mode BatchNorm).  `workspace` is the forward's (its activations and
+ * BN statistics are read); packed_t comes from neraf_resnet3d_pack_weights_bwd.  dfeat fp32 [1024] ->
+ * w_grads (HOST array, 43 device pointers shaped like the Conv3d weights, overwritten) and bn_grads (HOST
+ * array, 2 per BatchNorm3d: d weight, d bias).  If n_cells > 0 the gradient w.r.t. channels [0, n_ch) of
+ * the grid cells [cell_start, cell_start+n_cells) (flat x-major index, the refresh window of
+ * NeRAF_model.py:306-311) is written to dgrid_cells fp32 [n_ch, n_cells]. */
+size_t neraf_resnet3d_bwd_packed_bytes(const neraf_resnet3d_desc* d);
+size_t neraf_resnet3d_bwd_workspace_bytes(const neraf_resnet3d_desc* d);
+int neraf_resnet3d_pack_weights_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const float* const* conv_w, void* packed_t,
+                                    neraf_stream_t stream);
+int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed_t, const float* const* conv_w,
+                       const float* const* bn, void* workspace, void* bwd_workspace, const float* dfeat,
+                       float* const* w_grads, float* const* bn_grads, size_t cell_start, int n_cells, int n_ch,
+                       float* dgrid_cells, neraf_stream_t stream);
 
 #ifdef __cplusplus
 }

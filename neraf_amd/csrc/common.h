@@ -72,7 +72,9 @@ enum { ACT_NONE = 0, ACT_LEAKY = 1, ACT_TANH10 = 2, ACT_RELU = 3 };
 // 2: cin == 8, one filter tap per 16-byte chunk (the 7->64 channel stem, NeRAF_resnet3d.py:120).
 struct ConvGeom {
   int loader;
-  int din, dout, stride, pad, ksize, cin;
+  int din, dout, stride, pad, ksize, cin;   // din = edge of the SOURCE tensor, dout = edge of the result
+  int tflip;     // transposed convolution (dgrad): source offset is -tap instead of +tap
+  int tstride;   // transposed convolution of a stride-2 conv: a tap contributes only where (z + pad - tap) is even
   const half_t* zero_page;   // >= 16 bytes of zeros: source of every out-of-bounds / padding-tap chunk
 };
 
@@ -87,6 +89,7 @@ struct GemmParams {
   int act;
   const half_t* lmask; int ldmask;   // optional: v *= (lmask[m][n] > 0 ? 1 : slope)  (leaky/relu backward)
   float mask_slope;
+  const half_t* add16; int ldadd;    // optional fp16 matrix added to the result before the stores (gradient accumulation)
   half_t* C16; int ldc16;            // optional row-major fp16 out [Mpad, >=Npad]
   half_t* C16T; int ldc16t;          // optional transposed fp16 out [Npad, >=Mpad]
   float* C32; int ldc32;             // optional fp32 out, masked to M x N

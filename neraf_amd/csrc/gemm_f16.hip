@@ -75,6 +75,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= ((float)mk[r] > 0.f) ? 1.f : p.mask_slope;
       }
+      if (p.add16) {
+        const half4 ad = *reinterpret_cast<const half4*>(p.add16 + (size_t)m * p.ldadd + n0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)ad[r];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (m >= p.M || (n0 + r) >= p.N) v[r] = 0.f;
@@ -268,10 +273,14 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
       const int tap = kt / cpb, cb = kt - tap * cpb;
       const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
       const int din = p.conv.din;
+      const int sdz = p.conv.tflip ? -dz : dz, sdy = p.conv.tflip ? -dy : dy, sdx = p.conv.tflip ? -dx : dx;
+      const bool half_grid = p.conv.tstride == 2;
 #pragma unroll
       for (int i = 0; i < T::A_CH; ++i) {
-        const int iz = az[i] + dz, iy = ay[i] + dy, ix = ax[i] + dx;
-        const bool ok = (unsigned)iz < (unsigned)din && (unsigned)iy < (unsigned)din && (unsigned)ix < (unsigned)din;
+        int iz = az[i] + sdz, iy = ay[i] + sdy, ix = ax[i] + sdx;
+        bool ok = true;
+        if (half_grid) { ok = ((iz | iy | ix) & 1) == 0; iz >>= 1; iy >>= 1; ix >>= 1; }   // negatives stay negative -> rejected below
+        ok = ok && (unsigned)iz < (unsigned)din && (unsigned)iy < (unsigned)din && (unsigned)ix < (unsigned)din;
         const half_t* src = ok ? p.A + ((size_t)(iz * din + iy) * din + ix) * p.conv.cin + cb * 64 + alc[i] * 8 : p.conv.zero_page;
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
       }
@@ -375,6 +384,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
     if (p.bias) v += p.bias[n];
     v = act_apply(v, p.act);
     if (p.lmask) v *= ((float)p.lmask[(size_t)m * p.ldmask + n] > 0.f) ? 1.f : p.mask_slope;
+    if (p.add16) v += (float)p.add16[(size_t)m * p.ldadd + n];
     if (m >= p.M || n >= p.N) v = 0.f;
     tile[ty + i * 8][tx] = v;
     if (p.C16) p.C16[(size_t)m * p.ldc16 + n] = (half_t)v;

@@ -1,0 +1,528 @@
+// ResNet3D scene encoder, backward (train-mode BatchNorm): d loss / d feat[1024] -> gradients of the 43 Conv3d
+// weights, the 43 BatchNorm3d affine pairs and (for the cells refreshed this step) of the voxel grid
+// (NeRAF_model.py:395-400 keeps that edge alive: "Backprop on vision too", NeRAF_pipeline.py:487).
+//
+// Every contraction re-uses gemm_f16.hip:
+//   dgrad  : dX = dY (*) W^T as the same implicit GEMM with a transposed-convolution loader (tap offsets negated,
+//            stride-2 taps filtered by parity), B = weights packed [cin][tap*cout + cout];
+//   wgrad  : dW[cout][tap,cin] = sum_m dY[m][cout] X[m@tap][cin] as an NT GEMM over the voxels (split-K), fed by
+//            transposed copies dY^T [cout][M] and im2col(X)^T [tap*cin + c][M] written by one tiling-transpose kernel;
+//   BN     : two passes per layer (per-channel reductions sum dy, sum dy*xhat; then the element-wise dx), with the
+//            ReLU mask of the consumer folded into both.
+// The fp16 gradient chain is scaled by a power of two chosen from max|d feat| and un-scaled in every fp32 output.
+#include "resnet3d_common.h"
+#include <algorithm>
+
+namespace {
+
+// ---- packed weights for dgrad: Wt[cin][tap*cout + co] = W[co][cin][tap] ------------------------------------------
+struct PackTTable {
+  int n;
+  const float* src[48];
+  unsigned long long begin[49];
+  unsigned long long dst_off[48];
+  int cout[48], cin[48], taps[48], kcols[48], nrows[48];
+};
+
+__global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(PackTTable t, char* __restrict__ packed) {
+  const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= t.begin[t.n]) return;
+  int lo = 0, hi = t.n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.begin[mid] <= idx) lo = mid; else hi = mid - 1; }
+  const int i = lo;
+  const unsigned long long e = idx - t.begin[i];
+  const int kc = t.kcols[i];
+  const int n = (int)(e / kc), k = (int)(e % kc);          // n = cin index, k = tap*cout + co
+  const int tap = k / t.cout[i], co = k % t.cout[i];
+  float v = 0.f;
+  if (n < t.cin[i] && tap < t.taps[i]) v = t.src[i][((size_t)co * t.cin[i] + n) * t.taps[i] + tap];
+  reinterpret_cast<half_t*>(packed + t.dst_off[i])[e] = (half_t)v;
+}
+
+// ---- tiling transpose / im2col^T: out[k][m] = X[src(m, tap(k))][c(k)], zero outside ------------------------------
+struct Im2colArgs {
+  const half_t* x; int cin;          // source [din^3][cin]
+  int din, dout, ksize, stride, pad;
+  int M, Mpad;                       // result voxels (columns), padded column count (= leading dimension)
+  int K, Krows;                      // real rows taps*cin, rows written (multiple of 128, zero beyond K)
+  half_t* out;
+};
+
+__global__ __launch_bounds__(256) void im2col_t_kernel(Im2colArgs a) {
+  __shared__ half_t tile[64][72];    // [m][k] with padding
+  const int m0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  // read: 64 rows (m) x 8 chunks (16 B = 8 k-values)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int c = it * 256 + tid, row = c >> 3, ch = c & 7;
+    const int m = m0 + row, k = k0 + ch * 8;
+    half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+    if (m < a.M && k < a.K) {
+      const int tap = k / a.cin, cc = k % a.cin;
+      const int x = m % a.dout, y = (m / a.dout) % a.dout, z = m / (a.dout * a.dout);
+      const int dz = tap / (a.ksize * a.ksize), dy = (tap / a.ksize) % a.ksize, dx = tap % a.ksize;
+      const int iz = z * a.stride - a.pad + dz, iy = y * a.stride - a.pad + dy, ix = x * a.stride - a.pad + dx;
+      if ((unsigned)iz < (unsigned)a.din && (unsigned)iy < (unsigned)a.din && (unsigned)ix < (unsigned)a.din)
+        v = *reinterpret_cast<const half8*>(a.x + ((size_t)(iz * a.din + iy) * a.din + ix) * a.cin + cc);
+    }
+    *reinterpret_cast<half8*>(&tile[row][ch * 8]) = v;
+  }
+  __syncthreads();
+  // write: 64 rows (k) x 8 chunks (8 consecutive m)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int c = it * 256 + tid, krow = c >> 3, ch = c & 7;
+    const int k = k0 + krow;
+    if (k >= a.Krows) continue;
+    half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tile[ch * 8 + j][krow];
+    *reinterpret_cast<half8*>(a.out + (size_t)k * a.Mpad + m0 + ch * 8) = v;
+  }
+}
+
+// ---- BatchNorm backward ----------------------------------------------------------------------------------------
+struct BnBwdArgs {
+  BnSrc s;                    // x (pre-BN), forward statistics, gamma
+  const half_t* g16; const float* g32;     // upstream gradient w.r.t. the post-activation tensor (one of them)
+  const half_t* act;          // post-activation tensor for the ReLU mask (null = no mask)
+  int M, Mpad, C;
+  float* sums;                // [2][cpad]: sum dy, sum dy*xhat
+  half_t* dx;                 // apply: gradient w.r.t. the pre-BN conv output [Mpad][C]
+  half_t* dy_masked;          // apply (optional): g * (act > 0) for the identity residual branch
+  float* dgamma; float* dbeta; const float* inv_scale;   // apply (block 0 writes the un-scaled affine gradients)
+};
+
+__device__ __forceinline__ void bn_mean_rstd(const BnSrc& s, int c, float inv_m, float& mean, float& rstd) {
+  mean = s.stats[c] * inv_m;
+  const float var = fmaxf(s.stats[s.cpad + c] * inv_m - mean * mean, 0.f);
+  rstd = rsqrtf(var + 1e-5f);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs p) {
+  extern __shared__ float sm[];      // mean[C] rstd[C] acc[2][C]
+  float* mean = sm; float* rstd = sm + p.C; float* acc = sm + 2 * p.C;
+  const float inv_m = 1.f / (float)p.M;
+  for (int c = threadIdx.x; c < p.C; c += 256) { bn_mean_rstd(p.s, c, inv_m, mean[c], rstd[c]); acc[c] = 0.f; acc[p.C + c] = 0.f; }
+  __syncthreads();
+  const int cpr = p.C >> 3;
+  const int rows_per_it = 256 / cpr > 0 ? 256 / cpr : 1;
+  const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (rsub < rows_per_it) {
+    for (int row = blockIdx.x * rows_per_it + rsub; row < p.M; row += gridDim.x * rows_per_it) {
+      const size_t off = (size_t)row * p.C + chunk * 8;
+      const half8 x = *reinterpret_cast<const half8*>(p.s.x + off);
+      float g[8];
+      if (p.g16) { const half8 gv = *reinterpret_cast<const half8*>(p.g16 + off); for (int j = 0; j < 8; ++j) g[j] = (float)gv[j]; }
+      else { for (int j = 0; j < 8; ++j) g[j] = p.g32[off + j]; }
+      if (p.act) { const half8 av = *reinterpret_cast<const half8*>(p.act + off); for (int j = 0; j < 8; ++j) if (!((float)av[j] > 0.f)) g[j] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = chunk * 8 + j;
+        s1[j] += g[j];
+        s2[j] += g[j] * ((float)x[j] - mean[c]) * rstd[c];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { atomicAdd(&acc[chunk * 8 + j], s1[j]); atomicAdd(&acc[p.C + chunk * 8 + j], s2[j]); }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.C; c += 256) { atomicAdd(p.sums + c, acc[c]); atomicAdd(p.sums + p.s.cpad + c, acc[p.C + c]); }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
+  extern __shared__ float sm[];      // mean rstd k1 k2 k3
+  float* mean = sm; float* rstd = sm + p.C; float* k1 = sm + 2 * p.C; float* k2 = sm + 3 * p.C; float* k3 = sm + 4 * p.C;
+  const float inv_m = 1.f / (float)p.M;
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    bn_mean_rstd(p.s, c, inv_m, mean[c], rstd[c]);
+    const float dbeta = p.sums[c], dgamma = p.sums[p.s.cpad + c];
+    k1[c] = p.s.gamma[c] * rstd[c]; k2[c] = dbeta * inv_m; k3[c] = dgamma * inv_m;
+    if (blockIdx.x == 0 && p.dgamma) { p.dgamma[c] = dgamma * p.inv_scale[0]; p.dbeta[c] = dbeta * p.inv_scale[0]; }
+  }
+  __syncthreads();
+  const int cpr = p.C >> 3;
+  const size_t total = (size_t)p.Mpad * cpr;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const size_t row = idx / cpr; const int c0 = (int)(idx % cpr) * 8;
+    const size_t off = row * p.C + c0;
+    half8 o, om;
+    if (row < (size_t)p.M) {
+      const half8 x = *reinterpret_cast<const half8*>(p.s.x + off);
+      float g[8];
+      if (p.g16) { const half8 gv = *reinterpret_cast<const half8*>(p.g16 + off); for (int j = 0; j < 8; ++j) g[j] = (float)gv[j]; }
+      else { for (int j = 0; j < 8; ++j) g[j] = p.g32[off + j]; }
+      if (p.act) { const half8 av = *reinterpret_cast<const half8*>(p.act + off); for (int j = 0; j < 8; ++j) if (!((float)av[j] > 0.f)) g[j] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        const float xh = ((float)x[j] - mean[c]) * rstd[c];
+        o[j] = (half_t)(k1[c] * (g[j] - k2[c] - xh * k3[c]));
+        om[j] = (half_t)g[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { o[j] = (half_t)0.f; om[j] = (half_t)0.f; }
+    }
+    *reinterpret_cast<half8*>(p.dx + off) = o;
+    if (p.dy_masked) *reinterpret_cast<half8*>(p.dy_masked + off) = om;
+  }
+}
+
+// ---- pools --------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dfeat, const float* __restrict__ scale, int M, int Mpad,
+                                                         int C, half_t* __restrict__ g) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)Mpad * C) return;
+  const int row = (int)(idx / C), c = (int)(idx % C);
+  g[idx] = (half_t)(row < M ? dfeat[c] * scale[0] / (float)M : 0.f);
+}
+
+// maxpool(3,2,1) of relu(bn(x)) backward: route g[out voxel] to the arg-max input (first maximum), zero if the max is <= 0
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(BnSrc s, int din, int dout, size_t m_in, const half_t* __restrict__ g,
+                                                         float* __restrict__ dpost) {
+  __shared__ float sc[64], sh[64];
+  if (threadIdx.x < 64) bn_scale_shift(s, threadIdx.x, 1.f / (float)m_in, sc[threadIdx.x], sh[threadIdx.x]);
+  __syncthreads();
+  const size_t total = cube(dout) * 8;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t vox = idx >> 3; const int c0 = (int)(idx & 7) * 8;
+  const int x = (int)(vox % dout), y = (int)((vox / dout) % dout), z = (int)(vox / ((size_t)dout * dout));
+  float best[8]; size_t arg[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { best[j] = -3.0e38f; arg[j] = 0; }
+  for (int dz = -1; dz <= 1; ++dz) {
+    const int iz = 2 * z + dz; if ((unsigned)iz >= (unsigned)din) continue;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int iy = 2 * y + dy; if ((unsigned)iy >= (unsigned)din) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int ix = 2 * x + dx; if ((unsigned)ix >= (unsigned)din) continue;
+        const size_t iv = ((size_t)iz * din + iy) * din + ix;
+        const half8 v = *reinterpret_cast<const half8*>(s.x + iv * 64 + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float a = fmaxf(fmaf((float)v[j], sc[c0 + j], sh[c0 + j]), 0.f);      // same fp32 values the forward max-pool compared
+          if (a > best[j]) { best[j] = a; arg[j] = iv; }
+        }
+      }
+    }
+  }
+  const half8 gv = *reinterpret_cast<const half8*>(g + vox * 64 + c0);
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (best[j] > 0.f && (float)gv[j] != 0.f) atomicAdd(dpost + arg[j] * 64 + c0 + j, (float)gv[j]);
+}
+
+// dW temp [cout][tap*cin + c] (fp32) -> PyTorch layout [cout][cin_real][taps]
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ tmp, int cout, int cin, int cin_real, int taps,
+                                                          float* __restrict__ dst) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)cout * cin_real * taps) return;
+  const int tap = (int)(idx % taps), c = (int)((idx / taps) % cin_real), n = (int)(idx / ((size_t)taps * cin_real));
+  dst[idx] = tmp[(size_t)n * (taps * cin) + tap * cin + c];
+}
+
+// stem input gradient for a window of cells: dgrid[c][cell] = sum_taps sum_co dY[(z+2-dz)/2,...][co] W[co][c][tap] / S
+__global__ __launch_bounds__(256) void stem_dgrid_kernel(const half_t* __restrict__ dy, const float* __restrict__ W, int S, int dout,
+                                                        size_t start, int n, int nch, const float* __restrict__ inv_scale,
+                                                        float* __restrict__ dgrid) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * nch) return;
+  const int c = idx / n, i = idx % n;
+  const size_t cell = start + i;
+  const int x = (int)(cell % S), y = (int)((cell / S) % S), z = (int)(cell / ((size_t)S * S));
+  float acc = 0.f;
+  for (int dz = 0; dz < 5; ++dz) {
+    const int nz = z + 2 - dz; if (nz < 0 || (nz & 1) || (nz >> 1) >= dout) continue;
+    for (int dyy = 0; dyy < 5; ++dyy) {
+      const int ny = y + 2 - dyy; if (ny < 0 || (ny & 1) || (ny >> 1) >= dout) continue;
+      for (int dx = 0; dx < 5; ++dx) {
+        const int nx = x + 2 - dx; if (nx < 0 || (nx & 1) || (nx >> 1) >= dout) continue;
+        const half_t* d = dy + ((size_t)((nz >> 1) * dout + (ny >> 1)) * dout + (nx >> 1)) * 64;
+        const int tap = (dz * 5 + dyy) * 5 + dx;
+        for (int co = 0; co < 64; ++co) acc = fmaf((float)d[co], W[((size_t)co * 7 + c) * 125 + tap], acc);
+      }
+    }
+  }
+  dgrid[(size_t)c * n + i] = acc * inv_scale[0];
+}
+
+__global__ __launch_bounds__(256) void amax_f32_kernel(const float* __restrict__ v, int n, unsigned* __restrict__ amax_bits) {
+  float m = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const float a = fabsf(v[i]); m = (a == a && a > m) ? a : m; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
+}
+
+__global__ void make_scale_kernel(float* __restrict__ scale, int target_log2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float amax = __uint_as_float(reinterpret_cast<unsigned*>(scale)[2]);
+    float S = 1.f;
+    if (amax > 0.f && amax < 3.0e38f) {
+      int e = target_log2 - (int)floorf(log2f(amax));
+      e = e > 100 ? 100 : (e < -100 ? -100 : e);
+      S = exp2f((float)e);
+    }
+    scale[0] = S; scale[1] = 1.f / S;
+  }
+}
+
+// ---- backward workspace ---------------------------------------------------------------------------------------------
+struct BwdLayout {
+  size_t wt[64];              // dgrad weights (in the packed-dgrad blob)
+  size_t packed_total;
+  size_t scale;               // fp32[4]
+  size_t sums[64];            // per conv/BN: [2][cpad] fp32
+  size_t sums_begin, sums_bytes;
+  size_t g[2];                // ping-pong gradient w.r.t. block outputs, fp16, largest activation
+  size_t dy[3];               // dY of the three convs of a block (+ ds shares slot 2 after use) ; sized for the largest
+  size_t dyds, gm, da;        // downsample dY, masked g (identity residual), d(a1|a2) scratch
+  size_t dpost;               // fp32 [din1^3][64] stem
+  size_t dyT, xcolT;          // transposed operands of the wgrad GEMM
+  size_t wtmp;                // fp32 temp for un-permuted weight gradients
+  size_t splitk; size_t splitk_bytes;
+  size_t total;
+};
+
+void make_bwd_layout(const Arch& A, BwdLayout* L) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += round_up_sz(bytes, 256); return o; };
+  for (int i = 0; i < A.nconv; ++i) {
+    const ConvSpec& c = A.conv[i];
+    const int nrows = c.cin == 64 || c.cin == 8 ? 64 : round_up(c.cin, 128);
+    L->wt[i] = take((size_t)nrows * c.k * c.k * c.k * c.cout * 2);
+  }
+  L->packed_total = off;
+  off = 0;
+  L->scale = take(256);
+  L->sums_begin = off;
+  for (int i = 0; i < A.nconv; ++i) L->sums[i] = take((size_t)2 * round_up(A.conv[i].cout, 128) * 4);
+  L->sums_bytes = off - L->sums_begin;
+  size_t max_act = 0, max_xcol = 0, max_dyT = 0, max_wtmp = 0;
+  for (int i = 0; i < A.nconv; ++i) {
+    const ConvSpec& c = A.conv[i];
+    const size_t rows_out = rows_pad(c.dout), rows_in = rows_pad(c.din);
+    if (i > 0) {
+      max_act = std::max(max_act, rows_out * c.cout * 2);
+      max_act = std::max(max_act, rows_in * c.cin * 2);
+    }
+    max_xcol = std::max(max_xcol, (size_t)round_up(c.k * c.k * c.k * c.cin, 128) * rows_out * 2);
+    max_dyT = std::max(max_dyT, (size_t)round_up(c.cout, 128) * rows_out * 2);
+    max_wtmp = std::max(max_wtmp, (size_t)c.cout * c.k * c.k * c.k * c.cin * 4);
+  }
+  const size_t stem_act = rows_pad(A.conv[0].dout) * 64 * 2;
+  for (int i = 0; i < 2; ++i) L->g[i] = take(max_act);
+  for (int i = 0; i < 3; ++i) L->dy[i] = take(std::max(max_act, stem_act));
+  L->dyds = take(max_act); L->gm = take(max_act); L->da = take(max_act);
+  L->dpost = take(cube(A.conv[0].dout) * 64 * 4);
+  L->dyT = take(max_dyT); L->xcolT = take(max_xcol);
+  L->wtmp = take(max_wtmp);
+  L->splitk_bytes = (size_t)64 << 20;
+  L->splitk = take(L->splitk_bytes);
+  L->total = off;
+}
+
+struct Ctx {
+  neraf_ctx* ctx; hipStream_t st; const Arch* A; const Layout* L; const BwdLayout* B;
+  const char* packed_t; char* ws; char* bws; const float* const* bn; float* const* w_grads; float* const* bn_grads;
+  const float* inv_scale;
+};
+
+int bn_backward(const Ctx& c, int ci, const half_t* g16, const float* g32, const half_t* act, half_t* dx, half_t* dy_masked) {
+  const ConvSpec& cs = c.A->conv[ci];
+  BnBwdArgs p{};
+  p.s = bn_src((const half_t*)(c.ws + c.L->pre[ci]), (const float*)(c.ws + c.L->stat[ci]), c.bn, ci, cs.cout, 1);
+  p.g16 = g16; p.g32 = g32; p.act = act;
+  p.M = (int)cube(cs.dout); p.Mpad = (int)rows_pad(cs.dout); p.C = cs.cout;
+  p.sums = (float*)(c.bws + c.B->sums[ci]);
+  p.dx = dx; p.dy_masked = dy_masked;
+  p.dgamma = c.bn_grads[2 * ci]; p.dbeta = c.bn_grads[2 * ci + 1]; p.inv_scale = c.inv_scale;
+  const int cpr = p.C >> 3;
+  const int rows_per_it = 256 / cpr > 0 ? 256 / cpr : 1;
+  int blocks = (p.M + rows_per_it - 1) / rows_per_it;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), (size_t)4 * p.C * sizeof(float), c.st, p);
+  const size_t total = (size_t)p.Mpad * cpr;
+  long ab = (long)((total + 255) / 256);
+  if (ab > 2048) ab = 2048;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ab), dim3(256), (size_t)5 * p.C * sizeof(float), c.st, p);
+  NERAF_HIP_CHECK(c.ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+// dW of conv ci from dY [rows_out][cout] and its input activation x_in [din^3][cin]
+int conv_wgrad(const Ctx& c, int ci, const half_t* dy, const half_t* x_in) {
+  const ConvSpec& cs = c.A->conv[ci];
+  const int M = (int)cube(cs.dout), Mpad = (int)rows_pad(cs.dout);
+  const int taps = cs.k * cs.k * cs.k, K = taps * cs.cin;
+  half_t* dyT = (half_t*)(c.bws + c.B->dyT);
+  half_t* xT = (half_t*)(c.bws + c.B->xcolT);
+  Im2colArgs a{};
+  a.x = dy; a.cin = cs.cout; a.din = cs.dout; a.dout = cs.dout; a.ksize = 1; a.stride = 1; a.pad = 0;
+  a.M = M; a.Mpad = Mpad; a.K = cs.cout; a.Krows = round_up(cs.cout, 128); a.out = dyT;
+  hipLaunchKernelGGL(im2col_t_kernel, dim3(Mpad / 64, a.Krows / 64), dim3(256), 0, c.st, a);
+  Im2colArgs b{};
+  b.x = x_in; b.cin = cs.cin; b.din = cs.din; b.dout = cs.dout; b.ksize = cs.k; b.stride = cs.stride; b.pad = cs.pad;
+  b.M = M; b.Mpad = Mpad; b.K = K; b.Krows = round_up(K, 128); b.out = xT;
+  hipLaunchKernelGGL(im2col_t_kernel, dim3(Mpad / 64, b.Krows / 64), dim3(256), 0, c.st, b);
+  NERAF_HIP_CHECK(c.ctx, hipGetLastError());
+  const bool direct = (cs.k == 1 && ci != 0);
+  const int cin_real = ci == 0 ? 7 : cs.cin;
+  GemmParams g{};
+  g.A = dyT; g.lda = Mpad; g.B = xT; g.ldb = Mpad;
+  g.M = cs.cout; g.N = K; g.K = Mpad; g.Mpad = a.Krows; g.Npad = b.Krows; g.alpha = 1.f; g.alpha_dev = c.inv_scale;
+  g.C32 = direct ? c.w_grads[ci] : (float*)(c.bws + c.B->wtmp); g.ldc32 = K;
+  g.splitk_ws = (float*)(c.bws + c.B->splitk); g.splitk_ws_bytes = c.B->splitk_bytes;
+  if (int e = launch_gemm_f16(c.ctx, g, c.st)) return e;
+  if (!direct) {
+    const size_t n = (size_t)cs.cout * cin_real * taps;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.st, (const float*)(c.bws + c.B->wtmp),
+                       cs.cout, cs.cin, cin_real, taps, c.w_grads[ci]);
+    NERAF_HIP_CHECK(c.ctx, hipGetLastError());
+  }
+  return NERAF_OK;
+}
+
+// dX [din^3][cin] = conv_transpose(dY [dout^3][cout], W) (+ add16)
+int conv_dgrad(const Ctx& c, int ci, const half_t* dy, const half_t* add16, half_t* dx) {
+  const ConvSpec& cs = c.A->conv[ci];
+  GemmParams g{};
+  const int taps = cs.k * cs.k * cs.k;
+  g.A = dy; g.lda = cs.cout;
+  g.B = (const half_t*)(c.packed_t + c.B->wt[ci]); g.ldb = taps * cs.cout;
+  g.M = (int)cube(cs.din); g.N = cs.cin; g.K = taps * cs.cout; g.Mpad = (int)rows_pad(cs.din);
+  g.Npad = cs.cin == 64 ? 64 : round_up(cs.cin, 128); g.tile_n = cs.cin == 64 ? 64 : 0; g.alpha = 1.f;
+  g.add16 = add16; g.ldadd = cs.cin;
+  g.C16 = dx; g.ldc16 = cs.cin;
+  g.splitk_ws = (float*)(c.bws + c.B->splitk); g.splitk_ws_bytes = c.B->splitk_bytes;
+  if (cs.k == 1 && cs.stride == 1) {
+    g.conv.loader = 0;
+  } else {
+    g.conv.loader = 1; g.conv.cin = cs.cout; g.conv.din = cs.dout; g.conv.dout = cs.din; g.conv.stride = 1; g.conv.pad = -cs.pad;
+    g.conv.ksize = cs.k; g.conv.tflip = 1; g.conv.tstride = cs.stride;
+    g.conv.zero_page = (const half_t*)(c.ws + c.L->zero_page);
+  }
+  return launch_gemm_f16(c.ctx, g, c.st);
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" size_t neraf_resnet3d_bwd_packed_bytes(const neraf_resnet3d_desc* d) {
+  Arch A; BwdLayout B;
+  if (make_arch(d, &A)) return 0;
+  make_bwd_layout(A, &B);
+  return B.packed_total;
+}
+
+extern "C" size_t neraf_resnet3d_bwd_workspace_bytes(const neraf_resnet3d_desc* d) {
+  Arch A; BwdLayout B;
+  if (make_arch(d, &A)) return 0;
+  make_bwd_layout(A, &B);
+  return B.total;
+}
+
+extern "C" int neraf_resnet3d_pack_weights_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const float* const* conv_w, void* packed_t,
+                                               neraf_stream_t stream) {
+  Arch A; BwdLayout B;
+  if (make_arch(d, &A) || !conv_w || !packed_t) return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_pack_weights_bwd: bad arguments");
+  make_bwd_layout(A, &B);
+  PackTTable t{};
+  t.n = A.nconv;
+  unsigned long long acc = 0;
+  for (int i = 0; i < A.nconv; ++i) {
+    const ConvSpec& c = A.conv[i];
+    const int nrows = c.cin == 64 || c.cin == 8 ? 64 : round_up(c.cin, 128);
+    t.src[i] = conv_w[i]; t.begin[i] = acc; t.dst_off[i] = B.wt[i];
+    t.cout[i] = c.cout; t.cin[i] = i == 0 ? 7 : c.cin; t.taps[i] = c.k * c.k * c.k; t.kcols[i] = t.taps[i] * c.cout; t.nrows[i] = nrows;
+    acc += (unsigned long long)nrows * t.kcols[i];
+  }
+  t.begin[A.nconv] = acc;
+  hipLaunchKernelGGL(pack_dgrad_weights_kernel, dim3((unsigned)((acc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, (char*)packed_t);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed_t, const float* const* conv_w,
+                                  const float* const* bn, void* workspace, void* bwd_workspace, const float* dfeat,
+                                  float* const* w_grads, float* const* bn_grads, size_t cell_start, int n_cells, int n_ch,
+                                  float* dgrid_cells, neraf_stream_t stream) {
+  Arch A; Layout L; BwdLayout B;
+  if (make_arch(d, &A) || !packed_t || !conv_w || !bn || !workspace || !bwd_workspace || !dfeat || !w_grads || !bn_grads ||
+      (n_cells > 0 && (!dgrid_cells || n_ch < 1 || n_ch > 7 || cell_start + (size_t)n_cells > cube(d->grid_size))))
+    return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_bwd: bad arguments");
+  make_layout(A, &L);
+  make_bwd_layout(A, &B);
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace; char* bws = (char*)bwd_workspace;
+  float* scale = (float*)(bws + B.scale);
+  NERAF_HIP_CHECK(ctx, hipMemsetAsync(scale, 0, 16, st));
+  NERAF_HIP_CHECK(ctx, hipMemsetAsync(bws + B.sums_begin, 0, B.sums_bytes, st));
+  hipLaunchKernelGGL(amax_f32_kernel, dim3(4), dim3(256), 0, st, dfeat, 1024, reinterpret_cast<unsigned*>(scale) + 2);
+  // d feat is spread over M voxels by the average pool; aim the per-voxel gradient at ~2^4
+  const int Mlast = (int)cube(A.final_edge);
+  hipLaunchKernelGGL(make_scale_kernel, dim3(1), dim3(64), 0, st, scale, 4 + (int)ceilf(log2f((float)Mlast)));
+  Ctx c{ctx, st, &A, &L, &B, (const char*)packed_t, ws, bws, bn, w_grads, bn_grads, scale + 1};
+  half_t* g = (half_t*)(bws + B.g[0]);
+  half_t* g_next = (half_t*)(bws + B.g[1]);
+  {
+    const int Mpad = (int)rows_pad(A.final_edge);
+    const size_t n = (size_t)Mpad * 1024;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dfeat, scale, Mlast, Mpad, 1024, g);
+  }
+  half_t* dy0 = (half_t*)(bws + B.dy[0]); half_t* dy1 = (half_t*)(bws + B.dy[1]); half_t* dy2 = (half_t*)(bws + B.dy[2]);
+  half_t* dyds = (half_t*)(bws + B.dyds); half_t* gm = (half_t*)(bws + B.gm); half_t* da = (half_t*)(bws + B.da);
+  for (int b = A.nblock - 1; b >= 0; --b) {
+    const BlockSpec& Bk = A.block[b];
+    const int i0 = Bk.conv[0], i1 = Bk.conv[1], i2 = Bk.conv[2];
+    const half_t* x_in = b == 0 ? (const half_t*)(ws + L.act_pool) : (const half_t*)(ws + L.out[b - 1]);
+    const half_t* out = (const half_t*)(ws + L.out[b]);
+    const half_t* a1 = (const half_t*)(ws + L.a1[b]);
+    const half_t* a2 = (const half_t*)(ws + L.a2[b]);
+    // out = relu(bn3(c3) + residual): dy = g * (out > 0) feeds bn3 and the residual branch
+    if (int e = bn_backward(c, i2, g, nullptr, out, dy2, Bk.ds < 0 ? gm : nullptr)) return e;
+    if (int e = conv_wgrad(c, i2, dy2, a2)) return e;
+    if (int e = conv_dgrad(c, i2, dy2, nullptr, da)) return e;                 // d a2
+    if (int e = bn_backward(c, i1, da, nullptr, a2, dy1, nullptr)) return e;
+    if (int e = conv_wgrad(c, i1, dy1, a1)) return e;
+    if (int e = conv_dgrad(c, i1, dy1, nullptr, da)) return e;                 // d a1
+    if (int e = bn_backward(c, i0, da, nullptr, a1, dy0, nullptr)) return e;
+    if (int e = conv_wgrad(c, i0, dy0, x_in)) return e;
+    if (Bk.ds >= 0) {
+      if (int e = bn_backward(c, Bk.ds, g, nullptr, out, dyds, nullptr)) return e;
+      if (int e = conv_wgrad(c, Bk.ds, dyds, x_in)) return e;
+      if (int e = conv_dgrad(c, Bk.ds, dyds, nullptr, da)) return e;           // residual-branch gradient w.r.t. x_in
+      if (int e = conv_dgrad(c, i0, dy0, da, g_next)) return e;
+    } else {
+      if (int e = conv_dgrad(c, i0, dy0, gm, g_next)) return e;                // identity residual
+    }
+    half_t* t = g; g = g_next; g_next = t;
+  }
+  // stem: max-pool -> relu -> bn1 -> conv1
+  {
+    const ConvSpec& c0 = A.conv[0];
+    float* dpost = (float*)(bws + B.dpost);
+    NERAF_HIP_CHECK(ctx, hipMemsetAsync(dpost, 0, cube(c0.dout) * 64 * 4, st));
+    BnSrc s = bn_src((const half_t*)(ws + L.pre[0]), (const float*)(ws + L.stat[0]), bn, 0, 64, 1);
+    const size_t total = cube(A.pooled) * 8;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, c0.dout, A.pooled, cube(c0.dout), g, dpost);
+    NERAF_HIP_CHECK(ctx, hipGetLastError());
+    if (int e = bn_backward(c, 0, nullptr, dpost, nullptr, dy0, nullptr)) return e;      // relu mask already applied by the routing
+    if (int e = conv_wgrad(c, 0, dy0, (const half_t*)(ws + L.x0))) return e;
+    if (n_cells > 0) {
+      const int n = n_cells * n_ch;
+      hipLaunchKernelGGL(stem_dgrid_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dy0, conv_w[0], A.S, c0.dout, cell_start, n_cells, n_ch,
+                         scale + 1, dgrid_cells);
+      NERAF_HIP_CHECK(ctx, hipGetLastError());
+    }
+  }
+  return NERAF_OK;
+}

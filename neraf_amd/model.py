@@ -179,8 +179,6 @@ class NeRAFAudioModel(nn.Module):
     def get_outputs(self, batch_audio: Dict[str, torch.Tensor]) -> torch.Tensor:        # :531-566
         dev = self.aabb.device
         feat = self.scene_feature() if self.use_grid else torch.zeros(0, device=dev)
-        if self.training and self.use_grid:
-            feat = feat.detach().requires_grad_(True)       # d loss / d feature is produced (ResNet3D backward: next round)
         return self.field.forward_queries(feat, batch_audio["time_query"].to(dev), batch_audio["mic_pose"].to(dev),
                                           batch_audio["source_pose"].to(dev), batch_audio["rot"].to(dev), self.aabb, self.max_len)
 

@@ -5,8 +5,10 @@ The module tree only holds parameters: it reproduces the reference's sub-module 
 keys are identical (``backbone_net.conv1.weight``, ``backbone_net.layer2.0.downsample.1.running_var`` ...)
 and reference checkpoints load with ``load_state_dict``.  ``forward`` never calls a torch conv: it hands
 the 43 Conv3d weights and 43 BatchNorm3d parameter sets to ``neraf_resnet3d_fwd`` (implicit-GEMM MFMA
-convolutions with fused BN statistics, include/neraf_hip.h).  Forward only in round 1: the returned
-feature carries no autograd graph (the backward kernels are the next build row).
+convolutions with fused BN statistics, include/neraf_hip.h).  In training mode the feature carries an autograd
+node (``_ResNet3DFn``) whose backward runs ``neraf_resnet3d_bwd`` (dgrad / wgrad GEMMs, BatchNorm backward) and
+returns gradients for every Conv3d weight and BatchNorm3d affine parameter; the gradient w.r.t. the cells of the
+grid refreshed this step is handed to ``grid_grad_sink`` (the edge into the radiance field, NeRAF_model.py:395-400).
 """
 from __future__ import annotations
 
@@ -18,6 +20,49 @@ import torch.nn as nn
 
 from . import _lib
 from .field import _dev_index, _stream_ptr
+
+
+class _ResNet3DFn(torch.autograd.Function):
+    """feat[1024] = ResNet3D(grid); parameters = 43 conv weights followed by 43 x (bn.weight, bn.bias)."""
+
+    @staticmethod
+    def forward(ctx, net: "ResNet3D", feat: torch.Tensor, window, sink, *params: torch.Tensor):
+        # the forward kernels already ran (ResNet3D.forward); this node only attaches the backward
+        ctx.net, ctx.window, ctx.sink = net, window, sink
+        ctx.n = len(params)
+        ctx.save_for_backward(*params)
+        return feat.clone()
+
+    @staticmethod
+    def backward(ctx, dfeat: torch.Tensor):
+        lib = _lib.load()
+        net: ResNet3D = ctx.net
+        params = ctx.saved_tensors
+        nconv = len(params) // 3
+        conv_w = list(params[:nconv])
+        dev = _dev_index(dfeat)
+        h, st = _lib.ctx(dev), _stream_ptr()
+        device = dfeat.device
+        pairs = net.conv_bn_pairs()
+        bn: List[torch.Tensor] = []
+        for _, b in pairs:
+            bn += [b.weight.detach(), b.bias.detach(), b.running_mean, b.running_var]
+        packed_t = torch.empty(lib.neraf_resnet3d_bwd_packed_bytes(C.byref(net._desc)), dtype=torch.uint8, device=device)
+        _lib.check(lib.neraf_resnet3d_pack_weights_bwd(h, C.byref(net._desc), _lib.ptr_array(conv_w), packed_t.data_ptr(), st), dev)
+        if net._bws is None or net._bws.device != device:
+            net._bws = torch.empty(lib.neraf_resnet3d_bwd_workspace_bytes(C.byref(net._desc)), dtype=torch.uint8, device=device)
+        w_grads = [torch.empty_like(w) for w in conv_w]
+        bn_grads = [torch.empty_like(p) for p in params[nconv:]]
+        start, n_cells, n_ch = ctx.window if ctx.window is not None else (0, 0, 0)
+        dgrid = torch.empty((n_ch, n_cells), dtype=torch.float32, device=device) if n_cells > 0 else None
+        dfeat = dfeat.reshape(-1).float().contiguous()
+        _lib.check(lib.neraf_resnet3d_bwd(h, C.byref(net._desc), packed_t.data_ptr(), _lib.ptr_array(conv_w), _lib.ptr_array(bn),
+                                          net._ws.data_ptr(), net._bws.data_ptr(), dfeat.data_ptr(), _lib.ptr_array(w_grads),
+                                          _lib.ptr_array(bn_grads), start, n_cells, n_ch,
+                                          dgrid.data_ptr() if dgrid is not None else None, st), dev)
+        if ctx.sink is not None and dgrid is not None:
+            ctx.sink(dgrid)
+        return (None, None, None, None, *w_grads, *bn_grads)
 
 
 class _Bottleneck(nn.Module):
@@ -77,7 +122,10 @@ class ResNet3D(nn.Module):
                 m.bias.data.zero_()
         self._desc = _lib.ResnetDesc(self.grid_size, in_channels, N_features)
         self._ws = None
+        self._bws = None
         self._packed, self._packed_key = None, None
+        self.grid_window = None      # (cell_start, n_cells, n_channels): grid cells whose gradient the backward should produce
+        self.grid_grad_sink = None   # callable(dgrid_cells fp32 [n_ch, n_cells]) invoked inside the backward
 
     def conv_bn_pairs(self):
         pairs = [(self.conv1, self.bn1)]
@@ -121,6 +169,11 @@ class ResNet3D(nn.Module):
                 _lib.check(lib.neraf_resnet3d_update_running_stats(h, C.byref(self._desc), self._ws.data_ptr(),
                                                                    _lib.ptr_array(bn), float(mom), st), dev)
                 torch._foreach_add_([b.num_batches_tracked for _, b in pairs], 1)   # one launch for the 43 counters
+        if self.training and torch.is_grad_enabled() and any(c.weight.requires_grad for c, _ in pairs):
+            params = [c.weight for c, _ in pairs]
+            for _, b in pairs:
+                params += [b.weight, b.bias]
+            feat = _ResNet3DFn.apply(self, feat, self.grid_window, self.grid_grad_sink, *params)
         return feat.reshape(1, 1024, 1, 1, 1)
 
 

@@ -70,3 +70,37 @@ def test_resnet3d_running_stats_update():
     np.testing.assert_allclose(bn1.running_mean.cpu().numpy(), (0.9 * rm0 + 0.1 * mean).numpy(), rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose(bn1.running_var.cpu().numpy(), (0.9 * rv0 + 0.1 * var).numpy(), rtol=2e-3, atol=2e-4)
     assert int(bn1.num_batches_tracked) == 1
+
+
+def test_resnet3d_backward_vs_reference_golden(golden):
+    """Weight / BatchNorm-affine / input gradients against the reference module's autograd (G1, 64^3 grid).
+    Tolerance: relative L2 5e-2 per tensor (fp16 gradient chain through 43 conv+BN layers, ReLU / max-pool routing
+    decided on fp16 activations)."""
+    dev = torch.device("cuda:0")
+    g = golden("g1_resnet3d_64")
+    S = 64
+    net = _model(dev, 1 / S)
+    net.train()
+    bb = net.backbone_net
+    x = T(synth.uniform(f"g1.grid{S}", (1, 7, S, S, S), 0.0, 1.0)).to(dev)
+    wsum = T(synth.uniform("g1.outw", (1024,), -1.0, 1.0)).to(dev)
+    got = {}
+    bb.grid_window = (0, S ** 3, 7)
+    bb.grid_grad_sink = lambda d: got.__setitem__("dx", d.clone())
+    y = net(x)
+    (y.flatten() * wsum).sum().backward()
+    bb.grid_window, bb.grid_grad_sink = None, None
+    tol = 5e-2
+    assert rel_l2(bb.conv1.weight.grad, T(g["dw_conv1"])) <= tol
+    assert rel_l2(bb.layer1[0].conv2.weight.grad[:4, :4], T(g["dw_l1_0_conv2_slab"])) <= tol
+    assert rel_l2(bb.layer3[5].conv3.weight.grad[:8, :8, 0, 0, 0], T(g["dw_l3_5_conv3_slab"])) <= tol
+    for name, p in (("dw_l1_0_conv2_stats", bb.layer1[0].conv2.weight.grad), ("dw_l3_5_conv3_stats", bb.layer3[5].conv3.weight.grad)):
+        gd = p.double().cpu()
+        np.testing.assert_allclose([gd.abs().mean().item(), gd.pow(2).mean().sqrt().item()], g[name][1:], rtol=tol)
+    assert rel_l2(bb.bn1.weight.grad, T(g["dgamma_bn1"])) <= tol
+    assert rel_l2(bb.bn1.bias.grad, T(g["dbeta_bn1"])) <= tol
+    assert rel_l2(bb.layer2[0].downsample[1].weight.grad, T(g["dgamma_l2_0_ds"])) <= tol
+    pi = g["probe_idx"]
+    dx = got["dx"].reshape(7, S, S, S).cpu()
+    assert rel_l2(dx[pi[:, 0], pi[:, 1], pi[:, 2], pi[:, 3]], T(g["dx_probe"])) <= tol
+    np.testing.assert_allclose(dx.double().pow(2).mean().sqrt().item(), g["dx_stats"][2], rtol=tol)
