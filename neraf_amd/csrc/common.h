@@ -13,6 +13,9 @@ typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -98,6 +101,7 @@ struct GemmParams {
   ConvGeom conv;                     // conv.loader == 0 for a plain GEMM
   float* splitk_ws; size_t splitk_ws_bytes;   // optional fp32 scratch enabling split-K for under-filled grids
   int tile_n;                        // 0 = auto; 64 forces the 128x64 tile (Cout = 64 layers)
+  int bf16;                          // 1: every 16-bit operand/result (A, B, lmask, add16, C16, C16T) is bfloat16 (gradient chains)
 };
 
 int launch_gemm_f16(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream);

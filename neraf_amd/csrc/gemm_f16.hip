@@ -31,6 +31,17 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
+// element traits: fp16 (forward paths, scaled gradient chains) or bf16 (deep gradient chains that need fp32's range)
+template <bool BF> struct ET;
+template <> struct ET<false> {
+  typedef _Float16 s; typedef half8 v8; typedef half4 v4;
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct ET<true> {
+  typedef __bf16 s; typedef bf16x8 v8; typedef bf16x4 v4;
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
 template <int BM, int BN>
 struct Tile {
   static constexpr int WM = BM / 2, WN = BN / 2;
@@ -45,10 +56,12 @@ struct Tile {
 
 // ------------------------------------------------------------------------------------------------------
 // Epilogue of the GEMM kernel (the split-K reducer applies the same operations element-wise).
-template <int BM, int BN>
+template <int BM, int BN, bool BF>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[Tile<BM, BN>::FM][Tile<BM, BN>::FN],
                                               char* smem, int bm, int bn, int lane, int wave) {
   using T = Tile<BM, BN>;
+  using E = typename ET<BF>::s;
+  using E4 = typename ET<BF>::v4;
   constexpr int WM = T::WM, WN = T::WN, FM = T::FM, FN = T::FN;
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fq = lane >> 4;
@@ -71,12 +84,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act);
       if (p.lmask) {
-        const half4 mk = *reinterpret_cast<const half4*>(p.lmask + (size_t)m * p.ldmask + n0);
+        const E4 mk = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.lmask) + (size_t)m * p.ldmask + n0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= ((float)mk[r] > 0.f) ? 1.f : p.mask_slope;
       }
       if (p.add16) {
-        const half4 ad = *reinterpret_cast<const half4*>(p.add16 + (size_t)m * p.ldadd + n0);
+        const E4 ad = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.add16) + (size_t)m * p.ldadd + n0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)ad[r];
       }
@@ -111,15 +124,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   }
 
   if (p.C16) {
-    half_t* im = reinterpret_cast<half_t*>(img);
+    E* im = reinterpret_cast<E*>(img);
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        half4 h;
+        E4 h;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = (half_t)acc[i][j][r];
-        *reinterpret_cast<half4*>(im + (i * 16 + m_l) * T::IMG16_LD + j * 16 + n_l) = h;
+        for (int r = 0; r < 4; ++r) h[r] = (E)acc[i][j][r];
+        *reinterpret_cast<E4*>(im + (i * 16 + m_l) * T::IMG16_LD + j * 16 + n_l) = h;
       }
     __syncthreads();
     constexpr int CPR = WN / 8;          // 16-B chunks per row
@@ -134,14 +147,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   }
 
   if (p.C16T) {
-    half_t* im = reinterpret_cast<half_t*>(img);
+    E* im = reinterpret_cast<E*>(img);
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          im[(j * 16 + n_l + r) * T::IMG16T_LD + i * 16 + m_l] = (half_t)acc[i][j][r];
+          im[(j * 16 + n_l + r) * T::IMG16T_LD + i * 16 + m_l] = (E)acc[i][j][r];
     __syncthreads();
     constexpr int CPR = WM / 8;
     constexpr int RPI = 64 / CPR;
@@ -195,9 +208,10 @@ struct PipeTile {
 };
 
 // LOADER: 0 plain GEMM, 1 conv tap-per-K-step (cin % 64 == 0), 2 conv tap-per-chunk (cin == 8).  KS = filter size.
-template <int BM, int BN, int NST, int LOADER, int KS>
+template <int BM, int BN, int NST, int LOADER, int KS, bool BF>
 __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int splits) {
   using T = Tile<BM, BN>;
+  using E8 = typename ET<BF>::v8;
   constexpr int WM = T::WM, WN = T::WN, FM = T::FM, FN = T::FN;
   constexpr int LOADS = T::A_CH + T::B_CH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -334,19 +348,19 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
     const char* sb = sa + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      half8 xa[FM], wb[FN];
+      E8 xa[FM], wb[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i)
-        xa[i] = *reinterpret_cast<const half8*>(sa + a_row_off + i * 16 * 128 + ch_off[ks]);
+        xa[i] = *reinterpret_cast<const E8*>(sa + a_row_off + i * 16 * 128 + ch_off[ks]);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
-        wb[j] = *reinterpret_cast<const half8*>(sb + b_row_off + j * 16 * 128 + ch_off[ks]);
+        wb[j] = *reinterpret_cast<const E8*>(sb + b_row_off + j * 16 * 128 + ch_off[ks]);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
           // D[r = n][c = m] : W fragment is the MFMA "A" operand, X fragment the "B" operand
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = ET<BF>::mfma(wb[j], xa[i], acc[i][j]);
     }
     if (++stage == NST) stage = 0;
   }
@@ -365,11 +379,13 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
       }
     return;
   }
-  gemm_epilogue<BM, BN>(p, acc, smem, bm, bn, lane, wave);
+  gemm_epilogue<BM, BN, BF>(p, acc, smem, bm, bn, lane, wave);
 }
 
 // Split-K reducer: sums the partial slabs and applies the same epilogue element-wise on 32x32 tiles.
+template <bool BF>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int splits) {
+  using E = typename ET<BF>::s;
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
@@ -383,11 +399,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
     v *= alpha;
     if (p.bias) v += p.bias[n];
     v = act_apply(v, p.act);
-    if (p.lmask) v *= ((float)p.lmask[(size_t)m * p.ldmask + n] > 0.f) ? 1.f : p.mask_slope;
-    if (p.add16) v += (float)p.add16[(size_t)m * p.ldadd + n];
+    if (p.lmask) v *= ((float)reinterpret_cast<const E*>(p.lmask)[(size_t)m * p.ldmask + n] > 0.f) ? 1.f : p.mask_slope;
+    if (p.add16) v += (float)reinterpret_cast<const E*>(p.add16)[(size_t)m * p.ldadd + n];
     if (m >= p.M || n >= p.N) v = 0.f;
     tile[ty + i * 8][tx] = v;
-    if (p.C16) p.C16[(size_t)m * p.ldc16 + n] = (half_t)v;
+    if (p.C16) reinterpret_cast<E*>(p.C16)[(size_t)m * p.ldc16 + n] = (E)v;
     if (p.C32 && m < p.M && n < p.N) p.C32[(size_t)m * p.ldc32 + n] = v;
   }
   __syncthreads();
@@ -395,7 +411,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int n = n0 + ty + i * 8, m = m0 + tx;
-      p.C16T[(size_t)n * p.ldc16t + m] = (half_t)tile[tx][ty + i * 8];
+      reinterpret_cast<E*>(p.C16T)[(size_t)n * p.ldc16t + m] = (E)tile[tx][ty + i * 8];
     }
   }
   if ((p.colsum || p.colsumsq) && ty == 0) {
@@ -407,28 +423,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
   }
 }
 
-template <int BM, int BN, int NST, int LOADER, int KS>
+template <int BM, int BN, int NST, int LOADER, int KS, bool BF>
 int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t stream) {
   using PT = PipeTile<BM, BN, NST>;
   static bool attr_set = false;
   if (!attr_set) {
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS>),
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, PT::LDS_BYTES));
     attr_set = true;
   }
   const int ntiles = (p.Mpad / BM) * (p.Npad / BN);
   ProfScope prof(ctx, stream, LOADER != 0 ? PROF_CONV : (BM * BN == 128 * 128 ? PROF_GEMM128 : PROF_GEMM64), 2.0 * p.M * p.N * p.K);
-  hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS>), dim3(ntiles * splits), dim3(256), PT::LDS_BYTES,
+  hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF>), dim3(ntiles * splits), dim3(256), PT::LDS_BYTES,
                      stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   if (splits > 1) {
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(p.Npad / 32, p.Mpad / 32), dim3(256), 0, stream, p, splits);
+    hipLaunchKernelGGL(splitk_reduce_kernel<BF>, dim3(p.Npad / 32, p.Mpad / 32), dim3(256), 0, stream, p, splits);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
   }
   return NERAF_OK;
 }
 
-template <int LOADER, int KS>
+template <int LOADER, int KS, bool BF>
 int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   const int cus = ctx ? ctx->num_cus : 256;
   const int nk = p.K / BK;
@@ -446,9 +462,9 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
     const size_t need = (size_t)splits * p.Mpad * p.Npad * 4;
     if (splits < 2 || need > p.splitk_ws_bytes) splits = 1;
   }
-  if (bm == 128 && bn == 128) return launch_pipe<128, 128, 4, LOADER, KS>(ctx, p, splits, stream);
-  if (bm == 128 && bn == 64) return launch_pipe<128, 64, 4, LOADER, KS>(ctx, p, splits, stream);
-  return launch_pipe<64, 64, 4, LOADER, KS>(ctx, p, splits, stream);
+  if (bm == 128 && bn == 128) return launch_pipe<128, 128, 4, LOADER, KS, BF>(ctx, p, splits, stream);
+  if (bm == 128 && bn == 64) return launch_pipe<128, 64, 4, LOADER, KS, BF>(ctx, p, splits, stream);
+  return launch_pipe<64, 64, 4, LOADER, KS, BF>(ctx, p, splits, stream);
 }
 
 }  // namespace
@@ -462,15 +478,15 @@ int launch_gemm_f16(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
       (p.lmask && (p.ldmask % 4)))
     return neraf_fail(ctx, NERAF_EINVAL, "gemm: leading dimensions must keep 16-byte alignment");
   switch (p.conv.loader) {
-    case 0: return dispatch_tile<0, 1>(ctx, p, stream);
+    case 0: return p.bf16 ? dispatch_tile<0, 1, true>(ctx, p, stream) : dispatch_tile<0, 1, false>(ctx, p, stream);
     case 1:
       if ((p.conv.cin % 64) || !p.conv.zero_page) return neraf_fail(ctx, NERAF_EINVAL, "conv loader 1: cin % 64 and zero page");
-      if (p.conv.ksize == 3) return dispatch_tile<1, 3>(ctx, p, stream);
-      if (p.conv.ksize == 1) return dispatch_tile<1, 1>(ctx, p, stream);
+      if (p.conv.ksize == 3) return p.bf16 ? dispatch_tile<1, 3, true>(ctx, p, stream) : dispatch_tile<1, 3, false>(ctx, p, stream);
+      if (p.conv.ksize == 1) return p.bf16 ? dispatch_tile<1, 1, true>(ctx, p, stream) : dispatch_tile<1, 1, false>(ctx, p, stream);
       return neraf_fail(ctx, NERAF_EINVAL, "conv loader 1: ksize must be 1 or 3");
     case 2:
-      if (p.conv.cin != 8 || p.conv.ksize != 5 || !p.conv.zero_page) return neraf_fail(ctx, NERAF_EINVAL, "conv loader 2: cin 8, ksize 5");
-      return dispatch_tile<2, 5>(ctx, p, stream);
+      if (p.conv.cin != 8 || p.conv.ksize != 5 || !p.conv.zero_page || p.bf16) return neraf_fail(ctx, NERAF_EINVAL, "conv loader 2: cin 8, ksize 5, fp16");
+      return dispatch_tile<2, 5, false>(ctx, p, stream);
   }
   return neraf_fail(ctx, NERAF_EINVAL, "gemm: unknown loader");
 }

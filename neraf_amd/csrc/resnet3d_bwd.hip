@@ -9,7 +9,9 @@
 //            transposed copies dY^T [cout][M] and im2col(X)^T [tap*cin + c][M] written by one tiling-transpose kernel;
 //   BN     : two passes per layer (per-channel reductions sum dy, sum dy*xhat; then the element-wise dx), with the
 //            ReLU mask of the consumer folded into both.
-// The fp16 gradient chain is scaled by a power of two chosen from max|d feat| and un-scaled in every fp32 output.
+// The gradient chain (dY tensors, dgrad weights, wgrad operands) is bfloat16 -- BatchNorm backward multiplies by
+// gamma/sigma at every one of the 43 layers, which takes the magnitudes out of fp16's range in either direction --
+// with fp32 accumulation; a power-of-two scale from max|d feat| only centres the values, every fp32 output undoes it.
 #include "resnet3d_common.h"
 #include <algorithm>
 
@@ -36,20 +38,20 @@ __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(PackTTable t, c
   const int tap = k / t.cout[i], co = k % t.cout[i];
   float v = 0.f;
   if (n < t.cin[i] && tap < t.taps[i]) v = t.src[i][((size_t)co * t.cin[i] + n) * t.taps[i] + tap];
-  reinterpret_cast<half_t*>(packed + t.dst_off[i])[e] = (half_t)v;
+  reinterpret_cast<bf16_t*>(packed + t.dst_off[i])[e] = (bf16_t)v;
 }
 
 // ---- tiling transpose / im2col^T: out[k][m] = X[src(m, tap(k))][c(k)], zero outside ------------------------------
 struct Im2colArgs {
-  const half_t* x; int cin;          // source [din^3][cin]
+  const void* x; int src_bf16; int cin;          // source [din^3][cin], fp16 (forward activations) or bf16 (gradients)
   int din, dout, ksize, stride, pad;
   int M, Mpad;                       // result voxels (columns), padded column count (= leading dimension)
   int K, Krows;                      // real rows taps*cin, rows written (multiple of 128, zero beyond K)
-  half_t* out;
+  bf16_t* out;
 };
 
 __global__ __launch_bounds__(256) void im2col_t_kernel(Im2colArgs a) {
-  __shared__ half_t tile[64][72];    // [m][k] with padding
+  __shared__ bf16_t tile[64][72];    // [m][k] with padding
   const int m0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
   const int tid = threadIdx.x;
   // read: 64 rows (m) x 8 chunks (16 B = 8 k-values)
@@ -57,18 +59,25 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(Im2colArgs a) {
   for (int it = 0; it < 2; ++it) {
     const int c = it * 256 + tid, row = c >> 3, ch = c & 7;
     const int m = m0 + row, k = k0 + ch * 8;
-    half8 v;
+    bf16x8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
     if (m < a.M && k < a.K) {
       const int tap = k / a.cin, cc = k % a.cin;
       const int x = m % a.dout, y = (m / a.dout) % a.dout, z = m / (a.dout * a.dout);
       const int dz = tap / (a.ksize * a.ksize), dy = (tap / a.ksize) % a.ksize, dx = tap % a.ksize;
       const int iz = z * a.stride - a.pad + dz, iy = y * a.stride - a.pad + dy, ix = x * a.stride - a.pad + dx;
-      if ((unsigned)iz < (unsigned)a.din && (unsigned)iy < (unsigned)a.din && (unsigned)ix < (unsigned)a.din)
-        v = *reinterpret_cast<const half8*>(a.x + ((size_t)(iz * a.din + iy) * a.din + ix) * a.cin + cc);
+      if ((unsigned)iz < (unsigned)a.din && (unsigned)iy < (unsigned)a.din && (unsigned)ix < (unsigned)a.din) {
+        const size_t off = ((size_t)(iz * a.din + iy) * a.din + ix) * a.cin + cc;
+        if (a.src_bf16) v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.x) + off);
+        else {
+          const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(a.x) + off);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (bf16_t)(float)h[j];
+        }
+      }
     }
-    *reinterpret_cast<half8*>(&tile[row][ch * 8]) = v;
+    *reinterpret_cast<bf16x8*>(&tile[row][ch * 8]) = v;
   }
   __syncthreads();
   // write: 64 rows (k) x 8 chunks (8 consecutive m)
@@ -77,22 +86,22 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(Im2colArgs a) {
     const int c = it * 256 + tid, krow = c >> 3, ch = c & 7;
     const int k = k0 + krow;
     if (k >= a.Krows) continue;
-    half8 v;
+    bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = tile[ch * 8 + j][krow];
-    *reinterpret_cast<half8*>(a.out + (size_t)k * a.Mpad + m0 + ch * 8) = v;
+    *reinterpret_cast<bf16x8*>(a.out + (size_t)k * a.Mpad + m0 + ch * 8) = v;
   }
 }
 
 // ---- BatchNorm backward ----------------------------------------------------------------------------------------
 struct BnBwdArgs {
   BnSrc s;                    // x (pre-BN), forward statistics, gamma
-  const half_t* g16; const float* g32;     // upstream gradient w.r.t. the post-activation tensor (one of them)
+  const bf16_t* g16; const float* g32;     // upstream gradient w.r.t. the post-activation tensor (one of them)
   const half_t* act;          // post-activation tensor for the ReLU mask (null = no mask)
   int M, Mpad, C;
   float* sums;                // [2][cpad]: sum dy, sum dy*xhat
-  half_t* dx;                 // apply: gradient w.r.t. the pre-BN conv output [Mpad][C]
-  half_t* dy_masked;          // apply (optional): g * (act > 0) for the identity residual branch
+  bf16_t* dx;                 // apply: gradient w.r.t. the pre-BN conv output [Mpad][C]
+  bf16_t* dy_masked;          // apply (optional): g * (act > 0) for the identity residual branch
   float* dgamma; float* dbeta; const float* inv_scale;   // apply (block 0 writes the un-scaled affine gradients)
 };
 
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs p) {
       const size_t off = (size_t)row * p.C + chunk * 8;
       const half8 x = *reinterpret_cast<const half8*>(p.s.x + off);
       float g[8];
-      if (p.g16) { const half8 gv = *reinterpret_cast<const half8*>(p.g16 + off); for (int j = 0; j < 8; ++j) g[j] = (float)gv[j]; }
+      if (p.g16) { const bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.g16 + off); for (int j = 0; j < 8; ++j) g[j] = (float)gv[j]; }
       else { for (int j = 0; j < 8; ++j) g[j] = p.g32[off + j]; }
       if (p.act) { const half8 av = *reinterpret_cast<const half8*>(p.act + off); for (int j = 0; j < 8; ++j) if (!((float)av[j] > 0.f)) g[j] = 0.f; }
 #pragma unroll
@@ -152,40 +161,40 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const size_t row = idx / cpr; const int c0 = (int)(idx % cpr) * 8;
     const size_t off = row * p.C + c0;
-    half8 o, om;
+    bf16x8 o, om;
     if (row < (size_t)p.M) {
       const half8 x = *reinterpret_cast<const half8*>(p.s.x + off);
       float g[8];
-      if (p.g16) { const half8 gv = *reinterpret_cast<const half8*>(p.g16 + off); for (int j = 0; j < 8; ++j) g[j] = (float)gv[j]; }
+      if (p.g16) { const bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.g16 + off); for (int j = 0; j < 8; ++j) g[j] = (float)gv[j]; }
       else { for (int j = 0; j < 8; ++j) g[j] = p.g32[off + j]; }
       if (p.act) { const half8 av = *reinterpret_cast<const half8*>(p.act + off); for (int j = 0; j < 8; ++j) if (!((float)av[j] > 0.f)) g[j] = 0.f; }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = c0 + j;
         const float xh = ((float)x[j] - mean[c]) * rstd[c];
-        o[j] = (half_t)(k1[c] * (g[j] - k2[c] - xh * k3[c]));
-        om[j] = (half_t)g[j];
+        o[j] = (bf16_t)(k1[c] * (g[j] - k2[c] - xh * k3[c]));
+        om[j] = (bf16_t)g[j];
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { o[j] = (half_t)0.f; om[j] = (half_t)0.f; }
+      for (int j = 0; j < 8; ++j) { o[j] = (bf16_t)0.f; om[j] = (bf16_t)0.f; }
     }
-    *reinterpret_cast<half8*>(p.dx + off) = o;
-    if (p.dy_masked) *reinterpret_cast<half8*>(p.dy_masked + off) = om;
+    *reinterpret_cast<bf16x8*>(p.dx + off) = o;
+    if (p.dy_masked) *reinterpret_cast<bf16x8*>(p.dy_masked + off) = om;
   }
 }
 
 // ---- pools --------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dfeat, const float* __restrict__ scale, int M, int Mpad,
-                                                         int C, half_t* __restrict__ g) {
+                                                         int C, bf16_t* __restrict__ g) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)Mpad * C) return;
   const int row = (int)(idx / C), c = (int)(idx % C);
-  g[idx] = (half_t)(row < M ? dfeat[c] * scale[0] / (float)M : 0.f);
+  g[idx] = (bf16_t)(row < M ? dfeat[c] * scale[0] / (float)M : 0.f);
 }
 
 // maxpool(3,2,1) of relu(bn(x)) backward: route g[out voxel] to the arg-max input (first maximum), zero if the max is <= 0
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(BnSrc s, int din, int dout, size_t m_in, const half_t* __restrict__ g,
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(BnSrc s, int din, int dout, size_t m_in, const bf16_t* __restrict__ g,
                                                          float* __restrict__ dpost) {
   __shared__ float sc[64], sh[64];
   if (threadIdx.x < 64) bn_scale_shift(s, threadIdx.x, 1.f / (float)m_in, sc[threadIdx.x], sh[threadIdx.x]);
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(BnSrc s, int din, int 
       }
     }
   }
-  const half8 gv = *reinterpret_cast<const half8*>(g + vox * 64 + c0);
+  const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + vox * 64 + c0);
 #pragma unroll
   for (int j = 0; j < 8; ++j)
     if (best[j] > 0.f && (float)gv[j] != 0.f) atomicAdd(dpost + arg[j] * 64 + c0 + j, (float)gv[j]);
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
 }
 
 // stem input gradient for a window of cells: dgrid[c][cell] = sum_taps sum_co dY[(z+2-dz)/2,...][co] W[co][c][tap] / S
-__global__ __launch_bounds__(256) void stem_dgrid_kernel(const half_t* __restrict__ dy, const float* __restrict__ W, int S, int dout,
+__global__ __launch_bounds__(256) void stem_dgrid_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ W, int S, int dout,
                                                         size_t start, int n, int nch, const float* __restrict__ inv_scale,
                                                         float* __restrict__ dgrid) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(256) void stem_dgrid_kernel(const half_t* __restric
       const int ny = y + 2 - dyy; if (ny < 0 || (ny & 1) || (ny >> 1) >= dout) continue;
       for (int dx = 0; dx < 5; ++dx) {
         const int nx = x + 2 - dx; if (nx < 0 || (nx & 1) || (nx >> 1) >= dout) continue;
-        const half_t* d = dy + ((size_t)((nz >> 1) * dout + (ny >> 1)) * dout + (nx >> 1)) * 64;
+        const bf16_t* d = dy + ((size_t)((nz >> 1) * dout + (ny >> 1)) * dout + (nx >> 1)) * 64;
         const int tap = (dz * 5 + dyy) * 5 + dx;
         for (int co = 0; co < 64; ++co) acc = fmaf((float)d[co], W[((size_t)co * 7 + c) * 125 + tap], acc);
       }
@@ -336,7 +345,7 @@ struct Ctx {
   const float* inv_scale;
 };
 
-int bn_backward(const Ctx& c, int ci, const half_t* g16, const float* g32, const half_t* act, half_t* dx, half_t* dy_masked) {
+int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const half_t* act, bf16_t* dx, bf16_t* dy_masked) {
   const ConvSpec& cs = c.A->conv[ci];
   BnBwdArgs p{};
   p.s = bn_src((const half_t*)(c.ws + c.L->pre[ci]), (const float*)(c.ws + c.L->stat[ci]), c.bn, ci, cs.cout, 1);
@@ -359,25 +368,26 @@ int bn_backward(const Ctx& c, int ci, const half_t* g16, const float* g32, const
 }
 
 // dW of conv ci from dY [rows_out][cout] and its input activation x_in [din^3][cin]
-int conv_wgrad(const Ctx& c, int ci, const half_t* dy, const half_t* x_in) {
+int conv_wgrad(const Ctx& c, int ci, const bf16_t* dy, const half_t* x_in) {
   const ConvSpec& cs = c.A->conv[ci];
   const int M = (int)cube(cs.dout), Mpad = (int)rows_pad(cs.dout);
   const int taps = cs.k * cs.k * cs.k, K = taps * cs.cin;
-  half_t* dyT = (half_t*)(c.bws + c.B->dyT);
-  half_t* xT = (half_t*)(c.bws + c.B->xcolT);
+  bf16_t* dyT = (bf16_t*)(c.bws + c.B->dyT);
+  bf16_t* xT = (bf16_t*)(c.bws + c.B->xcolT);
   Im2colArgs a{};
-  a.x = dy; a.cin = cs.cout; a.din = cs.dout; a.dout = cs.dout; a.ksize = 1; a.stride = 1; a.pad = 0;
+  a.x = dy; a.src_bf16 = 1; a.cin = cs.cout; a.din = cs.dout; a.dout = cs.dout; a.ksize = 1; a.stride = 1; a.pad = 0;
   a.M = M; a.Mpad = Mpad; a.K = cs.cout; a.Krows = round_up(cs.cout, 128); a.out = dyT;
   hipLaunchKernelGGL(im2col_t_kernel, dim3(Mpad / 64, a.Krows / 64), dim3(256), 0, c.st, a);
   Im2colArgs b{};
-  b.x = x_in; b.cin = cs.cin; b.din = cs.din; b.dout = cs.dout; b.ksize = cs.k; b.stride = cs.stride; b.pad = cs.pad;
+  b.x = x_in; b.src_bf16 = 0; b.cin = cs.cin; b.din = cs.din; b.dout = cs.dout; b.ksize = cs.k; b.stride = cs.stride; b.pad = cs.pad;
   b.M = M; b.Mpad = Mpad; b.K = K; b.Krows = round_up(K, 128); b.out = xT;
   hipLaunchKernelGGL(im2col_t_kernel, dim3(Mpad / 64, b.Krows / 64), dim3(256), 0, c.st, b);
   NERAF_HIP_CHECK(c.ctx, hipGetLastError());
   const bool direct = (cs.k == 1 && ci != 0);
   const int cin_real = ci == 0 ? 7 : cs.cin;
   GemmParams g{};
-  g.A = dyT; g.lda = Mpad; g.B = xT; g.ldb = Mpad;
+  g.bf16 = 1;
+  g.A = (const half_t*)dyT; g.lda = Mpad; g.B = (const half_t*)xT; g.ldb = Mpad;
   g.M = cs.cout; g.N = K; g.K = Mpad; g.Mpad = a.Krows; g.Npad = b.Krows; g.alpha = 1.f; g.alpha_dev = c.inv_scale;
   g.C32 = direct ? c.w_grads[ci] : (float*)(c.bws + c.B->wtmp); g.ldc32 = K;
   g.splitk_ws = (float*)(c.bws + c.B->splitk); g.splitk_ws_bytes = c.B->splitk_bytes;
@@ -392,16 +402,17 @@ int conv_wgrad(const Ctx& c, int ci, const half_t* dy, const half_t* x_in) {
 }
 
 // dX [din^3][cin] = conv_transpose(dY [dout^3][cout], W) (+ add16)
-int conv_dgrad(const Ctx& c, int ci, const half_t* dy, const half_t* add16, half_t* dx) {
+int conv_dgrad(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* add16, bf16_t* dx) {
   const ConvSpec& cs = c.A->conv[ci];
   GemmParams g{};
   const int taps = cs.k * cs.k * cs.k;
-  g.A = dy; g.lda = cs.cout;
+  g.bf16 = 1;
+  g.A = (const half_t*)dy; g.lda = cs.cout;
   g.B = (const half_t*)(c.packed_t + c.B->wt[ci]); g.ldb = taps * cs.cout;
   g.M = (int)cube(cs.din); g.N = cs.cin; g.K = taps * cs.cout; g.Mpad = (int)rows_pad(cs.din);
   g.Npad = cs.cin == 64 ? 64 : round_up(cs.cin, 128); g.tile_n = cs.cin == 64 ? 64 : 0; g.alpha = 1.f;
-  g.add16 = add16; g.ldadd = cs.cin;
-  g.C16 = dx; g.ldc16 = cs.cin;
+  g.add16 = (const half_t*)add16; g.ldadd = cs.cin;
+  g.C16 = (half_t*)dx; g.ldc16 = cs.cin;
   g.splitk_ws = (float*)(c.bws + c.B->splitk); g.splitk_ws_bytes = c.B->splitk_bytes;
   if (cs.k == 1 && cs.stride == 1) {
     g.conv.loader = 0;
@@ -471,15 +482,15 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
   const int Mlast = (int)cube(A.final_edge);
   hipLaunchKernelGGL(make_scale_kernel, dim3(1), dim3(64), 0, st, scale, 4 + (int)ceilf(log2f((float)Mlast)));
   Ctx c{ctx, st, &A, &L, &B, (const char*)packed_t, ws, bws, bn, w_grads, bn_grads, scale + 1};
-  half_t* g = (half_t*)(bws + B.g[0]);
-  half_t* g_next = (half_t*)(bws + B.g[1]);
+  bf16_t* g = (bf16_t*)(bws + B.g[0]);
+  bf16_t* g_next = (bf16_t*)(bws + B.g[1]);
   {
     const int Mpad = (int)rows_pad(A.final_edge);
     const size_t n = (size_t)Mpad * 1024;
     hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dfeat, scale, Mlast, Mpad, 1024, g);
   }
-  half_t* dy0 = (half_t*)(bws + B.dy[0]); half_t* dy1 = (half_t*)(bws + B.dy[1]); half_t* dy2 = (half_t*)(bws + B.dy[2]);
-  half_t* dyds = (half_t*)(bws + B.dyds); half_t* gm = (half_t*)(bws + B.gm); half_t* da = (half_t*)(bws + B.da);
+  bf16_t* dy0 = (bf16_t*)(bws + B.dy[0]); bf16_t* dy1 = (bf16_t*)(bws + B.dy[1]); bf16_t* dy2 = (bf16_t*)(bws + B.dy[2]);
+  bf16_t* dyds = (bf16_t*)(bws + B.dyds); bf16_t* gm = (bf16_t*)(bws + B.gm); bf16_t* da = (bf16_t*)(bws + B.da);
   for (int b = A.nblock - 1; b >= 0; --b) {
     const BlockSpec& Bk = A.block[b];
     const int i0 = Bk.conv[0], i1 = Bk.conv[1], i2 = Bk.conv[2];
@@ -504,7 +515,7 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
     } else {
       if (int e = conv_dgrad(c, i0, dy0, gm, g_next)) return e;                // identity residual
     }
-    half_t* t = g; g = g_next; g_next = t;
+    bf16_t* t = g; g = g_next; g_next = t;
   }
   // stem: max-pool -> relu -> bn1 -> conv1
   {
