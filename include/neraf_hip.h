@@ -70,6 +70,12 @@ int neraf_gemm_f16(neraf_ctx* ctx, const void* A, int lda, const void* B, int ld
                    void* C16, int ldc16, void* C16T, int ldc16t, float* C32, int ldc32,
                    neraf_stream_t stream);
 
+/* The same contraction with bfloat16 operands / 16-bit results (used by the deep gradient chains). */
+int neraf_gemm_bf16(neraf_ctx* ctx, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                    int Mpad, int Npad, float alpha, const float* bias, int act,
+                    void* C16, int ldc16, void* C16T, int ldc16t, float* C32, int ldc32,
+                    neraf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * NAcF -- neural acoustic field MLP (NeRAFAudioSoundField, NeRAF_field.py:37-65) with the
  * query prologue of NeRAFAudioModel.get_outputs (NeRAF_model.py:531-564) fused in front
@@ -282,6 +288,14 @@ int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void*
                        const float* const* bn, void* workspace, void* bwd_workspace, const float* dfeat,
                        float* const* w_grads, float* const* bn_grads, size_t cell_start, int n_cells, int n_ch,
                        float* dgrid_cells, neraf_stream_t stream);
+
+/* Test aid: one conv + BatchNorm(train) + ReLU stage, forward and backward on caller data (allocates and
+ * synchronises internally; not part of the product path). */
+int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_real, int cout, int k, int stride, int pad, int din,
+                                   const void* x_f16, const float* w, const float* gamma, const float* beta, const float* g,
+                                   void* y_f16, float* dx, float* dw, float* dgamma, float* dbeta, neraf_stream_t stream);
+/* Test aid: byte offsets of the backward's intermediate bf16 buffers inside bwd_workspace. */
+int neraf_resnet3d_bwd_debug_offsets(const neraf_resnet3d_desc* d, size_t* off);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,9 @@ SIGNATURES = {
     "neraf_gemm_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "neraf_gemm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "neraf_nacf_packed_bytes": (C.c_size_t, [C.POINTER(NacfDesc)]),
     "neraf_nacf_workspace_bytes": (C.c_size_t, [C.POINTER(NacfDesc), C.c_int, C.c_int]),
     "neraf_nacf_pack_weights": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), c_fpp, C.c_void_p, C.c_void_p]),
@@ -105,6 +108,8 @@ SIGNATURES = {
     "neraf_resnet3d_pack_weights_bwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), c_fpp, C.c_void_p, C.c_void_p]),
     "neraf_resnet3d_bwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, c_fpp, C.c_void_p, C.c_void_p,
                                      C.c_void_p, c_fpp, c_fpp, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "neraf_debug_conv_bn_relu_stage": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 11),
+    "neraf_resnet3d_bwd_debug_offsets": (C.c_int, [C.POINTER(ResnetDesc), C.POINTER(C.c_size_t)]),
     "neraf_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

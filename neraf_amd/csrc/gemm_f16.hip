@@ -500,3 +500,15 @@ extern "C" int neraf_gemm_f16(neraf_ctx* ctx, const void* A, int lda, const void
   p.C16 = (half_t*)C16; p.ldc16 = ldc16; p.C16T = (half_t*)C16T; p.ldc16t = ldc16t; p.C32 = C32; p.ldc32 = ldc32;
   return launch_gemm_f16(ctx, p, (hipStream_t)stream);
 }
+
+// Same contraction with bfloat16 operands/results (the deep gradient chains use it; exported for tests).
+extern "C" int neraf_gemm_bf16(neraf_ctx* ctx, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                               int Mpad, int Npad, float alpha, const float* bias, int act, void* C16, int ldc16,
+                               void* C16T, int ldc16t, float* C32, int ldc32, neraf_stream_t stream) {
+  GemmParams p{};
+  p.bf16 = 1;
+  p.A = (const half_t*)A; p.lda = lda; p.B = (const half_t*)B; p.ldb = ldb;
+  p.M = M; p.N = N; p.K = K; p.Mpad = Mpad; p.Npad = Npad; p.alpha = alpha; p.bias = bias; p.act = act;
+  p.C16 = (half_t*)C16; p.ldc16 = ldc16; p.C16T = (half_t*)C16T; p.ldc16t = ldc16t; p.C32 = C32; p.ldc32 = ldc32;
+  return launch_gemm_f16(ctx, p, (hipStream_t)stream);
+}

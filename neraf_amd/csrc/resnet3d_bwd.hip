@@ -14,6 +14,7 @@
 // with fp32 accumulation; a power-of-two scale from max|d feat| only centres the values, every fp32 output undoes it.
 #include "resnet3d_common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -263,6 +264,11 @@ __global__ __launch_bounds__(256) void stem_dgrid_kernel(const bf16_t* __restric
   dgrid[(size_t)c * n + i] = acc * inv_scale[0];
 }
 
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ a, size_t n, float* __restrict__ o) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = (float)a[i];
+}
+
 __global__ __launch_bounds__(256) void amax_f32_kernel(const float* __restrict__ v, int n, unsigned* __restrict__ amax_bits) {
   float m = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const float a = fabsf(v[i]); m = (a == a && a > m) ? a : m; }
@@ -491,6 +497,9 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
   }
   bf16_t* dy0 = (bf16_t*)(bws + B.dy[0]); bf16_t* dy1 = (bf16_t*)(bws + B.dy[1]); bf16_t* dy2 = (bf16_t*)(bws + B.dy[2]);
   bf16_t* dyds = (bf16_t*)(bws + B.dyds); bf16_t* gm = (bf16_t*)(bws + B.gm); bf16_t* da = (bf16_t*)(bws + B.da);
+  // debugging aid: NERAF_RESNET_BWD_STOP=<n> returns after n conv stages of the LAST block so that tests can inspect
+  // the intermediate gradient buffers (offsets from neraf_resnet3d_bwd_debug_offsets)
+  static const int stop_after = [] { const char* e = getenv("NERAF_RESNET_BWD_STOP"); return e ? atoi(e) : 0; }();
   for (int b = A.nblock - 1; b >= 0; --b) {
     const BlockSpec& Bk = A.block[b];
     const int i0 = Bk.conv[0], i1 = Bk.conv[1], i2 = Bk.conv[2];
@@ -502,6 +511,7 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
     if (int e = bn_backward(c, i2, g, nullptr, out, dy2, Bk.ds < 0 ? gm : nullptr)) return e;
     if (int e = conv_wgrad(c, i2, dy2, a2)) return e;
     if (int e = conv_dgrad(c, i2, dy2, nullptr, da)) return e;                 // d a2
+    if (stop_after == 1) return NERAF_OK;
     if (int e = bn_backward(c, i1, da, nullptr, a2, dy1, nullptr)) return e;
     if (int e = conv_wgrad(c, i1, dy1, a1)) return e;
     if (int e = conv_dgrad(c, i1, dy1, nullptr, da)) return e;                 // d a1
@@ -535,5 +545,92 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
       NERAF_HIP_CHECK(ctx, hipGetLastError());
     }
   }
+  return NERAF_OK;
+}
+
+extern "C" int neraf_resnet3d_bwd_debug_offsets(const neraf_resnet3d_desc* d, size_t* off /* g0,g1,dy0,dy1,dy2,dyds,gm,da,dyT,xcolT */) {
+  Arch A; BwdLayout B;
+  if (make_arch(d, &A) || !off) return NERAF_EINVAL;
+  make_bwd_layout(A, &B);
+  off[0] = B.g[0]; off[1] = B.g[1]; off[2] = B.dy[0]; off[3] = B.dy[1]; off[4] = B.dy[2]; off[5] = B.dyds; off[6] = B.gm; off[7] = B.da;
+  off[8] = B.dyT; off[9] = B.xcolT;
+  return NERAF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Test entry: ONE conv + BatchNorm(train) + ReLU stage, forward statistics and backward, on caller data.  The full
+// encoder is chaotic under fp16 rounding (see oracle.audio.resnet3d_forward_fp16_storage), so the backward kernels are
+// verified stage by stage against autograd here (tests/test_gpu_resnet3d.py::test_conv_bn_relu_stage_backward).
+//   x    fp16 [din^3][cin]          w fp32 [cout][cin_real][k^3]        gamma, beta fp32 [cout]
+//   g    fp32 [dout^3][cout]  upstream gradient w.r.t. relu(bn(conv(x)))
+//   out: y fp16 [dout^3][cout] (post ReLU), dx fp32 [din^3][cin] (skipped for the stem), dw fp32 like w, dgamma, dbeta
+extern "C" int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_real, int cout, int k, int stride, int pad, int din,
+                                              const void* x_f16, const float* w, const float* gamma, const float* beta, const float* g,
+                                              void* y_f16, float* dx, float* dw, float* dgamma, float* dbeta, neraf_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Arch A{};
+  A.S = din; A.nconv = 1; A.nblock = 0; A.pooled = din; A.final_edge = din;
+  const int dout = (din + 2 * pad - k) / stride + 1;
+  A.conv[0] = ConvSpec{cin, cout, k, stride, pad, din, dout};
+  Layout L{}; BwdLayout B{};
+  make_layout(A, &L);
+  make_bwd_layout(A, &B);
+  // the stem branch of make_bwd_layout skips conv 0 when sizing activation buffers: size them for this stage explicitly
+  const size_t act = std::max(rows_pad(dout) * (size_t)cout, rows_pad(din) * (size_t)cin) * 2 + 256;
+  char *ws = nullptr, *bws = nullptr, *packed = nullptr, *packed_t = nullptr, *extra = nullptr;
+  NERAF_HIP_CHECK(ctx, hipMalloc(&ws, L.total));
+  NERAF_HIP_CHECK(ctx, hipMalloc(&bws, B.total));
+  NERAF_HIP_CHECK(ctx, hipMalloc(&packed, L.packed_total));
+  NERAF_HIP_CHECK(ctx, hipMalloc(&packed_t, B.packed_total + 256));
+  NERAF_HIP_CHECK(ctx, hipMalloc(&extra, 4 * act));
+  NERAF_HIP_CHECK(ctx, hipMemsetAsync(ws, 0, L.total, st));
+  NERAF_HIP_CHECK(ctx, hipMemsetAsync(bws, 0, B.total, st));
+  NERAF_HIP_CHECK(ctx, hipMemsetAsync(extra, 0, 4 * act, st));
+  const float* wl[1] = {w};
+  // forward: pack, conv (+stats), bn+relu
+  {
+    PackTable t{};
+    t.n = 1; t.src[0] = w; t.begin[0] = 0; t.dst_off[0] = L.w[0]; t.cout[0] = cout; t.cin_real[0] = cin_real; t.cin[0] = cin;
+    t.taps[0] = k * k * k; t.kpad[0] = conv_kpad(A.conv[0]); t.begin[1] = (unsigned long long)conv_npad(A.conv[0]) * conv_kpad(A.conv[0]);
+    hipLaunchKernelGGL(pack_all_conv_weights_kernel, dim3((unsigned)((t.begin[1] + 255) / 256)), dim3(256), 0, st, t, packed);
+  }
+  half_t* xin = (half_t*)extra;                      // padded copy of the input
+  NERAF_HIP_CHECK(ctx, hipMemcpyAsync(xin, x_f16, cube(din) * cin * 2, hipMemcpyDeviceToDevice, st));
+  if (int e = run_conv(ctx, st, A, L, 0, packed, ws, xin)) return e;
+  const float* bnp[4] = {gamma, beta, gamma, gamma};
+  half_t* yact = (half_t*)(extra + act);
+  {
+    BnApplyArgs a{};
+    a.a = bn_src((const half_t*)(ws + L.pre[0]), (const float*)(ws + L.stat[0]), bnp, 0, cout, 1);
+    a.M = (int)cube(dout); a.Mpad = (int)rows_pad(dout); a.C = cout; a.relu = 1; a.out = yact;
+    if (int e = run_bn_apply(ctx, st, a)) return e;
+  }
+  NERAF_HIP_CHECK(ctx, hipMemcpyAsync(y_f16, yact, cube(dout) * cout * 2, hipMemcpyDeviceToDevice, st));
+  // backward
+  float* scale = (float*)(bws + B.scale);
+  const float one[2] = {1.f, 1.f};
+  NERAF_HIP_CHECK(ctx, hipMemcpyAsync(scale, one, 8, hipMemcpyHostToDevice, st));
+  {
+    PackTTable t{};
+    t.n = 1; t.src[0] = w; t.begin[0] = 0; t.dst_off[0] = B.wt[0]; t.cout[0] = cout; t.cin[0] = cin_real; t.taps[0] = k * k * k;
+    t.kcols[0] = t.taps[0] * cout; t.nrows[0] = cin == 64 || cin == 8 ? 64 : round_up(cin, 128);
+    t.begin[1] = (unsigned long long)t.nrows[0] * t.kcols[0];
+    hipLaunchKernelGGL(pack_dgrad_weights_kernel, dim3((unsigned)((t.begin[1] + 255) / 256)), dim3(256), 0, st, t, packed_t);
+  }
+  float* wg[1] = {dw};
+  float* bng[2] = {dgamma, dbeta};
+  Ctx c{ctx, st, &A, &L, &B, packed_t, ws, bws, bnp, wg, bng, scale + 1};
+  bf16_t* dy = (bf16_t*)(extra + 2 * act);
+  bf16_t* dxb = (bf16_t*)(extra + 3 * act);
+  if (int e = bn_backward(c, 0, nullptr, g, yact, dy, nullptr)) return e;
+  if (int e = conv_wgrad(c, 0, dy, xin)) return e;
+  if (dx && cin % 64 == 0) {
+    if (int e = conv_dgrad(c, 0, dy, nullptr, dxb)) return e;
+    const size_t n = cube(din) * cin;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dxb, n, dx);
+  }
+  NERAF_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  (void)wl;
+  hipFree(ws); hipFree(bws); hipFree(packed); hipFree(packed_t); hipFree(extra);
   return NERAF_OK;
 }

@@ -118,4 +118,103 @@ inline BnSrc bn_src(const half_t* x, const float* stats, const float* const* bn,
 }
 
 
+// one launch for all 43 convolutions: table of per-conv descriptors in the kernel arguments
+struct PackTable {
+  int n;
+  const float* src[48];
+  unsigned long long begin[49];      // prefix of packed element counts
+  unsigned long long dst_off[48];    // byte offset of the conv's packed matrix
+  int cout[48], cin_real[48], cin[48], taps[48], kpad[48];
+};
+
+__global__ __launch_bounds__(256) void pack_all_conv_weights_kernel(PackTable t, char* __restrict__ packed) {
+  const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= t.begin[t.n]) return;
+  int lo = 0, hi = t.n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.begin[mid] <= idx) lo = mid; else hi = mid - 1; }
+  const int i = lo;
+  const unsigned long long e = idx - t.begin[i];
+  const int kpad = t.kpad[i], cin = t.cin[i];
+  const int n = (int)(e / kpad), k = (int)(e % kpad);
+  const int tap = k / cin, c = k % cin;
+  float v = 0.f;
+  if (n < t.cout[i] && tap < t.taps[i] && c < t.cin_real[i]) v = t.src[i][((size_t)n * t.cin_real[i] + c) * t.taps[i] + tap];
+  reinterpret_cast<half_t*>(packed + t.dst_off[i])[e] = (half_t)v;
+}
+
+// out = [relu]( bn(x) [+ residual | + bn_r(xr)] ) ; 8 channels (16 B) per thread; rows >= M are written as zeros
+struct BnApplyArgs {
+  BnSrc a; BnSrc r; const half_t* res;   // r.x != null: residual is bn_r(r.x); else res (may be null)
+  int M, Mpad, C; int relu;
+  half_t* out;
+};
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
+  extern __shared__ float sm[];            // scale[C] shift[C] (+ scale_r[C] shift_r[C])
+  float* sc = sm; float* sh = sm + p.C; float* scr = sm + 2 * p.C; float* shr = sm + 3 * p.C;
+  const float inv_m = 1.f / (float)p.M;
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    bn_scale_shift(p.a, c, inv_m, sc[c], sh[c]);
+    if (p.r.x) bn_scale_shift(p.r, c, inv_m, scr[c], shr[c]);
+  }
+  __syncthreads();
+  const int cpr = p.C >> 3;                 // 16-B chunks per row
+  const size_t total = (size_t)p.Mpad * cpr;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const size_t row = idx / cpr; const int c0 = (int)(idx % cpr) * 8;
+    half8 o;
+    if (row < (size_t)p.M) {
+      const half8 x = *reinterpret_cast<const half8*>(p.a.x + row * p.C + c0);
+      half8 rr;
+      if (p.r.x) rr = *reinterpret_cast<const half8*>(p.r.x + row * p.C + c0);
+      else if (p.res) rr = *reinterpret_cast<const half8*>(p.res + row * p.C + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = fmaf((float)x[j], sc[c0 + j], sh[c0 + j]);
+        if (p.r.x) v += fmaf((float)rr[j], scr[c0 + j], shr[c0 + j]);
+        else if (p.res) v += (float)rr[j];
+        if (p.relu) v = fmaxf(v, 0.f);
+        o[j] = (half_t)v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (half_t)0.f;
+    }
+    *reinterpret_cast<half8*>(p.out + row * p.C + c0) = o;
+  }
+}
+
+inline int run_conv(neraf_ctx* ctx, hipStream_t st, const Arch& A, const Layout& L, int ci, const char* packed, char* ws,
+             const half_t* input) {
+  const ConvSpec& c = A.conv[ci];
+  GemmParams g{};
+  const int M = (int)cube(c.dout);
+  g.A = input; g.lda = c.cin;
+  g.B = (const half_t*)(packed + L.w[ci]); g.ldb = conv_kpad(c);
+  g.M = M; g.N = c.cout; g.K = conv_kpad(c); g.Mpad = (int)rows_pad(c.dout); g.Npad = conv_npad(c); g.alpha = 1.f;
+  g.tile_n = c.cout == 64 ? 64 : 0;
+  g.C16 = (half_t*)(ws + L.pre[ci]); g.ldc16 = c.cout;
+  float* stats = (float*)(ws + L.stat[ci]);
+  g.colsum = stats; g.colsumsq = stats + round_up(c.cout, 128);
+  g.splitk_ws = (float*)(ws + L.splitk); g.splitk_ws_bytes = L.splitk_bytes;
+  if (c.k == 1 && c.stride == 1) {
+    g.conv.loader = 0;
+  } else {
+    g.conv.loader = c.cin == 8 ? 2 : 1;
+    g.conv.din = c.din; g.conv.dout = c.dout; g.conv.stride = c.stride; g.conv.pad = c.pad; g.conv.ksize = c.k; g.conv.cin = c.cin;
+    g.conv.zero_page = (const half_t*)(ws + L.zero_page);
+  }
+  return launch_gemm_f16(ctx, g, st);
+}
+
+inline int run_bn_apply(neraf_ctx* ctx, hipStream_t st, const BnApplyArgs& a) {
+  const size_t total = (size_t)a.Mpad * (a.C >> 3);
+  long blocks = (long)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * a.C * sizeof(float), st, a);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+
 }  // namespace

@@ -43,6 +43,31 @@ def T(a, dev=None):
 
 
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 256), (200, 300, 192), (1024, 256, 128)])
+def test_gemm_bf16_exact_small_integers(dev, M, N, K):
+    """bfloat16 instantiation (gradient chains): exact on small integers (8 significant bits suffice)."""
+    from neraf_amd import _lib
+    lib = _lib.load()
+    Mp, Np = (M + 127) // 128 * 128, (N + 127) // 128 * 128
+    rng = np.random.default_rng(99 + M + N)
+    A = rng.integers(-3, 4, size=(Mp, K)).astype(np.float32)
+    B = rng.integers(-2, 3, size=(Np, K)).astype(np.float32)
+    ref = (A[:M].astype(np.float64) @ B[:N].astype(np.float64).T).astype(np.float32)
+    Ad, Bd = T(A, dev).bfloat16(), T(B, dev).bfloat16()
+    C16 = torch.full((Mp, Np), 7.0, dtype=torch.bfloat16, device=dev)
+    C16T = torch.full((Np, Mp), 7.0, dtype=torch.bfloat16, device=dev)
+    C32 = torch.full((M, N), 7.0, dtype=torch.float32, device=dev)
+    _lib.check(lib.neraf_gemm_bf16(_lib.ctx(0), Ad.data_ptr(), K, Bd.data_ptr(), K, M, N, K, Mp, Np, 1.0, None, 0,
+                                   C16.data_ptr(), Np, C16T.data_ptr(), Mp, C32.data_ptr(), N,
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(C32.cpu().numpy(), ref)
+    full = np.zeros((Mp, Np), np.float32)
+    full[:M, :N] = ref
+    np.testing.assert_array_equal(C16.float().cpu().numpy(), T(full).bfloat16().float().numpy())
+    np.testing.assert_array_equal(C16T.float().cpu().numpy(), T(full).bfloat16().float().numpy().T)
+
+
 @pytest.mark.parametrize("M,N,K", [(2048, 2048, 256), (200, 300, 192), (2048, 513, 512), (130, 5096, 64)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_gemm_exact_small_integers(dev, M, N, K, act):
