@@ -149,7 +149,7 @@ extern "C" int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_
   for (int i = 0; i < A.nconv; ++i) {
     const ConvSpec& c = A.conv[i];
     t.src[i] = conv_w[i]; t.begin[i] = acc; t.dst_off[i] = L.w[i];
-    t.cout[i] = c.cout; t.cin_real[i] = i == 0 ? d->in_channels : c.cin; t.cin[i] = c.cin; t.taps[i] = c.k * c.k * c.k;
+    t.cout[i] = c.cout; t.cin_real[i] = c.cin_real; t.cin[i] = c.cin; t.taps[i] = c.k * c.k * c.k;
     t.kpad[i] = conv_kpad(c);
     acc += (unsigned long long)conv_npad(c) * conv_kpad(c);
   }

@@ -389,8 +389,8 @@ int conv_wgrad(const Ctx& c, int ci, const bf16_t* dy, const half_t* x_in) {
   b.M = M; b.Mpad = Mpad; b.K = K; b.Krows = round_up(K, 128); b.out = xT;
   hipLaunchKernelGGL(im2col_t_kernel, dim3(Mpad / 64, b.Krows / 64), dim3(256), 0, c.st, b);
   NERAF_HIP_CHECK(c.ctx, hipGetLastError());
-  const bool direct = (cs.k == 1 && ci != 0);
-  const int cin_real = ci == 0 ? 7 : cs.cin;
+  const bool direct = (cs.k == 1 && cs.cin_real == cs.cin);
+  const int cin_real = cs.cin_real;
   GemmParams g{};
   g.bf16 = 1;
   g.A = (const half_t*)dyT; g.lda = Mpad; g.B = (const half_t*)xT; g.ldb = Mpad;
@@ -459,7 +459,7 @@ extern "C" int neraf_resnet3d_pack_weights_bwd(neraf_ctx* ctx, const neraf_resne
     const ConvSpec& c = A.conv[i];
     const int nrows = c.cin == 64 || c.cin == 8 ? 64 : round_up(c.cin, 128);
     t.src[i] = conv_w[i]; t.begin[i] = acc; t.dst_off[i] = B.wt[i];
-    t.cout[i] = c.cout; t.cin[i] = i == 0 ? 7 : c.cin; t.taps[i] = c.k * c.k * c.k; t.kcols[i] = t.taps[i] * c.cout; t.nrows[i] = nrows;
+    t.cout[i] = c.cout; t.cin[i] = c.cin_real; t.taps[i] = c.k * c.k * c.k; t.kcols[i] = t.taps[i] * c.cout; t.nrows[i] = nrows;
     acc += (unsigned long long)nrows * t.kcols[i];
   }
   t.begin[A.nconv] = acc;
@@ -571,7 +571,7 @@ extern "C" int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_r
   Arch A{};
   A.S = din; A.nconv = 1; A.nblock = 0; A.pooled = din; A.final_edge = din;
   const int dout = (din + 2 * pad - k) / stride + 1;
-  A.conv[0] = ConvSpec{cin, cout, k, stride, pad, din, dout};
+  A.conv[0] = ConvSpec{cin, cout, k, stride, pad, din, dout, cin_real};
   Layout L{}; BwdLayout B{};
   make_layout(A, &L);
   make_bwd_layout(A, &B);

@@ -4,7 +4,7 @@
 
 namespace {
 
-struct ConvSpec { int cin, cout, k, stride, pad, din, dout; };
+struct ConvSpec { int cin, cout, k, stride, pad, din, dout; int cin_real; };   // cin_real < cin only for the stem (7 of 8)
 struct BlockSpec { int conv[3]; int ds; int planes; };   // indices into the conv list (state-dict order); ds = -1 if none
 
 struct Arch {
@@ -21,7 +21,7 @@ int make_arch(const neraf_resnet3d_desc* d, Arch* A) {
   if (!d || d->in_channels != 7 || d->n_features != 1024 || (d->grid_size != 128 && d->grid_size != 64)) return NERAF_EINVAL;
   A->S = d->grid_size;
   int n = 0;
-  A->conv[n++] = ConvSpec{8, 64, 5, 2, 2, A->S, A->S / 2};             // stem: 7 (padded to 8) -> 64, NeRAF_resnet3d.py:120
+  A->conv[n++] = ConvSpec{8, 64, 5, 2, 2, A->S, A->S / 2, 7};             // stem: 7 (padded to 8) -> 64, NeRAF_resnet3d.py:120
   A->pooled = A->S / 4;                                                  // MaxPool3d(3, 2, 1), :123
   int edge = A->pooled, in_planes = 64, nb = 0;
   const int planes_l[3] = {64, 128, 256}, blocks_l[3] = {3, 4, 6}, stride_l[3] = {1, 2, 2};   // :124-126, resnet50 :237
@@ -30,11 +30,11 @@ int make_arch(const neraf_resnet3d_desc* d, Arch* A) {
       const int s = b == 0 ? stride_l[li] : 1, p = planes_l[li];
       BlockSpec B{};
       B.planes = p;
-      B.conv[0] = n; A->conv[n++] = ConvSpec{in_planes, p, 1, 1, 0, edge, edge};             // :81
-      B.conv[1] = n; A->conv[n++] = ConvSpec{p, p, 3, s, 1, edge, edge / s};                  // :83-84
-      B.conv[2] = n; A->conv[n++] = ConvSpec{p, p * 4, 1, 1, 0, edge / s, edge / s};          // :86
+      B.conv[0] = n; A->conv[n++] = ConvSpec{in_planes, p, 1, 1, 0, edge, edge, in_planes};             // :81
+      B.conv[1] = n; A->conv[n++] = ConvSpec{p, p, 3, s, 1, edge, edge / s, p};                  // :83-84
+      B.conv[2] = n; A->conv[n++] = ConvSpec{p, p * 4, 1, 1, 0, edge / s, edge / s, p};          // :86
       B.ds = -1;
-      if (b == 0 && (s != 1 || in_planes != p * 4)) { B.ds = n; A->conv[n++] = ConvSpec{in_planes, p * 4, 1, s, 0, edge, edge / s}; }  // :169-174
+      if (b == 0 && (s != 1 || in_planes != p * 4)) { B.ds = n; A->conv[n++] = ConvSpec{in_planes, p * 4, 1, s, 0, edge, edge / s, in_planes}; }  // :169-174
       A->block[nb++] = B;
       in_planes = p * 4;
       edge /= s;
