@@ -55,11 +55,12 @@ class JointStep:
        1. NeRAFVisionModel.get_outputs on the ray batch (sampler, 2 proposal nets, 2 PDF resamplings, fused field
           query, composite) + get_loss_dict (rgb MSE, interlevel, distortion)
        2. audio_model.query_grid_one_batch: 4096 cells x 18 directions through the field, mean, slab write
-       3. ResNet3D(7x128^3 grid) -> 1024 feature (train-mode BatchNorm)  -- FORWARD ONLY (its backward: next round)
+       3. ResNet3D(7x128^3 grid) -> 1024 feature (train-mode BatchNorm)
        4. audio get_outputs (GPU prologue + NAcF MLP) -> STFT loss
-       5. ONE backward over the summed loss dict: radiance half (loss grads, proposal backward, fused field backward,
-          weight-grad GEMMs) + NAcF (all grads + d/d feature) -> [RCCL all-reduce] -> GradScaler + fused Adam on the
-          radiance parameters (hash tables, MLPs, embedding; lr 1e-2) and the NAcF parameters (lr 1e-4)."""
+       5. ONE backward over the summed loss dict: NAcF (all grads + d/d feature) -> ResNet3D backward (dgrad/wgrad GEMMs,
+          BatchNorm backward) -> grid-window gradient -> refresh backward into the field; radiance half (loss grads,
+          proposal backward, fused field backward, weight-grad GEMMs) -> [RCCL all-reduce] -> GradScaler + fused Adam on
+          the radiance parameters (lr 1e-2) and the audio parameters (NAcF + ResNet3D, lr 1e-4)."""
 
     def __init__(self, dev, R, B, world):
         from neraf_amd import synth
@@ -82,7 +83,7 @@ class JointStep:
         self.bundle = RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev))
         self.batch = {k: T(v).to(dev) for k, v in synth.audio_batch(B, C_, F_, T_, tag=f"bench.r{rank}").items()}
         self.gt = {"image": T(rb["rgb"]).to(dev)}
-        self.params = list(self.am.field.parameters())
+        self.params = list(self.am.parameters())      # NAcF MLP + ResNet3D: the 'audio_fields' group (NeRAF_model.py:730-737)
         self.vparams = list(self.vm.parameters())
         try:
             self.opt = torch.optim.Adam(self.params, lr=1e-4, eps=1e-15, fused=True)       # NeRAF_config.py:124-127
@@ -265,10 +266,10 @@ def main():
                 "workload": ("RAF FurnishedRoom joint step (BASELINE configs[2] shape: %d rays + %d RIR slices x 513 bins per GPU): "
                              "radiance forward (sampler, 2 proposal nets, 2 PDF resamplings, fused field query, composite) + rgb/"
                              "interlevel/distortion losses -> grid refresh (%d cells x 18 dirs) -> ResNet3D forward on the 7x128^3 "
-                             "grid -> audio prologue + NAcF MLP -> STFT loss -> one backward (radiance half: loss grads, proposal "
-                             "nets, fused field backward, weight-grad GEMMs; NAcF: all grads + d/d feature) -> %sGradScaler + fused "
-                             "Adam on radiance + NAcF parameters.  NOT inside the step yet: ResNet3D backward and the grid->field "
-                             "gradient edge (ResNet3D is forward-only), camera optimizer."
+                             "grid -> audio prologue + NAcF MLP -> STFT loss -> one backward (NAcF -> ResNet3D -> refreshed grid cells -> "
+                             "field; radiance losses -> proposal nets + fused field backward + weight-grad GEMMs) -> %sGradScaler + "
+                             "fused Adam on radiance + audio (NAcF, ResNet3D) parameters.  Not modelled: camera-pose optimizer "
+                             "(nerfstudio CameraOptimizer), data loading."
                              % (a.rays, a.slices, a.rays, "RCCL all-reduce -> " if world > 1 else "")),
                 "rays_per_gpu": a.rays, "slices_per_gpu": a.slices, "parallelism": f"dp{world}",
             },

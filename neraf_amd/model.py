@@ -16,8 +16,9 @@ Differences from the reference that are deliberate (and cheaper):
     copies 73,728 frustums per step, :311-337);
   * the ResNet3D feature is cached between calls while the grid and the encoder weights are unchanged
     (the reference recomputes it for every eval RIR, :680-684, although the grid is static).
-Round-1 limits: the refresh does not yet carry the autograd edge from the grid into the radiance field
-(NeRAF_model.py:395-400 keeps it), and the ResNet3D is forward-only, so the audio loss trains the NAcF MLP.
+The audio loss trains the NAcF MLP, the ResNet3D and -- through the grid cells refreshed in the same step
+(NeRAF_model.py:395-400, "Backprop on vision too" NeRAF_pipeline.py:487) -- the radiance field: the refresh is an
+autograd node (``_RefreshFn``) whose values the ResNet3D node receives as ``window_vals``.
 """
 from __future__ import annotations
 
@@ -53,6 +54,38 @@ class NeRAFAudioModelConfig:
     N_freq_stft: int = 257
     hop_len: int = 128
     win_len: int = 512
+
+
+class _RefreshFn(torch.autograd.Function):
+    """vals [4, n] = (mean_dirs rgb, alpha) of the refreshed cells as a function of the radiance-field parameters
+    (NeRAF_model.py:339-357, :386).  Forward = fused field query in AABB mode; backward = fused field backward."""
+
+    @staticmethod
+    def forward(ctx, field, oris, dd, nd: int, delta: float, *params: torch.Tensor):
+        n = oris.shape[0] // nd
+        z = torch.zeros((oris.shape[0], 2), device=oris.device)
+        cam = torch.zeros(oris.shape[0], dtype=torch.int32, device=oris.device)      # camera index 0, :334
+        packed = field.packed()
+        rgb, den = field.query(oris, dd, z, cam, use_average_embedding=False, packed=packed)    # [nd*n,1,3], [nd*n,1]
+        rgb_m = rgb.reshape(nd, n, 3).mean(0)                                          # :352-356
+        den_m = den.reshape(nd, n).mean(0)                                             # :357
+        alpha = torch.clip(1 - torch.exp(-delta * den_m), 0, 1)                        # :386
+        ctx.field, ctx.nd, ctx.delta, ctx.packed = field, nd, delta, packed
+        ctx.save_for_backward(oris, dd, z, cam, den, den_m, alpha)
+        return torch.cat([rgb_m.t(), alpha[None, :]], dim=0).contiguous()              # [4, n]
+
+    @staticmethod
+    def backward(ctx, dvals: torch.Tensor):
+        oris, dd, z, cam, den, den_m, alpha = ctx.saved_tensors
+        nd, delta = ctx.nd, ctx.delta
+        n = oris.shape[0] // nd
+        dvals = dvals.float()
+        d_rgb = (dvals[:3].t() / nd).repeat(nd, 1).reshape(nd * n, 1, 3).contiguous()
+        inside = ((alpha > 0) & (alpha < 1)).float()
+        d_den_m = dvals[3] * delta * torch.exp(-delta * den_m) * inside
+        d_den = (d_den_m / nd).repeat(nd).reshape(nd * n, 1).contiguous()
+        grads = ctx.field.backward_query(ctx.packed, oris, dd, z, cam, den, d_rgb, d_den)
+        return (None, None, None, None, None, *grads)
 
 
 class NeRAFAudioModel(nn.Module):
@@ -99,6 +132,7 @@ class NeRAFAudioModel(nn.Module):
             self.field = NeRAFAudioSoundField(n_query, config.W_field, sound_rez=self.mic_ch, N_frequencies=config.N_freq_stft)  # :207
         self._feat_cache = None
         self._feat_key = None
+        self._window = None
         self.eval_source_pose = self.eval_mic_pose = self.eval_rot = self.eval_gt = None
 
     # ---- A2: grid --------------------------------------------------------------------------------
@@ -121,11 +155,11 @@ class NeRAFAudioModel(nn.Module):
         return torch.stack(v, dim=0)
 
     # ---- A3: refresh -----------------------------------------------------------------------------
-    @torch.no_grad()
     def query_grid_one_batch(self, step, vision_field, renderer_rgb=None, batch_size=4096):
         if not self.use_grid:
             return
         lib = _lib.load()
+        self._window = None
         module = vision_field.module
         saved = module.spatial_distortion
         module.spatial_distortion = None                                                # :302
@@ -142,22 +176,33 @@ class NeRAFAudioModel(nn.Module):
             nd = dirs.shape[0]
             oris = ori.repeat(nd, 1)                                                    # direction-major concat, :327-333
             dd = dirs.repeat_interleave(batch_size, dim=0)
-            z = torch.zeros((oris.shape[0], 1), device=ori.device)
-            rs = RaySamples(Frustums(oris, dd, z, z), torch.zeros((oris.shape[0], 1), dtype=torch.int32, device=ori.device))
-            was = module.training
-            module.train(True)           # the reference queries with camera index 0's appearance embedding (:334)
-            out = vision_field.forward(rs)                                              # :339
-            module.train(was)
-            rgb = out[FieldHeadNames.RGB].contiguous()
-            den = out[FieldHeadNames.DENSITY].reshape(-1).contiguous()
-            # renderer_rgb with weights == 1 on a single sample returns rgb unchanged (:344-350); without a renderer the
-            # reference applies a sigmoid to the (already sigmoid) colour (:390)
-            if renderer_rgb is None:
-                rgb = torch.sigmoid(rgb)
-            dev = _dev_index(rgb)
             nvox = self.grid.shape[1] * self.grid.shape[2] * self.grid.shape[3]
-            _lib.check(lib.neraf_grid_refresh_write(_lib.ctx(dev), rgb.data_ptr(), den.data_ptr(), batch_size, nd, self._delta,
-                                                    self.grid.data_ptr(), nvox, i, _stream_ptr()), dev)
+            differentiable = (self.training and torch.is_grad_enabled() and renderer_rgb is not None
+                              and any(p.requires_grad for p in module.grad_params()))
+            if differentiable:
+                # the grid is detached and the fresh values keep their graph (:395-400): vals is an autograd node over the
+                # radiance-field parameters, consumed by the ResNet3D node in scene_feature()
+                vals = _RefreshFn.apply(module, oris.contiguous(), dd.contiguous(), nd, self._delta, *module.grad_params())
+                with torch.no_grad():
+                    self.grid.view(7, nvox)[0:4, i:i + batch_size] = vals
+                self._window = (i, batch_size, vals)
+            else:
+                with torch.no_grad():
+                    z = torch.zeros((oris.shape[0], 1), device=ori.device)
+                    rs = RaySamples(Frustums(oris, dd, z, z), torch.zeros((oris.shape[0], 1), dtype=torch.int32, device=ori.device))
+                    was = module.training
+                    module.train(True)           # the reference queries with camera index 0's appearance embedding (:334)
+                    out = vision_field.forward(rs)                                      # :339
+                    module.train(was)
+                    rgb = out[FieldHeadNames.RGB].contiguous()
+                    den = out[FieldHeadNames.DENSITY].reshape(-1).contiguous()
+                    # renderer_rgb with weights == 1 on a single sample returns rgb unchanged (:344-350); without a renderer
+                    # the reference applies a sigmoid to the (already sigmoid) colour (:390)
+                    if renderer_rgb is None:
+                        rgb = torch.sigmoid(rgb)
+                    dev = _dev_index(rgb)
+                    _lib.check(lib.neraf_grid_refresh_write(_lib.ctx(dev), rgb.data_ptr(), den.data_ptr(), batch_size, nd, self._delta,
+                                                            self.grid.data_ptr(), nvox, i, _stream_ptr()), dev)
             self.grid_batch_i += batch_size                                             # :402-404
             if self.grid_batch_i >= n_cells:
                 self.grid_batch_i = 0
@@ -170,7 +215,12 @@ class NeRAFAudioModel(nn.Module):
         """ResNet3D(grid) -> [1024].  Cached in eval mode while the grid is untouched."""
         if not self.training and self._feat_key is not None and self._feat_cache is not None:
             return self._feat_cache
-        feat = self.resnet3d(self.grid.unsqueeze(0)).flatten()                          # :554-557
+        win = getattr(self, "_window", None)
+        if self.training and win is not None:
+            feat = self.resnet3d(self.grid.unsqueeze(0), window=(win[0], win[1], 4), window_vals=win[2]).flatten()
+            self._window = None
+        else:
+            feat = self.resnet3d(self.grid.unsqueeze(0)).flatten()                      # :554-557
         if not self.training:
             self._feat_cache, self._feat_key = feat, True
         return feat

@@ -26,10 +26,12 @@ class _ResNet3DFn(torch.autograd.Function):
     """feat[1024] = ResNet3D(grid); parameters = 43 conv weights followed by 43 x (bn.weight, bn.bias)."""
 
     @staticmethod
-    def forward(ctx, net: "ResNet3D", feat: torch.Tensor, window, sink, *params: torch.Tensor):
-        # the forward kernels already ran (ResNet3D.forward); this node only attaches the backward
+    def forward(ctx, net: "ResNet3D", feat: torch.Tensor, window, sink, window_vals, *params: torch.Tensor):
+        # the forward kernels already ran (ResNet3D.forward); this node only attaches the backward.  ``window_vals``
+        # ([n_ch, n_cells], may be None) are the grad-carrying values that were written into the grid window this step
+        # (NeRAF_model.py:395-400): their gradient is the grid gradient at those cells.
         ctx.net, ctx.window, ctx.sink = net, window, sink
-        ctx.n = len(params)
+        ctx.has_vals = window_vals is not None
         ctx.save_for_backward(*params)
         return feat.clone()
 
@@ -62,7 +64,7 @@ class _ResNet3DFn(torch.autograd.Function):
                                           dgrid.data_ptr() if dgrid is not None else None, st), dev)
         if ctx.sink is not None and dgrid is not None:
             ctx.sink(dgrid)
-        return (None, None, None, None, *w_grads, *bn_grads)
+        return (None, None, None, None, dgrid if ctx.has_vals else None, *w_grads, *bn_grads)
 
 
 class _Bottleneck(nn.Module):
@@ -134,8 +136,10 @@ class ResNet3D(nn.Module):
                 pairs += blk.conv_bn_pairs()
         return pairs
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """x fp32 [1,7,S,S,S] -> [1,1024,1,1,1] (NeRAF_resnet3d.py:184-198)."""
+    def forward(self, x: torch.Tensor, window=None, window_vals: torch.Tensor = None) -> torch.Tensor:
+        """x fp32 [1,7,S,S,S] -> [1,1024,1,1,1] (NeRAF_resnet3d.py:184-198).  ``window`` = (cell_start, n_cells, n_ch) and
+        ``window_vals`` [n_ch, n_cells] (requires_grad) describe the grid cells refreshed this step, whose gradient is
+        returned to ``window_vals`` by the backward."""
         lib = _lib.load()
         S = self.grid_size
         if tuple(x.shape) != (1, 7, S, S, S):
@@ -173,7 +177,11 @@ class ResNet3D(nn.Module):
             params = [c.weight for c, _ in pairs]
             for _, b in pairs:
                 params += [b.weight, b.bias]
-            feat = _ResNet3DFn.apply(self, feat, self.grid_window, self.grid_grad_sink, *params)
+            if window is None:
+                window = self.grid_window
+            if window_vals is not None and not window_vals.requires_grad:
+                window_vals = None
+            feat = _ResNet3DFn.apply(self, feat, window, self.grid_grad_sink, window_vals, *params)
         return feat.reshape(1, 1024, 1, 1, 1)
 
 
@@ -187,5 +195,5 @@ class ResNet3D_helper(nn.Module):
             raise NotImplementedError("only backbone='resnet50', pretrained=False (what NeRAF instantiates, NeRAF_model.py:185)")
         self.backbone_net = ResNet3D(in_channels, (3, 4, 6), grid_step if grid_step is not None else 1 / 128, N_features)
 
-    def forward(self, x):
-        return self.backbone_net(x)
+    def forward(self, x, window=None, window_vals=None):
+        return self.backbone_net(x, window, window_vals)

@@ -229,6 +229,49 @@ class NerfactoField(nn.Module):
     def packed_bwd(self):
         return self._flat_weights()[self._frag_index_bwd].half().contiguous()
 
+    def dump_buffer(self, R: int, S: int, device) -> torch.Tensor:
+        """Persistent (X, dY) scratch of the field backward, one per (R, S) shape; zeroed ONCE (padding rows stay zero)."""
+        if not hasattr(self, "_dumps"):
+            self._dumps = {}
+        key = (R, S, str(device))
+        if key not in self._dumps:
+            self._dumps[key] = torch.zeros(_lib.load().neraf_field_backward_dump_bytes(R, S), dtype=torch.uint8, device=device)
+        return self._dumps[key]
+
+    def splitk_buffer(self, device) -> torch.Tensor:
+        if getattr(self, "_splitk", None) is None or self._splitk.device != device:
+            self._splitk = torch.empty(4 << 20, dtype=torch.float32, device=device)
+        return self._splitk
+
+    def backward_query(self, packed, origins, directions, e_bins, camera_indices, density, d_rgb, d_density):
+        """Gradients of the field parameters for upstream d_rgb [R,S,3] / d_density [R,S] of a structured query.
+        Returns [d table, d base_w0, d base_w1, d head_w0, d head_w1, d head_w2, d embedding]."""
+        lib = _lib.load()
+        dev = _dev_index(origins)
+        device = origins.device
+        R, S = e_bins.shape[0], e_bins.shape[1] - 1
+        tab, wfrag, emb = packed
+        wfrag_b = self.packed_bwd()
+        g_table = torch.zeros_like(self.table)
+        g_emb = torch.zeros_like(self.embedding)
+        g_w = [torch.empty_like(p) for p in (self.base_w0, self.base_w1, self.head_w0, self.head_w1, self.head_w2)]
+        dump = self.dump_buffer(R, S, device)
+        splitk = self.splitk_buffer(device)
+        cam = camera_indices.reshape(-1).to(torch.int32).contiguous() if camera_indices is not None else None
+        mode = 0 if self.spatial_distortion is not None else 1
+        ab = (C.c_float * 6)(*[float(v) for v in self.aabb.reshape(-1).cpu().tolist()])
+        _lib.check(lib.neraf_field_backward(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), wfrag.data_ptr(), wfrag_b.data_ptr(),
+                                            emb.data_ptr(), origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(),
+                                            cam.data_ptr() if cam is not None else None, R, S, mode, ab, self.average_init_density,
+                                            -1 if cam is not None else self.embedding.shape[0], density.data_ptr(),
+                                            d_rgb.data_ptr(), d_density.data_ptr(), g_table.data_ptr(),
+                                            g_emb.data_ptr() if cam is not None else None, _lib.ptr_array(g_w), dump.data_ptr(),
+                                            splitk.data_ptr(), splitk.numel() * 4, _stream_ptr()), dev)
+        return [g_table] + g_w + [g_emb]
+
+    def grad_params(self):
+        return [self.table, self.base_w0, self.base_w1, self.head_w0, self.head_w1, self.head_w2, self.embedding]
+
     def query(self, origins, directions, e_bins, camera_indices=None, use_average_embedding: bool = False, packed=None):
         """Structured query: R rays x S samples.  Returns (rgb [R,S,3], density [R,S])."""
         lib = _lib.load()
@@ -314,24 +357,7 @@ class _VisionLossFn(torch.autograd.Function):
                                          fine.s_bins.data_ptr(), gt.data_ptr(), R, S2, model.distortion_loss_mult, up.data_ptr(),
                                          d_rgb_s.data_ptr(), d_dens.data_ptr(), sums.data_ptr(), stream), dev)
         # ---- main field
-        tab, wfrag, emb = st["field_packed"]
-        wfrag_b = field.packed_bwd()
-        g_table = torch.zeros_like(field.table)
-        g_emb = torch.zeros_like(field.embedding)
-        g_w = [torch.empty_like(p) for p in (field.base_w0, field.base_w1, field.head_w0, field.head_w1, field.head_w2)]
-        dump = model._dump_buffer(R, S2, device)
-        splitk = model._splitk_buffer(device)
-        cam = st["cam"].reshape(-1).to(torch.int32).contiguous() if st["cam"] is not None else None
-        mode = 0 if field.spatial_distortion is not None else 1
-        ab = (C.c_float * 6)(*[float(v) for v in field.aabb.reshape(-1).cpu().tolist()])
-        _lib.check(lib.neraf_field_backward(h, C.byref(field.desc), tab.data_ptr(), wfrag.data_ptr(), wfrag_b.data_ptr(),
-                                            emb.data_ptr(), st["o"].data_ptr(), st["d"].data_ptr(), fine.e_bins.data_ptr(),
-                                            cam.data_ptr() if cam is not None else None, R, S2, mode, ab, field.average_init_density,
-                                            -1 if cam is not None else field.embedding.shape[0], st["dens"].data_ptr(),
-                                            d_rgb_s.data_ptr(), d_dens.data_ptr(), g_table.data_ptr(),
-                                            g_emb.data_ptr() if cam is not None else None, _lib.ptr_array(g_w), dump.data_ptr(),
-                                            splitk.data_ptr(), splitk.numel() * 4, stream), dev)
-        grads = [g_table] + g_w + [g_emb]
+        grads = field.backward_query(st["field_packed"], st["o"], st["d"], fine.e_bins, st["cam"], st["dens"], d_rgb_s, d_dens)
         # ---- proposal networks (interlevel loss); densities were computed under no_grad when not `updated`
         if not st["prop_updated"]:
             return (None, None, None, *grads, *([None] * (3 * len(model.proposal_networks))))
@@ -379,19 +405,6 @@ class NeRAFVisionModel(nn.Module):
     @property
     def device(self):
         return self.field.module.table.device
-
-    def _dump_buffer(self, R: int, S: int, device) -> torch.Tensor:
-        """Persistent (X, dY) scratch of the field backward; zeroed ONCE (its padding rows must stay zero)."""
-        key = (R, S, str(device))
-        if getattr(self, "_dump_key", None) != key:
-            n = _lib.load().neraf_field_backward_dump_bytes(R, S)
-            self._dump, self._dump_key = torch.zeros(n, dtype=torch.uint8, device=device), key
-        return self._dump
-
-    def _splitk_buffer(self, device) -> torch.Tensor:
-        if getattr(self, "_splitk", None) is None or self._splitk.device != device:
-            self._splitk = torch.empty(4 << 20, dtype=torch.float32, device=device)
-        return self._splitk
 
     def update_to_step(self, step: int):
         """ProposalNetworkSampler.step_cb [NS-recall]: called once per training iteration."""

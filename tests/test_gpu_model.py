@@ -118,3 +118,66 @@ def test_get_outputs_loss_and_eval_branch(models):
     assert rel <= 1e-2, rel
     np.testing.assert_array_equal(out["stft_ch_0"][:, :, 0].numpy(), np.flip(out["raw_output"][:, 0, :].cpu().numpy().T, 0))
     am.train()
+
+
+def test_refresh_gradient_edge_vs_oracle(models):
+    """The autograd edge from the refreshed grid cells into the radiance field (NeRAF_model.py:395-400): for a random
+    upstream d loss / d grid[0:4, window], gradients of the field parameters against autograd through the oracle's refresh
+    (field_forward in AABB mode -> mean over the 18 directions -> alpha).  Tolerance 6e-2 relative L2 (as the field tests)."""
+    from neraf_amd.model import _RefreshFn
+    from oracle import audio as O
+    vm, am, P16, spec, V, dev = models
+    f = vm.field.module
+    n, gs = 512, 1 / 64
+    coords = O.coordinates_to_render(gs)[1000:1000 + n]
+    dirs = O.fixed_viewing_directions()
+    aabb = f.aabb.cpu()
+    ori = O.refresh_world_positions(coords, aabb)
+    dvals = T(synth.normal("t.edge.dvals", (4, n)))
+    # oracle
+    P = {k: v.clone().requires_grad_(True) for k, v in P16.items()}
+    rg, dn = [], []
+    for j in range(18):
+        r, d = V.field_forward(ori, dirs[j].expand(n, -1), torch.zeros(n, dtype=torch.long), P, spec, contract=False, aabb=aabb)
+        rg.append(r); dn.append(d)
+    rgb_m, den_m = torch.stack(rg).mean(0), torch.stack(dn).mean(0)
+    vals_o = torch.cat([rgb_m.t(), torch.clip(1 - torch.exp(-1e-2 * den_m), 0, 1)[None]], 0)
+    (vals_o * dvals).sum().backward()
+    # HIP
+    old = f.spatial_distortion
+    f.spatial_distortion = None
+    for p in f.parameters():
+        p.grad = None
+    try:
+        oris = ori.repeat(18, 1).to(dev).contiguous()
+        dd = dirs.repeat_interleave(n, dim=0).to(dev).contiguous()
+        vals = _RefreshFn.apply(f, oris, dd, 18, 1e-2, *f.grad_params())
+        assert float((vals.detach().cpu() - vals_o.detach()).abs().max()) <= 4e-3
+        (vals * dvals.to(dev)).sum().backward()
+    finally:
+        f.spatial_distortion = old
+    for name, p in (("field.table", f.table), ("field.base_w0", f.base_w0), ("field.base_w1", f.base_w1), ("field.head_w0", f.head_w0),
+                    ("field.head_w1", f.head_w1), ("field.head_w2", f.head_w2)):
+        a, b = p.grad.double().cpu(), P[name].grad.double()
+        assert float((a - b).norm() / b.norm()) <= 6e-2, name
+    e = f.embedding.grad.double().cpu()
+    assert float((e[0] - P["field.embedding"].grad[0].double()).norm() / P["field.embedding"].grad[0].double().norm()) <= 6e-2
+    assert float(e[1:].abs().max()) == 0.0        # the refresh uses camera index 0 only
+
+
+def test_joint_backward_reaches_all_parameter_groups(models):
+    """One joint step: the audio loss reaches the NAcF MLP, the ResNet3D and (through the refreshed cells) the field."""
+    vm, am, P16, spec, V, dev = models
+    vm.train(); am.train()
+    for p in list(vm.parameters()) + list(am.parameters()):
+        p.grad = None
+    am.query_grid_one_batch(0, vm.field, renderer_rgb=vm.renderer_rgb, batch_size=2048)
+    b = {k: T(v).to(dev) for k, v in synth.audio_batch(128, 1, 513, 60, tag="t.joint").items()}
+    y = am.get_outputs(b)
+    ld = am.get_loss_dict(y, b)
+    (ld["audio_sc_loss"] + ld["audio_mag_loss"]).backward()
+    for name, p in (("nacf", am.field.soundfield[2].weight), ("resnet conv", am.resnet3d.backbone_net.layer2[1].conv2.weight),
+                    ("resnet bn", am.resnet3d.backbone_net.bn1.weight), ("field table", vm.field.module.table),
+                    ("field head", vm.field.module.head_w1)):
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0, name
+    assert vm.proposal_networks[0].table.grad is None          # the audio loss does not touch the proposal networks
