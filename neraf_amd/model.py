@@ -61,14 +61,19 @@ class _RefreshFn(torch.autograd.Function):
     (NeRAF_model.py:339-357, :386).  Forward = fused field query in AABB mode; backward = fused field backward."""
 
     @staticmethod
-    def forward(ctx, field, oris, dd, nd: int, delta: float, *params: torch.Tensor):
-        n = oris.shape[0] // nd
+    def forward(ctx, field, ori, dirs, nd: int, delta: float, *params: torch.Tensor):
+        """ori [n,3] cell centres (world), dirs [nd,3].  Internally the nd*n queries are laid out CELL-major (the nd
+        directions of a cell adjacent) -- the result does not depend on the order, and the backward's hash-gradient
+        pre-reduction then merges the nd identical positions into one atomic per table entry."""
+        n = ori.shape[0]
+        oris = ori.repeat_interleave(nd, dim=0).contiguous()
+        dd = dirs.repeat(n, 1).contiguous()
         z = torch.zeros((oris.shape[0], 2), device=oris.device)
         cam = torch.zeros(oris.shape[0], dtype=torch.int32, device=oris.device)      # camera index 0, :334
         packed = field.packed()
-        rgb, den = field.query(oris, dd, z, cam, use_average_embedding=False, packed=packed)    # [nd*n,1,3], [nd*n,1]
-        rgb_m = rgb.reshape(nd, n, 3).mean(0)                                          # :352-356
-        den_m = den.reshape(nd, n).mean(0)                                             # :357
+        rgb, den = field.query(oris, dd, z, cam, use_average_embedding=False, packed=packed)    # [n*nd,1,3], [n*nd,1]
+        rgb_m = rgb.reshape(n, nd, 3).mean(1)                                          # :352-356
+        den_m = den.reshape(n, nd).mean(1)                                             # :357
         alpha = torch.clip(1 - torch.exp(-delta * den_m), 0, 1)                        # :386
         ctx.field, ctx.nd, ctx.delta, ctx.packed = field, nd, delta, packed
         ctx.save_for_backward(oris, dd, z, cam, den, den_m, alpha)
@@ -80,10 +85,10 @@ class _RefreshFn(torch.autograd.Function):
         nd, delta = ctx.nd, ctx.delta
         n = oris.shape[0] // nd
         dvals = dvals.float()
-        d_rgb = (dvals[:3].t() / nd).repeat(nd, 1).reshape(nd * n, 1, 3).contiguous()
+        d_rgb = (dvals[:3].t() / nd).repeat_interleave(nd, dim=0).reshape(nd * n, 1, 3).contiguous()
         inside = ((alpha > 0) & (alpha < 1)).float()
         d_den_m = dvals[3] * delta * torch.exp(-delta * den_m) * inside
-        d_den = (d_den_m / nd).repeat(nd).reshape(nd * n, 1).contiguous()
+        d_den = (d_den_m / nd).repeat_interleave(nd).reshape(nd * n, 1).contiguous()
         grads = ctx.field.backward_query(ctx.packed, oris, dd, z, cam, den, d_rgb, d_den)
         return (None, None, None, None, None, *grads)
 
@@ -182,7 +187,7 @@ class NeRAFAudioModel(nn.Module):
             if differentiable:
                 # the grid is detached and the fresh values keep their graph (:395-400): vals is an autograd node over the
                 # radiance-field parameters, consumed by the ResNet3D node in scene_feature()
-                vals = _RefreshFn.apply(module, oris.contiguous(), dd.contiguous(), nd, self._delta, *module.grad_params())
+                vals = _RefreshFn.apply(module, ori.contiguous(), dirs.contiguous(), nd, self._delta, *module.grad_params())
                 with torch.no_grad():
                     self.grid.view(7, nvox)[0:4, i:i + batch_size] = vals
                 self._window = (i, batch_size, vals)

@@ -149,9 +149,7 @@ def test_refresh_gradient_edge_vs_oracle(models):
     for p in f.parameters():
         p.grad = None
     try:
-        oris = ori.repeat(18, 1).to(dev).contiguous()
-        dd = dirs.repeat_interleave(n, dim=0).to(dev).contiguous()
-        vals = _RefreshFn.apply(f, oris, dd, 18, 1e-2, *f.grad_params())
+        vals = _RefreshFn.apply(f, ori.to(dev).contiguous(), dirs.to(dev).contiguous(), 18, 1e-2, *f.grad_params())
         assert float((vals.detach().cpu() - vals_o.detach()).abs().max()) <= 4e-3
         (vals * dvals.to(dev)).sum().backward()
     finally:
