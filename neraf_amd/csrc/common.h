@@ -98,10 +98,16 @@ struct GemmParams {
   float* C32; int ldc32;             // optional fp32 out, masked to M x N
   float* colsum;                     // optional [Npad] fp32: atomically += column sums of the final values
   float* colsumsq;                   // optional [Npad] fp32: atomically += column sums of squares (BatchNorm statistics)
+  int stat_rep, stat_stride;         // colsum/colsumsq are replicated stat_rep (power of two, 0 = 1) times, stat_stride floats apart; a
+                                     // workgroup adds into replica (m-tile % stat_rep) -- same-line atomics serialise in the memory system
   ConvGeom conv;                     // conv.loader == 0 for a plain GEMM
   float* splitk_ws; size_t splitk_ws_bytes;   // optional fp32 scratch enabling split-K for under-filled grids
   int tile_n;                        // 0 = auto; 64 forces the 128x64 tile (Cout = 64 layers)
   int bf16;                          // 1: every 16-bit operand/result (A, B, lmask, add16, C16, C16T) is bfloat16 (gradient chains)
+  // grouped launch (plain loader, fp32 results only): ngroups > 1 runs ngroups GEMMs of identical padded shape (Mpad, Npad, K,
+  // lda, ldb) in one grid; group g takes A/B/C32/M/N/ldc32 from grp[g].  Used for the small-output weight gradients.
+  int ngroups;
+  struct Group { const half_t* A; const half_t* B; float* C32; int M, N, ldc32; } grp[6];
 };
 
 int launch_gemm_f16(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream);

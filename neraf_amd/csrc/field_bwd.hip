@@ -639,15 +639,18 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
     NERAF_HIP_CHECK(ctx, hipGetLastError());
   }
   // weight gradients: dW_l [out,in] = (1/S) dY_l [out,N] . X_l [in,N]^T   (NT GEMM, K = points, split-K)
+  // -- one grouped launch: five 64x64 output tiles, K split over the whole chip
   const int outs[5] = {64, 16, 64, 64, 16}, ins[5] = {32, 64, 64, 64, 64};
+  GemmParams gp{};
+  gp.lda = (int)npad; gp.ldb = (int)npad; gp.K = (int)npad; gp.Mpad = 64; gp.Npad = 64; gp.alpha = 1.f; gp.alpha_dev = scale + 1;
+  gp.splitk_ws = (float*)splitk_ws; gp.splitk_ws_bytes = splitk_bytes;
+  gp.ngroups = 5;
   for (int l = 0; l < 5; ++l) {
-    GemmParams gp{};
-    gp.A = (const half_t*)dump + (size_t)(2 * l + 1) * 128 * npad; gp.lda = (int)npad;
-    gp.B = (const half_t*)dump + (size_t)(2 * l) * 128 * npad; gp.ldb = (int)npad;
-    gp.M = outs[l]; gp.N = ins[l]; gp.K = (int)npad; gp.Mpad = 128; gp.Npad = 128; gp.alpha = 1.f; gp.alpha_dev = scale + 1;
-    gp.C32 = w_grads[l]; gp.ldc32 = ins[l];
-    gp.splitk_ws = (float*)splitk_ws; gp.splitk_ws_bytes = splitk_bytes;
-    if (int e = launch_gemm_f16(ctx, gp, st)) return e;
+    gp.grp[l].A = (const half_t*)dump + (size_t)(2 * l + 1) * 128 * npad;
+    gp.grp[l].B = (const half_t*)dump + (size_t)(2 * l) * 128 * npad;
+    gp.grp[l].M = outs[l]; gp.grp[l].N = ins[l]; gp.grp[l].C32 = w_grads[l]; gp.grp[l].ldc32 = ins[l];
   }
+  gp.A = gp.grp[0].A; gp.B = gp.grp[0].B; gp.M = 64; gp.N = 64; gp.C32 = w_grads[0]; gp.ldc32 = ins[0];
+  if (int e = launch_gemm_f16(ctx, gp, st)) return e;
   return NERAF_OK;
 }

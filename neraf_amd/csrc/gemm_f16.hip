@@ -58,7 +58,7 @@ struct Tile {
 // Epilogue of the GEMM kernel (the split-K reducer applies the same operations element-wise).
 template <int BM, int BN, bool BF>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[Tile<BM, BN>::FM][Tile<BM, BN>::FN],
-                                              char* smem, int bm, int bn, int lane, int wave) {
+                                              char* smem, int bm, int bn, int lane, int wave, int M, int N, float* C32, int ldc32) {
   using T = Tile<BM, BN>;
   using E = typename ET<BF>::s;
   using E4 = typename ET<BF>::v4;
@@ -95,7 +95,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (m >= p.M || (n0 + r) >= p.N) v[r] = 0.f;
+        if (m >= M || (n0 + r) >= N) v[r] = 0.f;
       acc[i][j] = v;
     }
   }
@@ -104,7 +104,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
   const int m_w0 = m_tile0 + wm * WM, n_w0 = n_tile0 + wn * WN;
 
   if (p.colsum || p.colsumsq) {
-    // column sums over this wave's WM rows: reduce over i and over the 16 lanes (lane&15) that share a column
+    // column sums over the workgroup's BM rows: over i and the 16 lanes (lane&15) sharing a column by shuffles, over the two
+    // wm waves through LDS, then ONE atomic per column per workgroup into replica (bm % stat_rep)
+    float* red = reinterpret_cast<float*>(smem);        // [wm][sum | sumsq][BN]
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -116,11 +118,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { x += __shfl_xor(x, o); y += __shfl_xor(y, o); }
         if (frow == 0) {
-          if (p.colsum) atomicAdd(p.colsum + n_w0 + j * 16 + n_l + r, x);
-          if (p.colsumsq) atomicAdd(p.colsumsq + n_w0 + j * 16 + n_l + r, y);
+          const int col = wn * WN + j * 16 + n_l + r;
+          red[(wm * 2 + 0) * BN + col] = x;
+          red[(wm * 2 + 1) * BN + col] = y;
         }
       }
     }
+    __syncthreads();
+    const int t = wave * 64 + lane;
+    if (t < 2 * BN) {
+      const int which = t / BN, col = t - which * BN;
+      const float v = red[which * BN + col] + red[(2 + which) * BN + col];
+      float* dst = which ? p.colsumsq : p.colsum;
+      const int rep = p.stat_rep > 1 ? (bm & (p.stat_rep - 1)) * p.stat_stride : 0;
+      if (dst) atomicAdd(dst + rep + n_tile0 + col, v);
+    }
+    __syncthreads();
   }
 
   if (p.C16) {
@@ -167,7 +180,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     __syncthreads();
   }
 
-  if (p.C32) {
+  if (C32) {
     float* im = reinterpret_cast<float*>(img);
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -180,11 +193,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll 4
       for (int row = 0; row < WM; ++row) {
         const int m = m_w0 + row;
-        if (m >= p.M) break;
+        if (m >= M) break;
 #pragma unroll
         for (int c0 = 0; c0 < WN; c0 += 64) {
           const int n = n_w0 + c0 + lane;
-          if (n < p.N) p.C32[(size_t)m * p.ldc32 + n] = im[row * T::IMG32_LD + c0 + lane];
+          if (n < N) C32[(size_t)m * ldc32 + n] = im[row * T::IMG32_LD + c0 + lane];
         }
       }
     } else {
@@ -192,7 +205,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       for (int r0 = 0; r0 < WM; r0 += RPI) {
         const int row = r0 + lane / WN, col = lane % WN;
         const int m = m_w0 + row, n = n_w0 + col;
-        if (m < p.M && n < p.N) p.C32[(size_t)m * p.ldc32 + n] = im[row * T::IMG32_LD + col];
+        if (m < M && n < N) C32[(size_t)m * ldc32 + n] = im[row * T::IMG32_LD + col];
       }
     }
   }
@@ -224,12 +237,19 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
   // ---- XCD-aware tile mapping (bijective for any tile count) + split-K slice
   const int tiles_m = p.Mpad / BM, tiles_n = p.Npad / BN;
   const int ntiles = tiles_m * tiles_n;
-  const int nblocks = ntiles * splits;
+  const int ngroups = p.ngroups > 1 ? p.ngroups : 1;
+  const int nblocks = ntiles * splits * ngroups;
   int bid = blockIdx.x;
   {
     const int q = nblocks >> 3, r = nblocks & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const half_t* Ag = p.A; const half_t* Bg0 = p.B;
+  float* C32g = p.C32; int Mg = p.M, Ng = p.N, ldc32g = p.ldc32, grp = 0;
+  if (ngroups > 1) {
+    grp = bid / (ntiles * splits); bid -= grp * ntiles * splits;
+    Ag = p.grp[grp].A; Bg0 = p.grp[grp].B; C32g = p.grp[grp].C32; Mg = p.grp[grp].M; Ng = p.grp[grp].N; ldc32g = p.grp[grp].ldc32;
   }
   const int split = bid % splits;      // the slices of one tile are neighbours -> same XCD, shared panels
   bid /= splits;
@@ -247,7 +267,7 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
   const int k_end = (k_begin + per) < nk_total ? (k_begin + per) : nk_total;
   const int nk = k_end > k_begin ? k_end - k_begin : 0;
 
-  const half_t* Bg = p.B + (size_t)bn * BN * p.ldb;
+  const half_t* Bg = Bg0 + (size_t)bn * BN * p.ldb;
   const half_t* b_src[T::B_CH];
 #pragma unroll
   for (int i = 0; i < T::B_CH; ++i) {
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
     az[i] = ay[i] = ax[i] = 0;
     a_src[i] = nullptr;
     if (LOADER == 0) {
-      a_src[i] = p.A + (size_t)(bm * BM + row) * p.lda + lc * 8;
+      a_src[i] = Ag + (size_t)(bm * BM + row) * p.lda + lc * 8;
     } else {
       const int m = bm * BM + row;
       const int d = p.conv.dout;
@@ -368,7 +388,7 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
 
   if (splits > 1) {
     // raw fp32 partial slab [split][Mpad][Npad]; finished by splitk_reduce_kernel
-    float* slab = p.splitk_ws + (size_t)split * p.Mpad * p.Npad;
+    float* slab = p.splitk_ws + ((size_t)grp * splits + split) * p.Mpad * p.Npad;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -379,47 +399,85 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
       }
     return;
   }
-  gemm_epilogue<BM, BN, BF>(p, acc, smem, bm, bn, lane, wave);
+  gemm_epilogue<BM, BN, BF>(p, acc, smem, bm, bn, lane, wave, Mg, Ng, C32g, ldc32g);
 }
 
-// Split-K reducer: sums the partial slabs and applies the same epilogue element-wise on 32x32 tiles.
+// Split-K reducer: sums the partial slabs (one float4 per thread per slab, eight loads in flight) and applies the same
+// epilogue element-wise on 32x32 tiles.
 template <bool BF>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int splits) {
   using E = typename ET<BF>::s;
+  using E4 = typename ET<BF>::v4;
   __shared__ float tile[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int t = threadIdx.x;
+  const int row = t >> 3, c4 = (t & 7) * 4;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int grp = blockIdx.z;
+  float* C32 = p.C32; int M = p.M, N = p.N, ldc32 = p.ldc32;
+  if (p.ngroups > 1) { C32 = p.grp[grp].C32; M = p.grp[grp].M; N = p.grp[grp].N; ldc32 = p.grp[grp].ldc32; }
   const float alpha = p.alpha_dev ? p.alpha * (*p.alpha_dev) : p.alpha;
   const size_t slab = (size_t)p.Mpad * p.Npad;
+  const int m = m0 + row, n = n0 + c4;
+  const float* src = p.splitk_ws + (size_t)grp * splits * slab + (size_t)m * p.Npad + n;
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= splits; s += 8) {
+    f32x4 a[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty + i * 8, n = n0 + tx;
-    float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += p.splitk_ws[s * slab + (size_t)m * p.Npad + n];
-    v *= alpha;
-    if (p.bias) v += p.bias[n];
-    v = act_apply(v, p.act);
-    if (p.lmask) v *= ((float)reinterpret_cast<const E*>(p.lmask)[(size_t)m * p.ldmask + n] > 0.f) ? 1.f : p.mask_slope;
-    if (p.add16) v += (float)reinterpret_cast<const E*>(p.add16)[(size_t)m * p.ldadd + n];
-    if (m >= p.M || n >= p.N) v = 0.f;
-    tile[ty + i * 8][tx] = v;
-    if (p.C16) reinterpret_cast<E*>(p.C16)[(size_t)m * p.ldc16 + n] = (E)v;
-    if (p.C32 && m < p.M && n < p.N) p.C32[(size_t)m * p.ldc32 + n] = v;
+    for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + u) * slab);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += a[u];
+  }
+  for (; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * slab);
+  v *= alpha;
+  if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act);
+  if (p.lmask) {
+    const E4 mk = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.lmask) + (size_t)m * p.ldmask + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= ((float)mk[r] > 0.f) ? 1.f : p.mask_slope;
+  }
+  if (p.add16) {
+    const E4 ad = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.add16) + (size_t)m * p.ldadd + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += (float)ad[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (m >= M || (n + r) >= N) v[r] = 0.f;
+    tile[row][c4 + r] = v[r];
+  }
+  if (p.C16) {
+    E4 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = (E)v[r];
+    *reinterpret_cast<E4*>(reinterpret_cast<E*>(p.C16) + (size_t)m * p.ldc16 + n) = h;
+  }
+  if (C32 && m < M) {
+    float* dst = C32 + (size_t)m * ldc32 + n;
+    if (n + 3 < N && (reinterpret_cast<size_t>(dst) & 15) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+    else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (n + r < N) dst[r] = v[r];
+    }
   }
   __syncthreads();
+  const int tx = t & 31, ty = t >> 5;
   if (p.C16T) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int n = n0 + ty + i * 8, m = m0 + tx;
-      reinterpret_cast<E*>(p.C16T)[(size_t)n * p.ldc16t + m] = (E)tile[tx][ty + i * 8];
+      const int nn = n0 + ty + i * 8, mm = m0 + tx;
+      reinterpret_cast<E*>(p.C16T)[(size_t)nn * p.ldc16t + mm] = (E)tile[tx][ty + i * 8];
     }
   }
   if ((p.colsum || p.colsumsq) && ty == 0) {
     float cs = 0.f, cs2 = 0.f;
 #pragma unroll 8
-    for (int i = 0; i < 32; ++i) { const float v = tile[i][tx]; cs += v; cs2 += v * v; }
-    if (p.colsum) atomicAdd(p.colsum + n0 + tx, cs);
-    if (p.colsumsq) atomicAdd(p.colsumsq + n0 + tx, cs2);
+    for (int i = 0; i < 32; ++i) { const float x = tile[i][tx]; cs += x; cs2 += x * x; }
+    const int rep = p.stat_rep > 1 ? (blockIdx.y & (p.stat_rep - 1)) * p.stat_stride : 0;
+    if (p.colsum) atomicAdd(p.colsum + rep + n0 + tx, cs);
+    if (p.colsumsq) atomicAdd(p.colsumsq + rep + n0 + tx, cs2);
   }
 }
 
@@ -433,12 +491,15 @@ int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
     attr_set = true;
   }
   const int ntiles = (p.Mpad / BM) * (p.Npad / BN);
-  ProfScope prof(ctx, stream, LOADER != 0 ? PROF_CONV : (BM * BN == 128 * 128 ? PROF_GEMM128 : PROF_GEMM64), 2.0 * p.M * p.N * p.K);
-  hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF>), dim3(ntiles * splits), dim3(256), PT::LDS_BYTES,
+  const int ng = p.ngroups > 1 ? p.ngroups : 1;
+  double flops = 2.0 * p.M * p.N * p.K;
+  if (ng > 1) { flops = 0.0; for (int g = 0; g < ng; ++g) flops += 2.0 * p.grp[g].M * p.grp[g].N * p.K; }
+  ProfScope prof(ctx, stream, LOADER != 0 ? PROF_CONV : (BM * BN == 128 * 128 ? PROF_GEMM128 : PROF_GEMM64), flops);
+  hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF>), dim3(ntiles * splits * ng), dim3(256), PT::LDS_BYTES,
                      stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   if (splits > 1) {
-    hipLaunchKernelGGL(splitk_reduce_kernel<BF>, dim3(p.Npad / 32, p.Mpad / 32), dim3(256), 0, stream, p, splits);
+    hipLaunchKernelGGL(splitk_reduce_kernel<BF>, dim3(p.Npad / 32, p.Mpad / 32, ng), dim3(256), 0, stream, p, splits);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
   }
   return NERAF_OK;
@@ -450,17 +511,19 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   const int nk = p.K / BK;
   // tile choice: 128x128 when it fills the chip; 128x64 for 64-wide outputs; otherwise 64x64 (4x the workgroups)
   int bm = 128, bn = 128;
-  if (p.tile_n == 64 && (p.Mpad % 128) == 0 && (p.Npad % 64) == 0) { bm = 128; bn = 64; }
-  else if ((p.Mpad / 128) * (p.Npad / 128) < cus) { bm = 64; bn = 64; }
-  const int ntiles = (p.Mpad / bm) * (p.Npad / bn);
+  const bool can128 = (p.Mpad % 128) == 0 && (p.Npad % 128) == 0;
+  if (p.tile_n == 64 && (p.Mpad % 128) == 0) { bm = 128; bn = 64; }
+  else if (!can128 || (p.Mpad / 128) * (p.Npad / 128) < cus) { bm = 64; bn = 64; }
+  const int ng = p.ngroups > 1 ? p.ngroups : 1;
+  const int ntiles = (p.Mpad / bm) * (p.Npad / bn) * ng;
   // split-K: only with scratch, when the grid under-fills the chip and every slice keeps >= 4 K-steps
   int splits = 1;
   if (p.splitk_ws && ntiles * 2 <= cus && nk >= 8) {
     splits = cus / ntiles;
     if (splits > nk / 4) splits = nk / 4;
-    if (splits > (ntiles <= 8 ? 32 : 16)) splits = ntiles <= 8 ? 32 : 16;
-    const size_t need = (size_t)splits * p.Mpad * p.Npad * 4;
-    if (splits < 2 || need > p.splitk_ws_bytes) splits = 1;
+    if (splits > 128) splits = 128;
+    while (splits >= 2 && (size_t)splits * ng * p.Mpad * p.Npad * 4 > p.splitk_ws_bytes) splits >>= 1;
+    if (splits < 2) splits = 1;
   }
   if (bm == 128 && bn == 128) return launch_pipe<128, 128, 4, LOADER, KS, BF>(ctx, p, splits, stream);
   if (bm == 128 && bn == 64) return launch_pipe<128, 64, 4, LOADER, KS, BF>(ctx, p, splits, stream);
@@ -471,9 +534,11 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
 
 int launch_gemm_f16(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   if (p.K <= 0 || (p.K % BK) != 0) return neraf_fail(ctx, NERAF_EINVAL, "gemm: K must be a positive multiple of 64");
-  const int nmult = p.tile_n == 64 ? 64 : 128;
-  if ((p.Mpad % 128) != 0 || (p.Npad % nmult) != 0 || p.M > p.Mpad || p.N > p.Npad || p.M <= 0 || p.N <= 0)
-    return neraf_fail(ctx, NERAF_EINVAL, "gemm: Mpad/Npad must be tile multiples covering M/N");
+  if ((p.Mpad % 64) != 0 || (p.Npad % 64) != 0 || p.M > p.Mpad || p.N > p.Npad || p.M <= 0 || p.N <= 0)
+    return neraf_fail(ctx, NERAF_EINVAL, "gemm: Mpad/Npad must be multiples of 64 covering M/N");
+  if (p.stat_rep > 1 && (p.stat_rep & (p.stat_rep - 1))) return neraf_fail(ctx, NERAF_EINVAL, "gemm: stat_rep must be a power of two");
+  if (p.ngroups > 1 && (p.ngroups > 6 || p.conv.loader != 0 || p.C16 || p.C16T || p.colsum || p.colsumsq || p.lmask || p.add16))
+    return neraf_fail(ctx, NERAF_EINVAL, "gemm: grouped launches are plain GEMMs with fp32 results only");
   if ((p.conv.loader == 0 && (p.lda % 8)) || (p.ldb % 8) || (p.C16 && (p.ldc16 % 8)) || (p.C16T && (p.ldc16t % 8)) ||
       (p.lmask && (p.ldmask % 4)))
     return neraf_fail(ctx, NERAF_EINVAL, "gemm: leading dimensions must keep 16-byte alignment");

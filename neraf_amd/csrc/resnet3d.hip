@@ -20,24 +20,12 @@ __global__ __launch_bounds__(256) void grid_to_ndhwc8_kernel(const float* __rest
   reinterpret_cast<half8*>(out)[v] = h;
 }
 
-// W fp32 [cout][cin_real][k^3] -> fp16 [npad][kpad], k index = tap * cin + c (tap-major, channel-minor)
-__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ W, int cout, int cin_real, int cin, int taps,
-                                                              int npad, int kpad, half_t* __restrict__ out) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)npad * kpad) return;
-  const int n = (int)(idx / kpad), k = (int)(idx % kpad);
-  const int tap = k / cin, c = k % cin;
-  float v = 0.f;
-  if (n < cout && tap < taps && c < cin_real) v = W[((size_t)n * cin_real + c) * taps + tap];
-  out[idx] = (half_t)v;
-}
-
 struct RunTable {
   int n;
   int begin[49];                     // prefix of channel counts
-  unsigned long long stat_off[48];
+  unsigned long long stat_off[48];   // finalised mean / biased variance [2][cpad]
   int cpad[48];
-  float inv_m[48], unbias[48];
+  float unbias[48];
   float* rmean[48]; float* rvar[48];
 };
 
@@ -47,9 +35,8 @@ __global__ __launch_bounds__(256) void bn_update_running_all_kernel(RunTable t, 
   int lo = 0, hi = t.n - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.begin[mid] <= idx) lo = mid; else hi = mid - 1; }
   const int i = lo, c = idx - t.begin[i];
-  const float* stats = reinterpret_cast<const float*>(ws + t.stat_off[i]);
-  const float mean = stats[c] * t.inv_m[i];
-  const float var = fmaxf(stats[t.cpad[i] + c] * t.inv_m[i] - mean * mean, 0.f);
+  const float* fin = reinterpret_cast<const float*>(ws + t.stat_off[i]);
+  const float mean = fin[c], var = fin[t.cpad[i] + c];
   t.rmean[i][c] = (1.f - mom) * t.rmean[i][c] + mom * mean;
   t.rvar[i][c] = (1.f - mom) * t.rvar[i][c] + mom * var * t.unbias[i];
 }
@@ -101,17 +88,6 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const half_t* __restrict__
   const float inv = 1.f / (float)M;
 #pragma unroll
   for (int j = 0; j < 8; ++j) atomicAdd(feat + chunk * 8 + j, s[j] * inv);
-}
-
-// running_mean / running_var update of nn.BatchNorm3d in training mode (momentum m, unbiased variance)
-__global__ void bn_update_running_kernel(const float* __restrict__ stats, int cpad, int C, float inv_m, float unbias, float mom,
-                                         float* __restrict__ rmean, float* __restrict__ rvar) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float mean = stats[c] * inv_m;
-  const float var = fmaxf(stats[cpad + c] * inv_m - mean * mean, 0.f);
-  rmean[c] = (1.f - mom) * rmean[c] + mom * mean;
-  rvar[c] = (1.f - mom) * rvar[c] + mom * var * unbias;
 }
 
 }  // namespace
@@ -178,7 +154,7 @@ extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
   if (int e = run_conv(ctx, st, A, L, 0, packed, ws, (const half_t*)(ws + L.x0))) return e;
   {
     const ConvSpec& c = A.conv[0];
-    BnSrc s = bn_src((const half_t*)(ws + L.pre[0]), (const float*)(ws + L.stat[0]), bn, 0, 64, use_batch_stats);
+    BnSrc s = bn_src_fwd(A, L, ws, bn, 0, use_batch_stats);
     const size_t total = cube(A.pooled) * 8;
     hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, c.dout, A.pooled,
                        cube(c.dout), (half_t*)(ws + L.act_pool));
@@ -191,20 +167,20 @@ extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
     const ConvSpec &c0 = A.conv[i0], &c1 = A.conv[i1], &c2 = A.conv[i2];
     if (int e = run_conv(ctx, st, A, L, i0, packed, ws, x)) return e;
     BnApplyArgs a{};
-    a.a = bn_src((const half_t*)(ws + L.pre[i0]), (const float*)(ws + L.stat[i0]), bn, i0, c0.cout, use_batch_stats);
+    a.a = bn_src_fwd(A, L, ws, bn, i0, use_batch_stats);
     a.M = (int)cube(c0.dout); a.Mpad = (int)rows_pad(c0.dout); a.C = c0.cout; a.relu = 1; a.out = (half_t*)(ws + L.a1[b]);
     if (int e = run_bn_apply(ctx, st, a)) return e;
     if (int e = run_conv(ctx, st, A, L, i1, packed, ws, (const half_t*)(ws + L.a1[b]))) return e;
     BnApplyArgs a2{};
-    a2.a = bn_src((const half_t*)(ws + L.pre[i1]), (const float*)(ws + L.stat[i1]), bn, i1, c1.cout, use_batch_stats);
+    a2.a = bn_src_fwd(A, L, ws, bn, i1, use_batch_stats);
     a2.M = (int)cube(c1.dout); a2.Mpad = (int)rows_pad(c1.dout); a2.C = c1.cout; a2.relu = 1; a2.out = (half_t*)(ws + L.a2[b]);
     if (int e = run_bn_apply(ctx, st, a2)) return e;
     if (int e = run_conv(ctx, st, A, L, i2, packed, ws, (const half_t*)(ws + L.a2[b]))) return e;
     BnApplyArgs a3{};
-    a3.a = bn_src((const half_t*)(ws + L.pre[i2]), (const float*)(ws + L.stat[i2]), bn, i2, c2.cout, use_batch_stats);
+    a3.a = bn_src_fwd(A, L, ws, bn, i2, use_batch_stats);
     if (B.ds >= 0) {
       if (int e = run_conv(ctx, st, A, L, B.ds, packed, ws, x)) return e;
-      a3.r = bn_src((const half_t*)(ws + L.pre[B.ds]), (const float*)(ws + L.stat[B.ds]), bn, B.ds, c2.cout, use_batch_stats);
+      a3.r = bn_src_fwd(A, L, ws, bn, B.ds, use_batch_stats);
     } else {
       a3.res = x;
     }
@@ -234,8 +210,8 @@ extern "C" int neraf_resnet3d_update_running_stats(neraf_ctx* ctx, const neraf_r
   for (int i = 0; i < A.nconv; ++i) {
     const ConvSpec& c = A.conv[i];
     const float m = (float)cube(c.dout);
-    t.begin[i] = acc; t.stat_off[i] = L.stat[i]; t.cpad[i] = round_up(c.cout, 128);
-    t.inv_m[i] = 1.f / m; t.unbias[i] = m / (m - 1.f);
+    t.begin[i] = acc; t.stat_off[i] = L.fin[i]; t.cpad[i] = round_up(c.cout, 128);
+    t.unbias[i] = m / (m - 1.f);
     t.rmean[i] = bn[4 * i + 2]; t.rvar[i] = bn[4 * i + 3];
     acc += c.cout;
   }

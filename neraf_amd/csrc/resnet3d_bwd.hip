@@ -42,12 +42,14 @@ __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(PackTTable t, c
   reinterpret_cast<bf16_t*>(packed + t.dst_off[i])[e] = (bf16_t)v;
 }
 
-// ---- tiling transpose / im2col^T: out[k][m] = X[src(m, tap(k))][c(k)], zero outside ------------------------------
+// ---- im2col^T: out[row(k)][m] = X[src(m, tap)][c] for k = tap*cin + c, zero outside -------------------------------------
+// The rows are stored in the order of the PyTorch weight layout, row(k) = c*taps + tap (channels beyond cin_real after all real
+// ones), so that the wgrad GEMM's fp32 result [cout][row] IS the weight gradient [cout][cin_real][taps] -- no un-permute pass.
 struct Im2colArgs {
-  const void* x; int src_bf16; int cin;          // source [din^3][cin], fp16 (forward activations) or bf16 (gradients)
+  const half_t* x; int cin, cin_real;   // source [din^3][cin] fp16 (forward activations)
   int din, dout, ksize, stride, pad;
   int M, Mpad;                       // result voxels (columns), padded column count (= leading dimension)
-  int K, Krows;                      // real rows taps*cin, rows written (multiple of 128, zero beyond K)
+  int K, Krows;                      // real rows taps*cin, rows written (multiple of 64, zero beyond K)
   bf16_t* out;
 };
 
@@ -70,12 +72,9 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(Im2colArgs a) {
       const int iz = z * a.stride - a.pad + dz, iy = y * a.stride - a.pad + dy, ix = x * a.stride - a.pad + dx;
       if ((unsigned)iz < (unsigned)a.din && (unsigned)iy < (unsigned)a.din && (unsigned)ix < (unsigned)a.din) {
         const size_t off = ((size_t)(iz * a.din + iy) * a.din + ix) * a.cin + cc;
-        if (a.src_bf16) v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.x) + off);
-        else {
-          const half8 h = *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(a.x) + off);
+        const half8 h = *reinterpret_cast<const half8*>(a.x + off);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (bf16_t)(float)h[j];
-        }
+        for (int j = 0; j < 8; ++j) v[j] = (bf16_t)(float)h[j];
       }
     }
     *reinterpret_cast<bf16x8*>(&tile[row][ch * 8]) = v;
@@ -87,92 +86,124 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(Im2colArgs a) {
     const int c = it * 256 + tid, krow = c >> 3, ch = c & 7;
     const int k = k0 + krow;
     if (k >= a.Krows) continue;
+    int orow = k;
+    if (k < a.K) {
+      const int taps = a.ksize * a.ksize * a.ksize;
+      const int tap = k / a.cin, cc = k - tap * a.cin;
+      orow = cc < a.cin_real ? cc * taps + tap : a.cin_real * taps + (cc - a.cin_real) * taps + tap;
+    }
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = tile[ch * 8 + j][krow];
-    *reinterpret_cast<bf16x8*>(a.out + (size_t)k * a.Mpad + m0 + ch * 8) = v;
+    *reinterpret_cast<bf16x8*>(a.out + (size_t)orow * a.Mpad + m0 + ch * 8) = v;
   }
 }
 
 // ---- BatchNorm backward ----------------------------------------------------------------------------------------
+// Both passes work on [rows][64-channel] panels.  Pass 1 reduces sum(dy) and sum(dy*xhat) (registers -> LDS -> one atomic per
+// channel per workgroup into a replicated accumulator, see kStatStride); pass 2 writes dx row-major AND transposed (the wgrad
+// GEMM's A operand), so no separate transpose pass exists.
 struct BnBwdArgs {
-  BnSrc s;                    // x (pre-BN), forward statistics, gamma
+  BnSrc s;                    // x (pre-BN), finalised forward statistics, gamma
   const bf16_t* g16; const float* g32;     // upstream gradient w.r.t. the post-activation tensor (one of them)
   const half_t* act;          // post-activation tensor for the ReLU mask (null = no mask)
   int M, Mpad, C;
-  float* sums;                // [2][cpad]: sum dy, sum dy*xhat
+  int rows_per_block;         // reduce: rows handled by one workgroup (multiple of 32)
+  float* sums; int rep;       // [rep][2][cpad] (replica stride kStatStride): sum dy, sum dy*xhat
   bf16_t* dx;                 // apply: gradient w.r.t. the pre-BN conv output [Mpad][C]
+  bf16_t* dxT;                // apply: the same, transposed [C][Mpad]
   bf16_t* dy_masked;          // apply (optional): g * (act > 0) for the identity residual branch
-  float* dgamma; float* dbeta; const float* inv_scale;   // apply (block 0 writes the un-scaled affine gradients)
+  float* dgamma; float* dbeta; const float* inv_scale;   // apply (row-block 0 writes the un-scaled affine gradients)
 };
 
-__device__ __forceinline__ void bn_mean_rstd(const BnSrc& s, int c, float inv_m, float& mean, float& rstd) {
-  mean = s.stats[c] * inv_m;
-  const float var = fmaxf(s.stats[s.cpad + c] * inv_m - mean * mean, 0.f);
-  rstd = rsqrtf(var + 1e-5f);
+__device__ __forceinline__ void bn_bwd_load(const BnBwdArgs& p, size_t off, float (&xv)[8], float (&g)[8]) {
+  const half8 x = *reinterpret_cast<const half8*>(p.s.x + off);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xv[j] = (float)x[j];
+  if (p.g16) {
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.g16 + off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = (float)gv[j];
+  } else {
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g32 + off), g1 = *reinterpret_cast<const f32x4*>(p.g32 + off + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { g[j] = g0[j]; g[4 + j] = g1[j]; }
+  }
+  if (p.act) {
+    const half8 av = *reinterpret_cast<const half8*>(p.act + off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (!((float)av[j] > 0.f)) g[j] = 0.f;
+  }
 }
 
+// grid (row blocks, C / 64)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs p) {
-  extern __shared__ float sm[];      // mean[C] rstd[C] acc[2][C]
-  float* mean = sm; float* rstd = sm + p.C; float* acc = sm + 2 * p.C;
-  const float inv_m = 1.f / (float)p.M;
-  for (int c = threadIdx.x; c < p.C; c += 256) { bn_mean_rstd(p.s, c, inv_m, mean[c], rstd[c]); acc[c] = 0.f; acc[p.C + c] = 0.f; }
+  __shared__ float mean[64], rstd[64];
+  __shared__ float red[2][32][65];
+  const int c_base = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  if (tid < 64) { float m, v; bn_mean_var(p.s, c_base + tid, 0.f, m, v); mean[tid] = m; rstd[tid] = rsqrtf(v + 1e-5f); }
   __syncthreads();
-  const int cpr = p.C >> 3;
-  const int rows_per_it = 256 / cpr > 0 ? 256 / cpr : 1;
-  const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr;
+  const int ch = tid & 7, rsub = tid >> 3;
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-  if (rsub < rows_per_it) {
-    for (int row = blockIdx.x * rows_per_it + rsub; row < p.M; row += gridDim.x * rows_per_it) {
-      const size_t off = (size_t)row * p.C + chunk * 8;
-      const half8 x = *reinterpret_cast<const half8*>(p.s.x + off);
-      float g[8];
-      if (p.g16) { const bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.g16 + off); for (int j = 0; j < 8; ++j) g[j] = (float)gv[j]; }
-      else { for (int j = 0; j < 8; ++j) g[j] = p.g32[off + j]; }
-      if (p.act) { const half8 av = *reinterpret_cast<const half8*>(p.act + off); for (int j = 0; j < 8; ++j) if (!((float)av[j] > 0.f)) g[j] = 0.f; }
+  const int r_begin = blockIdx.x * p.rows_per_block;
+  const int r_end = min(p.M, r_begin + p.rows_per_block);
+  for (int row = r_begin + rsub; row < r_end; row += 32) {
+    float xv[8], g[8];
+    bn_bwd_load(p, (size_t)row * p.C + c_base + ch * 8, xv, g);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = chunk * 8 + j;
-        s1[j] += g[j];
-        s2[j] += g[j] * ((float)x[j] - mean[c]) * rstd[c];
-      }
+    for (int j = 0; j < 8; ++j) {
+      s1[j] += g[j];
+      s2[j] += g[j] * (xv[j] - mean[ch * 8 + j]) * rstd[ch * 8 + j];
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { atomicAdd(&acc[chunk * 8 + j], s1[j]); atomicAdd(&acc[p.C + chunk * 8 + j], s2[j]); }
   }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[0][rsub][ch * 8 + j] = s1[j]; red[1][rsub][ch * 8 + j] = s2[j]; }
   __syncthreads();
-  for (int c = threadIdx.x; c < p.C; c += 256) { atomicAdd(p.sums + c, acc[c]); atomicAdd(p.sums + p.s.cpad + c, acc[p.C + c]); }
+  if (tid < 128) {
+    const int which = tid >> 6, col = tid & 63;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) acc += red[which][r][col];
+    const int rep = p.rep > 1 ? (blockIdx.x & (p.rep - 1)) * kStatStride : 0;
+    atomicAdd(p.sums + rep + which * p.s.cpad + c_base + col, acc);
+  }
 }
 
+// grid (Mpad / 64, C / 64)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
-  extern __shared__ float sm[];      // mean rstd k1 k2 k3
-  float* mean = sm; float* rstd = sm + p.C; float* k1 = sm + 2 * p.C; float* k2 = sm + 3 * p.C; float* k3 = sm + 4 * p.C;
+  __shared__ float mean[64], rstd[64], k1[64], k2[64], k3[64];
+  __shared__ bf16_t tile[64][72];    // [m][c] with padding
+  const int c_base = blockIdx.y * 64, m0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
   const float inv_m = 1.f / (float)p.M;
-  for (int c = threadIdx.x; c < p.C; c += 256) {
-    bn_mean_rstd(p.s, c, inv_m, mean[c], rstd[c]);
-    const float dbeta = p.sums[c], dgamma = p.sums[p.s.cpad + c];
-    k1[c] = p.s.gamma[c] * rstd[c]; k2[c] = dbeta * inv_m; k3[c] = dgamma * inv_m;
+  if (tid < 64) {
+    const int c = c_base + tid;
+    float m, v;
+    bn_mean_var(p.s, c, 0.f, m, v);
+    const float rs = rsqrtf(v + 1e-5f);
+    float dbeta = 0.f, dgamma = 0.f;
+    for (int r = 0; r < p.rep; ++r) { dbeta += p.sums[r * kStatStride + c]; dgamma += p.sums[r * kStatStride + p.s.cpad + c]; }
+    mean[tid] = m; rstd[tid] = rs;
+    k1[tid] = p.s.gamma[c] * rs; k2[tid] = dbeta * inv_m; k3[tid] = dgamma * inv_m;
     if (blockIdx.x == 0 && p.dgamma) { p.dgamma[c] = dgamma * p.inv_scale[0]; p.dbeta[c] = dbeta * p.inv_scale[0]; }
   }
   __syncthreads();
-  const int cpr = p.C >> 3;
-  const size_t total = (size_t)p.Mpad * cpr;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const size_t row = idx / cpr; const int c0 = (int)(idx % cpr) * 8;
-    const size_t off = row * p.C + c0;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = it * 256 + tid, row = e >> 3, ch = e & 7;
+    const int m = m0 + row;
+    const size_t off = (size_t)m * p.C + c_base + ch * 8;
     bf16x8 o, om;
-    if (row < (size_t)p.M) {
-      const half8 x = *reinterpret_cast<const half8*>(p.s.x + off);
-      float g[8];
-      if (p.g16) { const bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.g16 + off); for (int j = 0; j < 8; ++j) g[j] = (float)gv[j]; }
-      else { for (int j = 0; j < 8; ++j) g[j] = p.g32[off + j]; }
-      if (p.act) { const half8 av = *reinterpret_cast<const half8*>(p.act + off); for (int j = 0; j < 8; ++j) if (!((float)av[j] > 0.f)) g[j] = 0.f; }
+    if (m < p.M) {
+      float xv[8], g[8];
+      bn_bwd_load(p, off, xv, g);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int c = c0 + j;
-        const float xh = ((float)x[j] - mean[c]) * rstd[c];
+        const int c = ch * 8 + j;
+        const float xh = (xv[j] - mean[c]) * rstd[c];
         o[j] = (bf16_t)(k1[c] * (g[j] - k2[c] - xh * k3[c]));
         om[j] = (bf16_t)g[j];
       }
@@ -182,6 +213,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
     }
     *reinterpret_cast<bf16x8*>(p.dx + off) = o;
     if (p.dy_masked) *reinterpret_cast<bf16x8*>(p.dy_masked + off) = om;
+    *reinterpret_cast<bf16x8*>(&tile[row][ch * 8]) = o;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = it * 256 + tid, crow = e >> 3, ch = e & 7;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tile[ch * 8 + j][crow];
+    *reinterpret_cast<bf16x8*>(p.dxT + (size_t)(c_base + crow) * p.Mpad + m0 + ch * 8) = v;
   }
 }
 
@@ -228,15 +269,6 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(BnSrc s, int din, int 
 #pragma unroll
   for (int j = 0; j < 8; ++j)
     if (best[j] > 0.f && (float)gv[j] != 0.f) atomicAdd(dpost + arg[j] * 64 + c0 + j, (float)gv[j]);
-}
-
-// dW temp [cout][tap*cin + c] (fp32) -> PyTorch layout [cout][cin_real][taps]
-__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ tmp, int cout, int cin, int cin_real, int taps,
-                                                          float* __restrict__ dst) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)cout * cin_real * taps) return;
-  const int tap = (int)(idx % taps), c = (int)((idx / taps) % cin_real), n = (int)(idx / ((size_t)taps * cin_real));
-  dst[idx] = tmp[(size_t)n * (taps * cin) + tap * cin + c];
 }
 
 // stem input gradient for a window of cells: dgrid[c][cell] = sum_taps sum_co dY[(z+2-dz)/2,...][co] W[co][c][tap] / S
@@ -295,17 +327,30 @@ struct BwdLayout {
   size_t wt[64];              // dgrad weights (in the packed-dgrad blob)
   size_t packed_total;
   size_t scale;               // fp32[4]
-  size_t sums[64];            // per conv/BN: [2][cpad] fp32
+  size_t sums[64];            // per conv/BN: [rep][2][cpad] fp32 (replica stride kStatStride)
   size_t sums_begin, sums_bytes;
   size_t g[2];                // ping-pong gradient w.r.t. block outputs, fp16, largest activation
   size_t dy[3];               // dY of the three convs of a block (+ ds shares slot 2 after use) ; sized for the largest
   size_t dyds, gm, da;        // downsample dY, masked g (identity residual), d(a1|a2) scratch
   size_t dpost;               // fp32 [din1^3][64] stem
   size_t dyT, xcolT;          // transposed operands of the wgrad GEMM
-  size_t wtmp;                // fp32 temp for un-permuted weight gradients
   size_t splitk; size_t splitk_bytes;
   size_t total;
 };
+
+// row blocks / accumulator replicas of the BN-backward reduction of conv ci
+inline int bwd_rows_per_block(const ConvSpec& c) {
+  const int M = (int)cube(c.dout);
+  return std::max(128, round_up((M + 511) / 512, 32));
+}
+inline int bwd_stat_rep(const ConvSpec& c) {
+  if (2 * round_up(c.cout, 128) > kStatStride) return 1;
+  const int M = (int)cube(c.dout), rpb = bwd_rows_per_block(c);
+  const int nrb = (M + rpb - 1) / rpb;
+  int r = 1;
+  while (r < 16 && r * 8 < nrb) r <<= 1;
+  return r;
+}
 
 void make_bwd_layout(const Arch& A, BwdLayout* L) {
   size_t off = 0;
@@ -319,9 +364,12 @@ void make_bwd_layout(const Arch& A, BwdLayout* L) {
   off = 0;
   L->scale = take(256);
   L->sums_begin = off;
-  for (int i = 0; i < A.nconv; ++i) L->sums[i] = take((size_t)2 * round_up(A.conv[i].cout, 128) * 4);
+  for (int i = 0; i < A.nconv; ++i) {
+    const int rep = bwd_stat_rep(A.conv[i]);
+    L->sums[i] = take(rep > 1 ? (size_t)rep * kStatStride * 4 : (size_t)2 * round_up(A.conv[i].cout, 128) * 4);
+  }
   L->sums_bytes = off - L->sums_begin;
-  size_t max_act = 0, max_xcol = 0, max_dyT = 0, max_wtmp = 0;
+  size_t max_act = 0, max_xcol = 0, max_dyT = 0;
   for (int i = 0; i < A.nconv; ++i) {
     const ConvSpec& c = A.conv[i];
     const size_t rows_out = rows_pad(c.dout), rows_in = rows_pad(c.din);
@@ -331,7 +379,6 @@ void make_bwd_layout(const Arch& A, BwdLayout* L) {
     }
     max_xcol = std::max(max_xcol, (size_t)round_up(c.k * c.k * c.k * c.cin, 128) * rows_out * 2);
     max_dyT = std::max(max_dyT, (size_t)round_up(c.cout, 128) * rows_out * 2);
-    max_wtmp = std::max(max_wtmp, (size_t)c.cout * c.k * c.k * c.k * c.cin * 4);
   }
   const size_t stem_act = rows_pad(A.conv[0].dout) * 64 * 2;
   for (int i = 0; i < 2; ++i) L->g[i] = take(max_act);
@@ -339,7 +386,6 @@ void make_bwd_layout(const Arch& A, BwdLayout* L) {
   L->dyds = take(max_act); L->gm = take(max_act); L->da = take(max_act);
   L->dpost = take(cube(A.conv[0].dout) * 64 * 4);
   L->dyT = take(max_dyT); L->xcolT = take(max_xcol);
-  L->wtmp = take(max_wtmp);
   L->splitk_bytes = (size_t)64 << 20;
   L->splitk = take(L->splitk_bytes);
   L->total = off;
@@ -351,60 +397,44 @@ struct Ctx {
   const float* inv_scale;
 };
 
+// BN backward of conv ci: dx (row-major, into `dx`) and its transpose (into the shared dyT buffer, consumed by conv_wgrad(ci))
 int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const half_t* act, bf16_t* dx, bf16_t* dy_masked) {
   const ConvSpec& cs = c.A->conv[ci];
   BnBwdArgs p{};
-  p.s = bn_src((const half_t*)(c.ws + c.L->pre[ci]), (const float*)(c.ws + c.L->stat[ci]), c.bn, ci, cs.cout, 1);
+  p.s = bn_src_bwd(*c.A, *c.L, c.ws, c.bn, ci);
   p.g16 = g16; p.g32 = g32; p.act = act;
   p.M = (int)cube(cs.dout); p.Mpad = (int)rows_pad(cs.dout); p.C = cs.cout;
-  p.sums = (float*)(c.bws + c.B->sums[ci]);
-  p.dx = dx; p.dy_masked = dy_masked;
+  p.rows_per_block = bwd_rows_per_block(cs);
+  p.sums = (float*)(c.bws + c.B->sums[ci]); p.rep = bwd_stat_rep(cs);
+  p.dx = dx; p.dxT = (bf16_t*)(c.bws + c.B->dyT); p.dy_masked = dy_masked;
   p.dgamma = c.bn_grads[2 * ci]; p.dbeta = c.bn_grads[2 * ci + 1]; p.inv_scale = c.inv_scale;
-  const int cpr = p.C >> 3;
-  const int rows_per_it = 256 / cpr > 0 ? 256 / cpr : 1;
-  int blocks = (p.M + rows_per_it - 1) / rows_per_it;
-  if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), (size_t)4 * p.C * sizeof(float), c.st, p);
-  const size_t total = (size_t)p.Mpad * cpr;
-  long ab = (long)((total + 255) / 256);
-  if (ab > 2048) ab = 2048;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ab), dim3(256), (size_t)5 * p.C * sizeof(float), c.st, p);
+  const int nrb = (p.M + p.rows_per_block - 1) / p.rows_per_block;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nrb, p.C / 64), dim3(256), 0, c.st, p);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(p.Mpad / 64, p.C / 64), dim3(256), 0, c.st, p);
   NERAF_HIP_CHECK(c.ctx, hipGetLastError());
   return NERAF_OK;
 }
 
-// dW of conv ci from dY [rows_out][cout] and its input activation x_in [din^3][cin]
-int conv_wgrad(const Ctx& c, int ci, const bf16_t* dy, const half_t* x_in) {
+// dW of conv ci from dY^T [cout][Mpad] (left in the dyT buffer by bn_backward(ci)) and the conv's input activation
+// x_in [din^3][cin]: NT GEMM over the voxels, result written straight into the PyTorch-layout gradient tensor
+int conv_wgrad(const Ctx& c, int ci, const half_t* x_in) {
   const ConvSpec& cs = c.A->conv[ci];
   const int M = (int)cube(cs.dout), Mpad = (int)rows_pad(cs.dout);
   const int taps = cs.k * cs.k * cs.k, K = taps * cs.cin;
-  bf16_t* dyT = (bf16_t*)(c.bws + c.B->dyT);
+  const bf16_t* dyT = (const bf16_t*)(c.bws + c.B->dyT);
   bf16_t* xT = (bf16_t*)(c.bws + c.B->xcolT);
-  Im2colArgs a{};
-  a.x = dy; a.src_bf16 = 1; a.cin = cs.cout; a.din = cs.dout; a.dout = cs.dout; a.ksize = 1; a.stride = 1; a.pad = 0;
-  a.M = M; a.Mpad = Mpad; a.K = cs.cout; a.Krows = round_up(cs.cout, 128); a.out = dyT;
-  hipLaunchKernelGGL(im2col_t_kernel, dim3(Mpad / 64, a.Krows / 64), dim3(256), 0, c.st, a);
   Im2colArgs b{};
-  b.x = x_in; b.src_bf16 = 0; b.cin = cs.cin; b.din = cs.din; b.dout = cs.dout; b.ksize = cs.k; b.stride = cs.stride; b.pad = cs.pad;
-  b.M = M; b.Mpad = Mpad; b.K = K; b.Krows = round_up(K, 128); b.out = xT;
+  b.x = x_in; b.cin = cs.cin; b.cin_real = cs.cin_real; b.din = cs.din; b.dout = cs.dout; b.ksize = cs.k; b.stride = cs.stride; b.pad = cs.pad;
+  b.M = M; b.Mpad = Mpad; b.K = K; b.Krows = round_up(K, 64); b.out = xT;
   hipLaunchKernelGGL(im2col_t_kernel, dim3(Mpad / 64, b.Krows / 64), dim3(256), 0, c.st, b);
   NERAF_HIP_CHECK(c.ctx, hipGetLastError());
-  const bool direct = (cs.k == 1 && cs.cin_real == cs.cin);
-  const int cin_real = cs.cin_real;
   GemmParams g{};
   g.bf16 = 1;
   g.A = (const half_t*)dyT; g.lda = Mpad; g.B = (const half_t*)xT; g.ldb = Mpad;
-  g.M = cs.cout; g.N = K; g.K = Mpad; g.Mpad = a.Krows; g.Npad = b.Krows; g.alpha = 1.f; g.alpha_dev = c.inv_scale;
-  g.C32 = direct ? c.w_grads[ci] : (float*)(c.bws + c.B->wtmp); g.ldc32 = K;
+  g.M = cs.cout; g.N = taps * cs.cin_real; g.K = Mpad; g.Mpad = cs.cout; g.Npad = b.Krows; g.alpha = 1.f; g.alpha_dev = c.inv_scale;
+  g.C32 = c.w_grads[ci]; g.ldc32 = taps * cs.cin_real;
   g.splitk_ws = (float*)(c.bws + c.B->splitk); g.splitk_ws_bytes = c.B->splitk_bytes;
-  if (int e = launch_gemm_f16(c.ctx, g, c.st)) return e;
-  if (!direct) {
-    const size_t n = (size_t)cs.cout * cin_real * taps;
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.st, (const float*)(c.bws + c.B->wtmp),
-                       cs.cout, cs.cin, cin_real, taps, c.w_grads[ci]);
-    NERAF_HIP_CHECK(c.ctx, hipGetLastError());
-  }
-  return NERAF_OK;
+  return launch_gemm_f16(c.ctx, g, c.st);
 }
 
 // dX [din^3][cin] = conv_transpose(dY [dout^3][cout], W) (+ add16)
@@ -509,17 +539,17 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
     const half_t* a2 = (const half_t*)(ws + L.a2[b]);
     // out = relu(bn3(c3) + residual): dy = g * (out > 0) feeds bn3 and the residual branch
     if (int e = bn_backward(c, i2, g, nullptr, out, dy2, Bk.ds < 0 ? gm : nullptr)) return e;
-    if (int e = conv_wgrad(c, i2, dy2, a2)) return e;
+    if (int e = conv_wgrad(c, i2, a2)) return e;
     if (int e = conv_dgrad(c, i2, dy2, nullptr, da)) return e;                 // d a2
     if (stop_after == 1) return NERAF_OK;
     if (int e = bn_backward(c, i1, da, nullptr, a2, dy1, nullptr)) return e;
-    if (int e = conv_wgrad(c, i1, dy1, a1)) return e;
+    if (int e = conv_wgrad(c, i1, a1)) return e;
     if (int e = conv_dgrad(c, i1, dy1, nullptr, da)) return e;                 // d a1
     if (int e = bn_backward(c, i0, da, nullptr, a1, dy0, nullptr)) return e;
-    if (int e = conv_wgrad(c, i0, dy0, x_in)) return e;
+    if (int e = conv_wgrad(c, i0, x_in)) return e;
     if (Bk.ds >= 0) {
       if (int e = bn_backward(c, Bk.ds, g, nullptr, out, dyds, nullptr)) return e;
-      if (int e = conv_wgrad(c, Bk.ds, dyds, x_in)) return e;
+      if (int e = conv_wgrad(c, Bk.ds, x_in)) return e;
       if (int e = conv_dgrad(c, Bk.ds, dyds, nullptr, da)) return e;           // residual-branch gradient w.r.t. x_in
       if (int e = conv_dgrad(c, i0, dy0, da, g_next)) return e;
     } else {
@@ -532,12 +562,12 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
     const ConvSpec& c0 = A.conv[0];
     float* dpost = (float*)(bws + B.dpost);
     NERAF_HIP_CHECK(ctx, hipMemsetAsync(dpost, 0, cube(c0.dout) * 64 * 4, st));
-    BnSrc s = bn_src((const half_t*)(ws + L.pre[0]), (const float*)(ws + L.stat[0]), bn, 0, 64, 1);
+    BnSrc s = bn_src_bwd(A, L, ws, bn, 0);
     const size_t total = cube(A.pooled) * 8;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, c0.dout, A.pooled, cube(c0.dout), g, dpost);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
     if (int e = bn_backward(c, 0, nullptr, dpost, nullptr, dy0, nullptr)) return e;      // relu mask already applied by the routing
-    if (int e = conv_wgrad(c, 0, dy0, (const half_t*)(ws + L.x0))) return e;
+    if (int e = conv_wgrad(c, 0, (const half_t*)(ws + L.x0))) return e;
     if (n_cells > 0) {
       const int n = n_cells * n_ch;
       hipLaunchKernelGGL(stem_dgrid_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dy0, conv_w[0], A.S, c0.dout, cell_start, n_cells, n_ch,
@@ -601,7 +631,7 @@ extern "C" int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_r
   half_t* yact = (half_t*)(extra + act);
   {
     BnApplyArgs a{};
-    a.a = bn_src((const half_t*)(ws + L.pre[0]), (const float*)(ws + L.stat[0]), bnp, 0, cout, 1);
+    a.a = bn_src_fwd(A, L, ws, bnp, 0, 1);
     a.M = (int)cube(dout); a.Mpad = (int)rows_pad(dout); a.C = cout; a.relu = 1; a.out = yact;
     if (int e = run_bn_apply(ctx, st, a)) return e;
   }
@@ -623,7 +653,7 @@ extern "C" int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_r
   bf16_t* dy = (bf16_t*)(extra + 2 * act);
   bf16_t* dxb = (bf16_t*)(extra + 3 * act);
   if (int e = bn_backward(c, 0, nullptr, g, yact, dy, nullptr)) return e;
-  if (int e = conv_wgrad(c, 0, dy, xin)) return e;
+  if (int e = conv_wgrad(c, 0, xin)) return e;
   if (dx && cin % 64 == 0) {
     if (int e = conv_dgrad(c, 0, dy, nullptr, dxb)) return e;
     const size_t n = cube(din) * cin;

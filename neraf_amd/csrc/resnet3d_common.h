@@ -49,12 +49,25 @@ inline int conv_npad(const ConvSpec& c) { return c.cout == 64 ? 64 : round_up(c.
 __host__ __device__ inline size_t cube(int e) { return (size_t)e * e * e; }
 inline size_t rows_pad(int e) { return round_up_sz(cube(e), 128); }
 
+// BatchNorm batch statistics are accumulated by the conv GEMM's epilogue with one atomic per column per workgroup.  Atomics
+// on one cache line serialise in the memory system (measured: the 32^3-voxel layers spent 60 of their 70 us there), so the
+// accumulators are replicated: m-tile t adds into replica t % rep, replicas 4 KiB apart; consumers sum the replicas.
+constexpr int kStatStride = 1024;          // floats between replicas (>= 2 * cpad for every layer)
+inline int stat_rep(const ConvSpec& c) {
+  const int tiles = (int)(rows_pad(c.dout) / 128);
+  if (2 * round_up(c.cout, 128) > kStatStride) return 1;
+  int r = 1;
+  while (r < 16 && r * 8 < tiles) r <<= 1;
+  return r;
+}
+
 struct Layout {
   size_t w[64];                 // packed fp16 weights [npad][kpad]
   size_t packed_total;
   // workspace
   size_t zero_page, x0;         // zero page, NDHWC8 input
-  size_t pre[64], stat[64];     // per conv: pre-BN output fp16 [rows_pad][cout], stats fp32 [2][cout]
+  size_t pre[64], stat[64];     // per conv: pre-BN output fp16 [rows_pad][cout], stats fp32 [rep][2][cpad] (replica stride kStatStride)
+  size_t fin[64];               // per conv: finalised batch statistics fp32 [2][cpad] = mean, biased variance (written by the BN pass)
   size_t act_pool;              // stem: pooled activation
   size_t a1[16], a2[16], out[16];   // per block post-activation tensors
   size_t splitk; size_t splitk_bytes;
@@ -71,8 +84,12 @@ void make_layout(const Arch& A, Layout* L) {
   L->zero_page = take(256);
   L->x0 = take(cube(A.S) * 8 * 2);
   L->stats_begin = off;
-  for (int i = 0; i < A.nconv; ++i) L->stat[i] = take((size_t)2 * round_up(A.conv[i].cout, 128) * 4);
+  for (int i = 0; i < A.nconv; ++i) {
+    const int rep = stat_rep(A.conv[i]);
+    L->stat[i] = take(rep > 1 ? (size_t)rep * kStatStride * 4 : (size_t)2 * round_up(A.conv[i].cout, 128) * 4);
+  }
   L->stats_bytes = off - L->stats_begin;
+  for (int i = 0; i < A.nconv; ++i) L->fin[i] = take((size_t)2 * round_up(A.conv[i].cout, 128) * 4);
   for (int i = 0; i < A.nconv; ++i) L->pre[i] = take(rows_pad(A.conv[i].dout) * A.conv[i].cout * 2);
   L->act_pool = take(rows_pad(A.pooled) * 64 * 2);
   for (int b = 0; b < A.nblock; ++b) {
@@ -90,30 +107,56 @@ void make_layout(const Arch& A, Layout* L) {
 
 struct BnSrc {
   const half_t* x;          // pre-BN conv output [rows][C]
-  const float* stats;       // [2][Cpad]: sum, sum of squares (batch statistics) -- or null
+  const float* stats;       // [rep][2][Cpad]: sum, sum of squares (batch statistics, replicated accumulators) -- or null
+  const float* fin_r;       // finalised [2][Cpad] mean / biased variance (backward and running-stat update read these) -- or null
+  float* fin_w;             // forward BN pass: block 0 writes the finalised statistics here -- or null
   const float* gamma; const float* beta; const float* rmean; const float* rvar;
-  int cpad;
+  int cpad, rep;
 };
 
-__device__ __forceinline__ void bn_scale_shift(const BnSrc& s, int c, float inv_m, float& scale, float& shift) {
-  float mean, var;
-  if (s.stats) {
-    mean = s.stats[c] * inv_m;
-    var = fmaxf(s.stats[s.cpad + c] * inv_m - mean * mean, 0.f);    // biased variance, as nn.BatchNorm3d normalises with
+__device__ __forceinline__ void bn_mean_var(const BnSrc& s, int c, float inv_m, float& mean, float& var) {
+  if (s.fin_r) {
+    mean = s.fin_r[c]; var = s.fin_r[s.cpad + c];
+  } else if (s.stats) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < s.rep; ++r) { a += s.stats[r * kStatStride + c]; b += s.stats[r * kStatStride + s.cpad + c]; }
+    mean = a * inv_m;
+    var = fmaxf(b * inv_m - mean * mean, 0.f);    // biased variance, as nn.BatchNorm3d normalises with
   } else {
     mean = s.rmean[c]; var = s.rvar[c];
   }
+}
+
+__device__ __forceinline__ void bn_scale_shift(const BnSrc& s, int c, float inv_m, float& scale, float& shift) {
+  float mean, var;
+  bn_mean_var(s, c, inv_m, mean, var);
+  if (s.fin_w && blockIdx.x == 0) { s.fin_w[c] = mean; s.fin_w[s.cpad + c] = var; }
   const float rstd = rsqrtf(var + 1e-5f);
   scale = s.gamma[c] * rstd;
   shift = s.beta[c] - mean * scale;
 }
 
 
-inline BnSrc bn_src(const half_t* x, const float* stats, const float* const* bn, int ci, int cout, int use_batch) {
+// forward BN pass: reads the replicated accumulators of conv ci, block 0 publishes mean / variance to L.fin[ci]
+inline BnSrc bn_src_fwd(const Arch& A, const Layout& L, char* ws, const float* const* bn, int ci, int use_batch) {
+  const ConvSpec& c = A.conv[ci];
   BnSrc s{};
-  s.x = x; s.stats = use_batch ? stats : nullptr;
+  s.x = (const half_t*)(ws + L.pre[ci]);
+  s.stats = use_batch ? (const float*)(ws + L.stat[ci]) : nullptr;
+  s.fin_w = use_batch ? (float*)(ws + L.fin[ci]) : nullptr;
   s.gamma = bn[4 * ci + 0]; s.beta = bn[4 * ci + 1]; s.rmean = bn[4 * ci + 2]; s.rvar = bn[4 * ci + 3];
-  s.cpad = round_up(cout, 128);
+  s.cpad = round_up(c.cout, 128); s.rep = stat_rep(c);
+  return s;
+}
+
+// backward: train-mode statistics as the forward BN pass published them
+inline BnSrc bn_src_bwd(const Arch& A, const Layout& L, const char* ws, const float* const* bn, int ci) {
+  const ConvSpec& c = A.conv[ci];
+  BnSrc s{};
+  s.x = (const half_t*)(ws + L.pre[ci]);
+  s.fin_r = (const float*)(ws + L.fin[ci]);
+  s.gamma = bn[4 * ci + 0]; s.beta = bn[4 * ci + 1]; s.rmean = bn[4 * ci + 2]; s.rvar = bn[4 * ci + 3];
+  s.cpad = round_up(c.cout, 128); s.rep = 1;
   return s;
 }
 
@@ -196,6 +239,7 @@ inline int run_conv(neraf_ctx* ctx, hipStream_t st, const Arch& A, const Layout&
   g.C16 = (half_t*)(ws + L.pre[ci]); g.ldc16 = c.cout;
   float* stats = (float*)(ws + L.stat[ci]);
   g.colsum = stats; g.colsumsq = stats + round_up(c.cout, 128);
+  g.stat_rep = stat_rep(c); g.stat_stride = kStatStride;
   g.splitk_ws = (float*)(ws + L.splitk); g.splitk_ws_bytes = L.splitk_bytes;
   if (c.k == 1 && c.stride == 1) {
     g.conv.loader = 0;
