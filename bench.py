@@ -236,7 +236,7 @@ def main():
         ms, n, w = C.c_double(), C.c_int(), C.c_double()
         _lib.check(lib.neraf_prof_summary(h, kid, C.byref(ms), C.byref(n), C.byref(w)), local)
         if n.value:
-            is_bytes = kid in (2, 3, 5, 6)     # gather / scatter kernels are priced in bytes against HBM
+            is_bytes = kid in (2, 3, 5, 6, 7)     # gather / scatter kernels are priced in bytes against HBM
             rate = w.value / (ms.value * 1e-3) / (1e9 if is_bytes else 1e12) if ms.value > 0 else 0.0
             fams.append({"kernel": lib.neraf_prof_kernel_name(kid).decode(), "bound": "hbm" if is_bytes else "mfma",
                          "launches_per_step": n.value / nprof, "avg_us": ms.value * 1e3 / n.value,

@@ -51,7 +51,8 @@ const char* neraf_last_error(neraf_ctx* ctx);
  * kernel ids: 0 = gemm_f16 128x128 tile (work = FLOPs), 1 = gemm_f16 64x64 tile (FLOPs),
  * 2 = proposal_density (work = gathered hash-table bytes), 3 = field_query (gathered bytes),
  * 4 = implicit-GEMM convolution instances of gemm_f16 (FLOPs, zero-padded taps/channels included),
- * 5 = proposal_backward, 6 = field_backward (work = gathered + atomically added table bytes);
+ * 5 = proposal_backward (gathered + atomically added table bytes), 6 = field_backward (MLP chain; work =
+ * gathered table bytes), 7 = field_scatter (work = 8 bytes per (sample, level, corner) 64-bit atomic);
  * neraf_prof_kernel_name(id) returns NULL past the end.
  * ---------------------------------------------------------------------------------- */
 int neraf_prof_enable(neraf_ctx* ctx, int on);
@@ -228,7 +229,9 @@ int neraf_proposal_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void
                             const float* origins, const float* dirs, const float* e_bins, const float* d_density, int R,
                             int S, float avg_density, float* table_grad, float* w_grad, neraf_stream_t stream);
 /* Fused field backward.  d_rgb [R,S,3], d_density [R,S] (and the forward density) -> table_grad fp32
- * [rows,2] and emb_grad fp32 [n_emb,32] (ACCUMULATED, caller zeroes) and the five MLP weight gradients
+ * [rows,2] (MUST BE ZERO on entry: during the call it holds packed 64-bit fixed-point sums, one integer
+ * atomic per table entry instead of two fp32 ones, unpacked in place before returning; the result is
+ * bit-reproducible), emb_grad fp32 [n_emb,32] (ACCUMULATED, caller zeroes) and the five MLP weight gradients
  * w_grads (HOST array of device pointers {base_w0 [64,32], base_w1 [16,64], head_w0 [64,64], head_w1
  * [64,64], head_w2 [16,64]}, overwritten).  wfrag_bwd_f16: 26 transposed-weight MFMA fragments packed by
  * the host layer.  dump: scratch of neraf_field_backward_dump_bytes(R,S) bytes that the caller ZEROES ONCE

@@ -50,6 +50,6 @@ extern "C" const char* neraf_prof_kernel_name(int kernel_id) {
   static const char* names[PROF_NUM_KERNELS] = {"gemm_f16_nt_pipe_kernel<128, 128, 4, *>", "gemm_f16_nt_pipe_kernel<64|128x64, 4, *>",
                                                       "proposal_density_kernel", "field_query_kernel",
                                                       "gemm_f16_nt_pipe_kernel<*, 4, conv loader 1|2>", "proposal_backward_kernel",
-                                                      "field_backward_kernel"};
+                                                      "field_backward_kernel", "field_scatter_kernel"};
   return (kernel_id >= 0 && kernel_id < PROF_NUM_KERNELS) ? names[kernel_id] : nullptr;
 }

@@ -19,7 +19,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_PROP_DENSITY = 2, PROF_FIELD_QUERY = 3, PROF_CONV = 4, PROF_PROP_BWD = 5, PROF_FIELD_BWD = 6, PROF_NUM_KERNELS = 7 };
+enum { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_PROP_DENSITY = 2, PROF_FIELD_QUERY = 3, PROF_CONV = 4, PROF_PROP_BWD = 5, PROF_FIELD_BWD = 6, PROF_FIELD_SCATTER = 7, PROF_NUM_KERNELS = 8 };
 
 struct ProfRec { hipEvent_t a, b; int kid; double work; };
 

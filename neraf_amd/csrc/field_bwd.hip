@@ -303,9 +303,10 @@ struct FieldBwdArgs {
   int R, S; int mode; float aabb[6]; float avg_density; int avg_row;
   const float* d_rgb; const float* d_density;      // upstream [N,3], [N]
   const float* scale;                              // device {S, 1/S}: fp16 chain scaling
-  float* table_grad;                               // fp32 [rows,2], accumulated
   float* emb_grad;                                 // fp32 [n_emb,32], accumulated (null in avg_row mode)
   half_t* dump; long npad;                         // fp16 [10][128][npad]: X_b0,dY_b0,X_b1,dY_b1,X_h0,dY_h0,X_h1,dY_h1,X_h2,dY_h2
+  unsigned* d_enc;                                 // half2 [16 levels][npad]: scaled gradient w.r.t. the encoding (rows 64.. of slot 0)
+  float* t_part;                                   // fp32 [blocks][16]: per-workgroup sums of max(|g0|,|g1|) per level (rows 64.. of slot 1)
 };
 
 __device__ __forceinline__ void dump_block(half_t* base, long npad, long n, int row0, const f32x4& v, float m) {
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
     l_scale[l] = a.g.scale[l]; l_res[l] = a.g.res[l]; l_size[l] = a.g.size[l]; l_off[l] = a.g.offset[l]; l_hash[l] = a.g.hashed[l];
   }
   __syncthreads();
+  __shared__ float t_sum[4][16];
   const int lane = threadIdx.x & 63;
   const int p = lane & 15, q = lane >> 4;
   half8 wf[NFRAG];
@@ -331,6 +333,7 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
   for (int f = 0; f < NFRAG; ++f) wf[f] = a.wfrag[f * 64 + lane];
   const half8* wb = a.wfrag_b + lane;            // fragment f at wb[f * 64]
   const float gscale = a.scale[0], inv_gscale = a.scale[1];
+  float tl[4] = {0.f, 0.f, 0.f, 0.f};
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const long N = (long)a.R * a.S;
   const long ngroups = a.npad / 16;              // covers the zero padding of the dumps as well
@@ -513,10 +516,150 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
 #pragma unroll
     for (int li = 0; li < 4; ++li) {
       const int l = 4 * q + li;
-      const float g0 = valid ? de[li >> 1][2 * (li & 1)] * inv_gscale : 0.f;
-      const float g1 = valid ? de[li >> 1][2 * (li & 1) + 1] * inv_gscale : 0.f;
-      scatter_level_seg<16>(a.table_grad, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], g0, g1, p);
+      half2v gh;
+      gh[0] = (half_t)(valid ? de[li >> 1][2 * (li & 1)] : 0.f);
+      gh[1] = (half_t)(valid ? de[li >> 1][2 * (li & 1) + 1] : 0.f);
+      a.d_enc[(long)l * a.npad + ncol] = *reinterpret_cast<const unsigned*>(&gh);
+      tl[li] += fmaxf(fabsf((float)gh[0]), fabsf((float)gh[1]));
     }
+  }
+  // per-level gradient mass of this workgroup (bounds every table entry's sum: the trilinear weights of a sample add to 1)
+#pragma unroll
+  for (int li = 0; li < 4; ++li) {
+    float v = tl[li];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+    if (p == 0) t_sum[threadIdx.x >> 6][4 * q + li] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16)
+    a.t_part[(long)blockIdx.x * 16 + threadIdx.x] = t_sum[0][threadIdx.x] + t_sum[1][threadIdx.x] + t_sum[2][threadIdx.x] + t_sum[3][threadIdx.x];
+}
+
+// ---- hash-grid gradient scatter in packed fixed point ---------------------------------------------------------------------
+// Scattered global atomics cost one L2 request per distinct cache line per instruction (MI355X: 21 G/s for fp32 adds at any
+// scope or working-set size, 23.7 G/s for 64-bit integer adds, tools/microbench/atomic_kinds.hip), and the two features of a
+// table entry are two fp32 atomics.  Here both features travel in ONE 64-bit integer atomic: each contribution is rounded to
+// int32 fixed point with a per-level power-of-two scale F_l, the pair is packed as (q1 << 32) + q0, and the sum decodes exactly
+// because F_l is chosen from the level's total gradient mass T_l (sum over samples of max|g|) so that no entry can leave
+// int32: |sum| <= T_l F_l + n/2 < 2^31.  Integer adds commute, so the table gradient is bit-reproducible run to run.
+__global__ __launch_bounds__(256) void field_level_scale_kernel(const float* __restrict__ t_part, int nblocks, float* __restrict__ lvl) {
+  __shared__ float red[16][17];
+  const int l = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  float v = 0.f;
+  for (int b = sl; b < nblocks; b += 16) v += t_part[(long)b * 16 + l];
+  red[sl][l] = v;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float T = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T += red[i][threadIdx.x];
+    float F = 1.f;
+    if (T > 0.f && T < 3.0e38f) {
+      int e = 29 - (int)ceilf(log2f(T));
+      e = e > 100 ? 100 : (e < -100 ? -100 : e);
+      F = exp2f((float)e);
+    }
+    lvl[threadIdx.x] = F; lvl[16 + threadIdx.x] = 1.f / F;
+  }
+}
+
+struct FieldScatterArgs {
+  GridLayout g;
+  const float* origins; const float* dirs; const float* e_bins;
+  int R, S; int mode; float aabb[6];
+  const unsigned* d_enc; long npad;
+  const float* lvl;                    // F_l [16], 1/F_l [16]
+  unsigned long long* acc;             // [rows]: packed fixed-point sums (the table_grad buffer, zero on entry)
+};
+
+__device__ __forceinline__ long long shfl_up_i64(long long v, int o) {
+  const int lo = __shfl_up((int)(v & 0xffffffffll), o), hi = __shfl_up((int)(v >> 32), o);
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+
+__global__ __launch_bounds__(256) void field_scatter_kernel(FieldScatterArgs a) {
+  __shared__ float l_scale[MAX_LEVELS], l_fix[MAX_LEVELS];
+  __shared__ int l_res[MAX_LEVELS];
+  __shared__ unsigned l_size[MAX_LEVELS], l_off[MAX_LEVELS];
+  __shared__ int l_hash[MAX_LEVELS];
+  if (threadIdx.x < 16) {
+    const int l = threadIdx.x;
+    l_scale[l] = a.g.scale[l]; l_res[l] = a.g.res[l]; l_size[l] = a.g.size[l]; l_off[l] = a.g.offset[l]; l_hash[l] = a.g.hashed[l];
+    l_fix[l] = a.lvl[l];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const long N = (long)a.R * a.S;
+  const long nwave = (N + 63) / 64;
+  for (long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < nwave; wv += (long)gridDim.x * 4) {
+    long n = wv * 64 + lane;
+    const bool valid = n < N;
+    if (!valid) n = N - 1;
+    const int ray = (int)(n / a.S), sidx = (int)(n % a.S);
+    const float t = 0.5f * (a.e_bins[(size_t)ray * (a.S + 1) + sidx] + a.e_bins[(size_t)ray * (a.S + 1) + sidx + 1]);
+    float x = fmaf(a.dirs[ray * 3 + 0], t, a.origins[ray * 3 + 0]);
+    float y = fmaf(a.dirs[ray * 3 + 1], t, a.origins[ray * 3 + 1]);
+    float z = fmaf(a.dirs[ray * 3 + 2], t, a.origins[ray * 3 + 2]);
+    map_position(x, y, z, a.mode, a.aabb);
+    for (int l = 0; l < 16; ++l) {
+      const unsigned raw = valid ? a.d_enc[(long)l * a.npad + n] : 0u;
+      const half2v gh = *reinterpret_cast<const half2v*>(&raw);
+      const float F = l_fix[l];
+      const float g0 = (float)gh[0] * F, g1 = (float)gh[1] * F;
+      const float scale = l_scale[l];
+      const int res = l_res[l]; const unsigned size = l_size[l], offset = l_off[l]; const int hashed = l_hash[l];
+      const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+      const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+      const float wx = px - flx, wy = py - fly, wz = pz - flz;
+      const unsigned ix = (unsigned)(int)flx, iy = (unsigned)(int)fly, iz = (unsigned)(int)flz;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const unsigned cx = ix + (c & 1), cy = iy + ((c >> 1) & 1), cz = iz + ((c >> 2) & 1);
+        const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
+        unsigned idx;
+        if (hashed) idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1u);
+        else {
+          idx = cx + cy * (unsigned)res + cz * (unsigned)res * (unsigned)res;
+          if (idx >= size) idx -= size;
+        }
+        const int q0 = __float2int_rn(w * g0), q1 = __float2int_rn(w * g1);
+        long long v = ((long long)q1 << 32) + (long long)q0;
+        // segmented sum over runs of equal indices among the 64 consecutive samples (skipped when the wave has no run)
+        const unsigned prev = __shfl_up(idx, 1);
+        const unsigned next = __shfl_down(idx, 1);
+        int head = (lane == 0 || prev != idx) ? 1 : 0;
+        const bool tail = (lane == 63) || next != idx;
+        if (__any(!head)) {
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const long long up = shfl_up_i64(v, o);
+            const int hu = __shfl_up(head, o);
+            if (lane >= o) {
+              if (!head) v += up;
+              head |= hu;
+            }
+          }
+        }
+        if (tail && v != 0) atomicAdd(a.acc + offset + idx, (unsigned long long)v);
+      }
+    }
+  }
+}
+
+// packed fixed point -> fp32 pair, in place:  (lo, hi) * (1 / F_l) * (1 / S)
+__global__ __launch_bounds__(256) void field_unpack_grad_kernel(GridLayout g, const float* __restrict__ lvl, const float* __restrict__ scale,
+                                                               unsigned long long* __restrict__ acc) {
+  const int l = blockIdx.y;
+  const float m = lvl[16 + l] * scale[1];
+  const unsigned size = g.size[l], off = g.offset[l];
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < size; i += gridDim.x * 256) {
+    const long long v = (long long)acc[off + i];
+    if (v == 0) continue;                                   // bit pattern 0 is also fp32 (0, 0)
+    const int lo = (int)(v & 0xffffffffll);
+    const int hi = (int)((v - (long long)lo) >> 32);
+    float2 o = make_float2((float)lo * m, (float)hi * m);
+    reinterpret_cast<float2*>(acc)[off + i] = o;
   }
 }
 
@@ -618,8 +761,10 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
   a.R = R; a.S = S; a.mode = mode;
   for (int i = 0; i < 6; ++i) a.aabb[i] = aabb_host ? aabb_host[i] : 0.f;
   a.avg_density = avg_density; a.avg_row = avg_row; a.d_rgb = d_rgb; a.d_density = d_density;
-  a.table_grad = table_grad; a.emb_grad = emb_grad;
+  a.emb_grad = emb_grad;
   a.dump = (half_t*)dump; a.npad = npad;
+  a.d_enc = reinterpret_cast<unsigned*>((half_t*)dump + (size_t)64 * npad);                       // slot 0, rows 64..127
+  a.t_part = reinterpret_cast<float*>((half_t*)dump + (size_t)128 * npad + (size_t)64 * npad);    // slot 1, rows 64..
   float* scale = (float*)((char*)dump + (size_t)10 * 128 * npad * 2);
   a.scale = scale;
   NERAF_HIP_CHECK(ctx, hipMemsetAsync(scale, 0, 16, st));
@@ -634,8 +779,28 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
     long blocks = (groups + 3) / 4;
     const long cap = (long)(ctx ? ctx->num_cus : 256) * 8;
     if (blocks > cap) blocks = cap;
-    ProfScope prof(ctx, st, PROF_FIELD_BWD, (double)N * 16 * 8 * (4 + 8));   // gathered fp16x2 + atomically added fp32x2 bytes
-    hipLaunchKernelGGL(field_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    {
+      ProfScope prof(ctx, st, PROF_FIELD_BWD, (double)N * 16 * 8 * 4);       // gathered fp16x2 bytes
+      hipLaunchKernelGGL(field_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    }
+    NERAF_HIP_CHECK(ctx, hipGetLastError());
+    // hash-grid gradient: per-level fixed-point scale from the gradient mass, packed 64-bit scatter, in-place unpack
+    float* lvl = scale + 8;
+    hipLaunchKernelGGL(field_level_scale_kernel, dim3(1), dim3(256), 0, st, a.t_part, (int)blocks, lvl);
+    FieldScatterArgs sa{};
+    sa.g = a.g; sa.origins = origins; sa.dirs = dirs; sa.e_bins = e_bins; sa.R = R; sa.S = S; sa.mode = mode;
+    for (int i = 0; i < 6; ++i) sa.aabb[i] = a.aabb[i];
+    sa.d_enc = a.d_enc; sa.npad = npad; sa.lvl = lvl; sa.acc = reinterpret_cast<unsigned long long*>(table_grad);
+    long sblocks = ((N + 63) / 64 + 3) / 4;
+    if (sblocks > cap) sblocks = cap;
+    {
+      ProfScope prof(ctx, st, PROF_FIELD_SCATTER, (double)N * 16 * 8 * 8);   // one 8-byte atomic per (sample, level, corner) before merging
+      hipLaunchKernelGGL(field_scatter_kernel, dim3((unsigned)sblocks), dim3(256), 0, st, sa);
+    }
+    unsigned maxsize = 0;
+    for (int l = 0; l < 16; ++l) maxsize = a.g.size[l] > maxsize ? a.g.size[l] : maxsize;
+    hipLaunchKernelGGL(field_unpack_grad_kernel, dim3((maxsize + 1023) / 1024, 16), dim3(256), 0, st, a.g, lvl, scale,
+                       reinterpret_cast<unsigned long long*>(table_grad));
     NERAF_HIP_CHECK(ctx, hipGetLastError());
   }
   // weight gradients: dW_l [out,in] = (1/S) dY_l [out,N] . X_l [in,N]^T   (NT GEMM, K = points, split-K)

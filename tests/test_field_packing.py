@@ -141,3 +141,36 @@ def test_field_backward_fragment_dataflow_matches_autograd():
     np.testing.assert_allclose(dW_b0.T.T, t["base_w0"].grad.numpy(), rtol=1e-9, atol=1e-12)
     Xh0 = np.concatenate([sh, nat([d2]).T[:, 1:16], emb, np.zeros((16, 1))], axis=1)      # natural column order
     np.testing.assert_allclose(nat(dy3) @ Xh0, t["head_w0"].grad.numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_packed_fixed_point_pair_sums_decode_exactly():
+    """field_scatter_kernel packs both features of a table entry as (q1 << 32) + q0 and adds them with ONE 64-bit integer
+    atomic; field_unpack_grad_kernel decodes lo = int32(total), hi = (total - lo) >> 32.  Emulated here in int64: the decode is
+    exact for any sign pattern as long as each per-feature sum stays inside int32 (what the per-level scale guarantees)."""
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        n = int(rng.integers(1, 2000))
+        q0 = rng.integers(-(2 ** 31 - 1) // n, (2 ** 31 - 1) // n + 1, size=n).astype(np.int64)
+        q1 = rng.integers(-(2 ** 31 - 1) // n, (2 ** 31 - 1) // n + 1, size=n).astype(np.int64)
+        packed = (q1 << 32) + q0                       # what each lane adds (two's complement, as the kernel does)
+        total = np.int64(0)
+        for v in rng.permutation(packed):              # any order: integer adds commute -> bit-reproducible
+            total = np.int64(total + v)
+        lo = np.int64(np.int32(total & 0xFFFFFFFF))
+        hi = (total - lo) >> 32
+        assert lo == q0.sum() and hi == q1.sum()
+
+
+def test_fixed_point_level_scale_bound():
+    """F_l = 2^(29 - ceil(log2 T_l)) with T_l = sum_n max(|g0|, |g1|): every entry's |sum| <= T_l F_l + n_contrib / 2 < 2^31."""
+    rng = np.random.default_rng(6)
+    g = rng.standard_normal((4096, 2)).astype(np.float32) * 10.0 ** rng.uniform(-6, 3, size=(4096, 1)).astype(np.float32)
+    T = float(np.abs(g).max(axis=1).sum())
+    F = 2.0 ** (29 - int(np.ceil(np.log2(T))))
+    w = rng.dirichlet(np.ones(8), size=4096).astype(np.float32)          # trilinear weights of a sample add to 1
+    q = np.rint(w[:, :, None] * g[:, None, :] * F).astype(np.int64)
+    worst = np.abs(q).sum(axis=(0, 1)).max()                             # all contributions landing in one entry
+    assert worst < 2 ** 31
+    # resolution: the quantised total matches the float total to ~1e-6 of the gradient mass
+    tot = (w[:, :, None] * g[:, None, :]).sum(axis=(0, 1))
+    np.testing.assert_allclose(q.sum(axis=(0, 1)) / F, tot, atol=1e-6 * T)
