@@ -216,10 +216,13 @@ int neraf_composite(neraf_ctx* ctx, const float* density, const float* rgb, cons
  * gradients of {rgb_loss, interlevel_loss, distortion_loss} (NULL = compute loss values only);
  * `sums` (device, fp32[4], caller zeroes) accumulates {sum (rgb-gt)^2, sum_rays distortion,
  * sum outer-loss, -}; the host layer divides by 3R / R / (R*S2) and applies the multipliers.
+ * neraf_render_loss with up3 == NULL and d_rgb_s != NULL computes the loss values AND unit gradients in the
+ * same pass: d_rgb_s / d_density for d rgb_loss = 1 and d_density_dist for d distortion_loss = 1 (the
+ * gradient is linear in the upstream scalars, so the backward pass is two scalings instead of a re-run).
  * ---------------------------------------------------------------------------------- */
 int neraf_render_loss(neraf_ctx* ctx, const float* density, const float* rgb_s, const float* e_bins, const float* s_bins,
                       const float* gt_rgb, int R, int S, float distortion_mult, const float* up3, float* d_rgb_s,
-                      float* d_density, float* sums, neraf_stream_t stream);
+                      float* d_density, float* d_density_dist, float* sums, neraf_stream_t stream);
 int neraf_interlevel_loss(neraf_ctx* ctx, const float* c_bins, const float* w_fine, int S2, const float* p_bins,
                           const float* p_ebins, const float* p_density, int Sp, int R, float mult, const float* up3,
                           float* d_density, float* sums, neraf_stream_t stream);

@@ -82,7 +82,7 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                     C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_render_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                    C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                    C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_interlevel_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_proposal_backward": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -160,3 +160,20 @@ def ptr_array(tensors) -> "C.Array":
     for i, t in enumerate(tensors):
         arr[i] = t.data_ptr() if t is not None else None
     return arr
+
+
+_HOST_F32 = {}
+
+
+def host_f32(t):
+    """ctypes float array with the values of a small device tensor (AABBs).  Cached per (storage, version): a ``.cpu()`` per
+    call is a stream synchronisation, which drains the launch queue five times per training step."""
+    key = (t.data_ptr(), t._version, t.numel())
+    hit = _HOST_F32.get(key)
+    if hit is None:
+        vals = [float(v) for v in t.detach().reshape(-1).cpu().tolist()]
+        hit = (C.c_float * len(vals))(*vals)
+        if len(_HOST_F32) > 64:
+            _HOST_F32.clear()
+        _HOST_F32[key] = hit
+    return hit

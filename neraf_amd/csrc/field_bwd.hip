@@ -23,6 +23,8 @@ struct RenderLossArgs {
   int R, S; float dist_mult;
   const float* up;         // device [3]: upstream gradients of {rgb_loss, interlevel_loss, distortion_loss}; null = values only
   float* d_rgb_s; float* d_density;     // outputs (may be null when up == null)
+  float* d_density_dist;   // up == null and d_rgb_s != null: UNIT gradients -- d_rgb_s, d_density for d rgb_loss = 1 and, separately,
+                           // d_density_dist for d distortion_loss = 1 (the caller combines them with the real upstream scalars)
   float* sums;             // device [>=2]: += sum (rgb-gt)^2 , += sum_rays distortion
 };
 
@@ -75,28 +77,37 @@ __global__ __launch_bounds__(256) void render_loss_kernel(RenderLossArgs a) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) l_dist += __shfl_xor(l_dist, o);
   if (lane == 0 && active) { atomicAdd(a.sums + 0, l_rgb); atomicAdd(a.sums + 1, l_dist); }
-  if (!a.up) return;
-  const float up_rgb = a.up[0], up_dist = a.up[2] * a.dist_mult / (float)a.R;
-  // d loss / d w_i
-  float gw = 0.f;
+  const bool unit = !a.up && a.d_rgb_s;
+  if (!a.up && !unit) return;
+  const float up_rgb = unit ? 1.f : a.up[0], up_dist = (unit ? 1.f : a.up[2]) * a.dist_mult / (float)a.R;
+  // d loss / d w_i, kept apart for the two losses in unit mode
+  float gw_r = 0.f;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) gw += up_rgb * g[k] * (c[k] - cl[k]);
-  gw += up_dist * (2.f * inner + 2.f * w * ds * (1.f / 3.f));
-  if (!on || bad) gw = 0.f;
+  for (int k = 0; k < 3; ++k) gw_r += up_rgb * g[k] * (c[k] - cl[k]);
+  float gw_d = up_dist * (2.f * inner + 2.f * w * ds * (1.f / 3.f));
+  if (!on || bad) { gw_r = 0.f; gw_d = 0.f; }
   // d loss / d colour_i
   if (on && active) {
     float* o = a.d_rgb_s + ((size_t)ray * S + lane) * 3;
 #pragma unroll
     for (int k = 0; k < 3; ++k) o[k] = up_rgb * g[k] * (w + (lane == S - 1 ? (1.f - sw) : 0.f));
   }
-  // get_weights backward: d dd_i = gw_i T_i exp(-dd_i) - sum_{k>i} gw_k w_k ; d sigma_i = delta_i d dd_i
-  const float gww = gw * w;
-  const float incl2 = wave_incl_scan(gww, lane);
-  float tot = gww;
+  // get_weights backward (linear in gw): d dd_i = gw_i T_i exp(-dd_i) - sum_{k>i} gw_k w_k ; d sigma_i = delta_i d dd_i
+  auto weights_bwd = [&](float gw) {
+    const float gww = gw * w;
+    const float incl2 = wave_incl_scan(gww, lane);
+    float tot = gww;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-  const float ddd = gw * Ti * ex - (tot - incl2);
-  if (on && active) a.d_density[(size_t)ray * S + lane] = de * ddd;
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    return de * (gw * Ti * ex - (tot - incl2));
+  };
+  if (unit) {
+    const float dr = weights_bwd(gw_r), dd2 = weights_bwd(gw_d);
+    if (on && active) { a.d_density[(size_t)ray * S + lane] = dr; a.d_density_dist[(size_t)ray * S + lane] = dd2; }
+  } else {
+    const float dsum = weights_bwd(gw_r + gw_d);
+    if (on && active) a.d_density[(size_t)ray * S + lane] = dsum;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -307,6 +318,8 @@ struct FieldBwdArgs {
   half_t* dump; long npad;                         // fp16 [10][128][npad]: X_b0,dY_b0,X_b1,dY_b1,X_h0,dY_h0,X_h1,dY_h1,X_h2,dY_h2
   unsigned* d_enc;                                 // half2 [16 levels][npad]: scaled gradient w.r.t. the encoding (rows 64.. of slot 0)
   float* t_part;                                   // fp32 [blocks][16]: per-workgroup sums of max(|g0|,|g1|) per level (rows 64.. of slot 1)
+  float* e_part; int* e_part_row;                  // fp32 [blocks][32] + row: per-workgroup appearance-embedding gradient of the
+                                                   // workgroup's leading embedding row (rows 64.. of slots 2 / 3)
 };
 
 __device__ __forceinline__ void dump_block(half_t* base, long npad, long n, int row0, const f32x4& v, float m) {
@@ -326,6 +339,16 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
   }
   __syncthreads();
   __shared__ float t_sum[4][16];
+  __shared__ float e_acc[32];
+  __shared__ int e_blk_s;
+  if (threadIdx.x < 32) e_acc[threadIdx.x] = 0.f;
+  if (threadIdx.x == 0) {
+    long n0 = (long)blockIdx.x * 64; const long Nn = (long)a.R * a.S;
+    if (n0 >= Nn) n0 = Nn - 1;
+    e_blk_s = (a.avg_row < 0 && a.cam_idx) ? a.cam_idx[n0 / a.S] : -1;
+  }
+  __syncthreads();
+  const int e_blk = e_blk_s;
   const int lane = threadIdx.x & 63;
   const int p = lane & 15, q = lane >> 4;
   half8 wf[NFRAG];
@@ -460,10 +483,12 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
         demb[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[(15 + ib * 2) * 64], b1, demb[ib], 0, 0, 0);
       }
     }
-    // appearance-embedding gradient: reduce over the 16 points of the group when they share the row
+    // appearance-embedding gradient: reduce over the 16 points of the group when they share the row; groups on the workgroup's
+    // leading row accumulate in LDS (the refresh queries every sample with camera 0: 1.5e5 same-line global atomics otherwise)
     if (a.emb_grad && a.avg_row < 0) {
       const int e0 = __shfl(erow, lane & 48);                    // row of point 0 of this group (same q)
       const bool uniform = __all(e0 == erow || !valid);
+      const bool to_lds = uniform && __all(e0 == e_blk);
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
@@ -472,7 +497,10 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
           if (uniform) {
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
-            if (p == 0 && v != 0.f) atomicAdd(a.emb_grad + (size_t)e0 * 32 + 16 * ib + 4 * q + r, v);
+            if (p == 0 && v != 0.f) {
+              if (to_lds) atomicAdd(&e_acc[16 * ib + 4 * q + r], v);
+              else atomicAdd(a.emb_grad + (size_t)e0 * 32 + 16 * ib + 4 * q + r, v);
+            }
           } else if (valid && v != 0.f) {
             atomicAdd(a.emb_grad + (size_t)erow * 32 + 16 * ib + 4 * q + r, v);
           }
@@ -534,6 +562,8 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
   __syncthreads();
   if (threadIdx.x < 16)
     a.t_part[(long)blockIdx.x * 16 + threadIdx.x] = t_sum[0][threadIdx.x] + t_sum[1][threadIdx.x] + t_sum[2][threadIdx.x] + t_sum[3][threadIdx.x];
+  if (threadIdx.x < 32) a.e_part[(long)blockIdx.x * 32 + threadIdx.x] = e_acc[threadIdx.x];
+  if (threadIdx.x == 0) a.e_part_row[blockIdx.x] = e_blk;
 }
 
 // ---- hash-grid gradient scatter in packed fixed point ---------------------------------------------------------------------
@@ -543,25 +573,46 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
 // int32 fixed point with a per-level power-of-two scale F_l, the pair is packed as (q1 << 32) + q0, and the sum decodes exactly
 // because F_l is chosen from the level's total gradient mass T_l (sum over samples of max|g|) so that no entry can leave
 // int32: |sum| <= T_l F_l + n/2 < 2^31.  Integer adds commute, so the table gradient is bit-reproducible run to run.
-__global__ __launch_bounds__(256) void field_level_scale_kernel(const float* __restrict__ t_part, int nblocks, float* __restrict__ lvl) {
-  __shared__ float red[16][17];
-  const int l = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  float v = 0.f;
-  for (int b = sl; b < nblocks; b += 16) v += t_part[(long)b * 16 + l];
-  red[sl][l] = v;
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    float T = 0.f;
+// grid 17: workgroups 0..15 turn level l's gradient mass into its fixed-point scale; workgroup 16 folds the per-workgroup
+// appearance-embedding partials into emb_grad (runs of equal rows are summed first: one atomic per element per run and slice)
+__global__ __launch_bounds__(256) void field_finalize_kernel(const float* __restrict__ t_part, int nblocks, float* __restrict__ lvl,
+                                                            const float* __restrict__ e_part, const int* __restrict__ e_part_row,
+                                                            float* __restrict__ emb_grad) {
+  __shared__ float red[4];
+  if (blockIdx.x < 16) {
+    const int l = blockIdx.x;
+    float v = 0.f;
+    for (int b = threadIdx.x; b < nblocks; b += 256) v += t_part[(long)b * 16 + l];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) T += red[i][threadIdx.x];
-    float F = 1.f;
-    if (T > 0.f && T < 3.0e38f) {
-      int e = 29 - (int)ceilf(log2f(T));
-      e = e > 100 ? 100 : (e < -100 ? -100 : e);
-      F = exp2f((float)e);
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float T = red[0] + red[1] + red[2] + red[3];
+      float F = 1.f;
+      if (T > 0.f && T < 3.0e38f) {
+        int e = 29 - (int)ceilf(log2f(T));
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        F = exp2f((float)e);
+      }
+      lvl[l] = F; lvl[16 + l] = 1.f / F;
     }
-    lvl[threadIdx.x] = F; lvl[16 + threadIdx.x] = 1.f / F;
+    return;
   }
+  if (!emb_grad) return;
+  const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int per = (nblocks + 7) / 8;
+  int cur = -1; float acc = 0.f;
+  for (int b = sl * per; b < min(nblocks, (sl + 1) * per); ++b) {
+    const int row = e_part_row[b];
+    const float v = e_part[(long)b * 32 + c];
+    if (row != cur) {
+      if (cur >= 0 && acc != 0.f) atomicAdd(emb_grad + (size_t)cur * 32 + c, acc);
+      cur = row; acc = 0.f;
+    }
+    acc += v;
+  }
+  if (cur >= 0 && acc != 0.f) atomicAdd(emb_grad + (size_t)cur * 32 + c, acc);
 }
 
 struct FieldScatterArgs {
@@ -698,10 +749,11 @@ __global__ void field_make_scale_kernel(float* __restrict__ scale) {
 // =================================================================================================
 extern "C" int neraf_render_loss(neraf_ctx* ctx, const float* density, const float* rgb_s, const float* e_bins,
                                  const float* s_bins, const float* gt_rgb, int R, int S, float distortion_mult, const float* up3,
-                                 float* d_rgb_s, float* d_density, float* sums, neraf_stream_t stream) {
-  if (R <= 0 || S <= 0 || S > 64 || !density || !rgb_s || !e_bins || !s_bins || !gt_rgb || !sums || (up3 && (!d_rgb_s || !d_density)))
+                                 float* d_rgb_s, float* d_density, float* d_density_dist, float* sums, neraf_stream_t stream) {
+  if (R <= 0 || S <= 0 || S > 64 || !density || !rgb_s || !e_bins || !s_bins || !gt_rgb || !sums || (up3 && (!d_rgb_s || !d_density)) ||
+      (!up3 && d_rgb_s && (!d_density || !d_density_dist)))
     return neraf_fail(ctx, NERAF_EINVAL, "render_loss: bad arguments (S <= 64)");
-  RenderLossArgs a{density, rgb_s, e_bins, s_bins, gt_rgb, R, S, distortion_mult, up3, d_rgb_s, d_density, sums};
+  RenderLossArgs a{density, rgb_s, e_bins, s_bins, gt_rgb, R, S, distortion_mult, up3, d_rgb_s, d_density, d_density_dist, sums};
   hipLaunchKernelGGL(render_loss_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
@@ -765,6 +817,8 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
   a.dump = (half_t*)dump; a.npad = npad;
   a.d_enc = reinterpret_cast<unsigned*>((half_t*)dump + (size_t)64 * npad);                       // slot 0, rows 64..127
   a.t_part = reinterpret_cast<float*>((half_t*)dump + (size_t)128 * npad + (size_t)64 * npad);    // slot 1, rows 64..
+  a.e_part = reinterpret_cast<float*>((half_t*)dump + (size_t)2 * 128 * npad + (size_t)64 * npad);    // slot 2, rows 64..
+  a.e_part_row = reinterpret_cast<int*>((half_t*)dump + (size_t)3 * 128 * npad + (size_t)64 * npad);  // slot 3, rows 64..
   float* scale = (float*)((char*)dump + (size_t)10 * 128 * npad * 2);
   a.scale = scale;
   NERAF_HIP_CHECK(ctx, hipMemsetAsync(scale, 0, 16, st));
@@ -786,7 +840,8 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
     NERAF_HIP_CHECK(ctx, hipGetLastError());
     // hash-grid gradient: per-level fixed-point scale from the gradient mass, packed 64-bit scatter, in-place unpack
     float* lvl = scale + 8;
-    hipLaunchKernelGGL(field_level_scale_kernel, dim3(1), dim3(256), 0, st, a.t_part, (int)blocks, lvl);
+    hipLaunchKernelGGL(field_finalize_kernel, dim3(17), dim3(256), 0, st, a.t_part, (int)blocks, lvl, a.e_part, a.e_part_row,
+                       (avg_row < 0) ? emb_grad : nullptr);
     FieldScatterArgs sa{};
     sa.g = a.g; sa.origins = origins; sa.dirs = dirs; sa.e_bins = e_bins; sa.R = R; sa.S = S; sa.mode = mode;
     for (int i = 0; i < 6; ++i) sa.aabb[i] = a.aabb[i];

@@ -19,27 +19,55 @@
 namespace {
 
 // ---- packed weights for dgrad: Wt[cin][tap*cout + co] = W[co][cin][tap] ------------------------------------------
+// One launch for all convolutions; a workgroup transposes a [32 co][32 cin][taps] brick through LDS: the fp32 source is read in
+// contiguous runs of 32*taps floats, the bf16 destination written in 64-byte runs along co.
 struct PackTTable {
   int n;
   const float* src[48];
-  unsigned long long begin[49];
+  int tile_begin[49];                // prefix of (cout/32)*(nrows/32) bricks
   unsigned long long dst_off[48];
   int cout[48], cin[48], taps[48], kcols[48], nrows[48];
 };
 
 __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(PackTTable t, char* __restrict__ packed) {
-  const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= t.begin[t.n]) return;
+  extern __shared__ bf16_t brick[];          // [taps][32 n][34 co]
   int lo = 0, hi = t.n - 1;
-  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.begin[mid] <= idx) lo = mid; else hi = mid - 1; }
+  const int bid = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.tile_begin[mid] <= bid) lo = mid; else hi = mid - 1; }
   const int i = lo;
-  const unsigned long long e = idx - t.begin[i];
+  const int tile = bid - t.tile_begin[i];
+  const int n_tiles = t.nrows[i] / 32;
+  const int co0 = (tile / n_tiles) * 32, n0 = (tile % n_tiles) * 32;
+  const int taps = t.taps[i], cin = t.cin[i], cout = t.cout[i];
+  const int run = 32 * taps;
+  for (int e = threadIdx.x; e < 32 * run; e += 256) {
+    const int co_l = e / run, rem = e - co_l * run;
+    const int n_l = rem / taps, tap = rem - n_l * taps;
+    float v = 0.f;
+    if (n0 + n_l < cin) v = t.src[i][((size_t)(co0 + co_l) * cin + n0) * taps + rem];
+    brick[(tap * 32 + n_l) * 34 + co_l] = (bf16_t)v;
+  }
+  __syncthreads();
+  bf16_t* dst = reinterpret_cast<bf16_t*>(packed + t.dst_off[i]);
   const int kc = t.kcols[i];
-  const int n = (int)(e / kc), k = (int)(e % kc);          // n = cin index, k = tap*cout + co
-  const int tap = k / t.cout[i], co = k % t.cout[i];
-  float v = 0.f;
-  if (n < t.cin[i] && tap < t.taps[i]) v = t.src[i][((size_t)co * t.cin[i] + n) * t.taps[i] + tap];
-  reinterpret_cast<bf16_t*>(packed + t.dst_off[i])[e] = (bf16_t)v;
+  for (int e = threadIdx.x; e < 32 * run; e += 256) {
+    const int co_l = e & 31, rest = e >> 5;
+    const int n_l = rest & 31, tap = rest >> 5;
+    dst[(size_t)(n0 + n_l) * kc + tap * cout + co0 + co_l] = brick[(tap * 32 + n_l) * 34 + co_l];
+  }
+}
+
+int launch_pack_dgrad(neraf_ctx* ctx, const PackTTable& t, int ntiles, int max_taps, char* packed_t, hipStream_t st) {
+  const size_t lds = (size_t)max_taps * 32 * 34 * sizeof(bf16_t);
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_dgrad_weights_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(pack_dgrad_weights_kernel, dim3((unsigned)ntiles), dim3(256), lds, st, t, packed_t);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
 }
 
 // ---- im2col^T: out[row(k)][m] = X[src(m, tap)][c] for k = tap*cin + c, zero outside -------------------------------------
@@ -484,18 +512,18 @@ extern "C" int neraf_resnet3d_pack_weights_bwd(neraf_ctx* ctx, const neraf_resne
   make_bwd_layout(A, &B);
   PackTTable t{};
   t.n = A.nconv;
-  unsigned long long acc = 0;
+  int acc = 0, max_taps = 1;
   for (int i = 0; i < A.nconv; ++i) {
     const ConvSpec& c = A.conv[i];
     const int nrows = c.cin == 64 || c.cin == 8 ? 64 : round_up(c.cin, 128);
-    t.src[i] = conv_w[i]; t.begin[i] = acc; t.dst_off[i] = B.wt[i];
+    t.src[i] = conv_w[i]; t.tile_begin[i] = acc; t.dst_off[i] = B.wt[i];
     t.cout[i] = c.cout; t.cin[i] = c.cin_real; t.taps[i] = c.k * c.k * c.k; t.kcols[i] = t.taps[i] * c.cout; t.nrows[i] = nrows;
-    acc += (unsigned long long)nrows * t.kcols[i];
+    if (i == 0) continue;              // the stem has no dgrad GEMM (its input gradient is stem_dgrid_kernel's)
+    acc += (c.cout / 32) * (nrows / 32);
+    max_taps = std::max(max_taps, t.taps[i]);
   }
-  t.begin[A.nconv] = acc;
-  hipLaunchKernelGGL(pack_dgrad_weights_kernel, dim3((unsigned)((acc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, (char*)packed_t);
-  NERAF_HIP_CHECK(ctx, hipGetLastError());
-  return NERAF_OK;
+  t.tile_begin[A.nconv] = acc;       // conv 0 owns an empty range [0, 0): the search never lands on it
+  return launch_pack_dgrad(ctx, t, acc, max_taps, (char*)packed_t, (hipStream_t)stream);
 }
 
 extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed_t, const float* const* conv_w,
@@ -640,12 +668,13 @@ extern "C" int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_r
   float* scale = (float*)(bws + B.scale);
   const float one[2] = {1.f, 1.f};
   NERAF_HIP_CHECK(ctx, hipMemcpyAsync(scale, one, 8, hipMemcpyHostToDevice, st));
-  {
+  if (dx && cin % 64 == 0) {
     PackTTable t{};
-    t.n = 1; t.src[0] = w; t.begin[0] = 0; t.dst_off[0] = B.wt[0]; t.cout[0] = cout; t.cin[0] = cin_real; t.taps[0] = k * k * k;
-    t.kcols[0] = t.taps[0] * cout; t.nrows[0] = cin == 64 || cin == 8 ? 64 : round_up(cin, 128);
-    t.begin[1] = (unsigned long long)t.nrows[0] * t.kcols[0];
-    hipLaunchKernelGGL(pack_dgrad_weights_kernel, dim3((unsigned)((t.begin[1] + 255) / 256)), dim3(256), 0, st, t, packed_t);
+    const int nrows = cin == 64 || cin == 8 ? 64 : round_up(cin, 128);
+    t.n = 1; t.src[0] = w; t.tile_begin[0] = 0; t.dst_off[0] = B.wt[0]; t.cout[0] = cout; t.cin[0] = cin_real; t.taps[0] = k * k * k;
+    t.kcols[0] = t.taps[0] * cout; t.nrows[0] = nrows;
+    t.tile_begin[1] = (cout / 32) * (nrows / 32);
+    if (int e = launch_pack_dgrad(ctx, t, t.tile_begin[1], t.taps[0], packed_t, st)) return e;
   }
   float* wg[1] = {dw};
   float* bng[2] = {dgamma, dbeta};

@@ -184,7 +184,7 @@ class NeRAFAudioSoundField(nn.Module):
         r = rot.to(torch.float64).contiguous()
         training = torch.is_grad_enabled() and (feat.requires_grad or any(p.requires_grad for p in self.parameters()))
         ws = self._workspace(B, training, mic.device)
-        ab = (C.c_float * 6)(*[float(v) for v in aabb.detach().reshape(-1).cpu().tolist()])
+        ab = _lib.host_f32(aabb)
         _lib.check(lib.neraf_nacf_encode_queries(_lib.ctx(dev), C.byref(self._desc), tq.data_ptr(), mic.data_ptr(),
                                                  src.data_ptr(), r.data_ptr(), ab, int(max_len), B, ws.data_ptr(),
                                                  int(training), _stream_ptr()), dev)

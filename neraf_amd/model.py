@@ -126,7 +126,9 @@ class NeRAFAudioModel(nn.Module):
             self.field = NeRAFAudioSoundField(self.N_features + n_query, config.W_field, sound_rez=self.mic_ch,
                                               N_frequencies=config.N_freq_stft)                            # :189
             self._delta = 1e-2                                                                             # :191
-            self.view_dirs = self._generate_fixed_viewing_directions() if config.use_multiple_viewing_directions else None
+            # a buffer, so that it follows .to(device): a CPU tensor copied per step is a blocking, stream-ordered H2D copy
+            self.register_buffer("view_dirs", self._generate_fixed_viewing_directions()
+                                 if config.use_multiple_viewing_directions else None, persistent=False)
             S = self.resnet3d.backbone_net.grid_size
             ax = torch.arange(0 + self.grid_step / 2, 1, self.grid_step)                                   # :200
             coords = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).view(-1, 3)

@@ -259,7 +259,7 @@ class NerfactoField(nn.Module):
         splitk = self.splitk_buffer(device)
         cam = camera_indices.reshape(-1).to(torch.int32).contiguous() if camera_indices is not None else None
         mode = 0 if self.spatial_distortion is not None else 1
-        ab = (C.c_float * 6)(*[float(v) for v in self.aabb.reshape(-1).cpu().tolist()])
+        ab = _lib.host_f32(self.aabb)
         _lib.check(lib.neraf_field_backward(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), wfrag.data_ptr(), wfrag_b.data_ptr(),
                                             emb.data_ptr(), origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(),
                                             cam.data_ptr() if cam is not None else None, R, S, mode, ab, self.average_init_density,
@@ -283,7 +283,7 @@ class NerfactoField(nn.Module):
         avg_row = self.embedding.shape[0] if (use_average_embedding or camera_indices is None) else -1
         cam = camera_indices.reshape(-1).to(torch.int32).contiguous() if camera_indices is not None else None
         mode = 0 if self.spatial_distortion is not None else 1
-        ab = (C.c_float * 6)(*[float(v) for v in self.aabb.reshape(-1).cpu().tolist()])
+        ab = _lib.host_f32(self.aabb)
         _lib.check(lib.neraf_field_query(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), wfrag.data_ptr(), emb.data_ptr(),
                                          origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(),
                                          cam.data_ptr() if cam is not None else None, R, S, mode, ab,
@@ -322,9 +322,15 @@ class _VisionLossFn(torch.autograd.Function):
         fine = st["samples"][-1]
         R, S2 = st["dens"].shape
         sums = torch.zeros(4, dtype=torch.float32, device=gt.device)
+        # values and UNIT gradients in one pass (the backward only scales them by the upstream scalars)
+        need_grad = any(ctx.needs_input_grad[3:])
+        f32 = dict(dtype=torch.float32, device=gt.device)
+        unit = (torch.empty((R, S2, 3), **f32), torch.empty((R, S2), **f32), torch.empty((R, S2), **f32)) if need_grad else None
         _lib.check(lib.neraf_render_loss(h, st["dens"].data_ptr(), st["rgb_s"].data_ptr(), fine.e_bins.data_ptr(),
-                                         fine.s_bins.data_ptr(), gt.data_ptr(), R, S2, model.distortion_loss_mult, None, None, None,
-                                         sums.data_ptr(), stream), dev)
+                                         fine.s_bins.data_ptr(), gt.data_ptr(), R, S2, model.distortion_loss_mult, None,
+                                         unit[0].data_ptr() if unit else None, unit[1].data_ptr() if unit else None,
+                                         unit[2].data_ptr() if unit else None, sums.data_ptr(), stream), dev)
+        ctx.unit = unit
         for i in range(2):
             ps = st["samples"][i]
             Sp = ps.e_bins.shape[1] - 1
@@ -351,11 +357,9 @@ class _VisionLossFn(torch.autograd.Function):
         R, S2 = st["dens"].shape
         field = model.field.module
         sums = torch.zeros(4, **f32)
-        d_rgb_s = torch.empty((R, S2, 3), **f32)
-        d_dens = torch.empty((R, S2), **f32)
-        _lib.check(lib.neraf_render_loss(h, st["dens"].data_ptr(), st["rgb_s"].data_ptr(), fine.e_bins.data_ptr(),
-                                         fine.s_bins.data_ptr(), gt.data_ptr(), R, S2, model.distortion_loss_mult, up.data_ptr(),
-                                         d_rgb_s.data_ptr(), d_dens.data_ptr(), sums.data_ptr(), stream), dev)
+        u_rgb, u_dens, u_dens_dist = ctx.unit
+        d_rgb_s = u_rgb * up[0]
+        d_dens = torch.addcmul(u_dens * up[0], u_dens_dist, up[2])
         # ---- main field
         grads = field.backward_query(st["field_packed"], st["o"], st["d"], fine.e_bins, st["cam"], st["dens"], d_rgb_s, d_dens)
         # ---- proposal networks (interlevel loss); densities were computed under no_grad when not `updated`
