@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
 // int32 fixed point with a per-level power-of-two scale F_l, the pair is packed as (q1 << 32) + q0, and the sum decodes exactly
 // because F_l is chosen from the level's total gradient mass T_l (sum over samples of max|g|) so that no entry can leave
 // int32: |sum| <= T_l F_l + n/2 < 2^31.  Integer adds commute, so the table gradient is bit-reproducible run to run.
-// grid 17: workgroups 0..15 turn level l's gradient mass into its fixed-point scale; workgroup 16 folds the per-workgroup
+// workgroups 0..15 turn level l's gradient mass into its fixed-point scale; workgroups 16.. fold the per-workgroup
 // appearance-embedding partials into emb_grad (runs of equal rows are summed first: one atomic per element per run and slice)
 __global__ __launch_bounds__(256) void field_finalize_kernel(const float* __restrict__ t_part, int nblocks, float* __restrict__ lvl,
                                                             const float* __restrict__ e_part, const int* __restrict__ e_part_row,
@@ -600,17 +600,24 @@ __global__ __launch_bounds__(256) void field_finalize_kernel(const float* __rest
     return;
   }
   if (!emb_grad) return;
+  // workgroup 16 + j folds partials 64j .. 64j+63: eight sub-slices of eight, runs of equal rows summed in registers first
   const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int per = (nblocks + 7) / 8;
+  const int b0 = (blockIdx.x - 16) * 64 + sl * 8;
+  int rows[8]; float vals[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int b = b0 + i;
+    rows[i] = b < nblocks ? e_part_row[b] : -1;
+    vals[i] = b < nblocks ? e_part[(long)b * 32 + c] : 0.f;
+  }
   int cur = -1; float acc = 0.f;
-  for (int b = sl * per; b < min(nblocks, (sl + 1) * per); ++b) {
-    const int row = e_part_row[b];
-    const float v = e_part[(long)b * 32 + c];
-    if (row != cur) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (rows[i] != cur) {
       if (cur >= 0 && acc != 0.f) atomicAdd(emb_grad + (size_t)cur * 32 + c, acc);
-      cur = row; acc = 0.f;
+      cur = rows[i]; acc = 0.f;
     }
-    acc += v;
+    acc += vals[i];
   }
   if (cur >= 0 && acc != 0.f) atomicAdd(emb_grad + (size_t)cur * 32 + c, acc);
 }
@@ -840,8 +847,9 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
     NERAF_HIP_CHECK(ctx, hipGetLastError());
     // hash-grid gradient: per-level fixed-point scale from the gradient mass, packed 64-bit scatter, in-place unpack
     float* lvl = scale + 8;
-    hipLaunchKernelGGL(field_finalize_kernel, dim3(17), dim3(256), 0, st, a.t_part, (int)blocks, lvl, a.e_part, a.e_part_row,
-                       (avg_row < 0) ? emb_grad : nullptr);
+    const bool fold_emb = avg_row < 0 && emb_grad;
+    hipLaunchKernelGGL(field_finalize_kernel, dim3(16 + (fold_emb ? (unsigned)((blocks + 63) / 64) : 0u)), dim3(256), 0, st, a.t_part,
+                       (int)blocks, lvl, a.e_part, a.e_part_row, fold_emb ? emb_grad : nullptr);
     FieldScatterArgs sa{};
     sa.g = a.g; sa.origins = origins; sa.dirs = dirs; sa.e_bins = e_bins; sa.R = R; sa.S = S; sa.mode = mode;
     for (int i = 0; i < 6; ++i) sa.aabb[i] = a.aabb[i];

@@ -10,14 +10,16 @@ namespace {
 
 // ---- kernels ---------------------------------------------------------------------------------------------
 // fp32 grid [7][S^3] (NeRAF_model.py:271-277) -> fp16 channels-last [S^3][8] (channel 7 = 0)
-__global__ __launch_bounds__(256) void grid_to_ndhwc8_kernel(const float* __restrict__ grid, size_t nvox, half_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void grid_to_ndhwc8_kernel(const float* __restrict__ grid, size_t nvox, half_t* __restrict__ out,
+                                                            bf16_t* __restrict__ out_bf) {
   const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (v >= nvox) return;
-  half8 h;
+  half8 h; bf16x8 b;
 #pragma unroll
-  for (int c = 0; c < 7; ++c) h[c] = (half_t)grid[c * nvox + v];
-  h[7] = (half_t)0.f;
+  for (int c = 0; c < 7; ++c) { h[c] = (half_t)grid[c * nvox + v]; b[c] = (bf16_t)(float)h[c]; }
+  h[7] = (half_t)0.f; b[7] = (bf16_t)0.f;
   reinterpret_cast<half8*>(out)[v] = h;
+  if (out_bf) reinterpret_cast<bf16x8*>(out_bf)[v] = b;
 }
 
 struct RunTable {
@@ -42,7 +44,8 @@ __global__ __launch_bounds__(256) void bn_update_running_all_kernel(RunTable t, 
 }
 
 // stem: out[32^3-like][64] = maxpool3(s2,p1)( relu(bn(x)) ), x pre-BN [din^3][64]
-__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnSrc s, int din, int dout, size_t m_in, half_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnSrc s, int din, int dout, size_t m_in, half_t* __restrict__ out,
+                                                             bf16_t* __restrict__ out_bf) {
   __shared__ float sc[64], sh[64];
   if (threadIdx.x < 64) bn_scale_shift(s, threadIdx.x, 1.f / (float)m_in, sc[threadIdx.x], sh[threadIdx.x]);
   __syncthreads();
@@ -70,6 +73,12 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnSrc s, int din, 
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = (half_t)best[j];
   *reinterpret_cast<half8*>(out + vox * 64 + c0) = o;
+  if (out_bf) {
+    bf16x8 ob;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ob[j] = (bf16_t)(float)o[j];
+    *reinterpret_cast<bf16x8*>(out_bf + vox * 64 + c0) = ob;
+  }
 }
 
 // AvgPool3d over all remaining voxels (NeRAF_resnet3d.py:143/:149): feat[c] = mean_rows x[row][c]; feat pre-zeroed
@@ -149,7 +158,9 @@ extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
   NERAF_HIP_CHECK(ctx, hipMemsetAsync(ws + L.stats_begin, 0, L.stats_bytes, st));
   NERAF_HIP_CHECK(ctx, hipMemsetAsync(feat, 0, 1024 * sizeof(float), st));
   const size_t nvox = cube(A.S);
-  hipLaunchKernelGGL(grid_to_ndhwc8_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, grid, nvox, (half_t*)(ws + L.x0));
+  const bool shadow = use_batch_stats != 0;      // training forward: keep bfloat16 copies for the weight-gradient GEMMs
+  hipLaunchKernelGGL(grid_to_ndhwc8_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, grid, nvox, (half_t*)(ws + L.x0),
+                     shadow ? (bf16_t*)(ws + L.x0_bf) : nullptr);
   // stem: conv1 -> bn1 -> relu -> maxpool (NeRAF_resnet3d.py:185-188)
   if (int e = run_conv(ctx, st, A, L, 0, packed, ws, (const half_t*)(ws + L.x0))) return e;
   {
@@ -157,7 +168,7 @@ extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
     BnSrc s = bn_src_fwd(A, L, ws, bn, 0, use_batch_stats);
     const size_t total = cube(A.pooled) * 8;
     hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, c.dout, A.pooled,
-                       cube(c.dout), (half_t*)(ws + L.act_pool));
+                       cube(c.dout), (half_t*)(ws + L.act_pool), shadow ? (bf16_t*)(ws + L.act_pool_bf) : nullptr);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
   }
   const half_t* x = (const half_t*)(ws + L.act_pool);
@@ -169,11 +180,13 @@ extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
     BnApplyArgs a{};
     a.a = bn_src_fwd(A, L, ws, bn, i0, use_batch_stats);
     a.M = (int)cube(c0.dout); a.Mpad = (int)rows_pad(c0.dout); a.C = c0.cout; a.relu = 1; a.out = (half_t*)(ws + L.a1[b]);
+    a.out_bf = shadow ? (bf16_t*)(ws + L.a1_bf[b]) : nullptr;
     if (int e = run_bn_apply(ctx, st, a)) return e;
     if (int e = run_conv(ctx, st, A, L, i1, packed, ws, (const half_t*)(ws + L.a1[b]))) return e;
     BnApplyArgs a2{};
     a2.a = bn_src_fwd(A, L, ws, bn, i1, use_batch_stats);
     a2.M = (int)cube(c1.dout); a2.Mpad = (int)rows_pad(c1.dout); a2.C = c1.cout; a2.relu = 1; a2.out = (half_t*)(ws + L.a2[b]);
+    a2.out_bf = shadow ? (bf16_t*)(ws + L.a2_bf[b]) : nullptr;
     if (int e = run_bn_apply(ctx, st, a2)) return e;
     if (int e = run_conv(ctx, st, A, L, i2, packed, ws, (const half_t*)(ws + L.a2[b]))) return e;
     BnApplyArgs a3{};
@@ -185,6 +198,7 @@ extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
       a3.res = x;
     }
     a3.M = (int)cube(c2.dout); a3.Mpad = (int)rows_pad(c2.dout); a3.C = c2.cout; a3.relu = 1; a3.out = (half_t*)(ws + L.out[b]);
+    a3.out_bf = shadow ? (bf16_t*)(ws + L.out_bf[b]) : nullptr;
     if (int e = run_bn_apply(ctx, st, a3)) return e;
     x = (const half_t*)(ws + L.out[b]);
   }

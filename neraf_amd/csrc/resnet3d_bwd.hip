@@ -5,8 +5,9 @@
 // Every contraction re-uses gemm_f16.hip:
 //   dgrad  : dX = dY (*) W^T as the same implicit GEMM with a transposed-convolution loader (tap offsets negated,
 //            stride-2 taps filtered by parity), B = weights packed [cin][tap*cout + cout];
-//   wgrad  : dW[cout][tap,cin] = sum_m dY[m][cout] X[m@tap][cin] as an NT GEMM over the voxels (split-K), fed by
-//            transposed copies dY^T [cout][M] and im2col(X)^T [tap*cin + c][M] written by one tiling-transpose kernel;
+//   wgrad  : dW[cout][tap,cin] = sum_m dY[m][cout] X[m@tap][cin] as a "TN" GEMM over the voxels (split-K): both operand tiles
+//            are read as they lie in HBM ([voxel][channel] rows, the activation rows shifted by the filter tap) and transposed
+//            by the LDS read (ds_read_b64_tr_b16) -- no transposed copies, no im2col;
 //   BN     : two passes per layer (per-channel reductions sum dy, sum dy*xhat; then the element-wise dx), with the
 //            ReLU mask of the consumer folded into both.
 // The gradient chain (dY tensors, dgrad weights, wgrad operands) is bfloat16 -- BatchNorm backward multiplies by
@@ -70,67 +71,9 @@ int launch_pack_dgrad(neraf_ctx* ctx, const PackTTable& t, int ntiles, int max_t
   return NERAF_OK;
 }
 
-// ---- im2col^T: out[row(k)][m] = X[src(m, tap)][c] for k = tap*cin + c, zero outside -------------------------------------
-// The rows are stored in the order of the PyTorch weight layout, row(k) = c*taps + tap (channels beyond cin_real after all real
-// ones), so that the wgrad GEMM's fp32 result [cout][row] IS the weight gradient [cout][cin_real][taps] -- no un-permute pass.
-struct Im2colArgs {
-  const half_t* x; int cin, cin_real;   // source [din^3][cin] fp16 (forward activations)
-  int din, dout, ksize, stride, pad;
-  int M, Mpad;                       // result voxels (columns), padded column count (= leading dimension)
-  int K, Krows;                      // real rows taps*cin, rows written (multiple of 64, zero beyond K)
-  bf16_t* out;
-};
-
-__global__ __launch_bounds__(256) void im2col_t_kernel(Im2colArgs a) {
-  __shared__ bf16_t tile[64][72];    // [m][k] with padding
-  const int m0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-  const int tid = threadIdx.x;
-  // read: 64 rows (m) x 8 chunks (16 B = 8 k-values)
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int c = it * 256 + tid, row = c >> 3, ch = c & 7;
-    const int m = m0 + row, k = k0 + ch * 8;
-    bf16x8 v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
-    if (m < a.M && k < a.K) {
-      const int tap = k / a.cin, cc = k % a.cin;
-      const int x = m % a.dout, y = (m / a.dout) % a.dout, z = m / (a.dout * a.dout);
-      const int dz = tap / (a.ksize * a.ksize), dy = (tap / a.ksize) % a.ksize, dx = tap % a.ksize;
-      const int iz = z * a.stride - a.pad + dz, iy = y * a.stride - a.pad + dy, ix = x * a.stride - a.pad + dx;
-      if ((unsigned)iz < (unsigned)a.din && (unsigned)iy < (unsigned)a.din && (unsigned)ix < (unsigned)a.din) {
-        const size_t off = ((size_t)(iz * a.din + iy) * a.din + ix) * a.cin + cc;
-        const half8 h = *reinterpret_cast<const half8*>(a.x + off);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (bf16_t)(float)h[j];
-      }
-    }
-    *reinterpret_cast<bf16x8*>(&tile[row][ch * 8]) = v;
-  }
-  __syncthreads();
-  // write: 64 rows (k) x 8 chunks (8 consecutive m)
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int c = it * 256 + tid, krow = c >> 3, ch = c & 7;
-    const int k = k0 + krow;
-    if (k >= a.Krows) continue;
-    int orow = k;
-    if (k < a.K) {
-      const int taps = a.ksize * a.ksize * a.ksize;
-      const int tap = k / a.cin, cc = k - tap * a.cin;
-      orow = cc < a.cin_real ? cc * taps + tap : a.cin_real * taps + (cc - a.cin_real) * taps + tap;
-    }
-    bf16x8 v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = tile[ch * 8 + j][krow];
-    *reinterpret_cast<bf16x8*>(a.out + (size_t)orow * a.Mpad + m0 + ch * 8) = v;
-  }
-}
-
 // ---- BatchNorm backward ----------------------------------------------------------------------------------------
 // Both passes work on [rows][64-channel] panels.  Pass 1 reduces sum(dy) and sum(dy*xhat) (registers -> LDS -> one atomic per
-// channel per workgroup into a replicated accumulator, see kStatStride); pass 2 writes dx row-major AND transposed (the wgrad
-// GEMM's A operand), so no separate transpose pass exists.
+// channel per workgroup into a replicated accumulator, see kStatStride); pass 2 writes dx.
 struct BnBwdArgs {
   BnSrc s;                    // x (pre-BN), finalised forward statistics, gamma
   const bf16_t* g16; const float* g32;     // upstream gradient w.r.t. the post-activation tensor (one of them)
@@ -139,7 +82,6 @@ struct BnBwdArgs {
   int rows_per_block;         // reduce: rows handled by one workgroup (multiple of 32)
   float* sums; int rep;       // [rep][2][cpad] (replica stride kStatStride): sum dy, sum dy*xhat
   bf16_t* dx;                 // apply: gradient w.r.t. the pre-BN conv output [Mpad][C]
-  bf16_t* dxT;                // apply: the same, transposed [C][Mpad]
   bf16_t* dy_masked;          // apply (optional): g * (act > 0) for the identity residual branch
   float* dgamma; float* dbeta; const float* inv_scale;   // apply (row-block 0 writes the un-scaled affine gradients)
 };
@@ -203,7 +145,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs p) {
 // grid (Mpad / 64, C / 64)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
   __shared__ float mean[64], rstd[64], k1[64], k2[64], k3[64];
-  __shared__ bf16_t tile[64][72];    // [m][c] with padding
   const int c_base = blockIdx.y * 64, m0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
   const float inv_m = 1.f / (float)p.M;
@@ -241,16 +182,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
     }
     *reinterpret_cast<bf16x8*>(p.dx + off) = o;
     if (p.dy_masked) *reinterpret_cast<bf16x8*>(p.dy_masked + off) = om;
-    *reinterpret_cast<bf16x8*>(&tile[row][ch * 8]) = o;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int e = it * 256 + tid, crow = e >> 3, ch = e & 7;
-    bf16x8 v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = tile[ch * 8 + j][crow];
-    *reinterpret_cast<bf16x8*>(p.dxT + (size_t)(c_base + crow) * p.Mpad + m0 + ch * 8) = v;
   }
 }
 
@@ -299,6 +230,19 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(BnSrc s, int din, int 
     if (best[j] > 0.f && (float)gv[j] != 0.f) atomicAdd(dpost + arg[j] * 64 + c0 + j, (float)gv[j]);
 }
 
+// dW temp [cout][tap*cin + c] (fp32) -> PyTorch layout [cout][cin_real][taps]: a workgroup transposes one output channel's
+// [taps][cin] panel through LDS (both sides contiguous)
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ tmp, int cin, int cin_real, int taps,
+                                                          float* __restrict__ dst) {
+  extern __shared__ float panel[];          // [taps][cin + 1]
+  const int co = blockIdx.x;
+  const float* src = tmp + (size_t)co * taps * cin;
+  for (int e = threadIdx.x; e < taps * cin; e += 256) { const int tap = e / cin, c = e - tap * cin; panel[tap * (cin + 1) + c] = src[e]; }
+  __syncthreads();
+  float* d = dst + (size_t)co * cin_real * taps;
+  for (int e = threadIdx.x; e < cin_real * taps; e += 256) { const int c = e / taps, tap = e - c * taps; d[e] = panel[tap * (cin + 1) + c]; }
+}
+
 // stem input gradient for a window of cells: dgrid[c][cell] = sum_taps sum_co dY[(z+2-dz)/2,...][co] W[co][c][tap] / S
 __global__ __launch_bounds__(256) void stem_dgrid_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ W, int S, int dout,
                                                         size_t start, int n, int nch, const float* __restrict__ inv_scale,
@@ -322,6 +266,11 @@ __global__ __launch_bounds__(256) void stem_dgrid_kernel(const bf16_t* __restric
     }
   }
   dgrid[(size_t)c * n + i] = acc * inv_scale[0];
+}
+
+__global__ void f16_to_bf16_kernel(const half_t* __restrict__ a, size_t n, bf16_t* __restrict__ o) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = (bf16_t)(float)a[i];
 }
 
 __global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ a, size_t n, float* __restrict__ o) {
@@ -361,7 +310,7 @@ struct BwdLayout {
   size_t dy[3];               // dY of the three convs of a block (+ ds shares slot 2 after use) ; sized for the largest
   size_t dyds, gm, da;        // downsample dY, masked g (identity residual), d(a1|a2) scratch
   size_t dpost;               // fp32 [din1^3][64] stem
-  size_t dyT, xcolT;          // transposed operands of the wgrad GEMM
+  size_t wtmp;                // fp32 [cout][tap*cin + c] weight gradients before the layout change (k > 1 convs)
   size_t splitk; size_t splitk_bytes;
   size_t total;
 };
@@ -397,7 +346,7 @@ void make_bwd_layout(const Arch& A, BwdLayout* L) {
     L->sums[i] = take(rep > 1 ? (size_t)rep * kStatStride * 4 : (size_t)2 * round_up(A.conv[i].cout, 128) * 4);
   }
   L->sums_bytes = off - L->sums_begin;
-  size_t max_act = 0, max_xcol = 0, max_dyT = 0;
+  size_t max_act = 0, max_wtmp = 0;
   for (int i = 0; i < A.nconv; ++i) {
     const ConvSpec& c = A.conv[i];
     const size_t rows_out = rows_pad(c.dout), rows_in = rows_pad(c.din);
@@ -405,15 +354,14 @@ void make_bwd_layout(const Arch& A, BwdLayout* L) {
       max_act = std::max(max_act, rows_out * c.cout * 2);
       max_act = std::max(max_act, rows_in * c.cin * 2);
     }
-    max_xcol = std::max(max_xcol, (size_t)round_up(c.k * c.k * c.k * c.cin, 128) * rows_out * 2);
-    max_dyT = std::max(max_dyT, (size_t)round_up(c.cout, 128) * rows_out * 2);
+    if (c.k > 1) max_wtmp = std::max(max_wtmp, (size_t)c.cout * round_up(c.k * c.k * c.k * c.cin, 64) * 4);
   }
   const size_t stem_act = rows_pad(A.conv[0].dout) * 64 * 2;
   for (int i = 0; i < 2; ++i) L->g[i] = take(max_act);
   for (int i = 0; i < 3; ++i) L->dy[i] = take(std::max(max_act, stem_act));
   L->dyds = take(max_act); L->gm = take(max_act); L->da = take(max_act);
   L->dpost = take(cube(A.conv[0].dout) * 64 * 4);
-  L->dyT = take(max_dyT); L->xcolT = take(max_xcol);
+  L->wtmp = take(max_wtmp);
   L->splitk_bytes = (size_t)64 << 20;
   L->splitk = take(L->splitk_bytes);
   L->total = off;
@@ -425,7 +373,7 @@ struct Ctx {
   const float* inv_scale;
 };
 
-// BN backward of conv ci: dx (row-major, into `dx`) and its transpose (into the shared dyT buffer, consumed by conv_wgrad(ci))
+// BN backward of conv ci: gradient w.r.t. the conv output, into `dx`
 int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const half_t* act, bf16_t* dx, bf16_t* dy_masked) {
   const ConvSpec& cs = c.A->conv[ci];
   BnBwdArgs p{};
@@ -434,7 +382,7 @@ int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const
   p.M = (int)cube(cs.dout); p.Mpad = (int)rows_pad(cs.dout); p.C = cs.cout;
   p.rows_per_block = bwd_rows_per_block(cs);
   p.sums = (float*)(c.bws + c.B->sums[ci]); p.rep = bwd_stat_rep(cs);
-  p.dx = dx; p.dxT = (bf16_t*)(c.bws + c.B->dyT); p.dy_masked = dy_masked;
+  p.dx = dx; p.dy_masked = dy_masked;
   p.dgamma = c.bn_grads[2 * ci]; p.dbeta = c.bn_grads[2 * ci + 1]; p.inv_scale = c.inv_scale;
   const int nrb = (p.M + p.rows_per_block - 1) / p.rows_per_block;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nrb, p.C / 64), dim3(256), 0, c.st, p);
@@ -443,26 +391,33 @@ int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const
   return NERAF_OK;
 }
 
-// dW of conv ci from dY^T [cout][Mpad] (left in the dyT buffer by bn_backward(ci)) and the conv's input activation
-// x_in [din^3][cin]: NT GEMM over the voxels, result written straight into the PyTorch-layout gradient tensor
-int conv_wgrad(const Ctx& c, int ci, const half_t* x_in) {
+// dW of conv ci from dY [Mpad][cout] (bf16) and the bfloat16 shadow of the conv's input activation x_in [din^3][cin]
+int conv_wgrad(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* x_in) {
   const ConvSpec& cs = c.A->conv[ci];
-  const int M = (int)cube(cs.dout), Mpad = (int)rows_pad(cs.dout);
-  const int taps = cs.k * cs.k * cs.k, K = taps * cs.cin;
-  const bf16_t* dyT = (const bf16_t*)(c.bws + c.B->dyT);
-  bf16_t* xT = (bf16_t*)(c.bws + c.B->xcolT);
-  Im2colArgs b{};
-  b.x = x_in; b.cin = cs.cin; b.cin_real = cs.cin_real; b.din = cs.din; b.dout = cs.dout; b.ksize = cs.k; b.stride = cs.stride; b.pad = cs.pad;
-  b.M = M; b.Mpad = Mpad; b.K = K; b.Krows = round_up(K, 64); b.out = xT;
-  hipLaunchKernelGGL(im2col_t_kernel, dim3(Mpad / 64, b.Krows / 64), dim3(256), 0, c.st, b);
-  NERAF_HIP_CHECK(c.ctx, hipGetLastError());
+  const int Mpad = (int)rows_pad(cs.dout);
+  const int taps = cs.k * cs.k * cs.k;
   GemmParams g{};
-  g.bf16 = 1;
-  g.A = (const half_t*)dyT; g.lda = Mpad; g.B = (const half_t*)xT; g.ldb = Mpad;
-  g.M = cs.cout; g.N = taps * cs.cin_real; g.K = Mpad; g.Mpad = cs.cout; g.Npad = b.Krows; g.alpha = 1.f; g.alpha_dev = c.inv_scale;
-  g.C32 = c.w_grads[ci]; g.ldc32 = taps * cs.cin_real;
+  g.bf16 = 1; g.tn = 1;
+  g.A = (const half_t*)dy; g.lda = cs.cout;
+  g.B = (const half_t*)x_in; g.ldb = cs.cin;
+  g.M = cs.cout; g.Mpad = cs.cout; g.N = taps * cs.cin; g.Npad = round_up(taps * cs.cin, 64); g.K = Mpad;
+  g.alpha = 1.f; g.alpha_dev = c.inv_scale;
+  const bool direct = cs.k == 1;
+  g.C32 = direct ? c.w_grads[ci] : (float*)(c.bws + c.B->wtmp); g.ldc32 = taps * cs.cin;
   g.splitk_ws = (float*)(c.bws + c.B->splitk); g.splitk_ws_bytes = c.B->splitk_bytes;
-  return launch_gemm_f16(c.ctx, g, c.st);
+  if (!(cs.k == 1 && cs.stride == 1)) {
+    g.conv.loader = cs.cin == 8 ? 2 : 1;
+    g.conv.din = cs.din; g.conv.dout = cs.dout; g.conv.stride = cs.stride; g.conv.pad = cs.pad; g.conv.ksize = cs.k; g.conv.cin = cs.cin;
+    g.conv.zero_page = (const half_t*)(c.ws + c.L->zero_page);
+  }
+  if (int e = launch_gemm_f16(c.ctx, g, c.st)) return e;
+  if (!direct) {
+    const size_t lds = (size_t)taps * (cs.cin + 1) * sizeof(float);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(cs.cout), dim3(256), lds, c.st, (const float*)(c.bws + c.B->wtmp), cs.cin, cs.cin_real,
+                       taps, c.w_grads[ci]);
+    NERAF_HIP_CHECK(c.ctx, hipGetLastError());
+  }
+  return NERAF_OK;
 }
 
 // dX [din^3][cin] = conv_transpose(dY [dout^3][cout], W) (+ add16)
@@ -565,19 +520,22 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
     const half_t* out = (const half_t*)(ws + L.out[b]);
     const half_t* a1 = (const half_t*)(ws + L.a1[b]);
     const half_t* a2 = (const half_t*)(ws + L.a2[b]);
+    const bf16_t* x_in_bf = b == 0 ? (const bf16_t*)(ws + L.act_pool_bf) : (const bf16_t*)(ws + L.out_bf[b - 1]);
+    const bf16_t* a1_bf = (const bf16_t*)(ws + L.a1_bf[b]);
+    const bf16_t* a2_bf = (const bf16_t*)(ws + L.a2_bf[b]);
     // out = relu(bn3(c3) + residual): dy = g * (out > 0) feeds bn3 and the residual branch
     if (int e = bn_backward(c, i2, g, nullptr, out, dy2, Bk.ds < 0 ? gm : nullptr)) return e;
-    if (int e = conv_wgrad(c, i2, a2)) return e;
+    if (int e = conv_wgrad(c, i2, dy2, a2_bf)) return e;
     if (int e = conv_dgrad(c, i2, dy2, nullptr, da)) return e;                 // d a2
     if (stop_after == 1) return NERAF_OK;
     if (int e = bn_backward(c, i1, da, nullptr, a2, dy1, nullptr)) return e;
-    if (int e = conv_wgrad(c, i1, a1)) return e;
+    if (int e = conv_wgrad(c, i1, dy1, a1_bf)) return e;
     if (int e = conv_dgrad(c, i1, dy1, nullptr, da)) return e;                 // d a1
     if (int e = bn_backward(c, i0, da, nullptr, a1, dy0, nullptr)) return e;
-    if (int e = conv_wgrad(c, i0, x_in)) return e;
+    if (int e = conv_wgrad(c, i0, dy0, x_in_bf)) return e;
     if (Bk.ds >= 0) {
       if (int e = bn_backward(c, Bk.ds, g, nullptr, out, dyds, nullptr)) return e;
-      if (int e = conv_wgrad(c, Bk.ds, x_in)) return e;
+      if (int e = conv_wgrad(c, Bk.ds, dyds, x_in_bf)) return e;
       if (int e = conv_dgrad(c, Bk.ds, dyds, nullptr, da)) return e;           // residual-branch gradient w.r.t. x_in
       if (int e = conv_dgrad(c, i0, dy0, da, g_next)) return e;
     } else {
@@ -595,7 +553,7 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, c0.dout, A.pooled, cube(c0.dout), g, dpost);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
     if (int e = bn_backward(c, 0, nullptr, dpost, nullptr, dy0, nullptr)) return e;      // relu mask already applied by the routing
-    if (int e = conv_wgrad(c, 0, (const half_t*)(ws + L.x0))) return e;
+    if (int e = conv_wgrad(c, 0, dy0, (const bf16_t*)(ws + L.x0_bf))) return e;
     if (n_cells > 0) {
       const int n = n_cells * n_ch;
       hipLaunchKernelGGL(stem_dgrid_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dy0, conv_w[0], A.S, c0.dout, cell_start, n_cells, n_ch,
@@ -606,12 +564,12 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
   return NERAF_OK;
 }
 
-extern "C" int neraf_resnet3d_bwd_debug_offsets(const neraf_resnet3d_desc* d, size_t* off /* g0,g1,dy0,dy1,dy2,dyds,gm,da,dyT,xcolT */) {
+extern "C" int neraf_resnet3d_bwd_debug_offsets(const neraf_resnet3d_desc* d, size_t* off /* g0,g1,dy0,dy1,dy2,dyds,gm,da,wtmp,splitk */) {
   Arch A; BwdLayout B;
   if (make_arch(d, &A) || !off) return NERAF_EINVAL;
   make_bwd_layout(A, &B);
   off[0] = B.g[0]; off[1] = B.g[1]; off[2] = B.dy[0]; off[3] = B.dy[1]; off[4] = B.dy[2]; off[5] = B.dyds; off[6] = B.gm; off[7] = B.da;
-  off[8] = B.dyT; off[9] = B.xcolT;
+  off[8] = B.wtmp; off[9] = B.splitk;
   return NERAF_OK;
 }
 
@@ -640,10 +598,10 @@ extern "C" int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_r
   NERAF_HIP_CHECK(ctx, hipMalloc(&bws, B.total));
   NERAF_HIP_CHECK(ctx, hipMalloc(&packed, L.packed_total));
   NERAF_HIP_CHECK(ctx, hipMalloc(&packed_t, B.packed_total + 256));
-  NERAF_HIP_CHECK(ctx, hipMalloc(&extra, 4 * act));
+  NERAF_HIP_CHECK(ctx, hipMalloc(&extra, 5 * act));
   NERAF_HIP_CHECK(ctx, hipMemsetAsync(ws, 0, L.total, st));
   NERAF_HIP_CHECK(ctx, hipMemsetAsync(bws, 0, B.total, st));
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(extra, 0, 4 * act, st));
+  NERAF_HIP_CHECK(ctx, hipMemsetAsync(extra, 0, 5 * act, st));
   const float* wl[1] = {w};
   // forward: pack, conv (+stats), bn+relu
   {
@@ -682,7 +640,12 @@ extern "C" int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_r
   bf16_t* dy = (bf16_t*)(extra + 2 * act);
   bf16_t* dxb = (bf16_t*)(extra + 3 * act);
   if (int e = bn_backward(c, 0, nullptr, g, yact, dy, nullptr)) return e;
-  if (int e = conv_wgrad(c, 0, xin)) return e;
+  bf16_t* xin_bf = (bf16_t*)(extra + 4 * act);
+  {
+    const size_t n = rows_pad(din) * (size_t)cin;
+    hipLaunchKernelGGL(f16_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xin, n, xin_bf);
+  }
+  if (int e = conv_wgrad(c, 0, dy, xin_bf)) return e;
   if (dx && cin % 64 == 0) {
     if (int e = conv_dgrad(c, 0, dy, nullptr, dxb)) return e;
     const size_t n = cube(din) * cin;

@@ -70,6 +70,9 @@ struct Layout {
   size_t fin[64];               // per conv: finalised batch statistics fp32 [2][cpad] = mean, biased variance (written by the BN pass)
   size_t act_pool;              // stem: pooled activation
   size_t a1[16], a2[16], out[16];   // per block post-activation tensors
+  // bfloat16 shadows of every tensor a convolution reads (written by the same passes in training mode): the weight-gradient
+  // GEMM pairs them with the bfloat16 gradient chain, and the MFMA wants both operands in one type
+  size_t x0_bf, act_pool_bf, a1_bf[16], a2_bf[16], out_bf[16];
   size_t splitk; size_t splitk_bytes;
   size_t stats_begin, stats_bytes;
   size_t total;
@@ -101,6 +104,15 @@ void make_layout(const Arch& A, Layout* L) {
   }
   L->splitk_bytes = (size_t)64 << 20;
   L->splitk = take(L->splitk_bytes);
+  L->x0_bf = take(cube(A.S) * 8 * 2);
+  L->act_pool_bf = take(rows_pad(A.pooled) * 64 * 2);
+  for (int b = 0; b < A.nblock; ++b) {
+    const ConvSpec& c0 = A.conv[A.block[b].conv[0]]; const ConvSpec& c1 = A.conv[A.block[b].conv[1]];
+    const ConvSpec& c2 = A.conv[A.block[b].conv[2]];
+    L->a1_bf[b] = take(rows_pad(c0.dout) * c0.cout * 2);
+    L->a2_bf[b] = take(rows_pad(c1.dout) * c1.cout * 2);
+    L->out_bf[b] = take(rows_pad(c2.dout) * c2.cout * 2);
+  }
   L->total = off;
 }
 
@@ -190,6 +202,7 @@ struct BnApplyArgs {
   BnSrc a; BnSrc r; const half_t* res;   // r.x != null: residual is bn_r(r.x); else res (may be null)
   int M, Mpad, C; int relu;
   half_t* out;
+  bf16_t* out_bf;       // optional bfloat16 shadow of `out`
 };
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
@@ -224,6 +237,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
       for (int j = 0; j < 8; ++j) o[j] = (half_t)0.f;
     }
     *reinterpret_cast<half8*>(p.out + row * p.C + c0) = o;
+    if (p.out_bf) {
+      bf16x8 ob;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ob[j] = (bf16_t)(float)o[j];
+      *reinterpret_cast<bf16x8*>(p.out_bf + row * p.C + c0) = ob;
+    }
   }
 }
 
