@@ -85,12 +85,10 @@ class JointStep:
         self.gt = {"image": T(rb["rgb"]).to(dev)}
         self.params = list(self.am.parameters())      # NAcF MLP + ResNet3D: the 'audio_fields' group (NeRAF_model.py:730-737)
         self.vparams = list(self.vm.parameters())
-        try:
-            self.opt = torch.optim.Adam(self.params, lr=1e-4, eps=1e-15, fused=True)       # NeRAF_config.py:124-127
-            self.opt_v = torch.optim.Adam(self.vparams, lr=1e-2, eps=1e-15, fused=True)    # :116-123
-        except Exception:
-            self.opt = torch.optim.Adam(self.params, lr=1e-4, eps=1e-15, foreach=True)
-            self.opt_v = torch.optim.Adam(self.vparams, lr=1e-2, eps=1e-15, foreach=True)
+        from neraf_amd.optim import FusedAdam
+        # Adam(eps 1e-15) on the radiance parameters (lr 1e-2, NeRAF_config.py:116-123) and on the audio parameters (lr 1e-4,
+        # :124-127): two parameter groups of ONE optimizer, so the whole update is a single launch
+        self.opt = FusedAdam([{"params": self.vparams, "lr": 1e-2}, {"params": self.params, "lr": 1e-4}], eps=1e-15)
         self.scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
         self.i = 20000      # steady-state regime of the 400k-iteration schedule: anneal done, proposal nets updated every 6th step
 
@@ -101,7 +99,6 @@ class JointStep:
         self.i += 1
         self.vm.update_to_step(self.i)
         self.opt.zero_grad(set_to_none=True)
-        self.opt_v.zero_grad(set_to_none=True)
         out_v = self.vm.get_outputs(self.bundle)                                                   # NeRAF_pipeline.py:176
         lv = self.vm.get_loss_dict(out_v, self.gt)                                                 # :178
         self.am.query_grid_one_batch(self.i, self.vm.field, renderer_rgb=self.vm.renderer_rgb, batch_size=self.R)  # :181-184
@@ -112,7 +109,6 @@ class JointStep:
         if self.world > 1:
             from neraf_amd.parallel import allreduce_gradients
             allreduce_gradients(self.vparams + self.params, self.world)
-        self.scaler.step(self.opt_v)
         self.scaler.step(self.opt)
         self.scaler.update()
         return out_v["rgb"], loss

@@ -311,6 +311,23 @@ int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_real, int co
 /* Test aid: byte offsets of the backward's intermediate bf16 buffers inside bwd_workspace. */
 int neraf_resnet3d_bwd_debug_offsets(const neraf_resnet3d_desc* d, size_t* off);
 
+/* ------------------------------------------------------------------------------------
+ * Optimizer step (SURVEY 8f "optimizer fusion"): torch.optim.Adam as nerfstudio's Optimizers apply it to the
+ * `fields` and `audio_fields` groups (NeRAF_config.py:116-127), one launch per optimizer.  `table` is a device
+ * array of 48-byte records {float* p; const float* g; float* m; float* v; int64 numel; int32 group; int32 pad}
+ * and group_lr a HOST array of the n_groups (<= 8) learning rates (passed by value: schedulers change them every step);
+ * g_ptrs (device uint64[n], may be NULL) overrides the records' gradient pointers -- autograd hands out new gradient
+ * tensors every step, and this column can be refreshed with an asynchronous copy while the rest of the table stays;
+ * workgroup b updates elements [blk_chunk[b]*chunk, +chunk) of tensor blk_tensor[b] (chunk =
+ * neraf_fused_adam_chunk()).  step: device float[4] {t, 1/(1-b1^t), 1/sqrt(1-b2^t), -}, t incremented by the call; grad_scale / found_inf: the
+ * GradScaler's device scalars (NULL = no scaling); when *found_inf != 0 nothing is modified.
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), exactly torch's formula (no weight decay, no amsgrad).
+ * ---------------------------------------------------------------------------------- */
+int neraf_fused_adam_chunk(void);
+int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
+                     int n_blocks, const float* group_lr, int n_groups, double beta1, double beta2, double eps, float* step,
+                     const float* grad_scale, const float* found_inf, neraf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,9 @@ SIGNATURES = {
                                   C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "neraf_gemm_bf16_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "neraf_fused_adam_chunk": (C.c_int, []),
+    "neraf_fused_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_nacf_packed_bytes": (C.c_size_t, [C.POINTER(NacfDesc)]),
     "neraf_nacf_workspace_bytes": (C.c_size_t, [C.POINTER(NacfDesc), C.c_int, C.c_int]),
     "neraf_nacf_pack_weights": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), c_fpp, C.c_void_p, C.c_void_p]),

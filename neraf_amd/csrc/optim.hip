@@ -1,0 +1,86 @@
+// Fused multi-tensor Adam for the joint training step (the reference trains its fields with torch Adam through nerfstudio's
+// Optimizers, NeRAF_config.py:116-127, under a GradScaler): ONE launch updates every parameter tensor of an optimizer.
+// The per-tensor table (parameter, gradient, moment pointers, element count, learning rate) and the workgroup -> (tensor,
+// offset) map live in device memory owned by the host layer; the kernel un-scales the gradient by 1 / *grad_scale on the fly
+// and leaves everything untouched when *found_inf != 0 (GradScaler semantics), so no separate un-scale pass writes gradients.
+#include "common.h"
+
+namespace {
+
+struct AdamTensor { float* p; const float* g; float* m; float* v; long long numel; int group; int pad; };
+struct AdamLrs { float lr[8]; };
+static_assert(sizeof(AdamTensor) == 48, "table layout is shared with neraf_amd/optim.py");
+
+constexpr int kAdamChunk = 4096;       // elements per workgroup
+
+// step[0] += 1 (unless a gradient was non-finite); step[1] = 1 / (1 - b1^t), step[2] = 1 / sqrt(1 - b2^t), in double as torch does
+// on the host (1 - 0.999^t cancels catastrophically in fp32 for small t)
+__global__ void adam_advance_step_kernel(float* __restrict__ step, const float* __restrict__ found_inf, double beta1, double beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (!(found_inf && found_inf[0] != 0.f)) step[0] += 1.f;
+    const double t = (double)step[0];
+    step[1] = (float)(1.0 / (1.0 - pow(beta1, t)));
+    step[2] = (float)(1.0 / sqrt(1.0 - pow(beta2, t)));
+  }
+}
+
+__global__ __launch_bounds__(256) void fused_adam_kernel(const AdamTensor* __restrict__ table, const unsigned long long* __restrict__ g_ptrs,
+                                                        const int* __restrict__ blk_tensor,
+                                                        const int* __restrict__ blk_chunk, AdamLrs lrs, float beta1, float beta2,
+                                                        float omb1, float omb2, float eps,
+                                                        const float* __restrict__ step, const float* __restrict__ grad_scale,
+                                                        const float* __restrict__ found_inf) {
+  if (found_inf && found_inf[0] != 0.f) return;
+  AdamTensor t = table[blk_tensor[blockIdx.x]];
+  if (g_ptrs) t.g = reinterpret_cast<const float*>(g_ptrs[blk_tensor[blockIdx.x]]);
+  const long long base = (long long)blk_chunk[blockIdx.x] * kAdamChunk;
+  const float inv_scale = grad_scale ? 1.f / grad_scale[0] : 1.f;
+  const float step_size = lrs.lr[t.group & 7] * step[1], inv_sqrt_bc2 = step[2];
+  const bool vec = ((reinterpret_cast<size_t>(t.p) | reinterpret_cast<size_t>(t.g) | reinterpret_cast<size_t>(t.m) |
+                     reinterpret_cast<size_t>(t.v)) & 15) == 0;
+#pragma unroll
+  for (int it = 0; it < kAdamChunk / 1024; ++it) {
+    const long long i = base + it * 1024 + threadIdx.x * 4;
+    if (i >= t.numel) break;
+    if (vec && i + 3 < t.numel) {
+      f32x4 p = *reinterpret_cast<const f32x4*>(t.p + i), g = *reinterpret_cast<const f32x4*>(t.g + i);
+      f32x4 m = *reinterpret_cast<const f32x4*>(t.m + i), v = *reinterpret_cast<const f32x4*>(t.v + i);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gr = g[r] * inv_scale;
+        m[r] = beta1 * m[r] + omb1 * gr;
+        v[r] = beta2 * v[r] + omb2 * gr * gr;
+        p[r] -= step_size * m[r] / (sqrtf(v[r]) * inv_sqrt_bc2 + eps);
+      }
+      *reinterpret_cast<f32x4*>(t.p + i) = p; *reinterpret_cast<f32x4*>(t.m + i) = m; *reinterpret_cast<f32x4*>(t.v + i) = v;
+    } else {
+      for (int r = 0; r < 4 && i + r < t.numel; ++r) {
+        const float gr = t.g[i + r] * inv_scale;
+        const float m = beta1 * t.m[i + r] + omb1 * gr;
+        const float v = beta2 * t.v[i + r] + omb2 * gr * gr;
+        t.m[i + r] = m; t.v[i + r] = v;
+        t.p[i + r] -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int neraf_fused_adam_chunk(void) { return kAdamChunk; }
+
+extern "C" int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
+                                int n_blocks, const float* group_lr, int n_groups, double beta1, double beta2, double eps, float* step,
+                                const float* grad_scale, const float* found_inf, neraf_stream_t stream) {
+  if (!table || !blk_tensor || !blk_chunk || n_blocks <= 0 || !step || !group_lr || n_groups < 1 || n_groups > 8)
+    return neraf_fail(ctx, NERAF_EINVAL, "fused_adam: bad arguments (1..8 parameter groups)");
+  AdamLrs lrs{};
+  for (int i = 0; i < n_groups; ++i) lrs.lr[i] = group_lr[i];
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_advance_step_kernel, dim3(1), dim3(64), 0, st, step, found_inf, beta1, beta2);
+  hipLaunchKernelGGL(fused_adam_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, (const AdamTensor*)table, (const unsigned long long*)g_ptrs,
+                     blk_tensor, blk_chunk, lrs, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, step,
+                     grad_scale, found_inf);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}

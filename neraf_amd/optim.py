@@ -1,0 +1,112 @@
+"""Optimizer step of the joint training loop: ``FusedAdam`` is torch.optim.Adam (the optimizer nerfstudio's ``Optimizers``
+builds for the reference's ``fields`` and ``audio_fields`` groups, NeRAF_config.py:116-127) with every parameter tensor of all
+groups updated by ONE HIP launch (``neraf_fused_adam``, include/neraf_hip.h).  It plugs into ``torch.amp.GradScaler`` the way
+torch's own fused Adam does: the scaler hands over its device-side ``grad_scale`` / ``found_inf`` and the kernel un-scales on the
+fly and skips the update when a gradient was non-finite, so no pass ever writes un-scaled gradients.
+
+fp32 parameters and gradients only; no weight decay, no amsgrad (what the reference configures)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List
+
+import numpy as np
+import torch
+
+from . import _lib
+from .field import _dev_index, _stream_ptr
+
+_REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("numel", "<i8"), ("group", "<i4"), ("pad", "<i4")])
+assert _REC.itemsize == 48
+
+
+class FusedAdam(torch.optim.Optimizer):
+    _step_supports_amp_scaling = True        # GradScaler.step passes grad_scale / found_inf instead of synchronising
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        if len(self.param_groups) > 8:
+            raise ValueError("FusedAdam supports up to 8 parameter groups")
+        b, e = self.param_groups[0]["betas"], self.param_groups[0]["eps"]
+        if any(g["betas"] != b or g["eps"] != e for g in self.param_groups):
+            raise ValueError("FusedAdam: betas and eps must be the same in every group (the learning rate may differ)")
+        self._plans = {}                       # ids of the parameters holding a gradient -> device tables (the proposal networks
+                                               # only receive gradients every few steps: two plans alternate)
+        self._step_t = None
+
+    def _state_for(self, p: torch.Tensor):
+        st = self.state[p]
+        if not st:
+            if self._step_t is None:
+                self._step_t = torch.zeros(4, dtype=torch.float32, device=p.device)   # {t, 1/(1-b1^t), 1/sqrt(1-b2^t), -}
+            st["step"] = self._step_t[0]       # one device counter for the whole optimizer
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    def _build(self, entries: List[tuple], device) -> dict:
+        chunk = _lib.load().neraf_fused_adam_chunk()
+        rec = np.zeros(len(entries), dtype=_REC)
+        bt, bc = [], []
+        for i, (p, gi) in enumerate(entries):
+            if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                raise TypeError("FusedAdam: contiguous fp32 parameters and gradients only")
+            if p.device != device:
+                raise ValueError("FusedAdam: all parameters on one device")
+            st = self._state_for(p)
+            rec[i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi, 0)
+            n = (p.numel() + chunk - 1) // chunk
+            bt.append(np.full(n, i, np.int32)); bc.append(np.arange(n, dtype=np.int32))
+        n = len(entries)
+        return dict(table=torch.from_numpy(rec.view(np.uint8).copy()).to(device),
+                    blk_tensor=torch.from_numpy(np.concatenate(bt)).to(device),
+                    blk_chunk=torch.from_numpy(np.concatenate(bc)).to(device),
+                    # gradient-pointer column, refreshed asynchronously every step: (pinned, device, event, used) x 4
+                    ring=[[torch.empty(n, dtype=torch.int64).pin_memory(), torch.empty(n, dtype=torch.int64, device=device),
+                           torch.cuda.Event(), False] for _ in range(4)], ring_i=0)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        entries, sig, gp = [], [], []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                entries.append((p, gi))
+                sig.append(id(p))
+                gp.append(g.data_ptr())
+        if not entries:
+            return loss
+        p0 = entries[0][0]
+        sig = tuple(sig)
+        plan = self._plans.get(sig)
+        if plan is None:                       # a new set of parameters with gradients: build its device table (synchronises, once)
+            plan = self._plans[sig] = self._build(entries, p0.device)
+        # gradient tensors are new every step: refresh the pointer column through pinned memory, without synchronising
+        k = plan["ring_i"]
+        plan["ring_i"] = (k + 1) % 4
+        slot = plan["ring"][k]
+        pinned, gdev, ev = slot[0], slot[1], slot[2]
+        if slot[3]:
+            ev.synchronize()                   # four uses old: complete unless the host ran that far ahead
+        pinned.numpy()[:] = gp
+        gdev.copy_(pinned, non_blocking=True)
+        ev.record()
+        slot[3] = True
+        lib = _lib.load()
+        dev = _dev_index(p0)
+        lrs = (C.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
+        b1, b2 = self.param_groups[0]["betas"]
+        gs = getattr(self, "grad_scale", None)
+        fi = getattr(self, "found_inf", None)
+        _lib.check(lib.neraf_fused_adam(_lib.ctx(dev), plan["table"].data_ptr(), gdev.data_ptr(), plan["blk_tensor"].data_ptr(),
+                                        plan["blk_chunk"].data_ptr(), int(plan["blk_tensor"].numel()), lrs, len(self.param_groups), float(b1), float(b2),
+                                        float(self.param_groups[0]["eps"]), self._step_t.data_ptr(),
+                                        gs.data_ptr() if gs is not None else None, fi.data_ptr() if fi is not None else None,
+                                        _stream_ptr()), dev)
+        return loss
