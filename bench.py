@@ -244,6 +244,14 @@ def main():
 
     if rank == 0:
         samples = st.samples_per_step() * world * a.steps
+        # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot wrap itself from inside):
+        # tools/gpu_pmc.sh -> profiles/*_pmc_traffic.json (FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE)
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+        pmc = json.load(open(pmc_files[-1]))["families"] if pmc_files and a.rays == 4096 and a.slices == 2048 else {}
+        for k in fams:
+            t = pmc.get(k["kernel"])
+            k["traffic"] = t["hbm_bytes_per_launch"] if t else None
         dom = max(fams, key=lambda k: k["ms_per_step"]) if fams else None
         out = {
             "metric": "field-samples/sec (rays + RIR STFT bins)",
@@ -273,7 +281,8 @@ def main():
         if dom:
             peak = HBM_PEAK_GBS if dom["bound"] == "hbm" else MFMA_PEAK_TFLOPS
             out["roofline"] = {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": peak,
-                               "unit": dom["unit"], "frac": dom["achieved"] / peak, "traffic": None,
+                               "unit": dom["unit"], "frac": dom["achieved"] / peak, "traffic": dom["traffic"],
+                               "traffic_source": os.path.basename(pmc_files[-1]) if pmc and dom["traffic"] is not None else None,
                                "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                                "algorithmic_work_per_launch": dom["work_per_launch"],
                                "dense_equiv_gflop_per_step": {"nacf_fwd_bwd": 3 * NACF_DENSE_FLOP_PER_SLICE_FWD * a.slices / 1e9,
