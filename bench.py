@@ -288,6 +288,8 @@ def main():
                                "dense_equiv_gflop_per_step": {"nacf_fwd_bwd": 3 * NACF_DENSE_FLOP_PER_SLICE_FWD * a.slices / 1e9,
                                                               "resnet3d_fwd": RESNET_FWD_GFLOP},
                                "all_kernel_families": fams}
+        gc, gl = C.c_int(), C.c_int()
+        out["hip_graphs"] = {"enabled": bool(lib.neraf_graph_stats(h, C.byref(gc), C.byref(gl))), "captures": gc.value, "launches": gl.value}
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.rays, a.slices)
         print(json.dumps(out))

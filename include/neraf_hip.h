@@ -55,6 +55,10 @@ const char* neraf_last_error(neraf_ctx* ctx);
  * gathered table bytes), 7 = field_scatter (work = 8 bytes per (sample, level, corner) 64-bit atomic);
  * neraf_prof_kernel_name(id) returns NULL past the end.
  * ---------------------------------------------------------------------------------- */
+/* hipGraph cache statistics: the launch-bound call sequences (neraf_resnet3d_fwd / _bwd: 100-270 kernels of a few
+ * microseconds each) are captured once per distinct argument set and replayed with hipGraphLaunch (NERAF_GRAPHS=0 in the
+ * environment disables; profiling disables).  Returns 1 if graphs are enabled, 0 if not. */
+int neraf_graph_stats(neraf_ctx* ctx, int* captures, int* launches);
 int neraf_prof_enable(neraf_ctx* ctx, int on);
 int neraf_prof_summary(neraf_ctx* ctx, int kernel_id, double* total_ms, int* launches, double* work);
 const char* neraf_prof_kernel_name(int kernel_id);

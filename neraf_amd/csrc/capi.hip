@@ -1,5 +1,13 @@
 // Context management for libneraf_hip (C ABI, include/neraf_hip.h).
 #include "common.h"
+#include <stdlib.h>
+
+__global__ void neraf_zero_kernel(unsigned* __restrict__ p, size_t n_words) {
+  const size_t n4 = n_words / 4;
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) reinterpret_cast<u4*>(p)[i] = u4{0u, 0u, 0u, 0u};
+  if (blockIdx.x == 0 && threadIdx.x < (n_words & 3)) p[n4 * 4 + threadIdx.x] = 0u;
+}
 
 extern "C" int neraf_abi_version(void) { return NERAF_ABI_VERSION; }
 
@@ -14,11 +22,25 @@ extern "C" int neraf_ctx_create(neraf_ctx** out, int device) {
   if (!c) return NERAF_EINVAL;
   c->device = device;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  const char* g = getenv("NERAF_GRAPHS");
+  c->graphs_enabled = !(g && g[0] == '0');
   *out = c;
   return NERAF_OK;
 }
 
-extern "C" void neraf_ctx_destroy(neraf_ctx* ctx) { delete ctx; }
+extern "C" void neraf_ctx_destroy(neraf_ctx* ctx) {
+  if (!ctx) return;
+  for (auto& e : ctx->graphs) (void)hipGraphExecDestroy(e.exec);
+  if (ctx->capture_stream) (void)hipStreamDestroy(ctx->capture_stream);
+  delete ctx;
+}
+
+extern "C" int neraf_graph_stats(neraf_ctx* ctx, int* captures, int* launches) {
+  if (!ctx) return NERAF_EINVAL;
+  if (captures) *captures = ctx->graph_captures;
+  if (launches) *launches = ctx->graph_launches;
+  return ctx->graphs_enabled ? 1 : 0;
+}
 
 extern "C" const char* neraf_last_error(neraf_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 

@@ -144,19 +144,11 @@ extern "C" int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_
   return NERAF_OK;
 }
 
-extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed_, const float* const* bn,
-                                  const float* grid, void* workspace, float* feat, int use_batch_stats,
-                                  neraf_stream_t stream) {
-  Arch A; Layout L;
-  if (make_arch(d, &A) || !packed_ || !bn || !grid || !workspace || !feat)
-    return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_fwd: bad arguments (grid_size 64|128, in_channels 7, n_features 1024)");
-  make_layout(A, &L);
-  hipStream_t st = (hipStream_t)stream;
-  const char* packed = (const char*)packed_;
-  char* ws = (char*)workspace;
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(ws + L.zero_page, 0, 256, st));
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(ws + L.stats_begin, 0, L.stats_bytes, st));
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(feat, 0, 1024 * sizeof(float), st));
+static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, const char* packed, const float* const* bn, const float* grid,
+                             char* ws, float* feat, int use_batch_stats, hipStream_t st) {
+  neraf_zero_async(st, ws + L.zero_page, 256);
+  neraf_zero_async(st, ws + L.stats_begin, L.stats_bytes);
+  neraf_zero_async(st, feat, 1024 * sizeof(float));
   const size_t nvox = cube(A.S);
   const bool shadow = use_batch_stats != 0;      // training forward: keep bfloat16 copies for the weight-gradient GEMMs
   hipLaunchKernelGGL(grid_to_ndhwc8_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, grid, nvox, (half_t*)(ws + L.x0),
@@ -210,6 +202,22 @@ extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
     NERAF_HIP_CHECK(ctx, hipGetLastError());
   }
   return NERAF_OK;
+}
+
+extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed_, const float* const* bn,
+                                  const float* grid, void* workspace, float* feat, int use_batch_stats,
+                                  neraf_stream_t stream) {
+  Arch A; Layout L;
+  if (make_arch(d, &A) || !packed_ || !bn || !grid || !workspace || !feat)
+    return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_fwd: bad arguments (grid_size 64|128, in_channels 7, n_features 1024)");
+  make_layout(A, &L);
+  // ~107 launches of mostly 3-10 us kernels with arguments fixed by these values: replayed as one hipGraph
+  ArgHash k;
+  k.add(0x66776431u); k.add(d->grid_size); k.add(packed_); k.ptrs((const void* const*)bn, 4 * A.nconv); k.add(grid); k.add(workspace);
+  k.add(feat); k.add(use_batch_stats);
+  return neraf_run_graphed(ctx, (hipStream_t)stream, k.h, [&](hipStream_t st) {
+    return resnet3d_fwd_body(ctx, A, L, (const char*)packed_, bn, grid, (char*)workspace, feat, use_batch_stats, st);
+  });
 }
 
 extern "C" int neraf_resnet3d_update_running_stats(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* workspace,

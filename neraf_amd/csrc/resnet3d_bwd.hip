@@ -244,11 +244,14 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
 }
 
 // stem input gradient for a window of cells: dgrid[c][cell] = sum_taps sum_co dY[(z+2-dz)/2,...][co] W[co][c][tap] / S
+__global__ void set_u64_kernel(unsigned long long* p, unsigned long long v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
+
 __global__ __launch_bounds__(256) void stem_dgrid_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ W, int S, int dout,
-                                                        size_t start, int n, int nch, const float* __restrict__ inv_scale,
-                                                        float* __restrict__ dgrid) {
+                                                        const unsigned long long* __restrict__ start_dev, int n, int nch,
+                                                        const float* __restrict__ inv_scale, float* __restrict__ dgrid) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= n * nch) return;
+  const size_t start = (size_t)start_dev[0];     // device-side so that the captured launch sequence does not depend on the window
   const int c = idx / n, i = idx % n;
   const size_t cell = start + i;
   const int x = (int)(cell % S), y = (int)((cell / S) % S), z = (int)(cell / ((size_t)S * S));
@@ -481,21 +484,12 @@ extern "C" int neraf_resnet3d_pack_weights_bwd(neraf_ctx* ctx, const neraf_resne
   return launch_pack_dgrad(ctx, t, acc, max_taps, (char*)packed_t, (hipStream_t)stream);
 }
 
-extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed_t, const float* const* conv_w,
-                                  const float* const* bn, void* workspace, void* bwd_workspace, const float* dfeat,
-                                  float* const* w_grads, float* const* bn_grads, size_t cell_start, int n_cells, int n_ch,
-                                  float* dgrid_cells, neraf_stream_t stream) {
-  Arch A; Layout L; BwdLayout B;
-  if (make_arch(d, &A) || !packed_t || !conv_w || !bn || !workspace || !bwd_workspace || !dfeat || !w_grads || !bn_grads ||
-      (n_cells > 0 && (!dgrid_cells || n_ch < 1 || n_ch > 7 || cell_start + (size_t)n_cells > cube(d->grid_size))))
-    return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_bwd: bad arguments");
-  make_layout(A, &L);
-  make_bwd_layout(A, &B);
-  hipStream_t st = (hipStream_t)stream;
-  char* ws = (char*)workspace; char* bws = (char*)bwd_workspace;
+static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, const BwdLayout& B, const void* packed_t,
+                             const float* const* conv_w, const float* const* bn, char* ws, char* bws, const float* dfeat,
+                             float* const* w_grads, float* const* bn_grads, int n_cells, int n_ch, float* dgrid_cells, hipStream_t st) {
   float* scale = (float*)(bws + B.scale);
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(scale, 0, 16, st));
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(bws + B.sums_begin, 0, B.sums_bytes, st));
+  neraf_zero_async(st, scale, 16);
+  neraf_zero_async(st, bws + B.sums_begin, B.sums_bytes);
   hipLaunchKernelGGL(amax_f32_kernel, dim3(4), dim3(256), 0, st, dfeat, 1024, reinterpret_cast<unsigned*>(scale) + 2);
   // d feat is spread over M voxels by the average pool; aim the per-voxel gradient at ~2^4
   const int Mlast = (int)cube(A.final_edge);
@@ -510,9 +504,6 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
   }
   bf16_t* dy0 = (bf16_t*)(bws + B.dy[0]); bf16_t* dy1 = (bf16_t*)(bws + B.dy[1]); bf16_t* dy2 = (bf16_t*)(bws + B.dy[2]);
   bf16_t* dyds = (bf16_t*)(bws + B.dyds); bf16_t* gm = (bf16_t*)(bws + B.gm); bf16_t* da = (bf16_t*)(bws + B.da);
-  // debugging aid: NERAF_RESNET_BWD_STOP=<n> returns after n conv stages of the LAST block so that tests can inspect
-  // the intermediate gradient buffers (offsets from neraf_resnet3d_bwd_debug_offsets)
-  static const int stop_after = [] { const char* e = getenv("NERAF_RESNET_BWD_STOP"); return e ? atoi(e) : 0; }();
   for (int b = A.nblock - 1; b >= 0; --b) {
     const BlockSpec& Bk = A.block[b];
     const int i0 = Bk.conv[0], i1 = Bk.conv[1], i2 = Bk.conv[2];
@@ -527,7 +518,6 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
     if (int e = bn_backward(c, i2, g, nullptr, out, dy2, Bk.ds < 0 ? gm : nullptr)) return e;
     if (int e = conv_wgrad(c, i2, dy2, a2_bf)) return e;
     if (int e = conv_dgrad(c, i2, dy2, nullptr, da)) return e;                 // d a2
-    if (stop_after == 1) return NERAF_OK;
     if (int e = bn_backward(c, i1, da, nullptr, a2, dy1, nullptr)) return e;
     if (int e = conv_wgrad(c, i1, dy1, a1_bf)) return e;
     if (int e = conv_dgrad(c, i1, dy1, nullptr, da)) return e;                 // d a1
@@ -547,7 +537,7 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
   {
     const ConvSpec& c0 = A.conv[0];
     float* dpost = (float*)(bws + B.dpost);
-    NERAF_HIP_CHECK(ctx, hipMemsetAsync(dpost, 0, cube(c0.dout) * 64 * 4, st));
+    neraf_zero_async(st, dpost, cube(c0.dout) * 64 * 4);
     BnSrc s = bn_src_bwd(A, L, ws, bn, 0);
     const size_t total = cube(A.pooled) * 8;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, c0.dout, A.pooled, cube(c0.dout), g, dpost);
@@ -556,12 +546,37 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
     if (int e = conv_wgrad(c, 0, dy0, (const bf16_t*)(ws + L.x0_bf))) return e;
     if (n_cells > 0) {
       const int n = n_cells * n_ch;
-      hipLaunchKernelGGL(stem_dgrid_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dy0, conv_w[0], A.S, c0.dout, cell_start, n_cells, n_ch,
-                         scale + 1, dgrid_cells);
+      hipLaunchKernelGGL(stem_dgrid_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dy0, conv_w[0], A.S, c0.dout,
+                         reinterpret_cast<const unsigned long long*>(bws + B.scale + 64), n_cells, n_ch, scale + 1, dgrid_cells);
       NERAF_HIP_CHECK(ctx, hipGetLastError());
     }
   }
   return NERAF_OK;
+}
+
+extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed_t, const float* const* conv_w,
+                                  const float* const* bn, void* workspace, void* bwd_workspace, const float* dfeat,
+                                  float* const* w_grads, float* const* bn_grads, size_t cell_start, int n_cells, int n_ch,
+                                  float* dgrid_cells, neraf_stream_t stream) {
+  Arch A; Layout L; BwdLayout B;
+  if (make_arch(d, &A) || !packed_t || !conv_w || !bn || !workspace || !bwd_workspace || !dfeat || !w_grads || !bn_grads ||
+      (n_cells > 0 && (!dgrid_cells || n_ch < 1 || n_ch > 7 || cell_start + (size_t)n_cells > cube(d->grid_size))))
+    return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_bwd: bad arguments");
+  make_layout(A, &L);
+  make_bwd_layout(A, &B);
+  hipStream_t st = (hipStream_t)stream;
+  char* bws = (char*)bwd_workspace;
+  // the refresh window moves every step: its start travels through device memory, outside the captured sequence
+  hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long*>(bws + B.scale + 64),
+                     (unsigned long long)cell_start);
+  ArgHash k;
+  k.add(0x62776431u); k.add(d->grid_size); k.add(packed_t); k.ptrs((const void* const*)conv_w, A.nconv);
+  k.ptrs((const void* const*)bn, 4 * A.nconv); k.add(workspace); k.add(bwd_workspace); k.add(dfeat);
+  k.ptrs((const void* const*)w_grads, A.nconv); k.ptrs((const void* const*)bn_grads, 2 * A.nconv);
+  k.add(n_cells); k.add(n_ch); k.add(dgrid_cells);
+  return neraf_run_graphed(ctx, st, k.h, [&](hipStream_t s2) {
+    return resnet3d_bwd_body(ctx, A, L, B, packed_t, conv_w, bn, (char*)workspace, bws, dfeat, w_grads, bn_grads, n_cells, n_ch, dgrid_cells, s2);
+  });
 }
 
 extern "C" int neraf_resnet3d_bwd_debug_offsets(const neraf_resnet3d_desc* d, size_t* off /* g0,g1,dy0,dy1,dy2,dyds,gm,da,wtmp,splitk */) {

@@ -49,21 +49,35 @@ class _ResNet3DFn(torch.autograd.Function):
         bn: List[torch.Tensor] = []
         for _, b in pairs:
             bn += [b.weight.detach(), b.bias.detach(), b.running_mean, b.running_var]
-        packed_t = torch.empty(lib.neraf_resnet3d_bwd_packed_bytes(C.byref(net._desc)), dtype=torch.uint8, device=device)
+        # every buffer the kernels see is persistent (module-owned): the ~270-launch sequence is replayed as ONE hipGraph keyed by
+        # its argument pointers (include/neraf_hip.h, neraf_graph_stats), so the pointers must not change from step to step
+        if net._packed_t is None or net._packed_t.device != device:
+            net._packed_t = torch.empty(lib.neraf_resnet3d_bwd_packed_bytes(C.byref(net._desc)), dtype=torch.uint8, device=device)
+        packed_t = net._packed_t
         _lib.check(lib.neraf_resnet3d_pack_weights_bwd(h, C.byref(net._desc), _lib.ptr_array(conv_w), packed_t.data_ptr(), st), dev)
         if net._bws is None or net._bws.device != device:
             net._bws = torch.empty(lib.neraf_resnet3d_bwd_workspace_bytes(C.byref(net._desc)), dtype=torch.uint8, device=device)
-        w_grads = [torch.empty_like(w) for w in conv_w]
-        bn_grads = [torch.empty_like(p) for p in params[nconv:]]
+        sizes = [p.numel() for p in params]
+        if net._grad_flat is None or net._grad_flat.device != device or net._grad_flat.numel() != sum(sizes):
+            net._grad_flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+            net._grad_views = [v.view(p.shape) for v, p in zip(torch.split(net._grad_flat, sizes), params)]
+            net._grad_ptrs = (_lib.ptr_array(net._grad_views[:nconv]), _lib.ptr_array(net._grad_views[nconv:]))
+            net._dfeat_buf = torch.empty(1024, dtype=torch.float32, device=device)
         start, n_cells, n_ch = ctx.window if ctx.window is not None else (0, 0, 0)
-        dgrid = torch.empty((n_ch, n_cells), dtype=torch.float32, device=device) if n_cells > 0 else None
-        dfeat = dfeat.reshape(-1).float().contiguous()
+        if n_cells > 0 and (net._dgrid_buf is None or tuple(net._dgrid_buf.shape) != (n_ch, n_cells) or net._dgrid_buf.device != device):
+            net._dgrid_buf = torch.empty((n_ch, n_cells), dtype=torch.float32, device=device)
+        net._dfeat_buf.copy_(dfeat.reshape(-1))
         _lib.check(lib.neraf_resnet3d_bwd(h, C.byref(net._desc), packed_t.data_ptr(), _lib.ptr_array(conv_w), _lib.ptr_array(bn),
-                                          net._ws.data_ptr(), net._bws.data_ptr(), dfeat.data_ptr(), _lib.ptr_array(w_grads),
-                                          _lib.ptr_array(bn_grads), start, n_cells, n_ch,
-                                          dgrid.data_ptr() if dgrid is not None else None, st), dev)
+                                          net._ws.data_ptr(), net._bws.data_ptr(), net._dfeat_buf.data_ptr(), net._grad_ptrs[0],
+                                          net._grad_ptrs[1], start, n_cells, n_ch,
+                                          net._dgrid_buf.data_ptr() if n_cells > 0 else None, st), dev)
+        # hand autograd private copies (it may keep them as .grad or accumulate into them): one copy kernel, then views
+        flat = net._grad_flat.clone()
+        grads = [v.view(p.shape) for v, p in zip(torch.split(flat, sizes), params)]
+        dgrid = net._dgrid_buf.clone() if n_cells > 0 else None
         if ctx.sink is not None and dgrid is not None:
             ctx.sink(dgrid)
+        w_grads, bn_grads = grads[:nconv], grads[nconv:]
         return (None, None, None, None, dgrid if ctx.has_vals else None, *w_grads, *bn_grads)
 
 
@@ -126,6 +140,7 @@ class ResNet3D(nn.Module):
         self._ws = None
         self._bws = None
         self._packed, self._packed_key = None, None
+        self._packed_t = self._grad_flat = self._grad_views = self._grad_ptrs = self._dfeat_buf = self._dgrid_buf = self._feat_buf = None
         self.grid_window = None      # (cell_start, n_cells, n_channels): grid cells whose gradient the backward should produce
         self.grid_grad_sink = None   # callable(dgrid_cells fp32 [n_ch, n_cells]) invoked inside the backward
 
@@ -158,15 +173,18 @@ class ResNet3D(nn.Module):
         key = tuple((w.data_ptr(), w._version) for w in conv_w)
         being_trained = any(c.weight.grad is not None for c, _ in pairs)
         if self._packed is None or self._packed.device != x.device or key != self._packed_key or being_trained:
-            packed = torch.empty(lib.neraf_resnet3d_packed_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
-            _lib.check(lib.neraf_resnet3d_pack_weights(h, C.byref(self._desc), _lib.ptr_array(conv_w), packed.data_ptr(), st), dev)
-            self._packed, self._packed_key = packed, key
+            if self._packed is None or self._packed.device != x.device:      # persistent: its pointer is part of the graph key
+                self._packed = torch.empty(lib.neraf_resnet3d_packed_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
+            _lib.check(lib.neraf_resnet3d_pack_weights(h, C.byref(self._desc), _lib.ptr_array(conv_w), self._packed.data_ptr(), st), dev)
+            self._packed_key = key
         packed = self._packed
         if self._ws is None or self._ws.device != x.device:
             self._ws = torch.empty(lib.neraf_resnet3d_workspace_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
-        feat = torch.empty(1024, dtype=torch.float32, device=x.device)
+        if self._feat_buf is None or self._feat_buf.device != x.device:
+            self._feat_buf = torch.empty(1024, dtype=torch.float32, device=x.device)
         _lib.check(lib.neraf_resnet3d_fwd(h, C.byref(self._desc), packed.data_ptr(), _lib.ptr_array(bn), grid.data_ptr(),
-                                          self._ws.data_ptr(), feat.data_ptr(), int(self.training), st), dev)
+                                          self._ws.data_ptr(), self._feat_buf.data_ptr(), int(self.training), st), dev)
+        feat = self._feat_buf
         if self.training:
             mom = pairs[0][1].momentum if pairs[0][1].momentum is not None else 0.1
             if mom > 0:
@@ -181,7 +199,9 @@ class ResNet3D(nn.Module):
                 window = self.grid_window
             if window_vals is not None and not window_vals.requires_grad:
                 window_vals = None
-            feat = _ResNet3DFn.apply(self, feat, window, self.grid_grad_sink, window_vals, *params)
+            feat = _ResNet3DFn.apply(self, feat, window, self.grid_grad_sink, window_vals, *params)    # returns a copy
+        else:
+            feat = feat.clone()                 # never hand out the persistent output buffer
         return feat.reshape(1, 1024, 1, 1, 1)
 
 
