@@ -90,6 +90,14 @@ class JointStep:
         # :124-127): two parameter groups of ONE optimizer, so the whole update is a single launch
         self.opt = FusedAdam([{"params": self.vparams, "lr": 1e-2}, {"params": self.params, "lr": 1e-4}], eps=1e-15)
         self.scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
+        self.reducer = None
+        if world > 1:
+            # gradient averaging overlapped with the backward pass: groups in the order the backward completes them
+            from neraf_amd.parallel import GradientReducer
+            prop = [p for pn in self.vm.proposal_networks for p in pn.parameters()]
+            groups = [list(self.am.field.parameters()), list(self.am.resnet3d.parameters()), list(self.vm.field.parameters()), prop]
+            assert sum(len(g) for g in groups) == len(self.params) + len(self.vparams), "reducer groups must cover every parameter"
+            self.reducer = GradientReducer(groups)
         self.i = 20000      # steady-state regime of the 400k-iteration schedule: anneal done, proposal nets updated every 6th step
 
     def samples_per_step(self):
@@ -106,9 +114,8 @@ class JointStep:
         d = self.am.get_loss_dict(y, self.batch)                                                   # :191
         loss = lv["rgb_loss"] + lv["interlevel_loss"] + lv["distortion_loss"] + d["audio_sc_loss"] + d["audio_mag_loss"]
         self.scaler.scale(loss).backward()
-        if self.world > 1:
-            from neraf_amd.parallel import allreduce_gradients
-            allreduce_gradients(self.vparams + self.params, self.world)
+        if self.reducer is not None:
+            self.reducer.finish()
         self.scaler.step(self.opt)
         self.scaler.update()
         return out_v["rgb"], loss
@@ -187,12 +194,20 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    # NERAF_BENCH_SHARE_GPU=1 (test aid): several ranks share the visible GPUs and talk over gloo -- exercises the multi-rank
+    # code path (sharding, overlapped gradient reducer, global loss sums) on a 1-GPU box; never a measurement.
+    share = os.environ.get("NERAF_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL
     from neraf_amd import _lib
 
     st = JointStep(dev, a.rays, a.slices, world)

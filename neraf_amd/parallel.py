@@ -52,6 +52,115 @@ def allreduce_gradients(params: Iterable[torch.Tensor], world: Optional[int] = N
     return len(buckets)
 
 
+def _coalesce(grads: List[torch.Tensor]) -> Tuple[List[Tuple[torch.Tensor, List[torch.Tensor]]], List[torch.Tensor]]:
+    """Split gradient tensors into (a) maximal runs that tile one contiguous range of a shared storage -- e.g. the ResNet3D
+    gradients, which are views of one flat buffer -- returned as (flat view over the run, members), reducible IN PLACE with one
+    collective and no copies, and (b) the rest."""
+    by_storage = {}
+    for g in grads:
+        if g.is_contiguous():
+            by_storage.setdefault(g.untyped_storage().data_ptr(), []).append(g)
+    runs, rest, used = [], [], set()
+    for members in by_storage.values():
+        members.sort(key=lambda t: t.storage_offset())
+        i = 0
+        while i < len(members):
+            j, end = i, members[i].storage_offset() + members[i].numel()
+            while j + 1 < len(members) and members[j + 1].dtype == members[i].dtype and members[j + 1].storage_offset() == end:
+                j += 1
+                end += members[j].numel()
+            if j > i:
+                first = members[i]
+                n = end - first.storage_offset()
+                runs.append((first.as_strided((n,), (1,), first.storage_offset()), members[i:j + 1]))
+                used.update(id(t) for t in members[i:j + 1])
+            i = j + 1
+    rest = [g for g in grads if id(g) not in used]
+    return runs, rest
+
+
+class GradientReducer:
+    """Overlapped data-parallel gradient averaging for the joint step.
+
+    The parameters are given as GROUPS in the order the backward pass finishes them (NAcF, ResNet3D, radiance field, proposal
+    networks).  A post-accumulate hook counts the gradients of each group; the moment a group is complete its all-reduce is
+    launched asynchronously, so the collectives of the audio branch (~150 MB) travel over xGMI while the radiance backward is
+    still computing.  Few, large, in-place messages: runs of gradients that are views of one flat buffer are reduced as one
+    tensor without copies, tensors above ``direct_bytes`` individually, and only the small remainder through a flattened bucket.
+    ``finish()`` (before the optimizer step) waits, writes the bucketed remainder back and re-arms the hooks.  Groups whose
+    parameters received no gradient this step (the proposal networks between their update steps) send nothing -- the schedule
+    is the same on every rank."""
+
+    def __init__(self, groups: List[List[torch.nn.Parameter]], group=None, direct_bytes: int = 1 << 20, overlap: bool = True):
+        self.groups = [list(g) for g in groups]
+        self.pg = group
+        self.world = dist.get_world_size(group)
+        self.direct_bytes = direct_bytes
+        self.overlap = overlap
+        self._avg = dist.get_backend(group) == "nccl"       # RCCL averages in the collective; gloo has no AVG: sum, then divide
+        self._count = [0] * len(self.groups)
+        self._launched = [False] * len(self.groups)
+        self._pending = []       # (work handle, tensor to divide or None, [(grad, source slice)] to copy back)
+        self._hooks = []
+        if overlap:
+            for gi, params in enumerate(self.groups):
+                for p in params:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(gi)))
+
+    def _make_hook(self, gi: int):
+        def hook(_param):
+            self._count[gi] += 1
+            if self._count[gi] == len(self.groups[gi]) and not self._launched[gi]:
+                self._launch(gi)
+        return hook
+
+    def _launch(self, gi: int):
+        self._launched[gi] = True
+        grads = [p.grad for p in self.groups[gi] if p.grad is not None]
+        if not grads:
+            return
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        runs, rest = _coalesce(grads)
+        small = []
+        for flat, _members in runs:
+            self._pending.append((dist.all_reduce(flat, op=op, group=self.pg, async_op=True), None if self._avg else flat, []))
+        for g in rest:
+            if g.is_contiguous() and g.numel() * g.element_size() >= self.direct_bytes:
+                self._pending.append((dist.all_reduce(g, op=op, group=self.pg, async_op=True), None if self._avg else g, []))
+            else:
+                small.append(g)
+        by_dtype = {}
+        for g in small:
+            by_dtype.setdefault(g.dtype, []).append(g)
+        for bucket in by_dtype.values():
+            flat = torch._utils._flatten_dense_tensors(bucket)
+            back = list(zip(bucket, torch._utils._unflatten_dense_tensors(flat, bucket)))
+            self._pending.append((dist.all_reduce(flat, op=op, group=self.pg, async_op=True), None if self._avg else flat, back))
+
+    def finish(self) -> int:
+        """Launch whatever has not been launched (incomplete groups, or everything when ``overlap`` is off), wait for all
+        collectives, finalise, and re-arm.  Returns the number of collectives of this step."""
+        for gi in range(len(self.groups)):
+            if not self._launched[gi]:
+                self._launch(gi)
+        n = len(self._pending)
+        for work, div, back in self._pending:
+            work.wait()
+            if div is not None:
+                div.div_(self.world)
+            for g, src in back:
+                g.copy_(src)
+        self._pending = []
+        self._count = [0] * len(self.groups)
+        self._launched = [False] * len(self.groups)
+        return n
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 def allreduce_loss_sums(sums: torch.Tensor, n_local: int, group=None, uniform_shards: bool = False) -> int:
     """In-place all-reduce of the STFT-loss partial sums {sum (ymag-xmag)^2, sum ymag^2, sum |x-y|^p, -};
     returns the global element count.  With ``uniform_shards`` every rank is known to hold ``n_local`` bins and

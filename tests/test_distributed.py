@@ -46,8 +46,39 @@ def _worker(rank, world, port, q):
         for i, p in enumerate(params):
             p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
         nb = parallel.allreduce_gradients(params, bucket_bytes=4096)
+        # overlapped reducer: group 0 = three views of ONE flat gradient buffer (the ResNet3D case: reduced in place as a
+        # single tensor), group 1 = a large tensor (direct) + small ones (bucketed), group 2 = parameters without gradients
+        torch.manual_seed(7)
+        ga = [torch.nn.Parameter(torch.randn(40, 3)), torch.nn.Parameter(torch.randn(11)), torch.nn.Parameter(torch.randn(2, 2, 2))]
+        gb = [torch.nn.Parameter(torch.randn(600, 600)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(3, 3))]
+        gc = [torch.nn.Parameter(torch.randn(4))]
+        red = parallel.GradientReducer([ga, gb, gc], direct_bytes=1 << 20)
+
+        class ViewsOfFlat(torch.autograd.Function):       # returns gradients that are views of one buffer, like _ResNet3DFn
+            @staticmethod
+            def forward(ctx, *ps):
+                ctx.shapes = [p.shape for p in ps]
+                return sum(p.sum() for p in ps)
+
+            @staticmethod
+            def backward(ctx, g):
+                sizes = [int(np.prod(s)) for s in ctx.shapes]
+                flat = torch.arange(sum(sizes), dtype=torch.float32) * (rank + 1) * g
+                return tuple(v.view(s) for v, s in zip(torch.split(flat, sizes), ctx.shapes))
+
+        expect = []
+        for step in range(2):                              # two steps: the hooks must re-arm
+            for p in ga + gb + gc:
+                p.grad = None
+            loss = ViewsOfFlat.apply(*ga) + sum((p * (rank + 1.0) * (i + 1)).sum() for i, p in enumerate(gb))
+            loss.backward()
+            n_coll = red.finish()
+            flat_ref = torch.arange(sum(p.numel() for p in ga), dtype=torch.float32) * 1.5      # mean of rank factors 1 and 2
+            got = torch.cat([p.grad.reshape(-1) for p in ga])
+            expect.append((float((got - flat_ref).abs().max()), [float(p.grad.flatten()[0]) for p in gb], gc[0].grad is None, n_coll))
+        red.close()
         q.put((rank, n_total, float(sc), float(mag), float(sc_ref), float(mag_ref), float(sc_local), nb,
-               [float(p.grad.flatten()[0]) for p in params], (lo, hi)))
+               [float(p.grad.flatten()[0]) for p in params], (lo, hi), expect))
     finally:
         dist.destroy_process_group()
 
@@ -73,7 +104,11 @@ def test_world2_gloo_loss_and_gradients():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, n_total, sc, mag, sc_ref, mag_ref, sc_local, nb, g0, span in res:
+    for rank, n_total, sc, mag, sc_ref, mag_ref, sc_local, nb, g0, span, expect in res:
+        for err, gb0, gc_none, n_coll in expect:
+            assert err == 0.0                                   # the flat run was averaged exactly, in place
+            np.testing.assert_allclose(gb0, [1.5, 3.0, 4.5])   # mean over ranks of (rank+1)*(i+1)
+            assert gc_none and n_coll == 3                      # one flat run + one direct tensor + one bucket; nothing for group 2
         assert n_total == 64 * 513
         np.testing.assert_allclose(sc, sc_ref, rtol=1e-5)
         np.testing.assert_allclose(mag, mag_ref, rtol=1e-5)
