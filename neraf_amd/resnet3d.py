@@ -67,6 +67,17 @@ class _ResNet3DFn(torch.autograd.Function):
         if n_cells > 0 and (net._dgrid_buf is None or tuple(net._dgrid_buf.shape) != (n_ch, n_cells) or net._dgrid_buf.device != device):
             net._dgrid_buf = torch.empty((n_ch, n_cells), dtype=torch.float32, device=device)
         net._dfeat_buf.copy_(dfeat.reshape(-1))
+        if net.dp_group is not None:
+            # data parallel: every rank holds the same grid and weights, so the encoder's forward is identical everywhere and its
+            # backward is linear in d feat -- averaging these 1024 floats (4 KiB) over the ranks makes every weight gradient below
+            # the already-averaged one, and the 17 M ResNet3D parameters (68 MB) never enter the gradient all-reduce
+            import torch.distributed as dist
+            grp = None if net.dp_group is True else net.dp_group
+            if dist.get_backend(grp) == "nccl":
+                dist.all_reduce(net._dfeat_buf, op=dist.ReduceOp.AVG, group=grp)
+            else:
+                dist.all_reduce(net._dfeat_buf, group=grp)
+                net._dfeat_buf.div_(dist.get_world_size(grp))
         _lib.check(lib.neraf_resnet3d_bwd(h, C.byref(net._desc), packed_t.data_ptr(), _lib.ptr_array(conv_w), _lib.ptr_array(bn),
                                           net._ws.data_ptr(), net._bws.data_ptr(), net._dfeat_buf.data_ptr(), net._grad_ptrs[0],
                                           net._grad_ptrs[1], start, n_cells, n_ch,
@@ -141,6 +152,7 @@ class ResNet3D(nn.Module):
         self._bws = None
         self._packed, self._packed_key = None, None
         self._packed_t = self._grad_flat = self._grad_views = self._grad_ptrs = self._dfeat_buf = self._dgrid_buf = self._feat_buf = None
+        self.dp_group = None         # torch.distributed group (or True = default group): average d feat over ranks in the backward
         self.grid_window = None      # (cell_start, n_cells, n_channels): grid cells whose gradient the backward should produce
         self.grid_grad_sink = None   # callable(dgrid_cells fp32 [n_ch, n_cells]) invoked inside the backward
 
