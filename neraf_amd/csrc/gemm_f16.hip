@@ -653,8 +653,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(GemmParams p, int spl
     if (++stage == NST) stage = 0;
   }
 
-  float* slab = p.splitk_ws + (size_t)split * p.Mpad * p.Npad;
   const int frow = lane & 15, fq = lane >> 4;
+  if (splits == 1) {
+    // short contractions (K <= 512) or enough tiles to fill the chip: finish here, no slab / reducer pass
+    const float alpha = p.alpha_dev ? p.alpha * (*p.alpha_dev) : p.alpha;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = bm * BM + wm * 32 + i * 16 + frow;
+        const int n0 = bn * BN + wn * 32 + j * 16 + fq * 4;
+        if (m >= p.M) continue;
+        float* dst = p.C32 + (size_t)m * p.ldc32 + n0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n0 + r < p.N) dst[r] = acc[i][j][r] * alpha;
+      }
+    return;
+  }
+  float* slab = p.splitk_ws + (size_t)split * p.Mpad * p.Npad;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -681,14 +697,14 @@ int launch_tn(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   int splits = (2 * cus + ntiles - 1) / ntiles;          // ~2 workgroups per CU (64 KiB of LDS each)
   if (splits > nk / 4) splits = nk / 4;
   if (splits > 128) splits = 128;
-  if (splits < 1) splits = 1;
+  if (splits < 1 || nk <= 8 || ntiles >= cus) splits = 1;      // short K loop or a full chip already: direct epilogue
   while (splits > 1 && (size_t)splits * p.Mpad * p.Npad * 4 > p.splitk_ws_bytes) --splits;
   if ((size_t)splits * p.Mpad * p.Npad * 4 > p.splitk_ws_bytes) return neraf_fail(ctx, NERAF_EINVAL, "gemm tn: split-K scratch too small");
   {
     ProfScope prof(ctx, stream, PROF_GEMM64, 2.0 * p.M * p.N * p.K);
     hipLaunchKernelGGL((gemm_bf16_tn_kernel<NST, LOADER, KS>), dim3(ntiles * splits), dim3(256), LDS_BYTES, stream, p, splits);
   }
-  hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(p.Npad / 32, p.Mpad / 32, 1), dim3(256), 0, stream, p, splits);
+  if (splits > 1) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(p.Npad / 32, p.Mpad / 32, 1), dim3(256), 0, stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }

@@ -243,32 +243,48 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
   for (int e = threadIdx.x; e < cin_real * taps; e += 256) { const int c = e / taps, tap = e - c * taps; d[e] = panel[tap * (cin + 1) + c]; }
 }
 
-// stem input gradient for a window of cells: dgrid[c][cell] = sum_taps sum_co dY[(z+2-dz)/2,...][co] W[co][c][tap] / S
 __global__ void set_u64_kernel(unsigned long long* p, unsigned long long v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
 
-__global__ __launch_bounds__(256) void stem_dgrid_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ W, int S, int dout,
+// stem input gradient for a window of cells: dgrid[c][cell] = sum_taps sum_co dY[(z+2-dz)/2,...][co] W[co][c][tap] / S.
+// One wave per cell, lanes over the 64 output channels; the weights are first re-laid as Wt[tap][c][co] so that every load of
+// the inner loop is one coalesced row (W[co][c][tap] would cost 64 cache lines per load instruction).
+__global__ __launch_bounds__(256) void stem_w_relayout_kernel(const float* __restrict__ W, float* __restrict__ Wt) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;          // over [125][8][64]
+  if (idx >= 125 * 8 * 64) return;
+  const int co = idx & 63, c = (idx >> 6) & 7, tap = idx >> 9;
+  Wt[idx] = c < 7 ? W[((size_t)co * 7 + c) * 125 + tap] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void stem_dgrid_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ Wt, int S, int dout,
                                                         const unsigned long long* __restrict__ start_dev, int n, int nch,
                                                         const float* __restrict__ inv_scale, float* __restrict__ dgrid) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n * nch) return;
-  const size_t start = (size_t)start_dev[0];     // device-side so that the captured launch sequence does not depend on the window
-  const int c = idx / n, i = idx % n;
-  const size_t cell = start + i;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const size_t cell = (size_t)start_dev[0] + i;   // device-side so that the captured launch sequence does not depend on the window
   const int x = (int)(cell % S), y = (int)((cell / S) % S), z = (int)(cell / ((size_t)S * S));
-  float acc = 0.f;
+  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int dz = 0; dz < 5; ++dz) {
     const int nz = z + 2 - dz; if (nz < 0 || (nz & 1) || (nz >> 1) >= dout) continue;
     for (int dyy = 0; dyy < 5; ++dyy) {
       const int ny = y + 2 - dyy; if (ny < 0 || (ny & 1) || (ny >> 1) >= dout) continue;
       for (int dx = 0; dx < 5; ++dx) {
         const int nx = x + 2 - dx; if (nx < 0 || (nx & 1) || (nx >> 1) >= dout) continue;
-        const bf16_t* d = dy + ((size_t)((nz >> 1) * dout + (ny >> 1)) * dout + (nx >> 1)) * 64;
-        const int tap = (dz * 5 + dyy) * 5 + dx;
-        for (int co = 0; co < 64; ++co) acc = fmaf((float)d[co], W[((size_t)co * 7 + c) * 125 + tap], acc);
+        const float d = (float)dy[((size_t)((nz >> 1) * dout + (ny >> 1)) * dout + (nx >> 1)) * 64 + lane];
+        const float* w = Wt + (size_t)((dz * 5 + dyy) * 5 + dx) * 512 + lane;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) if (c < nch) acc[c] = fmaf(d, w[c * 64], acc[c]);
       }
     }
   }
-  dgrid[(size_t)c * n + i] = acc * inv_scale[0];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) {
+    if (c >= nch) break;
+    float v = acc[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) dgrid[(size_t)c * n + i] = v * inv_scale[0];
+  }
 }
 
 __global__ void f16_to_bf16_kernel(const half_t* __restrict__ a, size_t n, bf16_t* __restrict__ o) {
@@ -507,7 +523,6 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
   for (int b = A.nblock - 1; b >= 0; --b) {
     const BlockSpec& Bk = A.block[b];
     const int i0 = Bk.conv[0], i1 = Bk.conv[1], i2 = Bk.conv[2];
-    const half_t* x_in = b == 0 ? (const half_t*)(ws + L.act_pool) : (const half_t*)(ws + L.out[b - 1]);
     const half_t* out = (const half_t*)(ws + L.out[b]);
     const half_t* a1 = (const half_t*)(ws + L.a1[b]);
     const half_t* a2 = (const half_t*)(ws + L.a2[b]);
@@ -545,8 +560,9 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     if (int e = bn_backward(c, 0, nullptr, dpost, nullptr, dy0, nullptr)) return e;      // relu mask already applied by the routing
     if (int e = conv_wgrad(c, 0, dy0, (const bf16_t*)(ws + L.x0_bf))) return e;
     if (n_cells > 0) {
-      const int n = n_cells * n_ch;
-      hipLaunchKernelGGL(stem_dgrid_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dy0, conv_w[0], A.S, c0.dout,
+      float* Wt = (float*)(bws + B.wtmp);                     // free again: the stem's wgrad has been unpacked
+      hipLaunchKernelGGL(stem_w_relayout_kernel, dim3((125 * 8 * 64 + 255) / 256), dim3(256), 0, st, conv_w[0], Wt);
+      hipLaunchKernelGGL(stem_dgrid_kernel, dim3((n_cells + 3) / 4), dim3(256), 0, st, dy0, Wt, A.S, c0.dout,
                          reinterpret_cast<const unsigned long long*>(bws + B.scale + 64), n_cells, n_ch, scale + 1, dgrid_cells);
       NERAF_HIP_CHECK(ctx, hipGetLastError());
     }

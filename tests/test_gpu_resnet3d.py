@@ -162,3 +162,44 @@ def test_resnet3d_backward_full_chain(golden):
     np.testing.assert_allclose(dx.double().pow(2).mean().sqrt().item(), g["dx_stats"][2], rtol=0.1)
     pi = g["probe_idx"]
     assert rel_l2(dx[pi[:, 0], pi[:, 1], pi[:, 2], pi[:, 3]], T(g["dx_probe"])) <= 0.75
+
+
+def test_graph_replay_after_interleaved_graph_matches_first_launch():
+    """The forward / backward launch sequences are replayed as hipGraphs keyed by their arguments.  Regression for the one failure
+    that mode showed: train step -> eval forward (a different graph, un-normalised activations with momentum 0) -> train step
+    REPLAYED; with memset nodes inside the graphs the replay produced NaN gradients (un-zeroed BatchNorm accumulators)."""
+    import ctypes as C
+    from neraf_amd import _lib
+    dev = torch.device("cuda:0")
+    net = _model(dev, 1 / 64)
+    bb = net.backbone_net
+    for m in bb.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.momentum = 0.0
+    x = T(synth.uniform("g1.grid64", (1, 7, 64, 64, 64), 0.0, 1.0)).to(dev)
+    w = T(synth.normal("graph.w", (1024,))).to(dev)
+
+    def train_step():
+        net.train()
+        for p in net.parameters():
+            p.grad = None
+        (net(x).flatten() * w).sum().backward()
+        g = bb.layer2[1].conv2.weight.grad
+        assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(bb.bn1.weight.grad).all())
+        return float(g.double().pow(2).mean().sqrt()), float(bb.conv1.weight.grad.double().pow(2).mean().sqrt())
+
+    first = train_step()
+    net.eval()
+    with torch.no_grad():
+        net(x)
+    second = train_step()
+    third = train_step()
+    lib = _lib.load()
+    cap, lau = C.c_int(), C.c_int()
+    enabled = lib.neraf_graph_stats(_lib.ctx(0), C.byref(cap), C.byref(lau))
+    if enabled:
+        assert lau.value > cap.value            # at least one sequence was replayed
+    for a, b in zip(first, second):
+        np.testing.assert_allclose(b, a, rtol=0.2)
+    for a, b in zip(first, third):
+        np.testing.assert_allclose(b, a, rtol=0.2)
