@@ -32,6 +32,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .evaluator import GriffinLim, RAFEvaluator, SoundSpacesEvaluator
 from .field import NeRAFAudioSoundField, _dev_index, _stream_ptr
 from .losses import STFTLoss
 from .resnet3d import ResNet3D_helper
@@ -105,9 +106,13 @@ class NeRAFAudioModel(nn.Module):
             config.N_freq_stft, config.hop_len, config.win_len = 513, 256, 512
             self.max_len = int(config.max_len * config.fs) // config.hop_len
             self.mic_ch = 1
-        else:                                                       # :131-133
+            self.evaluator = RAFEvaluator(fs=config.fs)              # :130
+        else:                                                       # :131-134
             self.max_len = int(config.max_len)
             self.mic_ch = 2
+            self.evaluator = SoundSpacesEvaluator(fs=config.fs)
+        self.istft_transform = GriffinLim(n_fft=(config.N_freq_stft - 1) * 2, win_length=config.win_len, hop_length=config.hop_len,
+                                          power=1)                  # :139
         self.use_grid = config.use_grid
         self.loss_factor = config.loss_factor
         self.criterion_name = config.criterion
@@ -283,6 +288,29 @@ class NeRAFAudioModel(nn.Module):
             stft["grid_density"] = self.grid[3].mean(dim=2).unsqueeze(-1)
         stft["raw_output"] = out                                                        # :725-726
         return stft
+
+    # ---- metrics --------------------------------------------------------------
+    def get_metrics_dict(self, outputs: torch.Tensor, batch: Dict[str, torch.Tensor]):   # :568-581
+        with torch.no_grad():
+            mag_prd = torch.clip(torch.exp(outputs.detach().cpu()) - 1e-3, 0.0, 10000.0)
+            mag_gt = torch.clip(torch.exp(batch["data"].detach().cpu()) - 1e-3, 0.0, 10000.0)
+            return self.evaluator.get_stft_metrics(mag_prd, mag_gt)
+
+    def get_audio_metrics(self, outputs: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], generator=None) -> Dict[str, float]:
+        """The metric half of get_image_metrics_and_images (:738-761): magnitude STFTs -> Griffin-Lim waveforms (on the model's
+        device) -> T60 / EDT / C50 (and RAF's spectral error) against the ground-truth waveform.  batch: 'data' [C,F,T] log-magnitude,
+        'waveform' [C, n].  The image half (colour-mapped spectrogram panels) is viewer code and not built."""
+        with torch.no_grad():
+            stft = outputs["raw_output"].permute(1, 2, 0).detach().cpu()               # [C, F, T]
+            data = batch["data"].detach().cpu()
+            mag_prd = torch.clip(torch.exp(stft) - 1e-3, 0.0, 10000.0)
+            mag_gt = torch.clip(torch.exp(data) - 1e-3, 0.0, 10000.0)
+            dev = self.aabb.device
+            wav_gt = batch["waveform"].detach().cpu().numpy()
+            wav_istft_gt = self.istft_transform(mag_gt.to(dev), generator=generator).cpu().numpy()
+            wav_istft_prd = self.istft_transform(mag_prd.to(dev), generator=generator).cpu().numpy()
+            return self.evaluator.get_full_metrics(mag_prd.numpy(), mag_gt.numpy(), wav_gt, wav_istft_prd, wav_istft_gt,
+                                                   stft.numpy(), data.numpy())
 
     def get_param_groups(self):                                                         # :730-737
         params = list(self.field.parameters())

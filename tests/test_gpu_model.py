@@ -117,6 +117,16 @@ def test_get_outputs_loss_and_eval_branch(models):
     rel = float((out["raw_output"].cpu() - ye).norm() / ye.norm())
     assert rel <= 1e-2, rel
     np.testing.assert_array_equal(out["stft_ch_0"][:, :, 0].numpy(), np.flip(out["raw_output"][:, 0, :].cpu().numpy().T, 0))
+    # metric chain on the predicted RIR: Griffin-Lim on the GPU, T60 / EDT / C50 / RAF spectral error on the host
+    n = 60 * 256
+    tt = np.arange(n) / 48000.0
+    wav = (synth.normal("t.model.wav", (1, n), 1.0, np.float64) * np.exp(-tt / 0.06)).astype(np.float32)
+    mb = {"data": item["data"], "waveform": T(wav)}
+    met = am.get_audio_metrics(out, mb, generator=torch.Generator(device=dev).manual_seed(0))
+    assert set(met) == {"audio_T60", "audio_total_invalids_T60", "audio_stft_error", "audio_EDT", "audio_C50"}
+    assert all(np.isfinite(v) for v in met.values())
+    sm = am.get_metrics_dict(out["raw_output"].permute(1, 2, 0), {"data": item["data"]})
+    assert set(sm) == {"audio_mag", "audio_spectral_loss"} and np.isfinite(float(sm["audio_mag"]))
     am.train()
 
 
