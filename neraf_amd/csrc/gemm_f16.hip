@@ -731,6 +731,10 @@ int launch_gemm_tn_impl(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream)
   return neraf_fail(ctx, NERAF_EINVAL, "gemm tn: unknown loader");
 }
 
+// split-K only pays when the K loop is long: below this many K-steps the slab round trip + reducer launch cost more than the
+// shorter chain saves (NERAF_SPLIT_MIN_K overrides, for measurements)
+static const int kSplitMinK = [] { const char* e = getenv("NERAF_SPLIT_MIN_K"); return e ? atoi(e) : 32; }();
+
 template <int LOADER, int KS, bool BF>
 int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   const int cus = ctx ? ctx->num_cus : 256;
@@ -744,7 +748,7 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   const int ntiles = (p.Mpad / bm) * (p.Npad / bn) * ng;
   // split-K: only with scratch, when the grid under-fills the chip and every slice keeps >= 4 K-steps
   int splits = 1;
-  if (p.splitk_ws && ntiles * 2 <= cus && nk >= 8) {
+  if (p.splitk_ws && ntiles * 2 <= cus && nk >= kSplitMinK) {
     splits = cus / ntiles;
     if (splits > nk / 4) splits = nk / 4;
     if (splits > 128) splits = 128;
