@@ -312,8 +312,6 @@ int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void*
 int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_real, int cout, int k, int stride, int pad, int din,
                                    const void* x_f16, const float* w, const float* gamma, const float* beta, const float* g,
                                    void* y_f16, float* dx, float* dw, float* dgamma, float* dbeta, neraf_stream_t stream);
-/* Test aid: byte offsets of the backward's intermediate bf16 buffers inside bwd_workspace. */
-int neraf_resnet3d_bwd_debug_offsets(const neraf_resnet3d_desc* d, size_t* off);
 
 /* ------------------------------------------------------------------------------------
  * Optimizer step (SURVEY 8f "optimizer fusion"): torch.optim.Adam as nerfstudio's Optimizers apply it to the

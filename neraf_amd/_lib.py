@@ -115,7 +115,6 @@ SIGNATURES = {
     "neraf_resnet3d_bwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, c_fpp, C.c_void_p, C.c_void_p,
                                      C.c_void_p, c_fpp, c_fpp, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "neraf_debug_conv_bn_relu_stage": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 11),
-    "neraf_resnet3d_bwd_debug_offsets": (C.c_int, [C.POINTER(ResnetDesc), C.POINTER(C.c_size_t)]),
     "neraf_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -188,3 +188,17 @@ struct GemmParams {
 };
 
 int launch_gemm_f16(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream);
+
+// ---- grouped weight-gradient launch (gemm_f16.hip) ---------------------------------------------------------------------------
+// All convolution weight gradients of a backward pass are independent of one another and of the dgrad chain: they are described
+// here and computed by TWO launches at the end of the pass (the TN GEMM over every (convolution, tile, K-split), then one
+// reducer that also writes the PyTorch layout [cout][cin_real][taps]) instead of up to three launches per convolution.
+struct WgradItem {
+  const bf16_t* dy;      // [K rows = voxels (padded)][cout] gradient w.r.t. the conv output
+  const bf16_t* x;       // [din^3][cin] bfloat16 shadow of the conv input
+  float* out;            // fp32 [cout][cin_real][taps]
+  int cout, cin, cin_real, ksize, stride, pad, din, dout;
+  int K;                 // voxel rows of dy (multiple of 64)
+};
+int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const half_t* zero_page, float* slab_ws, size_t slab_bytes,
+                         const float* alpha_dev, hipStream_t stream);

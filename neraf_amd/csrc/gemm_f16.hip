@@ -731,6 +731,221 @@ int launch_gemm_tn_impl(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream)
   return neraf_fail(ctx, NERAF_EINVAL, "gemm tn: unknown loader");
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Grouped TN weight-gradient GEMM: the kernel of gemm_bf16_tn_kernel with the geometry taken per workgroup from a descriptor
+// table in the kernel arguments (runtime loader type / filter size), so that every convolution of the network shares one grid.
+struct WgDesc {                       // 64 bytes
+  const bf16_t* dy; const bf16_t* x; float* out;
+  unsigned long long slab_off;        // floats, into the shared slab buffer (unused when splits == 1)
+  int block_begin; int K;
+  unsigned short cout, cin, cin_real, taps, din, tiles_n, splits;
+  unsigned char dl, stride, ksize, loader; signed char pad; unsigned char r0, r1, r2, r3, r4;
+};
+static_assert(sizeof(WgDesc) == 64, "descriptor table must fit the 4 KiB kernel-argument segment");
+constexpr int kMaxWg = 48;
+struct WgTable { int n; int total_blocks; const half_t* zero_page; const float* alpha_dev; float* slab; WgDesc d[kMaxWg]; };
+
+__device__ __forceinline__ int wg_find(const WgTable& t, int bid) {
+  int lo = 0, hi = t.n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.d[mid].block_begin <= bid) lo = mid; else hi = mid - 1; }
+  return lo;
+}
+
+__device__ __forceinline__ size_t wg_out_index(const WgDesc& d, int m, int n) {   // n = tap * cin + c  ->  [cout][cin_real][taps]
+  const int tap = n / d.cin, c = n - tap * d.cin;
+  return ((size_t)m * d.cin_real + c) * d.taps + tap;
+}
+
+__global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
+  constexpr int BM = 64, BN = 64, NST = 4;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int gi = wg_find(t, blockIdx.x);
+  const WgDesc& D = t.d[gi];
+  int bid = blockIdx.x - D.block_begin;
+  const int splits = D.splits, tiles_n = D.tiles_n, tiles_m = D.cout / BM;
+  const int split = bid % splits;
+  bid /= splits;
+  const int bm = bid % tiles_m, bn = bid / tiles_m;
+  const int nk_total = D.K / BK;
+  const int per = (nk_total + splits - 1) / splits;
+  const int k_begin = split * per;
+  const int k_end = (k_begin + per) < nk_total ? (k_begin + per) : nk_total;
+  const int nk = k_end > k_begin ? k_end - k_begin : 0;
+  (void)tiles_n;
+
+  int lrow[2], lcs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + (tid >> 3);
+    lrow[i] = row;
+    lcs[i] = (tid & 7) ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1);
+  }
+  const int cout = D.cout, cin = D.cin, KS = D.ksize, loader = D.loader, din = D.din, stride = D.stride, pad = D.pad;
+  const bf16_t* Ab = D.dy + bm * BM;
+  const bf16_t* Bb = D.x;
+  int tap_dz = 0, tap_dy = 0, tap_dx = 0, cb = 0;
+  if (loader == 1) {
+    const int n0 = bn * BN;
+    const int tap = n0 / cin; cb = n0 - tap * cin;
+    tap_dz = tap / (KS * KS); tap_dy = (tap / KS) % KS; tap_dx = tap % KS;
+  }
+  const int dl = D.dl, dmask = (1 << dl) - 1;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(t.zero_page);
+
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  auto issue = [&](int kt, int stage) {
+    char* sa = smem + stage * STAGE_BYTES + wave * 1024;
+    char* sb = sa + BM * 128;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = kt * BK + lrow[i];
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ab + (size_t)m * cout + lcs[i] * 8), (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = kt * BK + lrow[i];
+      const bf16_t* src;
+      if (loader == 0) {
+        src = Bb + (size_t)m * cin + bn * BN + lcs[i] * 8;
+      } else {
+        const int x = m & dmask, y = (m >> dl) & dmask, z = m >> (2 * dl);
+        int dz = tap_dz, dy = tap_dy, dx = tap_dx;
+        if (loader == 2) {
+          const int tap = bn * 8 + lcs[i];
+          dz = tap / (KS * KS); dy = (tap / KS) % KS; dx = tap % KS;
+          if (tap >= KS * KS * KS) dz = 1 << 20;
+        }
+        const int iz = z * stride - pad + dz, iy = y * stride - pad + dy, ix = x * stride - pad + dx;
+        const bool ok = (unsigned)iz < (unsigned)din && (unsigned)iy < (unsigned)din && (unsigned)ix < (unsigned)din;
+        const size_t vox = ((size_t)(iz * din + iy) * din + ix);
+        src = ok ? (loader == 2 ? Bb + vox * 8 : Bb + vox * cin + cb + lcs[i] * 8) : zero;
+      }
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sb + i * 4096), 16, 0, 0);
+    }
+  };
+
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int swz = (((q >> 1) & 1) | ((g & 1) << 1)) << 1;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int ca = wm * 32 + f * 16 + 4 * pp, cbb = wn * 32 + f * 16 + 4 * pp;
+    a_off[f] = (8 * g + q) * 128 + ((((ca >> 3)) ^ swz) << 4) + ((pp & 1) << 3);
+    b_off[f] = (8 * g + q) * 128 + ((((cbb >> 3)) ^ swz) << 4) + ((pp & 1) << 3);
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < nk) issue(k_begin + s0, s0);
+  typedef __attribute__((address_space(3))) bf16x4* lds_v4_t;
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int after = nk - 1 - kt;
+    if (after >= 2) wait_vmcnt<8>();
+    else if (after >= 1) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NST - 1 < nk) {
+      int st2 = stage + NST - 1; if (st2 >= NST) st2 -= NST;
+      issue(k_begin + kt + NST - 1, st2);
+    }
+    char* sa = smem + stage * STAGE_BYTES;
+    char* sb = sa + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sa + a_off[f] + ks * 4096));
+        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sa + a_off[f] + ks * 4096 + 512));
+        const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sb + b_off[f] + ks * 4096));
+        const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sb + b_off[f] + ks * 4096 + 512));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { fa[f][e] = a0[e]; fa[f][4 + e] = a1[e]; fb[f][e] = b0[e]; fb[f][4 + e] = b1[e]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    if (++stage == NST) stage = 0;
+  }
+  const int frow = lane & 15, fq = lane >> 4;
+  const int N = D.taps * cin, Npad = tiles_n * BN;
+  if (splits == 1) {
+    const float alpha = t.alpha_dev ? *t.alpha_dev : 1.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = bm * BM + wm * 32 + i * 16 + frow;
+        const int n0 = bn * BN + wn * 32 + j * 16 + fq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + r;
+          if (n < N && (n % cin) < D.cin_real) D.out[wg_out_index(D, m, n)] = acc[i][j][r] * alpha;
+        }
+      }
+    return;
+  }
+  float* slab = t.slab + D.slab_off + (size_t)split * cout * Npad;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = bm * BM + wm * 32 + i * 16 + frow;
+      const int n0 = bn * BN + wn * 32 + j * 16 + fq * 4;
+      *reinterpret_cast<f32x4*>(slab + (size_t)m * Npad + n0) = acc[i][j];
+    }
+}
+
+// one workgroup per 32x32 output tile of every split item: sums the slabs, scales, writes the PyTorch layout
+struct WgRedTable { int n; const float* alpha_dev; const float* slab; int tile_begin[kMaxWg + 1]; unsigned char item[kMaxWg]; };
+
+__global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(WgTable t, WgRedTable r) {
+  int lo = 0, hi = r.n - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (r.tile_begin[mid] <= bid) lo = mid; else hi = mid - 1; }
+  const WgDesc& D = t.d[r.item[lo]];
+  const int tile = bid - r.tile_begin[lo];
+  const int Npad = D.tiles_n * 64, tn = Npad / 32;
+  const int m0 = (tile / tn) * 32, n0 = (tile % tn) * 32;
+  const int tt = threadIdx.x, row = tt >> 3, c4 = (tt & 7) * 4;
+  const int m = m0 + row, n = n0 + c4;
+  const size_t slab = (size_t)D.cout * Npad;
+  const float* src = r.slab + D.slab_off + (size_t)m * Npad + n;
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  const int splits = D.splits;
+  for (; s + 8 <= splits; s += 8) {
+    f32x4 a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + u) * slab);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += a[u];
+  }
+  for (; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * slab);
+  const float alpha = r.alpha_dev ? *r.alpha_dev : 1.f;
+  const int N = D.taps * D.cin;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int nn = n + rr;
+    if (nn < N && (nn % D.cin) < D.cin_real) D.out[wg_out_index(D, m, nn)] = v[rr] * alpha;
+  }
+}
+
 // split-K only pays when the K loop is long: below this many K-steps the slab round trip + reducer launch cost more than the
 // shorter chain saves (NERAF_SPLIT_MIN_K overrides, for measurements)
 static const int kSplitMinK = [] { const char* e = getenv("NERAF_SPLIT_MIN_K"); return e ? atoi(e) : 32; }();
@@ -761,6 +976,73 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const half_t* zero_page, float* slab_ws, size_t slab_bytes,
+                         const float* alpha_dev, hipStream_t stream) {
+  if (n <= 0 || n > kMaxWg || !items || !zero_page) return neraf_fail(ctx, NERAF_EINVAL, "wgrad_grouped: bad arguments");
+  constexpr int LDS_BYTES = 4 * 128 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set = true;
+  }
+  const int cus = ctx ? ctx->num_cus : 256;
+  WgTable t{};
+  WgRedTable r{};
+  t.n = n; t.zero_page = zero_page; t.alpha_dev = alpha_dev; t.slab = slab_ws;
+  r.alpha_dev = alpha_dev; r.slab = slab_ws;
+  // K-steps of work per item -> splits so that no workgroup runs more than ~target K-steps (the whole grid shares the chip)
+  double total_steps = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const WgradItem& it = items[i];
+    const int taps = it.ksize * it.ksize * it.ksize;
+    total_steps += (double)(it.cout / 64) * (round_up(taps * it.cin, 64) / 64) * (it.K / 64);
+  }
+  int target = (int)(total_steps / (cus * 8.0)) + 1;       // ~8 rounds of 2 workgroups per CU
+  if (target < 16) target = 16;
+  size_t slab_off = 0; int blocks = 0, red_tiles = 0, nred = 0;
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const WgradItem& it = items[i];
+    const int taps = it.ksize * it.ksize * it.ksize;
+    if ((it.cout % 64) || (it.K % 64) || it.dout <= 0 || (it.dout & (it.dout - 1)) || (it.cin % 64 && it.cin != 8) || taps * it.cin > 65535)
+      return neraf_fail(ctx, NERAF_EINVAL, "wgrad_grouped: cout % 64, K % 64, power-of-two output edge, cin % 64 (or the 8-channel stem)");
+    WgDesc& d = t.d[i];
+    d.dy = it.dy; d.x = it.x; d.out = it.out; d.K = it.K;
+    d.cout = (unsigned short)it.cout; d.cin = (unsigned short)it.cin; d.cin_real = (unsigned short)it.cin_real; d.taps = (unsigned short)taps;
+    d.din = (unsigned short)it.din; d.stride = (unsigned char)it.stride; d.ksize = (unsigned char)it.ksize; d.pad = (signed char)it.pad;
+    d.dl = (unsigned char)(31 - __builtin_clz((unsigned)it.dout));
+    d.loader = (it.ksize == 1 && it.stride == 1) ? 0 : (it.cin == 8 ? 2 : 1);
+    const int tiles_n = round_up(taps * it.cin, 64) / 64, tiles_m = it.cout / 64, nk = it.K / 64;
+    d.tiles_n = (unsigned short)tiles_n;
+    int splits = (nk + target - 1) / target;
+    if (splits > nk / 4) splits = nk / 4;
+    if (splits < 1) splits = 1;
+    if (splits > 128) splits = 128;
+    d.splits = (unsigned short)splits;
+    d.block_begin = blocks;
+    blocks += tiles_m * tiles_n * splits;
+    d.slab_off = slab_off;
+    if (splits > 1) {
+      slab_off += (size_t)splits * it.cout * tiles_n * 64;
+      r.item[nred] = (unsigned char)i; r.tile_begin[nred] = red_tiles; ++nred;
+      red_tiles += (it.cout / 32) * (tiles_n * 2);
+    }
+    flops += 2.0 * it.cout * taps * it.cin_real * (double)it.K;
+  }
+  if (slab_off * 4 > slab_bytes) return neraf_fail(ctx, NERAF_EINVAL, "wgrad_grouped: split-K scratch too small");
+  t.total_blocks = blocks;
+  r.n = nred; r.tile_begin[nred] = red_tiles;
+  {
+    ProfScope prof(ctx, stream, PROF_GEMM64, flops);
+    hipLaunchKernelGGL(wgrad_grouped_tn_kernel, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
+  }
+  if (nred > 0) hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(red_tiles), dim3(256), 0, stream, t, r);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
 
 int launch_gemm_f16(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   if (p.tn) return launch_gemm_tn_impl(ctx, p, stream);

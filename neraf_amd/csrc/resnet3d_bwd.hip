@@ -230,19 +230,6 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(BnSrc s, int din, int 
     if (best[j] > 0.f && (float)gv[j] != 0.f) atomicAdd(dpost + arg[j] * 64 + c0 + j, (float)gv[j]);
 }
 
-// dW temp [cout][tap*cin + c] (fp32) -> PyTorch layout [cout][cin_real][taps]: a workgroup transposes one output channel's
-// [taps][cin] panel through LDS (both sides contiguous)
-__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ tmp, int cin, int cin_real, int taps,
-                                                          float* __restrict__ dst) {
-  extern __shared__ float panel[];          // [taps][cin + 1]
-  const int co = blockIdx.x;
-  const float* src = tmp + (size_t)co * taps * cin;
-  for (int e = threadIdx.x; e < taps * cin; e += 256) { const int tap = e / cin, c = e - tap * cin; panel[tap * (cin + 1) + c] = src[e]; }
-  __syncthreads();
-  float* d = dst + (size_t)co * cin_real * taps;
-  for (int e = threadIdx.x; e < cin_real * taps; e += 256) { const int c = e / taps, tap = e - c * taps; d[e] = panel[tap * (cin + 1) + c]; }
-}
-
 __global__ void set_u64_kernel(unsigned long long* p, unsigned long long v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
 
 // stem input gradient for a window of cells: dgrid[c][cell] = sum_taps sum_co dY[(z+2-dz)/2,...][co] W[co][c][tap] / S.
@@ -326,8 +313,8 @@ struct BwdLayout {
   size_t sums[64];            // per conv/BN: [rep][2][cpad] fp32 (replica stride kStatStride)
   size_t sums_begin, sums_bytes;
   size_t g[2];                // ping-pong gradient w.r.t. block outputs, fp16, largest activation
-  size_t dy[3];               // dY of the three convs of a block (+ ds shares slot 2 after use) ; sized for the largest
-  size_t dyds, gm, da;        // downsample dY, masked g (identity residual), d(a1|a2) scratch
+  size_t dy[64];              // dY of every convolution [rows_pad(dout)][cout] bf16: all alive until the grouped weight-gradient launch
+  size_t gm, da;              // masked g (identity residual), d(a1|a2) scratch
   size_t dpost;               // fp32 [din1^3][64] stem
   size_t wtmp;                // fp32 [cout][tap*cin + c] weight gradients before the layout change (k > 1 convs)
   size_t splitk; size_t splitk_bytes;
@@ -373,12 +360,11 @@ void make_bwd_layout(const Arch& A, BwdLayout* L) {
       max_act = std::max(max_act, rows_out * c.cout * 2);
       max_act = std::max(max_act, rows_in * c.cin * 2);
     }
-    if (c.k > 1) max_wtmp = std::max(max_wtmp, (size_t)c.cout * round_up(c.k * c.k * c.k * c.cin, 64) * 4);
+    max_wtmp = std::max(max_wtmp, (size_t)125 * 8 * 64 * 4);      // Wt[tap][c][co] of the stem (stem_dgrid_kernel)
   }
-  const size_t stem_act = rows_pad(A.conv[0].dout) * 64 * 2;
   for (int i = 0; i < 2; ++i) L->g[i] = take(max_act);
-  for (int i = 0; i < 3; ++i) L->dy[i] = take(std::max(max_act, stem_act));
-  L->dyds = take(max_act); L->gm = take(max_act); L->da = take(max_act);
+  for (int i = 0; i < A.nconv; ++i) L->dy[i] = take(rows_pad(A.conv[i].dout) * A.conv[i].cout * 2);
+  L->gm = take(max_act); L->da = take(max_act);
   L->dpost = take(cube(A.conv[0].dout) * 64 * 4);
   L->wtmp = take(max_wtmp);
   L->splitk_bytes = (size_t)64 << 20;
@@ -410,33 +396,20 @@ int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const
   return NERAF_OK;
 }
 
-// dW of conv ci from dY [Mpad][cout] (bf16) and the bfloat16 shadow of the conv's input activation x_in [din^3][cin]
-int conv_wgrad(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* x_in) {
+inline WgradItem wgrad_item(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* x_in) {
   const ConvSpec& cs = c.A->conv[ci];
-  const int Mpad = (int)rows_pad(cs.dout);
-  const int taps = cs.k * cs.k * cs.k;
-  GemmParams g{};
-  g.bf16 = 1; g.tn = 1;
-  g.A = (const half_t*)dy; g.lda = cs.cout;
-  g.B = (const half_t*)x_in; g.ldb = cs.cin;
-  g.M = cs.cout; g.Mpad = cs.cout; g.N = taps * cs.cin; g.Npad = round_up(taps * cs.cin, 64); g.K = Mpad;
-  g.alpha = 1.f; g.alpha_dev = c.inv_scale;
-  const bool direct = cs.k == 1;
-  g.C32 = direct ? c.w_grads[ci] : (float*)(c.bws + c.B->wtmp); g.ldc32 = taps * cs.cin;
-  g.splitk_ws = (float*)(c.bws + c.B->splitk); g.splitk_ws_bytes = c.B->splitk_bytes;
-  if (!(cs.k == 1 && cs.stride == 1)) {
-    g.conv.loader = cs.cin == 8 ? 2 : 1;
-    g.conv.din = cs.din; g.conv.dout = cs.dout; g.conv.stride = cs.stride; g.conv.pad = cs.pad; g.conv.ksize = cs.k; g.conv.cin = cs.cin;
-    g.conv.zero_page = (const half_t*)(c.ws + c.L->zero_page);
-  }
-  if (int e = launch_gemm_f16(c.ctx, g, c.st)) return e;
-  if (!direct) {
-    const size_t lds = (size_t)taps * (cs.cin + 1) * sizeof(float);
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(cs.cout), dim3(256), lds, c.st, (const float*)(c.bws + c.B->wtmp), cs.cin, cs.cin_real,
-                       taps, c.w_grads[ci]);
-    NERAF_HIP_CHECK(c.ctx, hipGetLastError());
-  }
-  return NERAF_OK;
+  WgradItem it{};
+  it.dy = dy; it.x = x_in; it.out = c.w_grads[ci];
+  it.cout = cs.cout; it.cin = cs.cin; it.cin_real = cs.cin_real; it.ksize = cs.k; it.stride = cs.stride; it.pad = cs.pad;
+  it.din = cs.din; it.dout = cs.dout; it.K = (int)rows_pad(cs.dout);
+  return it;
+}
+
+// dW of ONE conv (the stage test entry); the network's backward collects all items and launches them together
+int conv_wgrad(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* x_in) {
+  const WgradItem it = wgrad_item(c, ci, dy, x_in);
+  return launch_wgrad_grouped(c.ctx, &it, 1, (const half_t*)(c.ws + c.L->zero_page), (float*)(c.bws + c.B->splitk), c.B->splitk_bytes,
+                              c.inv_scale, c.st);
 }
 
 // dX [din^3][cin] = conv_transpose(dY [dout^3][cout], W) (+ add16)
@@ -518,8 +491,8 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     const size_t n = (size_t)Mpad * 1024;
     hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dfeat, scale, Mlast, Mpad, 1024, g);
   }
-  bf16_t* dy0 = (bf16_t*)(bws + B.dy[0]); bf16_t* dy1 = (bf16_t*)(bws + B.dy[1]); bf16_t* dy2 = (bf16_t*)(bws + B.dy[2]);
-  bf16_t* dyds = (bf16_t*)(bws + B.dyds); bf16_t* gm = (bf16_t*)(bws + B.gm); bf16_t* da = (bf16_t*)(bws + B.da);
+  bf16_t* gm = (bf16_t*)(bws + B.gm); bf16_t* da = (bf16_t*)(bws + B.da);
+  WgradItem items[64]; int n_items = 0;     // every weight gradient is computed by ONE grouped launch at the end
   for (int b = A.nblock - 1; b >= 0; --b) {
     const BlockSpec& Bk = A.block[b];
     const int i0 = Bk.conv[0], i1 = Bk.conv[1], i2 = Bk.conv[2];
@@ -529,18 +502,20 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     const bf16_t* x_in_bf = b == 0 ? (const bf16_t*)(ws + L.act_pool_bf) : (const bf16_t*)(ws + L.out_bf[b - 1]);
     const bf16_t* a1_bf = (const bf16_t*)(ws + L.a1_bf[b]);
     const bf16_t* a2_bf = (const bf16_t*)(ws + L.a2_bf[b]);
+    bf16_t* dy0 = (bf16_t*)(bws + B.dy[i0]); bf16_t* dy1 = (bf16_t*)(bws + B.dy[i1]); bf16_t* dy2 = (bf16_t*)(bws + B.dy[i2]);
+    bf16_t* dyds = Bk.ds >= 0 ? (bf16_t*)(bws + B.dy[Bk.ds]) : nullptr;
     // out = relu(bn3(c3) + residual): dy = g * (out > 0) feeds bn3 and the residual branch
     if (int e = bn_backward(c, i2, g, nullptr, out, dy2, Bk.ds < 0 ? gm : nullptr)) return e;
-    if (int e = conv_wgrad(c, i2, dy2, a2_bf)) return e;
+    items[n_items++] = wgrad_item(c, i2, dy2, a2_bf);
     if (int e = conv_dgrad(c, i2, dy2, nullptr, da)) return e;                 // d a2
     if (int e = bn_backward(c, i1, da, nullptr, a2, dy1, nullptr)) return e;
-    if (int e = conv_wgrad(c, i1, dy1, a1_bf)) return e;
+    items[n_items++] = wgrad_item(c, i1, dy1, a1_bf);
     if (int e = conv_dgrad(c, i1, dy1, nullptr, da)) return e;                 // d a1
     if (int e = bn_backward(c, i0, da, nullptr, a1, dy0, nullptr)) return e;
-    if (int e = conv_wgrad(c, i0, dy0, x_in_bf)) return e;
+    items[n_items++] = wgrad_item(c, i0, dy0, x_in_bf);
     if (Bk.ds >= 0) {
       if (int e = bn_backward(c, Bk.ds, g, nullptr, out, dyds, nullptr)) return e;
-      if (int e = conv_wgrad(c, Bk.ds, dyds, x_in_bf)) return e;
+      items[n_items++] = wgrad_item(c, Bk.ds, dyds, x_in_bf);
       if (int e = conv_dgrad(c, Bk.ds, dyds, nullptr, da)) return e;           // residual-branch gradient w.r.t. x_in
       if (int e = conv_dgrad(c, i0, dy0, da, g_next)) return e;
     } else {
@@ -557,17 +532,19 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     const size_t total = cube(A.pooled) * 8;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, c0.dout, A.pooled, cube(c0.dout), g, dpost);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
+    bf16_t* dy0 = (bf16_t*)(bws + B.dy[0]);
     if (int e = bn_backward(c, 0, nullptr, dpost, nullptr, dy0, nullptr)) return e;      // relu mask already applied by the routing
-    if (int e = conv_wgrad(c, 0, dy0, (const bf16_t*)(ws + L.x0_bf))) return e;
+    items[n_items++] = wgrad_item(c, 0, dy0, (const bf16_t*)(ws + L.x0_bf));
     if (n_cells > 0) {
-      float* Wt = (float*)(bws + B.wtmp);                     // free again: the stem's wgrad has been unpacked
+      float* Wt = (float*)(bws + B.wtmp);
       hipLaunchKernelGGL(stem_w_relayout_kernel, dim3((125 * 8 * 64 + 255) / 256), dim3(256), 0, st, conv_w[0], Wt);
       hipLaunchKernelGGL(stem_dgrid_kernel, dim3((n_cells + 3) / 4), dim3(256), 0, st, dy0, Wt, A.S, c0.dout,
                          reinterpret_cast<const unsigned long long*>(bws + B.scale + 64), n_cells, n_ch, scale + 1, dgrid_cells);
       NERAF_HIP_CHECK(ctx, hipGetLastError());
     }
   }
-  return NERAF_OK;
+  // all 43 weight gradients: one TN GEMM grid over every (convolution, tile, K-split) + one reducer
+  return launch_wgrad_grouped(ctx, items, n_items, (const half_t*)(ws + L.zero_page), (float*)(bws + B.splitk), B.splitk_bytes, scale + 1, st);
 }
 
 extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed_t, const float* const* conv_w,
@@ -593,15 +570,6 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
   return neraf_run_graphed(ctx, st, k.h, [&](hipStream_t s2) {
     return resnet3d_bwd_body(ctx, A, L, B, packed_t, conv_w, bn, (char*)workspace, bws, dfeat, w_grads, bn_grads, n_cells, n_ch, dgrid_cells, s2);
   });
-}
-
-extern "C" int neraf_resnet3d_bwd_debug_offsets(const neraf_resnet3d_desc* d, size_t* off /* g0,g1,dy0,dy1,dy2,dyds,gm,da,wtmp,splitk */) {
-  Arch A; BwdLayout B;
-  if (make_arch(d, &A) || !off) return NERAF_EINVAL;
-  make_bwd_layout(A, &B);
-  off[0] = B.g[0]; off[1] = B.g[1]; off[2] = B.dy[0]; off[3] = B.dy[1]; off[4] = B.dy[2]; off[5] = B.dyds; off[6] = B.gm; off[7] = B.da;
-  off[8] = B.wtmp; off[9] = B.splitk;
-  return NERAF_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
