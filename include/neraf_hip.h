@@ -80,14 +80,14 @@ int neraf_gemm_bf16(neraf_ctx* ctx, const void* A, int lda, const void* B, int l
                     int Mpad, int Npad, float alpha, const float* bias, int act,
                     void* C16, int ldc16, void* C16T, int ldc16t, float* C32, int ldc32,
                     neraf_stream_t stream);
-/* "TN" form, bfloat16, both operands K-major: C32[m][n] = alpha * sum_k A[k][m] * B[k][n]  (A [K][lda], B [K][ldb];
- * Mpad, Npad, K multiples of 64).  This is the contraction behind the Conv3d weight gradients (cuDNN wgrad in the
- * reference, NeRAF_resnet3d.py:81-86 under autograd): the operand tiles are read from LDS with gfx950's
- * hardware-transposed ds_read_b64_tr_b16, so neither dY nor the activations are ever transposed or im2col'ed in
- * HBM.  splitk_ws: fp32 scratch of at least Mpad*Npad*4 bytes (more lets K be split over the chip). */
-int neraf_gemm_bf16_tn(neraf_ctx* ctx, const void* A, int lda, const void* B, int ldb, int M, int N, int K, int Mpad,
-                       int Npad, float alpha, float* C32, int ldc32, void* splitk_ws, size_t splitk_bytes,
-                       neraf_stream_t stream);
+/* "TN" form, bfloat16, both operands K-major and dense: C32[m][n] = sum_k A[k][m] * B[k][n]  (A [K][M], B [K][N], C32 [M][N];
+ * M, N, K multiples of 64).  This is the contraction behind the Conv3d weight gradients (cuDNN wgrad in the reference,
+ * NeRAF_resnet3d.py:81-86 under autograd): the operand tiles are read from LDS with gfx950's hardware-transposed
+ * ds_read_b64_tr_b16, so neither dY nor the activations are ever transposed or im2col'ed in HBM.  Inside the ResNet3D
+ * backward all 43 weight gradients run as ONE grid of this kernel; this entry is its plain single-matrix case.
+ * splitk_ws: fp32 scratch, at least 256 + 4*M*N bytes (more lets K be split over the chip). */
+int neraf_gemm_bf16_tn(neraf_ctx* ctx, const void* A, const void* B, int M, int N, int K, float* C32, void* splitk_ws,
+                       size_t splitk_bytes, neraf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * NAcF -- neural acoustic field MLP (NeRAFAudioSoundField, NeRAF_field.py:37-65) with the

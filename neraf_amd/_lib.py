@@ -46,8 +46,8 @@ SIGNATURES = {
     "neraf_gemm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
-    "neraf_gemm_bf16_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "neraf_gemm_bf16_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
     "neraf_fused_adam_chunk": (C.c_int, []),
     "neraf_fused_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                    C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

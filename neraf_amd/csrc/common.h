@@ -108,6 +108,7 @@ int neraf_run_graphed(neraf_ctx* ctx, hipStream_t user, uint64_t key, Body body)
     if (ctx->graphs.size() >= 12) {                  // evict the least recently used
       size_t lru = 0;
       for (size_t i = 1; i < ctx->graphs.size(); ++i) if (ctx->graphs[i].last_use < ctx->graphs[lru].last_use) lru = i;
+      (void)hipStreamSynchronize(user);              // rare path: the evicted graph's last replay must have drained
       (void)hipGraphExecDestroy(ctx->graphs[lru].exec);
       ctx->graphs.erase(ctx->graphs.begin() + lru);
     }
@@ -176,11 +177,6 @@ struct GemmParams {
   float* splitk_ws; size_t splitk_ws_bytes;   // optional fp32 scratch enabling split-K for under-filled grids
   int tile_n;                        // 0 = auto; 64 forces the 128x64 tile (Cout = 64 layers)
   int bf16;                          // 1: every 16-bit operand/result (A, B, lmask, add16, C16, C16T) is bfloat16 (gradient chains)
-  // tn = 1 (bf16 only): "TN" form for convolution weight gradients -- BOTH operands are stored K-major, A as [K][lda] (the
-  // M index runs along a row) and B as [K rows selected by conv][ldb], read from LDS with the hardware-transposed
-  // ds_read_b64_tr_b16; the result goes through the split-K slab + reducer (C32 only).  conv.loader here applies to B:
-  // 0 plain rows, 1 = the voxel row m shifted by the filter tap of the N-tile (cin % 64 == 0), 2 = eight taps per N-tile (cin 8).
-  int tn;
   // grouped launch (plain loader, fp32 results only): ngroups > 1 runs ngroups GEMMs of identical padded shape (Mpad, Npad, K,
   // lda, ldb) in one grid; group g takes A/B/C32/M/N/ldc32 from grp[g].  Used for the small-output weight gradients.
   int ngroups;

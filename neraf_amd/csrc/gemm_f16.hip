@@ -513,228 +513,8 @@ int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
 //   same 4-stage ring, and both MFMA operands are read with ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane group,
 //   delivered column-major).  The 32-byte segment index of a row is XORed with ((r>>1)&1) | ((r>>3)&1)<<1 on the DMA's
 //   SOURCE side, which makes every transposed read bank-conflict free (8 rows x 32 B of a 32-lane half cover all 64 banks).
-// Output: fp32 partial slab [split][Mpad][Npad]; splitk_reduce_kernel finishes (alpha, masks, C32).
-template <int NST, int LOADER, int KS>
-__global__ __launch_bounds__(256) void gemm_bf16_tn_kernel(GemmParams p, int splits) {
-  constexpr int BM = 64, BN = 64;
-  constexpr int STAGE_BYTES = (BM + BN) * 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const int tiles_m = p.Mpad / BM, tiles_n = p.Npad / BN;
-  const int ntiles = tiles_m * tiles_n;
-  const int nblocks = ntiles * splits;
-  int bid = blockIdx.x;
-  {
-    const int q = nblocks >> 3, r = nblocks & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int split = bid % splits;
-  bid /= splits;
-  const int bm = bid % tiles_m, bn = bid / tiles_m;      // the m-tiles of one n-tile are neighbours: they share the B rows
-
-  const int nk_total = p.K / BK;
-  const int per = (nk_total + splits - 1) / splits;
-  const int k_begin = split * per;
-  const int k_end = (k_begin + per) < nk_total ? (k_begin + per) : nk_total;
-  const int nk = k_end > k_begin ? k_end - k_begin : 0;
-
-  // per-thread chunk coordinates: LDS row (i*32 + tid/8), physical chunk tid&7 holds logical chunk lc
-  int lrow[2], lcs[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = i * 32 + (tid >> 3);
-    lrow[i] = row;
-    lcs[i] = (tid & 7) ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1);
-  }
-  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + bm * BM;
-  const bf16_t* Bb = reinterpret_cast<const bf16_t*>(p.B);
-  // B-tile geometry
-  int tap_dz = 0, tap_dy = 0, tap_dx = 0, cb = 0;
-  if (LOADER == 1) {
-    const int n0 = bn * BN;
-    const int tap = n0 / p.conv.cin; cb = n0 - tap * p.conv.cin;
-    tap_dz = tap / (KS * KS); tap_dy = (tap / KS) % KS; tap_dx = tap % KS;
-  }
-  const int dl = p.conv.dout > 0 ? 31 - __builtin_clz(p.conv.dout) : 0;     // dout is a power of two (checked by the launcher)
-  const int dmask = p.conv.dout - 1;
-
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-  auto issue = [&](int kt, int stage) {
-    char* sa = smem + stage * STAGE_BYTES + wave * 1024;
-    char* sb = sa + BM * 128;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = kt * BK + lrow[i];
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ab + (size_t)m * p.lda + lcs[i] * 8), (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = kt * BK + lrow[i];
-      const bf16_t* src;
-      if (LOADER == 0) {
-        src = Bb + (size_t)m * p.ldb + bn * BN + lcs[i] * 8;
-      } else {
-        const int x = m & dmask, y = (m >> dl) & dmask, z = m >> (2 * dl);
-        int dz = tap_dz, dy = tap_dy, dx = tap_dx;
-        if (LOADER == 2) {
-          const int tap = bn * 8 + lcs[i];
-          dz = tap / (KS * KS); dy = (tap / KS) % KS; dx = tap % KS;
-          if (tap >= KS * KS * KS) dz = 1 << 20;       // padding taps -> out of range -> zero page
-        }
-        const int iz = z * p.conv.stride - p.conv.pad + dz, iy = y * p.conv.stride - p.conv.pad + dy, ix = x * p.conv.stride - p.conv.pad + dx;
-        const int din = p.conv.din;
-        const bool ok = (unsigned)iz < (unsigned)din && (unsigned)iy < (unsigned)din && (unsigned)ix < (unsigned)din;
-        const size_t vox = ((size_t)(iz * din + iy) * din + ix);
-        src = ok ? (LOADER == 2 ? Bb + vox * 8 : Bb + vox * p.conv.cin + cb + lcs[i] * 8) : reinterpret_cast<const bf16_t*>(p.conv.zero_page);
-      }
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sb + i * 4096), 16, 0, 0);
-    }
-  };
-
-  // transposed-read addressing: group g = lane>>4 reads k rows 8g + 4h + q, lane (q, pp) supplies columns c0 + 4pp .. +3
-  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
-  const int swz = (((q >> 1) & 1) | ((g & 1) << 1)) << 1;
-  int a_off[2], b_off[2];          // byte offset of this lane's address inside a stage's A / B image, fragment i / j, (ks, h) = (0, 0)
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int ca = wm * 32 + f * 16 + 4 * pp, cbb = wn * 32 + f * 16 + 4 * pp;
-    a_off[f] = (8 * g + q) * 128 + ((((ca >> 3)) ^ swz) << 4) + ((pp & 1) << 3);
-    b_off[f] = (8 * g + q) * 128 + ((((cbb >> 3)) ^ swz) << 4) + ((pp & 1) << 3);
-  }
-
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int s0 = 0; s0 < NST - 1; ++s0)
-    if (s0 < nk) issue(k_begin + s0, s0);
-
-  typedef __attribute__((address_space(3))) bf16x4* lds_v4_t;
-  int stage = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int after = nk - 1 - kt;
-    if (NST >= 4 && after >= 2) wait_vmcnt<8>();
-    else if (NST >= 3 && after >= 1) wait_vmcnt<4>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + NST - 1 < nk) {
-      int st2 = stage + NST - 1; if (st2 >= NST) st2 -= NST;
-      issue(k_begin + kt + NST - 1, st2);
-    }
-    char* sa = smem + stage * STAGE_BYTES;
-    char* sb = sa + BM * 128;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[2], fb[2];
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sa + a_off[f] + ks * 4096));
-        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sa + a_off[f] + ks * 4096 + 512));
-        const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sb + b_off[f] + ks * 4096));
-        const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sb + b_off[f] + ks * 4096 + 512));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { fa[f][e] = a0[e]; fa[f][4 + e] = a1[e]; fb[f][e] = b0[e]; fb[f][4 + e] = b1[e]; }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]: 4 regs along n
-    }
-    if (++stage == NST) stage = 0;
-  }
-
-  const int frow = lane & 15, fq = lane >> 4;
-  if (splits == 1) {
-    // short contractions (K <= 512) or enough tiles to fill the chip: finish here, no slab / reducer pass
-    const float alpha = p.alpha_dev ? p.alpha * (*p.alpha_dev) : p.alpha;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int m = bm * BM + wm * 32 + i * 16 + frow;
-        const int n0 = bn * BN + wn * 32 + j * 16 + fq * 4;
-        if (m >= p.M) continue;
-        float* dst = p.C32 + (size_t)m * p.ldc32 + n0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (n0 + r < p.N) dst[r] = acc[i][j][r] * alpha;
-      }
-    return;
-  }
-  float* slab = p.splitk_ws + (size_t)split * p.Mpad * p.Npad;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = bm * BM + wm * 32 + i * 16 + frow;
-      const int n0 = bn * BN + wn * 32 + j * 16 + fq * 4;
-      *reinterpret_cast<f32x4*>(slab + (size_t)m * p.Npad + n0) = acc[i][j];
-    }
-}
-
-template <int LOADER, int KS>
-int launch_tn(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
-  constexpr int NST = 4;
-  constexpr int LDS_BYTES = NST * 128 * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_tn_kernel<NST, LOADER, KS>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_set = true;
-  }
-  const int cus = ctx ? ctx->num_cus : 256;
-  const int ntiles = (p.Mpad / 64) * (p.Npad / 64);
-  const int nk = p.K / BK;
-  int splits = (2 * cus + ntiles - 1) / ntiles;          // ~2 workgroups per CU (64 KiB of LDS each)
-  if (splits > nk / 4) splits = nk / 4;
-  if (splits > 128) splits = 128;
-  if (splits < 1 || nk <= 8 || ntiles >= cus) splits = 1;      // short K loop or a full chip already: direct epilogue
-  while (splits > 1 && (size_t)splits * p.Mpad * p.Npad * 4 > p.splitk_ws_bytes) --splits;
-  if ((size_t)splits * p.Mpad * p.Npad * 4 > p.splitk_ws_bytes) return neraf_fail(ctx, NERAF_EINVAL, "gemm tn: split-K scratch too small");
-  {
-    ProfScope prof(ctx, stream, PROF_GEMM64, 2.0 * p.M * p.N * p.K);
-    hipLaunchKernelGGL((gemm_bf16_tn_kernel<NST, LOADER, KS>), dim3(ntiles * splits), dim3(256), LDS_BYTES, stream, p, splits);
-  }
-  if (splits > 1) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(p.Npad / 32, p.Mpad / 32, 1), dim3(256), 0, stream, p, splits);
-  NERAF_HIP_CHECK(ctx, hipGetLastError());
-  return NERAF_OK;
-}
-
-int launch_gemm_tn_impl(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
-  if (!p.bf16 || !p.splitk_ws || !p.C32 || p.C16 || p.C16T || p.colsum || p.colsumsq || p.lmask || p.add16 || p.ngroups > 1)
-    return neraf_fail(ctx, NERAF_EINVAL, "gemm tn: bf16 operands, fp32 result through the split-K scratch only");
-  if (p.K <= 0 || (p.K % BK) || (p.Mpad % 64) || (p.Npad % 64) || p.M > p.Mpad || p.N > p.Npad || (p.lda % 8) ||
-      (p.conv.loader == 0 && (p.ldb % 8)))
-    return neraf_fail(ctx, NERAF_EINVAL, "gemm tn: K, Mpad, Npad multiples of 64; 16-byte aligned rows");
-  if (p.conv.loader != 0 && (!p.conv.zero_page || p.conv.dout <= 0 || (p.conv.dout & (p.conv.dout - 1))))
-    return neraf_fail(ctx, NERAF_EINVAL, "gemm tn: conv loaders need a zero page and a power-of-two output edge");
-  switch (p.conv.loader) {
-    case 0: return launch_tn<0, 1>(ctx, p, stream);
-    case 1:
-      if (p.conv.cin % 64) return neraf_fail(ctx, NERAF_EINVAL, "gemm tn loader 1: cin % 64");
-      if (p.conv.ksize == 3) return launch_tn<1, 3>(ctx, p, stream);
-      if (p.conv.ksize == 1) return launch_tn<1, 1>(ctx, p, stream);
-      return neraf_fail(ctx, NERAF_EINVAL, "gemm tn loader 1: ksize 1 or 3");
-    case 2:
-      if (p.conv.cin != 8 || p.conv.ksize != 5) return neraf_fail(ctx, NERAF_EINVAL, "gemm tn loader 2: cin 8, ksize 5");
-      return launch_tn<2, 5>(ctx, p, stream);
-  }
-  return neraf_fail(ctx, NERAF_EINVAL, "gemm tn: unknown loader");
-}
-
-
-// ------------------------------------------------------------------------------------------------------
-// Grouped TN weight-gradient GEMM: the kernel of gemm_bf16_tn_kernel with the geometry taken per workgroup from a descriptor
-// table in the kernel arguments (runtime loader type / filter size), so that every convolution of the network shares one grid.
+// Grouped form: the geometry is taken per workgroup from a descriptor table in the kernel arguments (runtime loader type /
+// filter size), so that every convolution of the network shares one grid.
 struct WgDesc {                       // 64 bytes
   const bf16_t* dy; const bf16_t* x; float* out;
   unsigned long long slab_off;        // floats, into the shared slab buffer (unused when splits == 1)
@@ -1045,7 +825,6 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
 
 
 int launch_gemm_f16(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
-  if (p.tn) return launch_gemm_tn_impl(ctx, p, stream);
   if (p.K <= 0 || (p.K % BK) != 0) return neraf_fail(ctx, NERAF_EINVAL, "gemm: K must be a positive multiple of 64");
   if ((p.Mpad % 64) != 0 || (p.Npad % 64) != 0 || p.M > p.Mpad || p.N > p.Npad || p.M <= 0 || p.N <= 0)
     return neraf_fail(ctx, NERAF_EINVAL, "gemm: Mpad/Npad must be multiples of 64 covering M/N");
@@ -1091,15 +870,16 @@ extern "C" int neraf_gemm_bf16(neraf_ctx* ctx, const void* A, int lda, const voi
   return launch_gemm_f16(ctx, p, (hipStream_t)stream);
 }
 
-// "TN" form with bfloat16 operands (both stored K-major): C32[m][n] = alpha * sum_k A[k][m] * B[k][n].  The convolution weight
-// gradients use it with a tap-shifting B loader; exported in its plain form for tests.  splitk_ws: >= Mpad*Npad*4 bytes.
-extern "C" int neraf_gemm_bf16_tn(neraf_ctx* ctx, const void* A, int lda, const void* B, int ldb, int M, int N, int K, int Mpad,
-                                  int Npad, float alpha, float* C32, int ldc32, void* splitk_ws, size_t splitk_bytes,
-                                  neraf_stream_t stream) {
-  GemmParams p{};
-  p.bf16 = 1; p.tn = 1;
-  p.A = (const half_t*)A; p.lda = lda; p.B = (const half_t*)B; p.ldb = ldb;
-  p.M = M; p.N = N; p.K = K; p.Mpad = Mpad; p.Npad = Npad; p.alpha = alpha; p.C32 = C32; p.ldc32 = ldc32;
-  p.splitk_ws = (float*)splitk_ws; p.splitk_ws_bytes = splitk_bytes;
-  return launch_gemm_f16(ctx, p, (hipStream_t)stream);
+// "TN" form with bfloat16 operands, both stored K-major and dense: C32[m][n] = sum_k A[k][m] * B[k][n], A [K][M], B [K][N], C32 [M][N];
+// M, N, K multiples of 64.  This is the plain (1x1x1-convolution) case of the grouped weight-gradient kernel, exported for tests.
+extern "C" int neraf_gemm_bf16_tn(neraf_ctx* ctx, const void* A, const void* B, int M, int N, int K, float* C32, void* splitk_ws,
+                                  size_t splitk_bytes, neraf_stream_t stream) {
+  if (!A || !B || !C32 || M <= 0 || N <= 0 || K <= 0 || (M % 64) || (N % 64) || (K % 64) || !splitk_ws || splitk_bytes < 256)
+    return neraf_fail(ctx, NERAF_EINVAL, "gemm_bf16_tn: M, N, K multiples of 64; scratch required");
+  WgradItem it{};
+  it.dy = (const bf16_t*)A; it.x = (const bf16_t*)B; it.out = C32;
+  it.cout = M; it.cin = N; it.cin_real = N; it.ksize = 1; it.stride = 1; it.pad = 0; it.din = 1; it.dout = 1; it.K = K;
+  // the first 256 bytes of the scratch serve as the zero page the loaders never touch in this plain form
+  return launch_wgrad_grouped(ctx, &it, 1, (const half_t*)splitk_ws, (float*)((char*)splitk_ws + 256), splitk_bytes - 256, nullptr,
+                              (hipStream_t)stream);
 }
