@@ -86,9 +86,16 @@ class JointStep:
         self.params = list(self.am.parameters())      # NAcF MLP + ResNet3D: the 'audio_fields' group (NeRAF_model.py:730-737)
         self.vparams = list(self.vm.parameters())
         from neraf_amd.optim import FusedAdam
-        # Adam(eps 1e-15) on the radiance parameters (lr 1e-2, NeRAF_config.py:116-123) and on the audio parameters (lr 1e-4,
-        # :124-127): two parameter groups of ONE optimizer, so the whole update is a single launch
-        self.opt = FusedAdam([{"params": self.vparams, "lr": 1e-2}, {"params": self.params, "lr": 1e-4}], eps=1e-15)
+        # The reference's optimizers (NeRAF_config.py:115-127): Adam(eps 1e-15) for "proposal_networks" (lr 1e-2), "fields" (lr 1e-2)
+        # and "audio_fields" (lr 1e-4) -- and NeRAF_pipeline.py:487 appends the radiance-field parameters to "audio_fields" as
+        # well, so they are stepped TWICE per iteration, by two optimizers with separate Adam states.  Mirrored here: the first
+        # two (identical hyper-parameters) are two groups of one launch, the third is its own optimizer over NAcF + ResNet3D +
+        # radiance field.
+        prop_params = [p for pn in self.vm.proposal_networks for p in pn.parameters()]
+        field_params = list(self.vm.field.parameters())
+        assert len(prop_params) + len(field_params) == len(self.vparams)
+        self.opt = FusedAdam([{"params": prop_params, "lr": 1e-2}, {"params": field_params, "lr": 1e-2}], eps=1e-15)
+        self.opt_audio = FusedAdam([{"params": self.params + field_params, "lr": 1e-4}], eps=1e-15)
         self.scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
         self.reducer = None
         if world > 1:
@@ -110,6 +117,7 @@ class JointStep:
         self.i += 1
         self.vm.update_to_step(self.i)
         self.opt.zero_grad(set_to_none=True)
+        self.opt_audio.zero_grad(set_to_none=True)
         out_v = self.vm.get_outputs(self.bundle)                                                   # NeRAF_pipeline.py:176
         lv = self.vm.get_loss_dict(out_v, self.gt)                                                 # :178
         self.am.query_grid_one_batch(self.i, self.vm.field, renderer_rgb=self.vm.renderer_rgb, batch_size=self.R)  # :181-184
@@ -119,7 +127,8 @@ class JointStep:
         self.scaler.scale(loss).backward()
         if self.reducer is not None:
             self.reducer.finish()
-        self.scaler.step(self.opt)
+        self.scaler.step(self.opt)            # proposal_networks + fields
+        self.scaler.step(self.opt_audio)      # audio_fields (+ the field parameters a second time, as the reference does)
         self.scaler.update()
         return out_v["rgb"], loss
 
@@ -290,7 +299,7 @@ def main():
                              "interlevel/distortion losses -> grid refresh (%d cells x 18 dirs) -> ResNet3D forward on the 7x128^3 "
                              "grid -> audio prologue + NAcF MLP -> STFT loss -> one backward (NAcF -> ResNet3D -> refreshed grid cells -> "
                              "field; radiance losses -> proposal nets + fused field backward + weight-grad GEMMs) -> %sGradScaler + "
-                             "fused Adam on radiance + audio (NAcF, ResNet3D) parameters.  Not modelled: camera-pose optimizer "
+                             "fused Adam: proposal_networks + fields (lr 1e-2), then audio_fields = NAcF + ResNet3D + fields again (lr 1e-4), as NeRAF_pipeline.py:487 groups them.  Not modelled: camera-pose optimizer "
                              "(nerfstudio CameraOptimizer), data loading."
                              % (a.rays, a.slices, a.rays, "RCCL all-reduce -> " if world > 1 else "")),
                 "rays_per_gpu": a.rays, "slices_per_gpu": a.slices, "parallelism": f"dp{world}",
