@@ -1,0 +1,59 @@
+"""Checkpoint interop (neraf_amd/checkpoint.py): a reference-shaped pipeline state (reference key names for the audio half,
+DDP "module." prefixes, the grid under "audio_model.grid", tcnn blobs and foreign buffers for the rest) loads into the models;
+a checkpoint written by this package round-trips completely.  CPU test (modules are only containers)."""
+import numpy as np
+import torch
+
+from neraf_amd import synth
+from neraf_amd.checkpoint import load_pipeline, pipeline_state_dict
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _models():
+    from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
+    from neraf_amd.vision import NeRAFVisionModel
+    am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 64), T(synth.audio_aabb()))
+    vm = NeRAFVisionModel(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 12)
+    return vm, am
+
+
+def test_reference_shaped_state_loads_audio_half_and_grid():
+    vm, am = _models()
+    ref = {}
+    for k, v in synth.nacf_state_dict(1187, 512, 1, 513).items():
+        ref["module.audio_model.field." + k] = T(v)                      # DDP prefix, reference parameter names (NeRAF_field.py:37-45)
+    for k, v in synth.resnet3d_state_dict(7).items():
+        ref["module.audio_model.resnet3d.backbone_net." + k] = T(v)      # NeRAF_resnet3d.py module tree
+    grid = torch.rand(7, 64, 64, 64)
+    ref["module.audio_model.grid"] = grid
+    ref["module.audio_model.istft_transform.window"] = torch.hann_window(512)     # torchaudio buffer the reference model carries
+    ref["module._model.field.mlp_base.params"] = torch.zeros(1000, dtype=torch.float16)   # tcnn blob
+    ref["module.datamanager.train_camera_optimizer.pose_adjustment"] = torch.zeros(3, 6)
+    rep = load_pipeline(ref, vm, am, step=123)
+    assert vm.step == 123
+    assert torch.equal(am.grid, grid)
+    assert torch.equal(am.field.soundfield[2].weight, T(synth.nacf_state_dict(1187, 512, 1, 513)["soundfield.2.weight"]))
+    sd = synth.resnet3d_state_dict(7)
+    assert torch.equal(am.resnet3d.backbone_net.layer3[5].bn3.running_var, T(sd["layer3.5.bn3.running_var"]))
+    assert rep["skipped_tcnn"] == ["_model.field.mlp_base.params"]
+    assert "audio_model.istft_transform.window" in rep["ignored"] and any(k.startswith("datamanager.") for k in rep["ignored"])
+    assert not [k for k in rep["missing"] if k.startswith("audio_model.field.") or k.startswith("audio_model.resnet3d.")]
+    assert vm.audio_model is am
+
+
+def test_native_checkpoint_round_trips():
+    vm, am = _models()
+    with torch.no_grad():
+        am.grid.uniform_(0, 1)
+        for p in list(vm.parameters()) + list(am.parameters()):
+            p.uniform_(-0.1, 0.1)
+    state = {k: v.clone() for k, v in pipeline_state_dict(vm, am).items()}
+    assert "audio_model.grid" in state and "_model.field.module.table" in state
+    vm2, am2 = _models()
+    rep = load_pipeline(state, vm2, am2)
+    assert rep["skipped_tcnn"] == [] and rep["missing"] == []
+    for (k, a), (_, b) in zip(sorted(pipeline_state_dict(vm, am).items()), sorted(pipeline_state_dict(vm2, am2).items())):
+        assert torch.equal(a, b), k
