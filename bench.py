@@ -102,11 +102,11 @@ class JointStep:
             # gradient averaging overlapped with the backward pass: groups in the order the backward completes them
             from neraf_amd.parallel import GradientReducer
             prop = [p for pn in self.vm.proposal_networks for p in pn.parameters()]
-            # the ResNet3D gradients are already global: its backward averages d feat (4 KiB) over the ranks instead (resnet3d.py)
-            self.am.resnet3d.backbone_net.dp_group = True
-            groups = [list(self.am.field.parameters()), list(self.vm.field.parameters()), prop]
-            n_resnet = len(list(self.am.resnet3d.parameters()))
-            assert sum(len(g) for g in groups) + n_resnet == len(self.params) + len(self.vparams), "groups must cover every parameter"
+            # every parameter group is averaged, the ResNet3D's too: its forward accumulates BatchNorm statistics with fp32
+            # atomics (order-dependent in the last bit) and the encoder is chaotic, so per-rank gradients differ and only an
+            # all-reduce keeps the replicas' weights identical (ResNet3D.dp_group -- average d feat instead -- is opt-in)
+            groups = [list(self.am.field.parameters()), list(self.am.resnet3d.parameters()), list(self.vm.field.parameters()), prop]
+            assert sum(len(g) for g in groups) == len(self.params) + len(self.vparams), "groups must cover every parameter"
             self.reducer = GradientReducer(groups)
         self.i = 20000      # steady-state regime of the 400k-iteration schedule: anneal done, proposal nets updated every 6th step
 

@@ -68,9 +68,11 @@ class _ResNet3DFn(torch.autograd.Function):
             net._dgrid_buf = torch.empty((n_ch, n_cells), dtype=torch.float32, device=device)
         net._dfeat_buf.copy_(dfeat.reshape(-1))
         if net.dp_group is not None:
-            # data parallel: every rank holds the same grid and weights, so the encoder's forward is identical everywhere and its
-            # backward is linear in d feat -- averaging these 1024 floats (4 KiB) over the ranks makes every weight gradient below
-            # the already-averaged one, and the 17 M ResNet3D parameters (68 MB) never enter the gradient all-reduce
+            # data parallel, OPT-IN: every rank holds the same grid and weights and the backward is linear in d feat, so
+            # averaging these 1024 floats (4 KiB) replaces the all-reduce of 17 M ResNet3D gradients (68 MB).  Exact only if the
+            # forward is bit-identical on every rank; the BatchNorm statistics are accumulated with fp32 atomics (last-bit order
+            # dependence, amplified by the chaotic encoder), so replicas drift unless the weights are re-synchronised -- the
+            # default path all-reduces the gradients instead (GradientReducer)
             import torch.distributed as dist
             grp = None if net.dp_group is True else net.dp_group
             if dist.get_backend(grp) == "nccl":
