@@ -239,10 +239,12 @@ int neraf_interlevel_loss(neraf_ctx* ctx, const float* c_bins, const float* w_fi
                           const float* p_ebins, const float* p_density, int Sp, int R, float mult, const float* up3,
                           float* d_density, float* sums, neraf_stream_t stream);
 /* Proposal network backward: d_density [R,S] -> table_grad fp32 [rows,2] and w_grad fp32 [16*16+16]
- * (layer 0 then layer-1 row), both ACCUMULATED (caller zeroes). */
+ * (layer 0 then layer-1 row), both ACCUMULATED (caller zeroes).  scratch (optional, >= 2048*272*4 bytes): per-workgroup
+ * weight-gradient partials, folded by a second launch instead of 272 same-line atomics per workgroup. */
 int neraf_proposal_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                             const float* origins, const float* dirs, const float* e_bins, const float* d_density, int R,
-                            int S, float avg_density, float* table_grad, float* w_grad, neraf_stream_t stream);
+                            int S, float avg_density, float* table_grad, float* w_grad, void* scratch, size_t scratch_bytes,
+                            neraf_stream_t stream);
 /* Fused field backward.  d_rgb [R,S,3], d_density [R,S] (and the forward density) -> table_grad fp32
  * [rows,2] (MUST BE ZERO on entry: during the call it holds packed 64-bit fixed-point sums, one integer
  * atomic per table entry instead of two fp32 ones, unpacked in place before returning; the result is

@@ -93,7 +93,7 @@ SIGNATURES = {
                                         C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_proposal_backward": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
-                                          C.c_void_p]),
+                                          C.c_void_p, C.c_size_t, C.c_void_p]),
     "neraf_field_backward_dump_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "neraf_field_backward": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

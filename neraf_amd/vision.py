@@ -375,9 +375,11 @@ class _VisionLossFn(torch.autograd.Function):
             ptab, pw = st["prop_packed"][i]
             g_pt = torch.zeros_like(pn.table)
             g_pw = torch.zeros(16 * 16 + 16, **f32)
+            scratch = torch.empty(2048 * 272, **f32)           # per-workgroup weight-gradient partials
             _lib.check(lib.neraf_proposal_backward(h, C.byref(pn.desc), ptab.data_ptr(), pw.data_ptr(), st["o"].data_ptr(),
                                                    st["d"].data_ptr(), ps.e_bins.data_ptr(), d_pd.data_ptr(), R, Sp,
-                                                   pn.average_init_density, g_pt.data_ptr(), g_pw.data_ptr(), stream), dev)
+                                                   pn.average_init_density, g_pt.data_ptr(), g_pw.data_ptr(), scratch.data_ptr(),
+                                                   scratch.numel() * 4, stream), dev)
             g_w1 = torch.zeros_like(pn.w1)
             g_w1[0] = g_pw[256:]
             grads += [g_pt, g_pw[:256].reshape(16, 16), g_w1]
