@@ -96,7 +96,8 @@ class JointStep:
         assert len(prop_params) + len(field_params) == len(self.vparams)
         self.opt = FusedAdam([{"params": prop_params, "lr": 1e-2}, {"params": field_params, "lr": 1e-2}], eps=1e-15)
         self.opt_audio = FusedAdam([{"params": self.params + field_params, "lr": 1e-4}], eps=1e-15)
-        self.scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
+        from neraf_amd.optim import GradScaler
+        self.scaler = GradScaler("cuda", init_scale=65536.0)
         self.reducer = None
         if world > 1:
             # gradient averaging overlapped with the backward pass: groups in the order the backward completes them

@@ -328,6 +328,9 @@ int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_real, int co
  * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), exactly torch's formula (no weight decay, no amsgrad).
  * ---------------------------------------------------------------------------------- */
 int neraf_fused_adam_chunk(void);
+/* GradScaler's non-finite check over the same tensor table: found_inf[0] = 1.0f if any gradient element is inf / nan, else 0. */
+int neraf_grads_nonfinite(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
+                          int n_blocks, float* found_inf, neraf_stream_t stream);
 int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
                      int n_blocks, const float* group_lr, int n_groups, double beta1, double beta2, double eps, float* step,
                      const float* grad_scale, const float* found_inf, neraf_stream_t stream);

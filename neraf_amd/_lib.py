@@ -49,6 +49,7 @@ SIGNATURES = {
     "neraf_gemm_bf16_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                      C.c_void_p]),
     "neraf_fused_adam_chunk": (C.c_int, []),
+    "neraf_grads_nonfinite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "neraf_fused_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                    C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_nacf_packed_bytes": (C.c_size_t, [C.POINTER(NacfDesc)]),

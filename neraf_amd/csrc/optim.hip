@@ -65,7 +65,45 @@ __global__ __launch_bounds__(256) void fused_adam_kernel(const AdamTensor* __res
   }
 }
 
+// found[0] = 1 if any gradient element of the table's tensors is inf / nan (GradScaler's check, one launch for all tensors)
+__global__ __launch_bounds__(256) void grads_nonfinite_kernel(const AdamTensor* __restrict__ table, const unsigned long long* __restrict__ g_ptrs,
+                                                             const int* __restrict__ blk_tensor, const int* __restrict__ blk_chunk,
+                                                             float* __restrict__ found) {
+  const int ti = blk_tensor[blockIdx.x];
+  const long long numel = table[ti].numel;
+  const float* g = g_ptrs ? reinterpret_cast<const float*>(g_ptrs[ti]) : table[ti].g;
+  const long long base = (long long)blk_chunk[blockIdx.x] * kAdamChunk;
+  bool bad = false;
+  const bool vec = (reinterpret_cast<size_t>(g) & 15) == 0;
+#pragma unroll
+  for (int it = 0; it < kAdamChunk / 1024; ++it) {
+    const long long i = base + it * 1024 + threadIdx.x * 4;
+    if (i >= numel) break;
+    if (vec && i + 3 < numel) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bad |= !(fabsf(v[r]) <= 3.4028234e38f);
+    } else {
+      for (int r = 0; r < 4 && i + r < numel; ++r) bad |= !(fabsf(g[i + r]) <= 3.4028234e38f);
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) found[0] = 1.f;
+}
+
+__global__ void set_f32_kernel(float* p, float v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
+
 }  // namespace
+
+extern "C" int neraf_grads_nonfinite(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
+                                     int n_blocks, float* found_inf, neraf_stream_t stream) {
+  if (!table || !blk_tensor || !blk_chunk || n_blocks <= 0 || !found_inf) return neraf_fail(ctx, NERAF_EINVAL, "grads_nonfinite: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(64), 0, st, found_inf, 0.f);
+  hipLaunchKernelGGL(grads_nonfinite_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, (const AdamTensor*)table,
+                     (const unsigned long long*)g_ptrs, blk_tensor, blk_chunk, found_inf);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
 
 extern "C" int neraf_fused_adam_chunk(void) { return kAdamChunk; }
 

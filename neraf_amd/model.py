@@ -71,7 +71,7 @@ class _RefreshFn(torch.autograd.Function):
         dd = dirs.repeat(n, 1).contiguous()
         z = torch.zeros((oris.shape[0], 2), device=oris.device)
         cam = torch.zeros(oris.shape[0], dtype=torch.int32, device=oris.device)      # camera index 0, :334
-        packed = field.packed()
+        packed = field.packed(with_average=False)       # the refresh queries with camera index 0's embedding (:334)
         rgb, den = field.query(oris, dd, z, cam, use_average_embedding=False, packed=packed)    # [n*nd,1,3], [n*nd,1]
         rgb_m = rgb.reshape(n, nd, 3).mean(1)                                          # :352-356
         den_m = den.reshape(n, nd).mean(1)                                             # :357

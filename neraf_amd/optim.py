@@ -33,6 +33,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._plans = {}                       # ids of the parameters holding a gradient -> device tables (the proposal networks
                                                # only receive gradients every few steps: two plans alternate)
         self._step_t = None
+        self._found = None
 
     def _state_for(self, p: torch.Tensor):
         st = self.state[p]
@@ -63,14 +64,11 @@ class FusedAdam(torch.optim.Optimizer):
                     blk_chunk=torch.from_numpy(np.concatenate(bc)).to(device),
                     # gradient-pointer column, refreshed asynchronously every step: (pinned, device, event, used) x 4
                     ring=[[torch.empty(n, dtype=torch.int64).pin_memory(), torch.empty(n, dtype=torch.int64, device=device),
-                           torch.cuda.Event(), False] for _ in range(4)], ring_i=0)
+                           torch.cuda.Event(), False] for _ in range(4)], ring_i=0, gp=None, gdev=None)
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
+    def _plan(self):
+        """Device tables for the parameters that currently hold a gradient, with the gradient-pointer column refreshed (through
+        pinned memory, without synchronising).  Cached while the gradient tensors are the same objects' storages."""
         entries, sig, gp = [], [], []
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
@@ -81,32 +79,74 @@ class FusedAdam(torch.optim.Optimizer):
                 sig.append(id(p))
                 gp.append(g.data_ptr())
         if not entries:
-            return loss
+            return None
         p0 = entries[0][0]
         sig = tuple(sig)
         plan = self._plans.get(sig)
         if plan is None:                       # a new set of parameters with gradients: build its device table (synchronises, once)
             plan = self._plans[sig] = self._build(entries, p0.device)
-        # gradient tensors are new every step: refresh the pointer column through pinned memory, without synchronising
-        k = plan["ring_i"]
-        plan["ring_i"] = (k + 1) % 4
-        slot = plan["ring"][k]
-        pinned, gdev, ev = slot[0], slot[1], slot[2]
-        if slot[3]:
-            ev.synchronize()                   # four uses old: complete unless the host ran that far ahead
-        pinned.numpy()[:] = gp
-        gdev.copy_(pinned, non_blocking=True)
-        ev.record()
-        slot[3] = True
+        gp = tuple(gp)
+        if plan.get("gp") != gp:               # gradient tensors are new every step: refresh the pointer column
+            k = plan["ring_i"]
+            plan["ring_i"] = (k + 1) % 4
+            slot = plan["ring"][k]
+            pinned, gdev, ev = slot[0], slot[1], slot[2]
+            if slot[3]:
+                ev.synchronize()               # four uses old: complete unless the host ran that far ahead
+            pinned.numpy()[:] = gp
+            gdev.copy_(pinned, non_blocking=True)
+            ev.record()
+            slot[3] = True
+            plan["gp"], plan["gdev"] = gp, gdev
+        plan["dev"] = _dev_index(p0)
+        return plan
+
+    def check_finite(self) -> torch.Tensor:
+        """found_inf (device float, 0 or 1) over every gradient of this optimizer: GradScaler's check in one launch."""
+        plan = self._plan()
+        if self._found is None:
+            dev = next(p for g in self.param_groups for p in g["params"]).device
+            self._found = torch.zeros(1, dtype=torch.float32, device=dev)
+        if plan is None:
+            return self._found.zero_()
         lib = _lib.load()
-        dev = _dev_index(p0)
+        _lib.check(lib.neraf_grads_nonfinite(_lib.ctx(plan["dev"]), plan["table"].data_ptr(), plan["gdev"].data_ptr(),
+                                             plan["blk_tensor"].data_ptr(), plan["blk_chunk"].data_ptr(), int(plan["blk_tensor"].numel()),
+                                             self._found.data_ptr(), _stream_ptr()), plan["dev"])
+        return self._found
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        plan = self._plan()
+        if plan is None:
+            return loss
+        lib = _lib.load()
+        dev = plan["dev"]
         lrs = (C.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
         b1, b2 = self.param_groups[0]["betas"]
         gs = getattr(self, "grad_scale", None)
         fi = getattr(self, "found_inf", None)
-        _lib.check(lib.neraf_fused_adam(_lib.ctx(dev), plan["table"].data_ptr(), gdev.data_ptr(), plan["blk_tensor"].data_ptr(),
-                                        plan["blk_chunk"].data_ptr(), int(plan["blk_tensor"].numel()), lrs, len(self.param_groups), float(b1), float(b2),
-                                        float(self.param_groups[0]["eps"]), self._step_t.data_ptr(),
+        _lib.check(lib.neraf_fused_adam(_lib.ctx(dev), plan["table"].data_ptr(), plan["gdev"].data_ptr(), plan["blk_tensor"].data_ptr(),
+                                        plan["blk_chunk"].data_ptr(), int(plan["blk_tensor"].numel()), lrs, len(self.param_groups),
+                                        float(b1), float(b2), float(self.param_groups[0]["eps"]), self._step_t.data_ptr(),
                                         gs.data_ptr() if gs is not None else None, fi.data_ptr() if fi is not None else None,
                                         _stream_ptr()), dev)
         return loss
+
+
+class GradScaler(torch.amp.GradScaler):
+    """torch.amp.GradScaler whose non-finite check of a ``FusedAdam``'s gradients is ONE launch over the optimizer's tensor table
+    (torch's check is a foreach pass per 100-odd tensors, after a Python loop over every parameter).  Everything else -- scale
+    growth / back-off, ``step`` / ``update`` -- is inherited; other optimizers take the inherited path."""
+
+    def _check_inf_per_device(self, optimizer):
+        if not isinstance(optimizer, FusedAdam):
+            return super()._check_inf_per_device(optimizer)
+        found = optimizer.check_finite()
+        state = self._per_optimizer_states[id(optimizer)]
+        state["found_inf_per_device"] = {found.device: found}
+        return state["found_inf_per_device"]

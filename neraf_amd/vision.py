@@ -221,9 +221,12 @@ class NerfactoField(nn.Module):
                           self.head_w1.detach().reshape(-1), self.head_w2.detach().reshape(-1),
                           torch.zeros(1, device=self.table.device)])
 
-    def packed(self):
+    def packed(self, with_average: bool = True):
+        """fp16 copies for the kernels: (table, 24 weight fragments, embedding rows).  ``with_average`` appends the mean embedding
+        as an extra row (eval / camera-less queries use it); training queries index real rows only and skip the reduction."""
         wfrag = self._flat_weights()[self._frag_index].half().contiguous()
-        emb = torch.cat([self.embedding.detach(), self.embedding.detach().mean(0, keepdim=True)], 0).half().contiguous()
+        e = self.embedding.detach()
+        emb = (torch.cat([e, e.mean(0, keepdim=True)], 0) if with_average else e).half().contiguous()
         return self.table.detach().half().contiguous(), wfrag, emb
 
     def packed_bwd(self):
@@ -281,6 +284,8 @@ class NerfactoField(nn.Module):
         rgb = torch.empty((R, S, 3), dtype=torch.float32, device=origins.device)
         den = torch.empty((R, S), dtype=torch.float32, device=origins.device)
         avg_row = self.embedding.shape[0] if (use_average_embedding or camera_indices is None) else -1
+        if avg_row >= 0 and emb.shape[0] <= avg_row:
+            raise ValueError("this query uses the average appearance embedding: pack with with_average=True")
         cam = camera_indices.reshape(-1).to(torch.int32).contiguous() if camera_indices is not None else None
         mode = 0 if self.spatial_distortion is not None else 1
         ab = _lib.host_f32(self.aabb)
@@ -471,7 +476,7 @@ class NeRAFVisionModel(nn.Module):
             samples_list.append(RaySamples(None, ray_bundle.camera_indices, s_prev, e_prev))
             s_prev, e_prev = s_n, e_n
         field = self.field.module
-        field_packed = field.packed()
+        field_packed = field.packed(with_average=not self.training or ray_bundle.camera_indices is None)
         rgb_s, dens = field.query(o, d, e_prev, ray_bundle.camera_indices, use_average_embedding=not self.training,
                                   packed=field_packed)
         w = torch.empty((R, S2), **f32)

@@ -42,7 +42,8 @@ def test_fused_adam_under_grad_scaler_skips_on_inf_and_unscales():
     pa, pb = _params(dev, 2), _params(dev, 2)
     oa = FusedAdam(pa, lr=1e-3, eps=1e-15)
     ob = torch.optim.Adam(pb, lr=1e-3, eps=1e-15)
-    sa = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    from neraf_amd.optim import GradScaler
+    sa = GradScaler("cuda", init_scale=1024.0)              # one-launch non-finite check over the optimizer's tensor table
     sb = torch.amp.GradScaler("cuda", init_scale=1024.0)
     g = torch.Generator().manual_seed(3)
     for it in range(5):
