@@ -391,7 +391,12 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
   half8 wf[NFRAG];
 #pragma unroll
   for (int f = 0; f < NFRAG; ++f) wf[f] = a.wfrag[f * 64 + lane];
-  const half8* wb = a.wfrag_b + lane;            // fragment f at wb[f * 64]
+  // the 26 backward fragments live in LDS (26 KiB): each is read once per 16-point group, and a global (L1/L2) load in front
+  // of every MFMA of the chain is a ~500-cycle dependency where the LDS read is ~64
+  __shared__ half8 wb_s[NFRAG_B * 64];
+  for (int i = threadIdx.x; i < NFRAG_B * 64; i += 256) wb_s[i] = a.wfrag_b[i];
+  __syncthreads();
+  const half8* wb = wb_s + lane;                 // fragment f at wb[f * 64]
   const float gscale = a.scale[0], inv_gscale = a.scale[1];
   float tl[4] = {0.f, 0.f, 0.f, 0.f};
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
