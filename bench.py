@@ -83,32 +83,17 @@ class JointStep:
         self.bundle = RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev))
         self.batch = {k: T(v).to(dev) for k, v in synth.audio_batch(B, C_, F_, T_, tag=f"bench.r{rank}").items()}
         self.gt = {"image": T(rb["rgb"]).to(dev)}
-        self.params = list(self.am.parameters())      # NAcF MLP + ResNet3D: the 'audio_fields' group (NeRAF_model.py:730-737)
-        self.vparams = list(self.vm.parameters())
-        from neraf_amd.optim import FusedAdam
-        # The reference's optimizers (NeRAF_config.py:115-127): Adam(eps 1e-15) for "proposal_networks" (lr 1e-2), "fields" (lr 1e-2)
-        # and "audio_fields" (lr 1e-4) -- and NeRAF_pipeline.py:487 appends the radiance-field parameters to "audio_fields" as
-        # well, so they are stepped TWICE per iteration, by two optimizers with separate Adam states.  Mirrored here: the first
-        # two (identical hyper-parameters) are two groups of one launch, the third is its own optimizer over NAcF + ResNet3D +
-        # radiance field.
-        prop_params = [p for pn in self.vm.proposal_networks for p in pn.parameters()]
-        field_params = list(self.vm.field.parameters())
-        assert len(prop_params) + len(field_params) == len(self.vparams)
-        self.opt = FusedAdam([{"params": prop_params, "lr": 1e-2}, {"params": field_params, "lr": 1e-2}], eps=1e-15)
-        self.opt_audio = FusedAdam([{"params": self.params + field_params, "lr": 1e-4}], eps=1e-15)
-        from neraf_amd.optim import GradScaler
-        self.scaler = GradScaler("cuda", init_scale=65536.0)
-        self.reducer = None
+        # the reference's pipeline object: get_train_loss_dict (NeRAF_pipeline.py:166-222) inside Trainer.train_iteration, with its
+        # parameter groups / optimizers (NeRAF_config.py:115-127; the field parameters are in "fields" AND "audio_fields", :487)
+        from neraf_amd.pipeline import FixedBatchDataManager, NeRAFPipeline
+        self.pipe = NeRAFPipeline(self.vm, self.am, datamanager=FixedBatchDataManager(self.bundle, self.gt, R),
+                                  audio_datamanager=FixedBatchDataManager(None, self.batch), start_step_audio=2000, world_size=world)
+        self.optimizers, self.scaler = self.pipe.make_optimizers(init_scale=65536.0)
         if world > 1:
-            # gradient averaging overlapped with the backward pass: groups in the order the backward completes them
-            from neraf_amd.parallel import GradientReducer
-            prop = [p for pn in self.vm.proposal_networks for p in pn.parameters()]
-            # every parameter group is averaged, the ResNet3D's too: its forward accumulates BatchNorm statistics with fp32
-            # atomics (order-dependent in the last bit) and the encoder is chaotic, so per-rank gradients differ and only an
-            # all-reduce keeps the replicas' weights identical (ResNet3D.dp_group -- average d feat instead -- is opt-in)
-            groups = [list(self.am.field.parameters()), list(self.am.resnet3d.parameters()), list(self.vm.field.parameters()), prop]
-            assert sum(len(g) for g in groups) == len(self.params) + len(self.vparams), "groups must cover every parameter"
-            self.reducer = GradientReducer(groups)
+            # gradient averaging overlapped with the backward pass; every group is all-reduced, the ResNet3D's too (its forward
+            # accumulates BatchNorm statistics with fp32 atomics, so per-rank gradients differ in the last bits and the chaotic
+            # encoder amplifies that: only an all-reduce keeps the replicas identical)
+            self.pipe.attach_gradient_reducer()
         self.i = 20000      # steady-state regime of the 400k-iteration schedule: anneal done, proposal nets updated every 6th step
 
     def samples_per_step(self):
@@ -116,22 +101,8 @@ class JointStep:
 
     def step(self):
         self.i += 1
-        self.vm.update_to_step(self.i)
-        self.opt.zero_grad(set_to_none=True)
-        self.opt_audio.zero_grad(set_to_none=True)
-        out_v = self.vm.get_outputs(self.bundle)                                                   # NeRAF_pipeline.py:176
-        lv = self.vm.get_loss_dict(out_v, self.gt)                                                 # :178
-        self.am.query_grid_one_batch(self.i, self.vm.field, renderer_rgb=self.vm.renderer_rgb, batch_size=self.R)  # :181-184
-        y = self.am.get_outputs(self.batch)                                                        # :188
-        d = self.am.get_loss_dict(y, self.batch)                                                   # :191
-        loss = lv["rgb_loss"] + lv["interlevel_loss"] + lv["distortion_loss"] + d["audio_sc_loss"] + d["audio_mag_loss"]
-        self.scaler.scale(loss).backward()
-        if self.reducer is not None:
-            self.reducer.finish()
-        self.scaler.step(self.opt)            # proposal_networks + fields
-        self.scaler.step(self.opt_audio)      # audio_fields (+ the field parameters a second time, as the reference does)
-        self.scaler.update()
-        return out_v["rgb"], loss
+        loss, _ = self.pipe.train_iteration(self.i, self.optimizers, self.scaler)
+        return loss
 
 
 def cpu_baseline(R, B):

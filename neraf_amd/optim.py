@@ -16,6 +16,10 @@ import torch
 from . import _lib
 from .field import _dev_index, _stream_ptr
 
+# Bumped by every FusedAdam.step: the kernel updates parameters in place without touching tensor version counters, so caches of
+# derived data (packed fp16 weights used in eval mode) key on this as well.
+UPDATE_EPOCH = 0
+
 _REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("numel", "<i8"), ("group", "<i4"), ("pad", "<i4")])
 assert _REC.itemsize == 48
 
@@ -34,6 +38,9 @@ class FusedAdam(torch.optim.Optimizer):
                                                # only receive gradients every few steps: two plans alternate)
         self._step_t = None
         self._found = None
+        self._fresh_plan = None
+        self._flat = [(p, gi) for gi, group in enumerate(self.param_groups) for p in group["params"]]
+        self._all_sig = tuple(id(e[0]) for e in self._flat)
 
     def _state_for(self, p: torch.Tensor):
         st = self.state[p]
@@ -69,17 +76,17 @@ class FusedAdam(torch.optim.Optimizer):
     def _plan(self):
         """Device tables for the parameters that currently hold a gradient, with the gradient-pointer column refreshed (through
         pinned memory, without synchronising).  Cached while the gradient tensors are the same objects' storages."""
-        entries, sig, gp = [], [], []
-        for gi, group in enumerate(self.param_groups):
-            for p in group["params"]:
-                g = p.grad
-                if g is None:
-                    continue
-                entries.append((p, gi))
-                sig.append(id(p))
+        if len(self._flat) != sum(len(g["params"]) for g in self.param_groups):       # add_param_group since construction
+            self._flat = [(p, gi) for gi, group in enumerate(self.param_groups) for p in group["params"]]
+        entries, gp = [], []
+        for e in self._flat:
+            g = e[0].grad
+            if g is not None:
+                entries.append(e)
                 gp.append(g.data_ptr())
         if not entries:
             return None
+        sig = [id(e[0]) for e in entries] if len(entries) != len(self._flat) else self._all_sig
         p0 = entries[0][0]
         sig = tuple(sig)
         plan = self._plans.get(sig)
@@ -91,7 +98,7 @@ class FusedAdam(torch.optim.Optimizer):
             plan["ring_i"] = (k + 1) % 4
             slot = plan["ring"][k]
             pinned, gdev, ev = slot[0], slot[1], slot[2]
-            if slot[3]:
+            if slot[3] and not ev.query():
                 ev.synchronize()               # four uses old: complete unless the host ran that far ahead
             pinned.numpy()[:] = gp
             gdev.copy_(pinned, non_blocking=True)
@@ -101,9 +108,11 @@ class FusedAdam(torch.optim.Optimizer):
         plan["dev"] = _dev_index(p0)
         return plan
 
-    def check_finite(self) -> torch.Tensor:
+    def check_finite(self, _keep_plan_for_step: bool = False) -> torch.Tensor:
         """found_inf (device float, 0 or 1) over every gradient of this optimizer: GradScaler's check in one launch."""
         plan = self._plan()
+        if _keep_plan_for_step:               # GradScaler.step calls step() right after: no second walk over the parameters
+            self._fresh_plan = plan
         if self._found is None:
             dev = next(p for g in self.param_groups for p in g["params"]).device
             self._found = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -121,7 +130,10 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        plan = self._plan()
+        global UPDATE_EPOCH
+        UPDATE_EPOCH += 1
+        plan = self._fresh_plan if self._fresh_plan is not None else self._plan()
+        self._fresh_plan = None
         if plan is None:
             return loss
         lib = _lib.load()
@@ -146,7 +158,7 @@ class GradScaler(torch.amp.GradScaler):
     def _check_inf_per_device(self, optimizer):
         if not isinstance(optimizer, FusedAdam):
             return super()._check_inf_per_device(optimizer)
-        found = optimizer.check_finite()
+        found = optimizer.check_finite(_keep_plan_for_step=True)
         state = self._per_optimizer_states[id(optimizer)]
         state["found_inf_per_device"] = {found.device: found}
         return state["found_inf_per_device"]

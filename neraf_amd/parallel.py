@@ -114,6 +114,12 @@ class GradientReducer:
                 self._launch(gi)
         return hook
 
+    def notify_group(self, gi: int):
+        """For engines that assign a group's gradients themselves instead of routing them through autograd (the ResNet3D
+        backward): the group's gradients are final, launch its collectives now."""
+        if not self._launched[gi]:
+            self._launch(gi)
+
     def _launch(self, gi: int):
         self._launched[gi] = True
         grads = [p.grad for p in self.groups[gi] if p.grad is not None]

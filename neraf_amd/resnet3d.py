@@ -23,46 +23,57 @@ from .field import _dev_index, _stream_ptr
 
 
 class _ResNet3DFn(torch.autograd.Function):
-    """feat[1024] = ResNet3D(grid); parameters = 43 conv weights followed by 43 x (bn.weight, bn.bias)."""
+    """feat[1024] = ResNet3D(grid).  The 129 parameters (43 conv weights, 43 x (bn.weight, bn.bias)) do NOT travel through
+    autograd: the backward kernels write all their gradients into one persistent flat buffer and this node assigns
+    ``p.grad`` = (cached) views of it directly, as FSDP-style flat-parameter engines do.  Routing 129 tensors through autograd cost
+    1.5-2 ms of host time per step (129 fresh view objects, 129 AccumulateGrad nodes, a 68 MB copy) for nothing.  Two flat
+    buffers alternate, so the gradients of step N stay valid while step N+1 computes; accumulation without zero_grad adds in
+    place.  ``anchor`` is a 1-element leaf that only keeps this node in the graph."""
 
     @staticmethod
-    def forward(ctx, net: "ResNet3D", feat: torch.Tensor, window, sink, window_vals, *params: torch.Tensor):
+    def forward(ctx, net: "ResNet3D", feat: torch.Tensor, window, sink, window_vals, anchor):
         # the forward kernels already ran (ResNet3D.forward); this node only attaches the backward.  ``window_vals``
         # ([n_ch, n_cells], may be None) are the grad-carrying values that were written into the grid window this step
         # (NeRAF_model.py:395-400): their gradient is the grid gradient at those cells.
         ctx.net, ctx.window, ctx.sink = net, window, sink
         ctx.has_vals = window_vals is not None
-        ctx.save_for_backward(*params)
         return feat.clone()
 
     @staticmethod
     def backward(ctx, dfeat: torch.Tensor):
         lib = _lib.load()
         net: ResNet3D = ctx.net
-        params = ctx.saved_tensors
-        nconv = len(params) // 3
-        conv_w = list(params[:nconv])
         dev = _dev_index(dfeat)
         h, st = _lib.ctx(dev), _stream_ptr()
         device = dfeat.device
-        pairs = net.conv_bn_pairs()
-        bn: List[torch.Tensor] = []
-        for _, b in pairs:
-            bn += [b.weight.detach(), b.bias.detach(), b.running_mean, b.running_var]
+        tb = net._host_tables()
+        params = tb["params"]
         # every buffer the kernels see is persistent (module-owned): the ~270-launch sequence is replayed as ONE hipGraph keyed by
         # its argument pointers (include/neraf_hip.h, neraf_graph_stats), so the pointers must not change from step to step
         if net._packed_t is None or net._packed_t.device != device:
             net._packed_t = torch.empty(lib.neraf_resnet3d_bwd_packed_bytes(C.byref(net._desc)), dtype=torch.uint8, device=device)
         packed_t = net._packed_t
-        _lib.check(lib.neraf_resnet3d_pack_weights_bwd(h, C.byref(net._desc), _lib.ptr_array(conv_w), packed_t.data_ptr(), st), dev)
+        _lib.check(lib.neraf_resnet3d_pack_weights_bwd(h, C.byref(net._desc), tb["conv_w_ptrs"], packed_t.data_ptr(), st), dev)
         if net._bws is None or net._bws.device != device:
             net._bws = torch.empty(lib.neraf_resnet3d_bwd_workspace_bytes(C.byref(net._desc)), dtype=torch.uint8, device=device)
-        sizes = [p.numel() for p in params]
-        if net._grad_flat is None or net._grad_flat.device != device or net._grad_flat.numel() != sum(sizes):
-            net._grad_flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-            net._grad_views = [v.view(p.shape) for v, p in zip(torch.split(net._grad_flat, sizes), params)]
-            net._grad_ptrs = (_lib.ptr_array(net._grad_views[:nconv]), _lib.ptr_array(net._grad_views[nconv:]))
+        if net._grad_bufs is None or net._grad_bufs[0]["flat"].device != device:
+            sizes = [p.numel() for p in params]
+            nconv = len(tb["pairs"])
+            net._grad_bufs = []
+            for _ in range(2):
+                flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+                views = [v.view(p.shape) for v, p in zip(torch.split(flat, sizes), params)]
+                net._grad_bufs.append(dict(flat=flat, views=views, lo=flat.data_ptr(), hi=flat.data_ptr() + flat.numel() * 4,
+                                           ptrs=(_lib.ptr_array(views[:nconv]), _lib.ptr_array(views[nconv:]))))
+            net._grad_turn = 0
             net._dfeat_buf = torch.empty(1024, dtype=torch.float32, device=device)
+        # pick the buffer that no live gradient aliases (normally they simply alternate)
+        g0 = params[0].grad
+        k = net._grad_turn
+        if g0 is not None and net._grad_bufs[k]["lo"] <= g0.data_ptr() < net._grad_bufs[k]["hi"]:
+            k ^= 1
+        buf = net._grad_bufs[k]
+        net._grad_turn = k ^ 1
         start, n_cells, n_ch = ctx.window if ctx.window is not None else (0, 0, 0)
         if n_cells > 0 and (net._dgrid_buf is None or tuple(net._dgrid_buf.shape) != (n_ch, n_cells) or net._dgrid_buf.device != device):
             net._dgrid_buf = torch.empty((n_ch, n_cells), dtype=torch.float32, device=device)
@@ -80,18 +91,26 @@ class _ResNet3DFn(torch.autograd.Function):
             else:
                 dist.all_reduce(net._dfeat_buf, group=grp)
                 net._dfeat_buf.div_(dist.get_world_size(grp))
-        _lib.check(lib.neraf_resnet3d_bwd(h, C.byref(net._desc), packed_t.data_ptr(), _lib.ptr_array(conv_w), _lib.ptr_array(bn),
-                                          net._ws.data_ptr(), net._bws.data_ptr(), net._dfeat_buf.data_ptr(), net._grad_ptrs[0],
-                                          net._grad_ptrs[1], start, n_cells, n_ch,
+        _lib.check(lib.neraf_resnet3d_bwd(h, C.byref(net._desc), packed_t.data_ptr(), tb["conv_w_ptrs"], tb["bn_ptrs"],
+                                          net._ws.data_ptr(), net._bws.data_ptr(), net._dfeat_buf.data_ptr(), buf["ptrs"][0],
+                                          buf["ptrs"][1], start, n_cells, n_ch,
                                           net._dgrid_buf.data_ptr() if n_cells > 0 else None, st), dev)
-        # hand autograd private copies (it may keep them as .grad or accumulate into them): one copy kernel, then views
-        flat = net._grad_flat.clone()
-        grads = [v.view(p.shape) for v, p in zip(torch.split(flat, sizes), params)]
+        if g0 is None:
+            for p, v in zip(params, buf["views"]):
+                if p.requires_grad:
+                    p.grad = v
+        else:                                      # gradient accumulation (no zero_grad since the last backward): add in place
+            live = [(p, v) for p, v in zip(params, buf["views"]) if p.requires_grad]
+            for p, v in live:
+                if p.grad is None:
+                    p.grad = v.clone()
+            torch._foreach_add_([p.grad for p, _ in live], [v for _, v in live])
+        if net.grads_ready_hook is not None:       # e.g. the data-parallel reducer: this group's gradients are final
+            net.grads_ready_hook()
         dgrid = net._dgrid_buf.clone() if n_cells > 0 else None
         if ctx.sink is not None and dgrid is not None:
             ctx.sink(dgrid)
-        w_grads, bn_grads = grads[:nconv], grads[nconv:]
-        return (None, None, None, None, dgrid if ctx.has_vals else None, *w_grads, *bn_grads)
+        return (None, None, None, None, dgrid if ctx.has_vals else None, None)
 
 
 class _Bottleneck(nn.Module):
@@ -153,7 +172,11 @@ class ResNet3D(nn.Module):
         self._ws = None
         self._bws = None
         self._packed, self._packed_key = None, None
-        self._packed_t = self._grad_flat = self._grad_views = self._grad_ptrs = self._dfeat_buf = self._dgrid_buf = self._feat_buf = None
+        self._tables = None
+        self._packed_t = self._grad_bufs = self._dfeat_buf = self._dgrid_buf = self._feat_buf = None
+        self._grad_turn = 0
+        self._anchor = None          # 1-element leaf keeping _ResNet3DFn in the autograd graph (the parameters bypass autograd)
+        self.grads_ready_hook = None # callable() invoked when the backward has assigned every parameter gradient
         self.dp_group = None         # torch.distributed group (or True = default group): average d feat over ranks in the backward
         self.grid_window = None      # (cell_start, n_cells, n_channels): grid cells whose gradient the backward should produce
         self.grid_grad_sink = None   # callable(dgrid_cells fp32 [n_ch, n_cells]) invoked inside the backward
@@ -164,6 +187,27 @@ class ResNet3D(nn.Module):
             for blk in getattr(self, f"layer{li}"):
                 pairs += blk.conv_bn_pairs()
         return pairs
+
+    def _host_tables(self):
+        """(pairs, conv weights, BN tensors, ctypes pointer arrays) of the 43 conv/BN pairs.  Building 215 detached views and three
+        pointer arrays costs ~0.5 ms of host time per call; they are cached and re-validated by comparing the 215 data pointers
+        (tens of microseconds), which catches .to(device), load_state_dict into new storage and parameter replacement alike."""
+        c = self._tables
+        if c is not None:
+            if [t.data_ptr() for t in c["live"]] == c["ptrs"]:
+                return c
+        pairs = self.conv_bn_pairs()
+        conv_w = [cv.weight.detach().contiguous() for cv, _ in pairs]
+        bn: List[torch.Tensor] = []
+        live: List[torch.Tensor] = [cv.weight for cv, _ in pairs]
+        for _, b in pairs:
+            bn += [b.weight.detach(), b.bias.detach(), b.running_mean, b.running_var]
+            live += [b.weight, b.bias, b.running_mean, b.running_var]
+        self._tables = c = dict(pairs=pairs, conv_w=conv_w, bn=bn, live=live, ptrs=[t.data_ptr() for t in live],
+                                conv_w_ptrs=_lib.ptr_array(conv_w), bn_ptrs=_lib.ptr_array(bn),
+                                nbt=[b.num_batches_tracked for _, b in pairs],
+                                params=[cv.weight for cv, _ in pairs] + [t for _, b in pairs for t in (b.weight, b.bias)])
+        return c
 
     def forward(self, x: torch.Tensor, window=None, window_vals: torch.Tensor = None) -> torch.Tensor:
         """x fp32 [1,7,S,S,S] -> [1,1024,1,1,1] (NeRAF_resnet3d.py:184-198).  ``window`` = (cell_start, n_cells, n_ch) and
@@ -176,44 +220,47 @@ class ResNet3D(nn.Module):
         dev = _dev_index(x)
         h, st = _lib.ctx(dev), _stream_ptr()
         grid = x.detach().float().contiguous()
-        pairs = self.conv_bn_pairs()
+        tb = self._host_tables()
+        pairs, conv_w = tb["pairs"], tb["conv_w"]
         assert len(pairs) == lib.neraf_resnet3d_num_convs(C.byref(self._desc))
-        conv_w: List[torch.Tensor] = [c.weight.detach().contiguous() for c, _ in pairs]
-        bn: List[torch.Tensor] = []
-        for _, b in pairs:
-            bn += [b.weight.detach(), b.bias.detach(), b.running_mean, b.running_var]
-        # fp16 implicit-GEMM weight blob: re-packed when a conv weight changed.  (data_ptr, _version) misses in-place
-        # updates by fused optimizers, so any weight that currently holds a gradient is treated as "being trained".
-        key = tuple((w.data_ptr(), w._version) for w in conv_w)
-        being_trained = any(c.weight.grad is not None for c, _ in pairs)
-        if self._packed is None or self._packed.device != x.device or key != self._packed_key or being_trained:
+        # fp16 implicit-GEMM weight blob: re-packed every training forward (optimizers update the weights in place without
+        # bumping tensor versions), in eval only when a weight's (storage, version) changed
+        repack = self.training or self._packed is None or self._packed.device != x.device
+        if not repack:
+            from . import optim
+            key = (optim.UPDATE_EPOCH,) + tuple((w.data_ptr(), w._version) for w in conv_w)
+            repack = key != self._packed_key
+        if repack:
             if self._packed is None or self._packed.device != x.device:      # persistent: its pointer is part of the graph key
                 self._packed = torch.empty(lib.neraf_resnet3d_packed_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
-            _lib.check(lib.neraf_resnet3d_pack_weights(h, C.byref(self._desc), _lib.ptr_array(conv_w), self._packed.data_ptr(), st), dev)
-            self._packed_key = key
+            _lib.check(lib.neraf_resnet3d_pack_weights(h, C.byref(self._desc), tb["conv_w_ptrs"], self._packed.data_ptr(), st), dev)
+            if self.training:
+                self._packed_key = None
+            else:
+                from . import optim
+                self._packed_key = (optim.UPDATE_EPOCH,) + tuple((w.data_ptr(), w._version) for w in conv_w)
         packed = self._packed
         if self._ws is None or self._ws.device != x.device:
             self._ws = torch.empty(lib.neraf_resnet3d_workspace_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
         if self._feat_buf is None or self._feat_buf.device != x.device:
             self._feat_buf = torch.empty(1024, dtype=torch.float32, device=x.device)
-        _lib.check(lib.neraf_resnet3d_fwd(h, C.byref(self._desc), packed.data_ptr(), _lib.ptr_array(bn), grid.data_ptr(),
+        _lib.check(lib.neraf_resnet3d_fwd(h, C.byref(self._desc), packed.data_ptr(), tb["bn_ptrs"], grid.data_ptr(),
                                           self._ws.data_ptr(), self._feat_buf.data_ptr(), int(self.training), st), dev)
         feat = self._feat_buf
         if self.training:
             mom = pairs[0][1].momentum if pairs[0][1].momentum is not None else 0.1
             if mom > 0:
                 _lib.check(lib.neraf_resnet3d_update_running_stats(h, C.byref(self._desc), self._ws.data_ptr(),
-                                                                   _lib.ptr_array(bn), float(mom), st), dev)
-                torch._foreach_add_([b.num_batches_tracked for _, b in pairs], 1)   # one launch for the 43 counters
+                                                                   tb["bn_ptrs"], float(mom), st), dev)
+                torch._foreach_add_(tb["nbt"], 1)   # one launch for the 43 counters
         if self.training and torch.is_grad_enabled() and any(c.weight.requires_grad for c, _ in pairs):
-            params = [c.weight for c, _ in pairs]
-            for _, b in pairs:
-                params += [b.weight, b.bias]
             if window is None:
                 window = self.grid_window
             if window_vals is not None and not window_vals.requires_grad:
                 window_vals = None
-            feat = _ResNet3DFn.apply(self, feat, window, self.grid_grad_sink, window_vals, *params)    # returns a copy
+            if self._anchor is None or self._anchor.device != x.device:
+                self._anchor = torch.zeros(1, dtype=torch.float32, device=x.device, requires_grad=True)
+            feat = _ResNet3DFn.apply(self, feat, window, self.grid_grad_sink, window_vals, self._anchor)    # returns a copy
         else:
             feat = feat.clone()                 # never hand out the persistent output buffer
         return feat.reshape(1, 1024, 1, 1, 1)

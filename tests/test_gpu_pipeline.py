@@ -1,0 +1,67 @@
+"""NeRAFPipeline (neraf_amd/pipeline.py) -- the reference's hot path under its own name, NeRAFPipeline.get_train_loss_dict
+(NeRAF_pipeline.py:166-222): loss-dict keys before / after start_step_audio, parameter groups (field parameters in both "fields"
+and "audio_fields", :487), two training iterations end to end through the fused optimizers, checkpoint round trip."""
+import numpy as np
+import pytest
+import torch
+
+from neraf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_pipeline_train_iterations_and_checkpoint():
+    from neraf_amd.data import DeviceRIRBank
+    from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
+    from neraf_amd.pipeline import FixedBatchDataManager, NeRAFPipeline, RIRBankDataManager
+    from neraf_amd.vision import NeRAFVisionModel, RayBundle
+    dev = torch.device("cuda:0")
+    vm = NeRAFVisionModel(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 210)
+    am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 64), T(synth.audio_aabb()))
+    am.field.load_state_dict({k: T(v) for k, v in synth.nacf_state_dict(1187, 512, 1, 513).items()})
+    am.resnet3d.backbone_net.load_state_dict({k: T(v) for k, v in synth.resnet3d_state_dict(7).items()})
+    vm.to(dev).train(); am.to(dev).train()
+    rb = synth.ray_batch(512, tag="pipe.rays")
+    bundle = RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev))
+    # audio: a device-resident bank of 6 synthetic RIRs, sampled on the GPU
+    n = 15360
+    tt = np.arange(n) / 48000.0
+    waves = torch.from_numpy(np.stack([synth.normal(f"pipe.rir{i}", (n,), 1.0, np.float64) * np.exp(-tt / 0.05) for i in range(6)])).float()
+    aabb = synth.audio_aabb()
+    pos = lambda tag: T(synth.uniform(tag, (6, 3), 0.2, 0.8)).double() * T(aabb[1] - aabb[0]).double() + T(aabb[0]).double()
+    bank = DeviceRIRBank.from_waveforms(waves, 48000, 60, pos("pipe.mic"), pos("pipe.src"), T(synth.uniform("pipe.rot", (6, 3), -3, 3)).double(),
+                                        device=dev)
+    pipe = NeRAFPipeline(vm, am, datamanager=FixedBatchDataManager(bundle, {"image": T(rb["rgb"]).to(dev)}, 512),
+                         audio_datamanager=RIRBankDataManager(bank, 256, generator=torch.Generator(device=dev).manual_seed(0)),
+                         start_step_audio=5)
+    groups = pipe.get_param_groups()
+    assert set(groups) == {"proposal_networks", "fields", "audio_fields"}
+    assert all(any(p is q for q in groups["audio_fields"]) for p in groups["fields"])      # stepped by both optimizers (:487)
+    _, ld, _ = pipe.get_train_loss_dict(3)                                                   # audio branch not started yet (:186)
+    assert set(ld) == {"rgb_loss", "interlevel_loss", "distortion_loss"}
+    _, ld, _ = pipe.get_train_loss_dict(6)
+    assert set(ld) == {"rgb_loss", "interlevel_loss", "distortion_loss", "audio_sc_loss", "audio_mag_loss"}
+    opts, scaler = pipe.make_optimizers(init_scale=1024.0)
+    before = {k: v.detach().clone() for k, v in (("table", vm.field.module.table), ("nacf", am.field.soundfield[1].weight),
+                                                 ("conv", am.resnet3d.backbone_net.layer2[0].conv1.weight), ("prop", vm.proposal_networks[0].w0))}
+    losses = []
+    for step in (7, 8):
+        loss, ld = pipe.train_iteration(step, opts, scaler)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
+    after = {"table": vm.field.module.table, "nacf": am.field.soundfield[1].weight,
+             "conv": am.resnet3d.backbone_net.layer2[0].conv1.weight, "prop": vm.proposal_networks[0].w0}
+    for k in before:
+        assert bool(torch.isfinite(after[k]).all()) and not torch.equal(before[k], after[k]), k
+    assert float(opts[0].state[vm.field.module.table]["step"]) == 2.0 and float(opts[1].state[vm.field.module.table]["step"]) == 2.0
+    # checkpoint: pipeline state in the reference's key space, loaded into a fresh pipeline
+    state = {k: v.detach().clone() for k, v in pipe.state_dict().items()}
+    vm2 = NeRAFVisionModel(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 210).to(dev)
+    am2 = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 64), T(synth.audio_aabb())).to(dev)
+    pipe2 = NeRAFPipeline(vm2, am2)
+    rep = pipe2.load_pipeline(state, step=8)
+    assert rep["missing"] == [] and torch.equal(am2.grid, am.grid) and torch.equal(vm2.field.module.table, vm.field.module.table)
