@@ -19,6 +19,7 @@
 // a second kernel reduces and finishes.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -42,24 +43,28 @@ template <> struct ET<true> {
   static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
-template <int BM, int BN>
+template <int BM, int BN, int WAVES_M = 2>
 struct Tile {
-  static constexpr int WM = BM / 2, WN = BN / 2;
+  static constexpr int NWAVES = WAVES_M * 2, NT = NWAVES * 64;
+  static constexpr int WM = BM / WAVES_M, WN = BN / 2;
   static constexpr int FM = WM / 16, FN = WN / 16;
-  static constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+  static constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;
   static constexpr int STAGE_BYTES = (BM + BN) * 128;
   static constexpr int IMG16_LD = WN + 8;    // halfs
   static constexpr int IMG16T_LD = WM + 8;   // halfs
   static constexpr int IMG32_LD = WN + 4;    // floats
-  static constexpr int EPI_BYTES_WAVE = WM * IMG32_LD * 4;
+  // the fp32 image is staged in C32_PASSES row slices when a whole wave tile per wave would not fit the LDS
+  static constexpr int C32_PASSES = (NWAVES * WM * IMG32_LD * 4 > 144 * 1024) ? 2 : 1;
+  static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+  static constexpr int EPI_BYTES_WAVE = cmax(cmax(WM / C32_PASSES * IMG32_LD * 4, WM * IMG16_LD * 2), WN * IMG16T_LD * 2);
 };
 
 // ------------------------------------------------------------------------------------------------------
 // Epilogue of the GEMM kernel (the split-K reducer applies the same operations element-wise).
-template <int BM, int BN, bool BF>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[Tile<BM, BN>::FM][Tile<BM, BN>::FN],
+template <int BM, int BN, bool BF, int WAVES_M = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[Tile<BM, BN, WAVES_M>::FM][Tile<BM, BN, WAVES_M>::FN],
                                               char* smem, int bm, int bn, int lane, int wave, int M, int N, float* C32, int ldc32) {
-  using T = Tile<BM, BN>;
+  using T = Tile<BM, BN, WAVES_M>;
   using E = typename ET<BF>::s;
   using E4 = typename ET<BF>::v4;
   constexpr int WM = T::WM, WN = T::WN, FM = T::FM, FN = T::FN;
@@ -107,6 +112,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     // column sums over the workgroup's BM rows: over i and the 16 lanes (lane&15) sharing a column by shuffles, over the two
     // wm waves through LDS, then ONE atomic per column per workgroup into replica (bm % stat_rep)
     float* red = reinterpret_cast<float*>(smem);        // [wm][sum | sumsq][BN]
+    static_assert(2 * BN <= T::NT, "one thread per (sum | sumsq, column)");
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -128,7 +134,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     const int t = wave * 64 + lane;
     if (t < 2 * BN) {
       const int which = t / BN, col = t - which * BN;
-      const float v = red[which * BN + col] + red[(2 + which) * BN + col];
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) v += red[(w * 2 + which) * BN + col];
       float* dst = which ? p.colsumsq : p.colsum;
       const int rep = p.stat_rep > 1 ? (bm & (p.stat_rep - 1)) * p.stat_stride : 0;
       if (dst) atomicAdd(dst + rep + n_tile0 + col, v);
@@ -149,10 +157,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       }
     __syncthreads();
     constexpr int CPR = WN / 8;          // 16-B chunks per row
-    constexpr int RPI = 64 / CPR;        // rows per wave-instruction
+    static_assert((WM * CPR) % 64 == 0, "whole wave-instructions");
 #pragma unroll
-    for (int it = 0; it < WM / RPI; ++it) {
-      const int row = it * RPI + lane / CPR, ch = lane % CPR;
+    for (int it = 0; it < WM * CPR / 64; ++it) {
+      const int idx = it * 64 + lane, row = idx / CPR, ch = idx - row * CPR;
       const uint4 d = *reinterpret_cast<const uint4*>(im + row * T::IMG16_LD + ch * 8);
       *reinterpret_cast<uint4*>(p.C16 + (size_t)(m_w0 + row) * p.ldc16 + n_w0 + ch * 8) = d;
     }
@@ -170,10 +178,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           im[(j * 16 + n_l + r) * T::IMG16T_LD + i * 16 + m_l] = (E)acc[i][j][r];
     __syncthreads();
     constexpr int CPR = WM / 8;
-    constexpr int RPI = 64 / CPR;
+    static_assert((WN * CPR) % 64 == 0, "whole wave-instructions");
 #pragma unroll
-    for (int it = 0; it < WN / RPI; ++it) {
-      const int row = it * RPI + lane / CPR, ch = lane % CPR;   // row = n, chunk along m
+    for (int it = 0; it < WN * CPR / 64; ++it) {
+      const int idx = it * 64 + lane, row = idx / CPR, ch = idx - row * CPR;   // row = n, chunk along m
       const uint4 d = *reinterpret_cast<const uint4*>(im + row * T::IMG16T_LD + ch * 8);
       *reinterpret_cast<uint4*>(p.C16T + (size_t)(n_w0 + row) * p.ldc16t + m_w0 + ch * 8) = d;
     }
@@ -182,30 +190,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 
   if (C32) {
     float* im = reinterpret_cast<float*>(img);
+    constexpr int FMP = FM / T::C32_PASSES, ROWS = WM / T::C32_PASSES;
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int pass = 0; pass < T::C32_PASSES; ++pass) {
+      if (pass) __syncthreads();
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-        *reinterpret_cast<f32x4*>(im + (i * 16 + m_l) * T::IMG32_LD + j * 16 + n_l) = acc[i][j];
-    __syncthreads();
-    // one float per lane, 64 consecutive columns per wave-instruction (256-B segments)
-    if (WN >= 64) {
+      for (int i = 0; i < FMP; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          *reinterpret_cast<f32x4*>(im + (i * 16 + m_l) * T::IMG32_LD + j * 16 + n_l) = acc[pass * FMP + i][j];
+      __syncthreads();
+      const int m_p0 = m_w0 + pass * ROWS;
+      if (WN % 64 == 0) {
+        // one float per lane, 64 consecutive columns per wave-instruction (256-B segments)
 #pragma unroll 4
-      for (int row = 0; row < WM; ++row) {
-        const int m = m_w0 + row;
-        if (m >= M) break;
+        for (int row = 0; row < ROWS; ++row) {
+          const int m = m_p0 + row;
+          if (m >= M) break;
 #pragma unroll
-        for (int c0 = 0; c0 < WN; c0 += 64) {
-          const int n = n_w0 + c0 + lane;
-          if (n < N) C32[(size_t)m * ldc32 + n] = im[row * T::IMG32_LD + c0 + lane];
+          for (int c0 = 0; c0 < WN; c0 += 64) {
+            const int n = n_w0 + c0 + lane;
+            if (n < N) C32[(size_t)m * ldc32 + n] = im[row * T::IMG32_LD + c0 + lane];
+          }
         }
-      }
-    } else {
-      constexpr int RPI = 64 / WN;
-      for (int r0 = 0; r0 < WM; r0 += RPI) {
-        const int row = r0 + lane / WN, col = lane % WN;
-        const int m = m_w0 + row, n = n_w0 + col;
-        if (m < M && n < N) C32[(size_t)m * ldc32 + n] = im[row * T::IMG32_LD + col];
+      } else {
+        // 64 consecutive elements of the [ROWS][WN] slice per wave-instruction
+        static_assert((ROWS * WN) % 64 == 0, "whole wave-instructions");
+#pragma unroll 4
+        for (int it = 0; it < ROWS * WN / 64; ++it) {
+          const int idx = it * 64 + lane, row = idx / WN, col = idx - row * WN;
+          const int m = m_p0 + row, n = n_w0 + col;
+          if (m < M && n < N) C32[(size_t)m * ldc32 + n] = im[row * T::IMG32_LD + col];
+        }
       }
     }
   }
@@ -217,7 +233,7 @@ template <int BM, int BN, int NST>
 struct PipeTile {
   using T = Tile<BM, BN>;
   static constexpr int LDS_BYTES =
-      (NST * T::STAGE_BYTES > 4 * T::EPI_BYTES_WAVE) ? NST * T::STAGE_BYTES : 4 * T::EPI_BYTES_WAVE;
+      (NST * T::STAGE_BYTES > T::NWAVES * T::EPI_BYTES_WAVE) ? NST * T::STAGE_BYTES : T::NWAVES * T::EPI_BYTES_WAVE;
 };
 
 // LOADER: 0 plain GEMM, 1 conv tap-per-K-step (cin % 64 == 0), 2 conv tap-per-chunk (cin == 8).  KS = filter size.
@@ -402,6 +418,148 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
   gemm_epilogue<BM, BN, BF>(p, acc, smem, bm, bn, lane, wave, Mg, Ng, C32g, ldc32g);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Wide plain-GEMM body for the big NAcF contractions: 256 x BN x 64 tile, 512 threads = 8 waves as 4 (m) x 2 (n), each wave a
+// 64 x BN/2 sub-tile.  What the 128x128 body is short of on these shapes is operand bytes per flop through the L2 -> LDS path
+// (32 KiB per 2.1 MFLOP K-step; measured ~45-55 GB/s per CU whatever the staging depth): the wide tile moves 52 KiB per
+// 5.2 MFLOP, and its two waves per SIMD overlap one wave's ds_reads and waits with the other's MFMAs.  BN = 160 exists because
+// the NAcF hidden width 5096 pads to 5120 = 32 x 160: with M = 2048 that is exactly 8 x 32 = 256 tiles, one per CU, where
+// 128-wide tiles would leave a quarter-filled second round.
+// The stage image is (256 + BN) rows x 128 B (A rows, then B rows); one LDS-DMA wave-instruction fills 8 rows, wave w issues
+// instructions w, w+8, ... so some waves issue one more than the others -- each wave counts its own in s_waitcnt vmcnt.
+template <int BN, int NST, bool BF>
+__global__ __launch_bounds__(512) void gemm_f16_nt_wide_kernel(GemmParams p, int splits) {
+  constexpr int BM = 256, WAVES_M = 4;
+  using T = Tile<BM, BN, WAVES_M>;
+  using E8 = typename ET<BF>::v8;
+  constexpr int WM = T::WM, WN = T::WN, FM = T::FM, FN = T::FN;
+  constexpr int NINSTR = (BM + BN) / 8, LBASE = NINSTR / 8, LREM = NINSTR % 8, LMAX = LBASE + (LREM ? 1 : 0);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles_m = p.Mpad / BM, tiles_n = p.Npad / BN;
+  const int nblocks = tiles_m * tiles_n * splits;
+  int bid = blockIdx.x;
+  {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int split = bid % splits;
+  bid /= splits;
+  constexpr int GROUP_M = 4;
+  const int group = bid / (GROUP_M * tiles_n);
+  const int first_m = group * GROUP_M;
+  const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+  const int in_group = bid - group * GROUP_M * tiles_n;
+  const int bm = first_m + in_group % gsz;
+  const int bn = in_group / gsz;
+
+  const int nk_total = p.K / BK;
+  const int per = (nk_total + splits - 1) / splits;
+  const int k_begin = split * per;
+  const int k_end = (k_begin + per) < nk_total ? (k_begin + per) : nk_total;
+  const int nk = k_end > k_begin ? k_end - k_begin : 0;
+
+  const half_t* src[LMAX];
+#pragma unroll
+  for (int i = 0; i < LMAX; ++i) {
+    int q = wave + 8 * i;
+    if (q >= NINSTR) q = NINSTR - 1;                      // never issued
+    const int row = q * 8 + (lane >> 3), lc = (lane & 7) ^ (lane >> 3);
+    src[i] = (row < BM ? p.A + (size_t)(bm * BM + row) * p.lda : p.B + (size_t)(bn * BN + row - BM) * p.ldb) + lc * 8;
+  }
+
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int a_row_off = (wm * WM + frow) * 128;
+  const int b_row_off = (BM + wn * WN + frow) * 128;
+  int ch_off[2];
+  ch_off[0] = ((0 + fq) ^ (frow & 7)) * 16;
+  ch_off[1] = ((4 + fq) ^ (frow & 7)) * 16;
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // K loop, "ping-pong": the two waves of a SIMD (wave w and w+4) run half a K-step apart, so one issues its LDS-DMA pieces and
+  // fragment reads (memory phase) while the other owns the matrix pipe (compute phase); every phase ends in one s_barrier.
+  //   waves 0-3:        mem(0) | comp(0) | mem(1) | comp(1) | ...
+  //   waves 4-7:  ----- |  mem(0) | comp(0) | mem(1) | ...
+  // mem(k) reads K-step k's fragments into registers, issues the pieces of K-step k+2 into the stage K-step k-1 used (its last
+  // reads retired, lgkmcnt(0), before the barrier that closed the other group's mem(k-1)), then waits until only those pieces
+  // are outstanding: K-step k+1 has landed for this wave before the barrier, one phase ahead of its first reader.
+  static_assert(NST == 3, "ring depth the phase schedule below is written for");
+  auto kloop = [&](auto lw) {
+    constexpr int L = decltype(lw)::value;               // LDS-DMA instructions this wave issues per stage
+    auto issue = [&](int kt, int stage) {
+      char* s = smem + stage * T::STAGE_BYTES + wave * 1024;   // wave-uniform base; HW adds lane*16
+#pragma unroll
+      for (int i = 0; i < L; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src[i] + (size_t)kt * BK), (lds_ptr_t)(s + i * 8192), 16, 0, 0);
+    };
+    if (nk > 0) issue(k_begin, 0);
+    if (nk > 1) { issue(k_begin + 1, 1); wait_vmcnt<L>(); } else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (wave >= 4) __builtin_amdgcn_s_barrier();
+    int stage = 0;                                         // stage of K-step k; K-step k+2 goes to stage - 1 (mod 3)
+    for (int k = 0; k < nk; ++k) {
+      E8 xa[2][FM], wb[2][FN];
+      const char* st = smem + stage * T::STAGE_BYTES;
+      if (k + 2 < nk) issue(k_begin + k + 2, stage == 0 ? 2 : stage - 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          xa[ks][i] = *reinterpret_cast<const E8*>(st + a_row_off + i * 16 * 128 + ch_off[ks]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          wb[ks][j] = *reinterpret_cast<const E8*>(st + b_row_off + j * 16 * 128 + ch_off[ks]);
+      }
+      if (k + 2 < nk) wait_vmcnt<L>(); else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = ET<BF>::mfma(wb[ks][j], xa[ks][i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      if (++stage == NST) stage = 0;
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();
+  };
+  if (LREM == 0 || wave < LREM) kloop(std::integral_constant<int, LMAX>{});
+  else kloop(std::integral_constant<int, LBASE>{});
+  __syncthreads();
+
+  if (splits > 1) {
+    float* slab = p.splitk_ws + (size_t)split * p.Mpad * p.Npad;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int m = bm * BM + wm * WM + i * 16 + frow;
+        const int n0 = bn * BN + wn * WN + j * 16 + fq * 4;
+        *reinterpret_cast<f32x4*>(slab + (size_t)m * p.Npad + n0) = acc[i][j];
+      }
+    return;
+  }
+  gemm_epilogue<BM, BN, BF, WAVES_M>(p, acc, smem, bm, bn, lane, wave, p.M, p.N, p.C32, p.ldc32);
+}
+
 // Split-K reducer: sums the partial slabs (one float4 per thread per slab, eight loads in flight) and applies the same
 // epilogue element-wise on 32x32 tiles.
 template <bool BF>
@@ -505,6 +663,28 @@ int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
   return NERAF_OK;
 }
 
+
+template <int BN, int NST, bool BF>
+int launch_wide(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t stream) {
+  using T = Tile<256, BN, 4>;
+  constexpr int LDS_BYTES = (NST * T::STAGE_BYTES > T::NWAVES * T::EPI_BYTES_WAVE) ? NST * T::STAGE_BYTES : T::NWAVES * T::EPI_BYTES_WAVE;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_nt_wide_kernel<BN, NST, BF>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set = true;
+  }
+  const int ntiles = (p.Mpad / 256) * (p.Npad / BN);
+  ProfScope prof(ctx, stream, PROF_GEMM128, 2.0 * p.M * p.N * p.K);
+  hipLaunchKernelGGL((gemm_f16_nt_wide_kernel<BN, NST, BF>), dim3(ntiles * splits), dim3(512), LDS_BYTES, stream, p, splits);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  if (splits > 1) {
+    hipLaunchKernelGGL(splitk_reduce_kernel<BF>, dim3(p.Npad / 32, p.Mpad / 32, 1), dim3(256), 0, stream, p, splits);
+    NERAF_HIP_CHECK(ctx, hipGetLastError());
+  }
+  return NERAF_OK;
+}
 
 // ------------------------------------------------------------------------------------------------------
 // "TN" weight-gradient GEMM (bf16): C[m][n] = sum_k A[k][m] * B[row(k, n-tile)][n], 64x64 tile, K-step 64.
@@ -728,6 +908,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(WgTable t, Wg
 
 // split-K only pays when the K loop is long: below this many K-steps the slab round trip + reducer launch cost more than the
 // shorter chain saves (NERAF_SPLIT_MIN_K overrides, for measurements)
+static const int kWide = [] { const char* e = getenv("NERAF_GEMM_WIDE"); return e ? atoi(e) : 1; }();
 static const int kSplitMinK = [] { const char* e = getenv("NERAF_SPLIT_MIN_K"); return e ? atoi(e) : 32; }();
 
 template <int LOADER, int KS, bool BF>
@@ -750,8 +931,14 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
     while (splits >= 2 && (size_t)splits * ng * p.Mpad * p.Npad * 4 > p.splitk_ws_bytes) splits >>= 1;
     if (splits < 2) splits = 1;
   }
-  if (bm == 128 && bn == 128) return launch_pipe<128, 128, 4, LOADER, KS, BF>(ctx, p, splits, stream);
-  if (bm == 128 && bn == 64) return launch_pipe<128, 64, 4, LOADER, KS, BF>(ctx, p, splits, stream);
+  if (LOADER == 0 && ng == 1 && kWide && (p.Mpad % 256) == 0) {
+    // wide body where its tiles fill the chip: 256x160 (the 5096-wide NAcF layers), else 256x128
+    if ((p.Npad % 160) == 0 && (p.Mpad / 256) * (p.Npad / 160) * 4 >= cus * 3) return launch_wide<160, 3, BF>(ctx, p, 1, stream);
+    if ((p.Npad % 128) == 0 && (p.Mpad / 256) * (p.Npad / 128) >= cus) return launch_wide<128, 3, BF>(ctx, p, 1, stream);
+  }
+  // staging depth: the 128-wide tiles run faster with two workgroups per CU (2 / 3 stages) than with one and a deep ring
+  if (bm == 128 && bn == 128) return launch_pipe<128, 128, 2, LOADER, KS, BF>(ctx, p, splits, stream);
+  if (bm == 128 && bn == 64) return launch_pipe<128, 64, 3, LOADER, KS, BF>(ctx, p, splits, stream);
   return launch_pipe<64, 64, 4, LOADER, KS, BF>(ctx, p, splits, stream);
 }
 

@@ -43,7 +43,7 @@ def T(a, dev=None):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(2048, 2048, 256), (200, 300, 192), (1024, 256, 128)])
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 256), (200, 300, 192), (1024, 256, 128), (2048, 5096, 192), (4096, 4096, 128)])
 def test_gemm_bf16_exact_small_integers(dev, M, N, K):
     """bfloat16 instantiation (gradient chains): exact on small integers (8 significant bits suffice)."""
     from neraf_amd import _lib
@@ -88,7 +88,9 @@ def test_gemm_bf16_tn_exact_small_integers(dev, M, N, K):
     np.testing.assert_array_equal(C32.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 2048, 256), (200, 300, 192), (2048, 513, 512), (130, 5096, 64)])
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 256), (200, 300, 192), (2048, 513, 512), (130, 5096, 64),
+                                   # the wide 8-wave bodies: 256x160 tiles (uneven LDS-DMA counts per wave), 256x128 tiles
+                                   (2048, 5096, 2048), (2000, 5000, 128), (4096, 4096, 256), (5096, 5096, 64)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_gemm_exact_small_integers(dev, M, N, K, act):
     """Asymmetric small-integer operands: every product/sum is exact in fp16 x fp16 -> fp32, so the MFMA

@@ -32,4 +32,12 @@ for M, N, K, o in shapes:
     for _ in range(n): run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / n
-    print(f"M{M:5d} N{N:5d} K{K:5d} out{o}: {us:8.1f} us  {2.0*M*N*K/us/1e6:8.1f} TF/s")
+    lib_us = float("nan")
+    if os.environ.get("NERAF_GEMM_BENCH_LIB"):      # hipBLASLt through torch, as an orientation figure only
+        Bt = B.t()
+        for _ in range(3): torch.matmul(A, Bt)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(n): torch.matmul(A, Bt)
+        e1.record(); torch.cuda.synchronize()
+        lib_us = e0.elapsed_time(e1) * 1e3 / n
+    print(f"M{M:5d} N{N:5d} K{K:5d} out{o}: {us:8.1f} us  {2.0*M*N*K/us/1e6:8.1f} TF/s   (library fp16 matmul, padded shape: {lib_us:8.1f} us)")
