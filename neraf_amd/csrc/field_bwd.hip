@@ -357,6 +357,7 @@ struct FieldBwdArgs {
   float* t_part;                                   // fp32 [blocks][16]: per-workgroup sums of max(|g0|,|g1|) per level (rows 64.. of slot 1)
   float* e_part; int* e_part_row;                  // fp32 [blocks][32] + row: per-workgroup appearance-embedding gradient of the
                                                    // workgroup's leading embedding row (rows 64.. of slots 2 / 3)
+  float* pos;                                      // optional fp32 [3][npad]: mapped sample positions for the owner scatter (slot 4, rows 64..)
 };
 
 __device__ __forceinline__ void dump_block(half_t* base, long npad, long n, int row0, const f32x4& v, float m) {
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
     float y = fmaf(dy, t, a.origins[ray * 3 + 1]);
     float z = fmaf(dz, t, a.origins[ray * 3 + 2]);
     const bool sel = map_position(x, y, z, a.mode, a.aabb);
+    if (a.pos && q == 0) { a.pos[ncol] = x; a.pos[a.npad + ncol] = y; a.pos[2 * a.npad + ncol] = z; }
     // ---------------- forward recompute (identical to field_query_kernel) ----------------
     half8 xin;
 #pragma unroll
@@ -671,6 +673,7 @@ struct FieldScatterArgs {
   const unsigned* d_enc; long npad;
   const float* lvl;                    // F_l [16], 1/F_l [16]
   unsigned long long* acc;             // [rows]: packed fixed-point sums (the table_grad buffer, zero on entry)
+  int l_end;                           // levels [0, l_end) are scattered here (the rest by the owner kernels below)
 };
 
 __device__ __forceinline__ long long shfl_up_i64(long long v, int o) {
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(256) void field_scatter_kernel(FieldScatterArgs a) 
     float y = fmaf(a.dirs[ray * 3 + 1], t, a.origins[ray * 3 + 1]);
     float z = fmaf(a.dirs[ray * 3 + 2], t, a.origins[ray * 3 + 2]);
     map_position(x, y, z, a.mode, a.aabb);
-    for (int l = 0; l < 16; ++l) {
+    for (int l = 0; l < a.l_end; ++l) {
       const unsigned raw = valid ? a.d_enc[(long)l * a.npad + n] : 0u;
       const half2v gh = *reinterpret_cast<const half2v*>(&raw);
       const float F = l_fix[l];
@@ -743,6 +746,169 @@ __global__ __launch_bounds__(256) void field_scatter_kernel(FieldScatterArgs a) 
         }
         if (tail && v != 0) atomicAdd(a.acc + offset + idx, (unsigned long long)v);
       }
+    }
+  }
+}
+
+// ---- owner scatter for the hashed levels ----------------------------------------------------------------------------------
+// Scattered 8-byte atomics retire at ~21-24 G/s on this chip whatever their scope or footprint (tools/microbench/atomic_*), and a
+// hashed level gives consecutive samples nothing to merge: 10 hashed levels x 8 corners x 196,608 samples cost ~0.5 ms.  Here a
+// workgroup OWNS a 2^14-entry slice of one level's table in LDS (128 KiB of packed sums), finds the corner updates that fall
+// into it, adds them with LDS atomics and writes the slice back with plain stores -- no global atomics, same integer sums.
+//   * idx = (cx ^ cy*P1 ^ cz*P2) mod 2^k and cx < 2^14, so the slice (idx >> 14) depends on (cy, cz) only: a sample has 4
+//     slice ids per level, and the two x-corners of a (cy, cz) pair always land in the same slice.
+//   * a dense pre-pass ORs those 4 ids into a 32-bit slice mask per (level, sample); the owner's scan reads one dword per sample,
+//     tests one bit, and pushes hits into a per-wave LDS queue; every 64 queued samples are expanded with all lanes busy (the
+//     hit rate per lane is 1/8, expanding in place would run the expensive part at 8 of 64 lanes).
+constexpr int OWN_SLICE_LOG2 = 14;
+constexpr int OWN_THREADS = 1024;
+constexpr int OWN_QUEUE = 128;
+constexpr unsigned HASH_P1 = 2654435761u, HASH_P2 = 805459861u;
+
+struct FieldOwnerArgs {
+  GridLayout g;
+  const float* pos; long npad; long N;
+  const unsigned* d_enc;
+  unsigned* ids;                       // [16][npad]: bit s set = some corner of the sample falls into slice s of that level
+  const float* lvl;
+  unsigned long long* acc;
+  int blk_begin[MAX_LEVELS + 1];       // owner workgroups of level l: [blk_begin[l], blk_begin[l+1]) = slices x rep[l]
+  unsigned char rep[MAX_LEVELS];       // coarse levels have few slices that every sample hits: rep[l] workgroups share a slice, each
+                                       // takes 1/rep[l] of the samples and adds its sums to the table with (few) global atomics
+};
+
+// corner index of a level (dense: x + y*res + z*res^2, wrapped once; hashed: tcnn's coherent prime hash)
+__device__ __forceinline__ unsigned corner_index(unsigned cx, unsigned cy, unsigned cz, int res, unsigned size, int hashed) {
+  if (hashed) return (cx ^ (cy * HASH_P1) ^ (cz * HASH_P2)) & (size - 1u);
+  unsigned idx = cx + cy * (unsigned)res + cz * (unsigned)res * (unsigned)res;
+  if (idx >= size) idx -= size;
+  return idx;
+}
+
+__global__ __launch_bounds__(256) void field_slice_ids_kernel(FieldOwnerArgs a) {
+  const int l = blockIdx.y;
+  const float scale = a.g.scale[l];
+  const int res = a.g.res[l]; const unsigned size = a.g.size[l]; const int hashed = a.g.hashed[l];
+  const unsigned nsl_mask = (size >> OWN_SLICE_LOG2) - 1u;     // hashed levels only
+  for (long n = (long)blockIdx.x * 256 + threadIdx.x; n < a.npad; n += (long)gridDim.x * 256) {
+    unsigned word = 0u;
+    if (n < a.N && a.d_enc[(long)l * a.npad + n] != 0u) {
+      const float py = fmaf(scale, a.pos[a.npad + n], 0.5f), pz = fmaf(scale, a.pos[2 * a.npad + n], 0.5f);
+      const unsigned iy = (unsigned)(int)floorf(py), iz = (unsigned)(int)floorf(pz);
+      if (hashed) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned t = ((iy + (k & 1)) * HASH_P1) ^ ((iz + (k >> 1)) * HASH_P2);
+          word |= 1u << ((t >> OWN_SLICE_LOG2) & nsl_mask);
+        }
+      } else {
+        const unsigned ix = (unsigned)(int)floorf(fmaf(scale, a.pos[n], 0.5f));
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          word |= 1u << (corner_index(ix + (c & 1), iy + ((c >> 1) & 1), iz + ((c >> 2) & 1), res, size, 0) >> OWN_SLICE_LOG2);
+      }
+    }
+    a.ids[(long)l * a.npad + n] = word;
+  }
+}
+
+__global__ __launch_bounds__(OWN_THREADS) void field_scatter_owner_kernel(FieldOwnerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long own[];     // [1 << OWN_SLICE_LOG2] sums, then the wave queues
+  constexpr unsigned NENT = 1u << OWN_SLICE_LOG2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  volatile unsigned* queue = reinterpret_cast<volatile unsigned*>(own + NENT) + wave * OWN_QUEUE;
+  int l = 0;
+  while (l + 1 < a.g.n_levels && (int)blockIdx.x >= a.blk_begin[l + 1]) ++l;
+  const int nrep = a.rep[l];
+  const unsigned nsl = (unsigned)(a.blk_begin[l + 1] - a.blk_begin[l]) / (unsigned)nrep;
+  const unsigned slice = (blockIdx.x - a.blk_begin[l]) % nsl, rep = (blockIdx.x - a.blk_begin[l]) / nsl;
+  const long span = (((a.N + nrep - 1) / nrep) + 4095) / 4096 * 4096;      // whole scan steps: 16 waves x 256 samples
+  const long n_begin = (long)rep * span, n_end = (n_begin + span) < a.N ? (n_begin + span) : a.N;
+  for (unsigned i = tid; i < NENT; i += OWN_THREADS) own[i] = 0ull;
+  __syncthreads();
+  const float scale = a.g.scale[l], F = a.lvl[l];
+  const int res = a.g.res[l]; const unsigned size = a.g.size[l]; const int hashed = a.g.hashed[l];
+  const unsigned mask = size - 1u;
+  const unsigned nsl_mask = (size >> OWN_SLICE_LOG2) - 1u;
+  const uint4* ids = reinterpret_cast<const uint4*>(a.ids + (long)l * a.npad);
+  const unsigned* genc = a.d_enc + (long)l * a.npad;
+  const float* xs = a.pos; const float* ys = a.pos + a.npad; const float* zs = a.pos + 2 * a.npad;
+
+  // expands queue entries [head, head + cnt) (cnt <= 64), one sample per lane: the corners that fall into this slice
+  auto expand = [&](unsigned head, int cnt) {
+    if (lane < cnt) {
+      const long n = (long)queue[(head + lane) & (OWN_QUEUE - 1)];
+      const unsigned raw = genc[n];
+      const float x = xs[n], y = ys[n], z = zs[n];
+      const half2v gh = *reinterpret_cast<const half2v*>(&raw);
+      const float g0 = (float)gh[0] * F, g1 = (float)gh[1] * F;
+      const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+      const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+      const float wx = px - flx, wy = py - fly, wz = pz - flz;
+      const unsigned ix = (unsigned)(int)flx, iy = (unsigned)(int)fly, iz = (unsigned)(int)flz;
+      auto add = [&](unsigned idx, float w) {
+        const int q0 = __float2int_rn(w * g0), q1 = __float2int_rn(w * g1);
+        const long long v = ((long long)q1 << 32) + (long long)q0;
+        if (v != 0) atomicAdd(&own[idx & (NENT - 1u)], (unsigned long long)v);
+      };
+      if (hashed) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int kb = k & 1, kc = k >> 1;
+          const unsigned t = ((iy + kb) * HASH_P1) ^ ((iz + kc) * HASH_P2);
+          if (((t >> OWN_SLICE_LOG2) & nsl_mask) != slice) continue;
+          const float wyv = kb ? wy : 1.f - wy, wzv = kc ? wz : 1.f - wz;
+#pragma unroll
+          for (int ka = 0; ka < 2; ++ka)
+            add(((ix + ka) ^ t) & mask, ((ka ? wx : 1.f - wx) * wyv) * wzv);   // the product order of field_scatter_kernel
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const unsigned idx = corner_index(ix + (c & 1), iy + ((c >> 1) & 1), iz + ((c >> 2) & 1), res, size, 0);
+          if ((idx >> OWN_SLICE_LOG2) != slice) continue;
+          add(idx, ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz));
+        }
+      }
+    }
+  };
+
+  // scan: 4 consecutive samples per lane and step (one 16-B load, the next step's already in flight)
+  unsigned head = 0; int qcount = 0;                      // wave-uniform
+  const long step = (long)(OWN_THREADS / 64) * 256;
+  long base = n_begin + (long)wave * 256;
+  const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+  uint4 cur = (base < n_end && base + lane * 4 < a.npad) ? ids[(base >> 2) + lane] : none;
+  for (; base < n_end; base += step) {
+    const long nb = base + step;
+    const uint4 nxt = (nb < n_end && nb + lane * 4 < a.npad) ? ids[(nb >> 2) + lane] : none;
+    const unsigned wv[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool has = (wv[j] >> slice) & 1u;
+      const unsigned long long b = __ballot(has);
+      if (b == 0ull) continue;
+      if (has) {
+        const int at = qcount + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0));
+        queue[(head + at) & (OWN_QUEUE - 1)] = (unsigned)(base + lane * 4 + j);
+      }
+      qcount += __popcll(b);
+      __builtin_amdgcn_wave_barrier();
+      if (qcount >= 64) { expand(head, 64); head += 64; qcount -= 64; __builtin_amdgcn_wave_barrier(); }
+    }
+    cur = nxt;
+  }
+  if (qcount > 0) expand(head, qcount);
+  __syncthreads();
+  const size_t e0 = (size_t)slice * NENT;
+  unsigned long long* dst = a.acc + a.g.offset[l] + e0;
+  if (nrep == 1) {
+    for (unsigned i = tid; i < NENT; i += OWN_THREADS)
+      if (e0 + i < size) dst[i] = own[i];
+  } else {
+    for (unsigned i = tid; i < NENT; i += OWN_THREADS) {
+      const unsigned long long v = own[i];
+      if (v != 0ull && e0 + i < size) atomicAdd(dst + i, v);
     }
   }
 }
@@ -875,6 +1041,34 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
   a.e_part_row = reinterpret_cast<int*>((half_t*)dump + (size_t)3 * 128 * npad + (size_t)64 * npad);  // slot 3, rows 64..
   float* scale = (float*)((char*)dump + (size_t)10 * 128 * npad * 2);
   a.scale = scale;
+  // owner scatter (no global atomics) for a large batch: every level in <= 32 slices of 2^14 entries, hashed levels of
+  // power-of-two size, and every coordinate below the slice size (the hashed slice id must not depend on x)
+  constexpr int kOwnLds = (1 << OWN_SLICE_LOG2) * 8 + (OWN_THREADS / 64) * OWN_QUEUE * 4;
+  const char* own_e = getenv("NERAF_FIELD_OWNER_SCATTER");      // read per call: the parity test flips it between two runs
+  const int own_env = own_e ? atoi(own_e) : 1;
+  bool use_owner = own_env && (N >= 131072 || own_env == 2) && N < (1l << 30);   // 2 = also for small batches (tests)
+  int own_blk[MAX_LEVELS + 1] = {0};
+  unsigned char own_rep[MAX_LEVELS] = {0};
+  for (int l = 0; l < 16 && use_owner; ++l) {
+    const unsigned sz = a.g.size[l];
+    const unsigned nsl = (sz + (1u << OWN_SLICE_LOG2) - 1u) >> OWN_SLICE_LOG2;
+    use_owner = nsl <= 32 && a.g.res[l] + 1 < (1 << OWN_SLICE_LOG2) &&
+                (!a.g.hashed[l] || ((sz & (sz - 1)) == 0 && sz >= (2u << OWN_SLICE_LOG2)));
+    // a hashed slice sees ~1/8 of the samples (4 slice ids of 32); a dense level's sample touches 1-2 of its nsl slices
+    int rep = a.g.hashed[l] ? 1 : (int)((10 + nsl / 2) / nsl);
+    rep = rep < 1 ? 1 : (rep > 12 ? 12 : rep);
+    own_rep[l] = (unsigned char)rep;
+    own_blk[l + 1] = own_blk[l] + (int)nsl * rep;
+  }
+  if (use_owner) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&field_scatter_owner_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kOwnLds));
+      attr_set = true;
+    }
+    a.pos = reinterpret_cast<float*>((half_t*)dump + (size_t)4 * 128 * npad + (size_t)64 * npad);   // slot 4, rows 64..: pos [3][npad], ids
+  }
   NERAF_HIP_CHECK(ctx, hipMemsetAsync(scale, 0, 16, st));
   {
     long blocks = (N + 1023) / 1024; if (blocks > 256) blocks = 256;
@@ -901,11 +1095,22 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
     sa.g = a.g; sa.origins = origins; sa.dirs = dirs; sa.e_bins = e_bins; sa.R = R; sa.S = S; sa.mode = mode;
     for (int i = 0; i < 6; ++i) sa.aabb[i] = a.aabb[i];
     sa.d_enc = a.d_enc; sa.npad = npad; sa.lvl = lvl; sa.acc = reinterpret_cast<unsigned long long*>(table_grad);
+    sa.l_end = 16;
     long sblocks = ((N + 63) / 64 + 3) / 4;
     if (sblocks > cap) sblocks = cap;
     {
-      ProfScope prof(ctx, st, PROF_FIELD_SCATTER, (double)N * 16 * 8 * 8);   // one 8-byte atomic per (sample, level, corner) before merging
-      hipLaunchKernelGGL(field_scatter_kernel, dim3((unsigned)sblocks), dim3(256), 0, st, sa);
+      ProfScope prof(ctx, st, PROF_FIELD_SCATTER, (double)N * 16 * 8 * 8);   // one 8-byte update per (sample, level, corner) before merging
+      if (!use_owner) hipLaunchKernelGGL(field_scatter_kernel, dim3((unsigned)sblocks), dim3(256), 0, st, sa);
+      else {
+        FieldOwnerArgs oa{};
+        oa.g = a.g; oa.pos = a.pos; oa.npad = npad; oa.N = N; oa.d_enc = a.d_enc; oa.lvl = lvl; oa.acc = sa.acc;
+        oa.ids = reinterpret_cast<unsigned*>(a.pos + 3 * npad);
+        for (int l = 0; l <= 16; ++l) oa.blk_begin[l] = own_blk[l];
+        for (int l = 0; l < 16; ++l) oa.rep[l] = own_rep[l];
+        long iblocks = (npad + 255) / 256; if (iblocks > 512) iblocks = 512;
+        hipLaunchKernelGGL(field_slice_ids_kernel, dim3((unsigned)iblocks, 16), dim3(256), 0, st, oa);
+        hipLaunchKernelGGL(field_scatter_owner_kernel, dim3(own_blk[16]), dim3(OWN_THREADS), kOwnLds, st, oa);
+      }
     }
     unsigned maxsize = 0;
     for (int l = 0; l < 16; ++l) maxsize = a.g.size[l] > maxsize ? a.g.size[l] : maxsize;

@@ -60,6 +60,20 @@ def test_table_gradient_is_bit_reproducible_and_scales_exactly(vm):
         np.testing.assert_allclose(y.cpu().numpy(), 4.0 * x.cpu().numpy(), rtol=1e-5, atol=0)
 
 
+def test_owner_scatter_equals_atomic_scatter_bit_for_bit(vm, monkeypatch):
+    """The hashed levels' gradient is summed either by 64-bit global atomics or, for large batches, by workgroups that own a
+    table slice in LDS (field_scatter_owner_kernel): the same fixed-point integers are added, so the results are identical."""
+    m, dev = vm
+    monkeypatch.setenv("NERAF_FIELD_OWNER_SCATTER", "0")
+    a = _field_backward(m, dev, 1.0)
+    monkeypatch.setenv("NERAF_FIELD_OWNER_SCATTER", "1")
+    b = _field_backward(m, dev, 1.0)
+    assert float(a[0].abs().max()) > 0
+    assert torch.equal(a[0], b[0])
+    for x, y in zip(a[1:6], b[1:6]):                                 # nothing else may change (fp32 sums: not bit-stable)
+        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=1e-4, atol=1e-7)
+
+
 def test_full_size_render_invariants(vm):
     from neraf_amd.vision import RayBundle
     m, dev = vm

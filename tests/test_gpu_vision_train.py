@@ -54,9 +54,12 @@ def _oracle(P16, spec, V, rb, step, scale):
     return ld, P
 
 
-@pytest.mark.parametrize("R,scale", [(384, 1.0), (130, 4096.0)])
-def test_losses_and_gradients_vs_oracle(setup, R, scale):
+@pytest.mark.parametrize("R,scale,owner", [(384, 1.0, "0"), (130, 4096.0, "0"), (384, 1.0, "2")])
+def test_losses_and_gradients_vs_oracle(setup, R, scale, owner, monkeypatch):
+    """owner: NERAF_FIELD_OWNER_SCATTER -- "0" sums the hashed levels' table gradient with global atomics, "2" forces the
+    LDS-owner kernels (the default for batches of >= 131072 samples) at this oracle-sized batch."""
     from neraf_amd.vision import RayBundle
+    monkeypatch.setenv("NERAF_FIELD_OWNER_SCATTER", owner)
     m, P16, spec, V, dev = setup
     rb = synth.ray_batch(R, tag=f"t.vtrain{R}")
     ld_o, Po = _oracle(P16, spec, V, rb, 300, scale)
