@@ -5,6 +5,7 @@
 // squares that BatchNorm3d needs (batch = 1: statistics over the voxels, NeRAF_resnet3d.py:82-87 / SURVEY A4),
 // so BN costs one element-wise pass that is fused with ReLU, the residual add and (stem) the 3^3 max-pool.
 #include "resnet3d_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -128,18 +129,42 @@ extern "C" int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_
   if (make_arch(d, &A) || !conv_w || !packed) return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_pack_weights: bad arguments");
   make_layout(A, &L);
   hipStream_t st = (hipStream_t)stream;
+  // un-padded convolutions go through the brick packer; the rest (the 7-channel stem) through the element-wise one
   PackTable t{};
-  t.n = A.nconv;
+  BrickTable bt{};
   unsigned long long acc = 0;
+  int tiles = 0, max_run = 0;
   for (int i = 0; i < A.nconv; ++i) {
     const ConvSpec& c = A.conv[i];
-    t.src[i] = conv_w[i]; t.begin[i] = acc; t.dst_off[i] = L.w[i];
-    t.cout[i] = c.cout; t.cin_real[i] = c.cin_real; t.cin[i] = c.cin; t.taps[i] = c.k * c.k * c.k;
-    t.kpad[i] = conv_kpad(c);
+    const int taps = c.k * c.k * c.k;
+    if (brick_packable(c) && conv_kpad(c) == taps * c.cin && conv_npad(c) == c.cout) {
+      const int j = bt.n++;
+      const int cib = brick_cib(c);
+      bt.src[j] = conv_w[i]; bt.tile_begin[j] = tiles; bt.dst_off[j] = L.w[i];
+      bt.cout[j] = c.cout; bt.cin[j] = c.cin; bt.taps[j] = taps; bt.cib[j] = cib;
+      tiles += (c.cout / 32) * (c.cin / cib);
+      max_run = std::max(max_run, cib * taps);
+      continue;
+    }
+    const int j = t.n++;
+    t.src[j] = conv_w[i]; t.begin[j] = acc; t.dst_off[j] = L.w[i];
+    t.cout[j] = c.cout; t.cin_real[j] = c.cin_real; t.cin[j] = c.cin; t.taps[j] = taps;
+    t.kpad[j] = conv_kpad(c);
     acc += (unsigned long long)conv_npad(c) * conv_kpad(c);
   }
-  t.begin[A.nconv] = acc;
-  hipLaunchKernelGGL(pack_all_conv_weights_kernel, dim3((unsigned)((acc + 255) / 256)), dim3(256), 0, st, t, (char*)packed);
+  t.begin[t.n] = acc;
+  bt.tile_begin[bt.n] = tiles;
+  if (t.n > 0) hipLaunchKernelGGL(pack_all_conv_weights_kernel, dim3((unsigned)((acc + 255) / 256)), dim3(256), 0, st, t, (char*)packed);
+  if (bt.n > 0) {
+    const size_t lds = brick_lds_bytes(max_run);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+      NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_bricks_kernel<0>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_lds = lds;
+    }
+    hipLaunchKernelGGL(pack_bricks_kernel<0>, dim3((unsigned)tiles), dim3(256), lds, st, bt, (char*)packed);
+  }
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }

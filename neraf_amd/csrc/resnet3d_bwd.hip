@@ -457,20 +457,45 @@ extern "C" int neraf_resnet3d_pack_weights_bwd(neraf_ctx* ctx, const neraf_resne
   Arch A; BwdLayout B;
   if (make_arch(d, &A) || !conv_w || !packed_t) return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_pack_weights_bwd: bad arguments");
   make_bwd_layout(A, &B);
+  hipStream_t st = (hipStream_t)stream;
   PackTTable t{};
-  t.n = A.nconv;
-  int acc = 0, max_taps = 1;
-  for (int i = 0; i < A.nconv; ++i) {
+  BrickTable bt{};
+  int acc = 0, max_taps = 1, tiles = 0, max_run = 0;
+  for (int i = 1; i < A.nconv; ++i) {            // the stem has no dgrad GEMM (its input gradient is stem_dgrid_kernel's)
     const ConvSpec& c = A.conv[i];
+    const int taps = c.k * c.k * c.k;
     const int nrows = c.cin == 64 || c.cin == 8 ? 64 : round_up(c.cin, 128);
-    t.src[i] = conv_w[i]; t.tile_begin[i] = acc; t.dst_off[i] = B.wt[i];
-    t.cout[i] = c.cout; t.cin[i] = c.cin_real; t.taps[i] = c.k * c.k * c.k; t.kcols[i] = t.taps[i] * c.cout; t.nrows[i] = nrows;
-    if (i == 0) continue;              // the stem has no dgrad GEMM (its input gradient is stem_dgrid_kernel's)
+    if (brick_packable(c) && nrows == c.cin) {
+      const int j = bt.n++;
+      const int cib = brick_cib(c);
+      bt.src[j] = conv_w[i]; bt.tile_begin[j] = tiles; bt.dst_off[j] = B.wt[i];
+      bt.cout[j] = c.cout; bt.cin[j] = c.cin; bt.taps[j] = taps; bt.cib[j] = cib;
+      tiles += (c.cout / 32) * (c.cin / cib);
+      max_run = std::max(max_run, cib * taps);
+      continue;
+    }
+    const int j = t.n++;
+    t.src[j] = conv_w[i]; t.tile_begin[j] = acc; t.dst_off[j] = B.wt[i];
+    t.cout[j] = c.cout; t.cin[j] = c.cin_real; t.taps[j] = taps; t.kcols[j] = taps * c.cout; t.nrows[j] = nrows;
     acc += (c.cout / 32) * (nrows / 32);
-    max_taps = std::max(max_taps, t.taps[i]);
+    max_taps = std::max(max_taps, taps);
   }
-  t.tile_begin[A.nconv] = acc;       // conv 0 owns an empty range [0, 0): the search never lands on it
-  return launch_pack_dgrad(ctx, t, acc, max_taps, (char*)packed_t, (hipStream_t)stream);
+  t.tile_begin[t.n] = acc;
+  bt.tile_begin[bt.n] = tiles;
+  if (t.n > 0)
+    if (int e = launch_pack_dgrad(ctx, t, acc, max_taps, (char*)packed_t, st)) return e;
+  if (bt.n > 0) {
+    const size_t lds = brick_lds_bytes(max_run);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+      NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_bricks_kernel<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_lds = lds;
+    }
+    hipLaunchKernelGGL(pack_bricks_kernel<1>, dim3((unsigned)tiles), dim3(256), lds, st, bt, (char*)packed_t);
+    NERAF_HIP_CHECK(ctx, hipGetLastError());
+  }
+  return NERAF_OK;
 }
 
 static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, const BwdLayout& B, const void* packed_t,

@@ -197,6 +197,75 @@ __global__ __launch_bounds__(256) void pack_all_conv_weights_kernel(PackTable t,
   reinterpret_cast<half_t*>(packed + t.dst_off[i])[e] = (half_t)v;
 }
 
+// Brick packer for the un-padded convolutions (cin, cout multiples of 32): a workgroup moves a [32 co][CIB ci][taps] brick.
+// The fp32 source [cout][cin][taps] is read in contiguous runs of CIB*taps floats per co row, converted and parked in LDS in
+// source order; the destination is written in runs along its fastest index with no per-element divisions:
+//   MODE 0  forward layout   fp16  dst[co][tap*cin + ci]     (ld = taps*cin)
+//   MODE 1  dgrad layout     bf16  dst[ci][tap*cout + co]    (ld = taps*cout)
+// CIB is 32 for the 3x3x3 filters and up to 256 for the 1x1x1 ones (bricks of 27,648 / 8,192 elements).
+struct BrickTable {
+  int n;
+  const float* src[48];
+  int tile_begin[49];                // prefix of (cout/32)*(cin/CIB) bricks
+  unsigned long long dst_off[48];
+  int cout[48], cin[48], taps[48], cib[48];
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void pack_bricks_kernel(BrickTable t, char* __restrict__ packed) {
+  extern __shared__ unsigned short brick16[];          // [32 co][pitch]
+  int lo = 0, hi = t.n - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.tile_begin[mid] <= bid) lo = mid; else hi = mid - 1; }
+  const int i = lo;
+  const int tile = bid - t.tile_begin[i];
+  const int taps = t.taps[i], cin = t.cin[i], cout = t.cout[i], cib = t.cib[i];
+  const int ci_tiles = cin / cib;
+  const int co0 = (tile / ci_tiles) * 32, ci0 = (tile % ci_tiles) * cib;
+  const int run = cib * taps;                          // even
+  const int pitch = ((run >> 1) & 1) ? run : run + 2;  // odd number of dwords per row: column reads (MODE 1) hit distinct banks
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* src = t.src[i] + ((size_t)co0 * cin + ci0) * taps;
+  for (int co_l = wave; co_l < 32; co_l += 4) {
+    const float* row = src + (size_t)co_l * cin * taps;
+    unsigned short* dst = brick16 + co_l * pitch;
+    for (int idx = lane; idx < run; idx += 64) {
+      const float v = row[idx];
+      if (MODE == 0) { const half_t h = (half_t)v; dst[idx] = *reinterpret_cast<const unsigned short*>(&h); }
+      else { const bf16_t h = (bf16_t)v; dst[idx] = *reinterpret_cast<const unsigned short*>(&h); }
+    }
+  }
+  __syncthreads();
+  unsigned short* out = reinterpret_cast<unsigned short*>(packed + t.dst_off[i]);
+  if (MODE == 0) {
+    // runs of cib ci for every (co, tap)
+    const int lpr = cib < 256 ? cib : 256;             // lanes per run (cib is 32, 64, 128 or 256)
+    const int ci_l = threadIdx.x % lpr, rg = threadIdx.x / lpr, nrg = 256 / lpr;
+    const size_t ld = (size_t)taps * cin;
+    for (int co_l = rg; co_l < 32; co_l += nrg) {
+      const unsigned short* srow = brick16 + co_l * pitch + ci_l * taps;
+      unsigned short* drow = out + (size_t)(co0 + co_l) * ld + ci0 + ci_l;
+      for (int tap = 0; tap < taps; ++tap) drow[(size_t)tap * cin] = srow[tap];
+    }
+  } else {
+    // runs of 32 co for every (ci, tap)
+    const int co_l = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const size_t ld = (size_t)taps * cout;
+    for (int ci_l = rg; ci_l < cib; ci_l += 8) {
+      const unsigned short* srow = brick16 + co_l * pitch + ci_l * taps;
+      unsigned short* drow = out + (size_t)(ci0 + ci_l) * ld + co0 + co_l;
+      for (int tap = 0; tap < taps; ++tap) drow[(size_t)tap * cout] = srow[tap];
+    }
+  }
+}
+
+// conv qualifies for the brick packer: no padding anywhere in either packed layout
+inline bool brick_packable(const ConvSpec& c) {
+  return c.cin == c.cin_real && (c.cin % 64) == 0 && (c.cout % 64) == 0 && (c.k == 1 || c.k == 3);
+}
+inline int brick_cib(const ConvSpec& c) { return c.k == 1 ? (c.cin < 256 ? c.cin : 256) : 32; }
+inline size_t brick_lds_bytes(int max_run) { return (size_t)32 * (max_run + 2) * 2; }
+
 // out = [relu]( bn(x) [+ residual | + bn_r(xr)] ) ; 8 channels (16 B) per thread; rows >= M are written as zeros
 struct BnApplyArgs {
   BnSrc a; BnSrc r; const half_t* res;   // r.x != null: residual is bn_r(r.x); else res (may be null)
