@@ -267,6 +267,19 @@ int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* t
 int neraf_grid_refresh_write(neraf_ctx* ctx, const float* rgb, const float* density, int n, int ndirs, float delta,
                              float* grid, size_t nvox, size_t start, neraf_stream_t stream);
 
+/* The same epilogue as a differentiable node (the reference keeps the autograd edge of the refreshed cells,
+ * NeRAF_model.py:395-400): vals fp32 [4][n] = (mean rgb, alpha); cell_major = 1: query k = i*ndirs + j, 0: k = j*n + i.
+ * The backward maps dvals [4][n] to d_rgb [n*ndirs,3] / d_density [n*ndirs] (alpha's clip passes no gradient where active). */
+int neraf_grid_refresh_vals(neraf_ctx* ctx, const float* rgb, const float* density, int n, int ndirs, int cell_major, float delta,
+                            float* vals, neraf_stream_t stream);
+int neraf_grid_refresh_vals_bwd(neraf_ctx* ctx, const float* dvals, const float* density, int n, int ndirs, int cell_major,
+                                float delta, float* d_rgb, float* d_density, neraf_stream_t stream);
+
+/* World positions of the refresh queries, cell-major (NeRAF_model.py:315, :327-333): out[i*ndirs + j] = coords[i] * (aabb1 - aabb0)
+ * + aabb0 with coords fp32 [n,3] (a window of coordinates_to_render) and aabb_host = {min xyz, max xyz} on the host. */
+int neraf_refresh_origins(neraf_ctx* ctx, const float* coords, int n, int ndirs, const float* aabb_host, float* out,
+                          neraf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * ResNet3D scene encoder (ResNet3D_helper / ResNet3D.forward, NeRAF_resnet3d.py:116-201,266-285;
  * backbone 'resnet50' truncated after layer3, N_features = 1024; called at NeRAF_model.py:554-558

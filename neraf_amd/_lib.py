@@ -102,6 +102,11 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, c_fpp, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "neraf_grid_refresh_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                            C.c_size_t, C.c_size_t, C.c_void_p]),
+    "neraf_grid_refresh_vals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                          C.c_void_p]),
+    "neraf_grid_refresh_vals_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
+    "neraf_refresh_origins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
     "neraf_resnet3d_num_convs": (C.c_int, [C.POINTER(ResnetDesc)]),
     "neraf_resnet3d_packed_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),
     "neraf_resnet3d_workspace_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),

@@ -360,9 +360,90 @@ __global__ __launch_bounds__(256) void grid_refresh_write_kernel(const float* __
   grid[3 * nvox + start + i] = alpha;
 }
 
+// differentiable form of the same epilogue: vals [4][n] = (mean rgb, alpha) instead of the grid write, queries laid out
+// cell-major (k = i*ndirs + j) or direction-major (k = j*n + i)
+__global__ __launch_bounds__(256) void grid_refresh_vals_kernel(const float* __restrict__ rgb, const float* __restrict__ density,
+                                                               int n, int ndirs, int cell_major, float delta, float* __restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float r = 0.f, g = 0.f, b = 0.f, d = 0.f;
+  for (int j = 0; j < ndirs; ++j) {
+    const size_t k = cell_major ? (size_t)i * ndirs + j : (size_t)j * n + i;
+    r += rgb[k * 3 + 0]; g += rgb[k * 3 + 1]; b += rgb[k * 3 + 2]; d += density[k];
+  }
+  const float inv = 1.f / (float)ndirs;
+  vals[0 * (size_t)n + i] = r * inv;
+  vals[1 * (size_t)n + i] = g * inv;
+  vals[2 * (size_t)n + i] = b * inv;
+  vals[3 * (size_t)n + i] = fminf(fmaxf(1.f - expf(-delta * (d * inv)), 0.f), 1.f);
+}
+
+// its backward: d rgb = dvals[0..2] / ndirs for every direction; d density = dvals[3] * delta * exp(-delta * mean) / ndirs where
+// the clip is inactive (0 < alpha < 1), else 0
+__global__ __launch_bounds__(256) void grid_refresh_vals_bwd_kernel(const float* __restrict__ dvals, const float* __restrict__ density,
+                                                                   int n, int ndirs, int cell_major, float delta,
+                                                                   float* __restrict__ d_rgb, float* __restrict__ d_density) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float d = 0.f;
+  for (int j = 0; j < ndirs; ++j) d += density[cell_major ? (size_t)i * ndirs + j : (size_t)j * n + i];
+  const float inv = 1.f / (float)ndirs;
+  const float e = expf(-delta * (d * inv));
+  const float alpha = fminf(fmaxf(1.f - e, 0.f), 1.f);
+  const float dd = (alpha > 0.f && alpha < 1.f) ? dvals[3 * (size_t)n + i] * delta * e * inv : 0.f;
+  const float dr = dvals[i] * inv, dg = dvals[(size_t)n + i] * inv, db = dvals[2 * (size_t)n + i] * inv;
+  for (int j = 0; j < ndirs; ++j) {
+    const size_t k = cell_major ? (size_t)i * ndirs + j : (size_t)j * n + i;
+    d_rgb[k * 3 + 0] = dr; d_rgb[k * 3 + 1] = dg; d_rgb[k * 3 + 2] = db;
+    d_density[k] = dd;
+  }
+}
+
+// world positions of the refresh queries, cell-major: out[i*ndirs + j] = coords[i] * len + lo  (NeRAF_model.py:315, :327-333)
+__global__ __launch_bounds__(256) void refresh_origins_kernel(const float* __restrict__ coords, int n, int ndirs, float lx, float ly, float lz,
+                                                             float ox, float oy, float oz, float* __restrict__ out) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (size_t)n * ndirs) return;
+  const size_t i = k / ndirs;
+  // separately rounded multiply and add, as the reference's `coords * lengths + aabb[0]` evaluates
+  out[k * 3 + 0] = __fadd_rn(__fmul_rn(coords[i * 3 + 0], lx), ox);
+  out[k * 3 + 1] = __fadd_rn(__fmul_rn(coords[i * 3 + 1], ly), oy);
+  out[k * 3 + 2] = __fadd_rn(__fmul_rn(coords[i * 3 + 2], lz), oz);
+}
+
 }  // namespace
 
 // =================================================================================================
+extern "C" int neraf_grid_refresh_vals(neraf_ctx* ctx, const float* rgb, const float* density, int n, int ndirs, int cell_major,
+                                       float delta, float* vals, neraf_stream_t stream) {
+  if (!rgb || !density || !vals || n <= 0 || ndirs <= 0) return neraf_fail(ctx, NERAF_EINVAL, "grid_refresh_vals: bad arguments");
+  hipLaunchKernelGGL(grid_refresh_vals_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rgb, density, n, ndirs,
+                     cell_major, delta, vals);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" int neraf_grid_refresh_vals_bwd(neraf_ctx* ctx, const float* dvals, const float* density, int n, int ndirs, int cell_major,
+                                           float delta, float* d_rgb, float* d_density, neraf_stream_t stream) {
+  if (!dvals || !density || !d_rgb || !d_density || n <= 0 || ndirs <= 0)
+    return neraf_fail(ctx, NERAF_EINVAL, "grid_refresh_vals_bwd: bad arguments");
+  hipLaunchKernelGGL(grid_refresh_vals_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dvals, density, n, ndirs,
+                     cell_major, delta, d_rgb, d_density);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" int neraf_refresh_origins(neraf_ctx* ctx, const float* coords, int n, int ndirs, const float* aabb_host, float* out,
+                                     neraf_stream_t stream) {
+  if (!coords || !aabb_host || !out || n <= 0 || ndirs <= 0) return neraf_fail(ctx, NERAF_EINVAL, "refresh_origins: bad arguments");
+  const size_t total = (size_t)n * ndirs;
+  hipLaunchKernelGGL(refresh_origins_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, coords, n, ndirs,
+                     aabb_host[3] - aabb_host[0], aabb_host[4] - aabb_host[1], aabb_host[5] - aabb_host[2], aabb_host[0], aabb_host[1],
+                     aabb_host[2], out);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
 extern "C" int neraf_grid_refresh_write(neraf_ctx* ctx, const float* rgb, const float* density, int n, int ndirs, float delta,
                                         float* grid, size_t nvox, size_t start, neraf_stream_t stream) {
   if (!rgb || !density || !grid || n <= 0 || ndirs <= 0 || start + (size_t)n > nvox)

@@ -543,11 +543,11 @@ static int nacf_bwd_body(neraf_ctx* ctx, const neraf_nacf_desc* d, const Dims& D
                          const char* P, char* ws, int B, const float* out, const float* dout, float* const* grads,
                          int* slot0, hipStream_t st) {
   const int M = WL.Mpad;
-  for (int l = 0; l < 6; ++l) NERAF_HIP_CHECK(ctx, hipMemsetAsync(ws + WL.colsum[l], 0, (size_t)D.np[l] * 4, st));
+  // the six column-sum rows and the scale block are adjacent in the workspace (make_ws_layout): one fill
+  NERAF_HIP_CHECK(ctx, hipMemsetAsync(ws + WL.colsum[0], 0, WL.scale + 256 - WL.colsum[0], st));
   // heads: dz5 = dout * (10 - out^2/10)  -> fp16 [Mpad][np5] and transposed [np5(+128)][Mpad]
   float* scale = (float*)(ws + WL.scale);
   const float* inv_scale = scale + 1;
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(scale, 0, 16, st));
   {
     const size_t n = (size_t)B * D.n[5];
     int blocks = (int)((n + 1023) / 1024);

@@ -677,6 +677,6 @@ extern "C" int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_r
   }
   NERAF_HIP_CHECK(ctx, hipStreamSynchronize(st));
   (void)wl;
-  hipFree(ws); hipFree(bws); hipFree(packed); hipFree(packed_t); hipFree(extra);
+  (void)hipFree(ws); (void)hipFree(bws); (void)hipFree(packed); (void)hipFree(packed_t); (void)hipFree(extra);
   return NERAF_OK;
 }

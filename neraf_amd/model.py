@@ -62,36 +62,40 @@ class _RefreshFn(torch.autograd.Function):
     (NeRAF_model.py:339-357, :386).  Forward = fused field query in AABB mode; backward = fused field backward."""
 
     @staticmethod
-    def forward(ctx, field, ori, dirs, nd: int, delta: float, *params: torch.Tensor):
-        """ori [n,3] cell centres (world), dirs [nd,3].  Internally the nd*n queries are laid out CELL-major (the nd
-        directions of a cell adjacent) -- the result does not depend on the order, and the backward's hash-gradient
-        pre-reduction then merges the nd identical positions into one atomic per table entry."""
-        n = ori.shape[0]
-        oris = ori.repeat_interleave(nd, dim=0).contiguous()
-        dd = dirs.repeat(n, 1).contiguous()
-        z = torch.zeros((oris.shape[0], 2), device=oris.device)
-        cam = torch.zeros(oris.shape[0], dtype=torch.int32, device=oris.device)      # camera index 0, :334
+    def forward(ctx, field, coords, aabb, dirs, nd: int, delta: float, consts, *params: torch.Tensor):
+        """coords [n,3] cell centres in (0,1)^3 (a window of coordinates_to_render), aabb the radiance field's box, dirs [nd,3];
+        consts = (dd [n*nd,3], z [n*nd,2], cam [n*nd]) are the per-shape constants of the query.  The nd*n queries are laid out
+        CELL-major (the nd directions of a cell adjacent) -- the result does not depend on the order, and the backward's
+        hash-gradient pre-reduction then merges the nd identical positions into one update per table entry."""
+        lib = _lib.load()
+        n = coords.shape[0]
+        dev = _dev_index(coords)
+        dd, z, cam = consts
+        oris = torch.empty((n * nd, 3), dtype=torch.float32, device=coords.device)
+        _lib.check(lib.neraf_refresh_origins(_lib.ctx(dev), coords.data_ptr(), n, nd, _lib.host_f32(aabb), oris.data_ptr(),
+                                             _stream_ptr()), dev)                          # :315, :327-333
         packed = field.packed(with_average=False)       # the refresh queries with camera index 0's embedding (:334)
         rgb, den = field.query(oris, dd, z, cam, use_average_embedding=False, packed=packed)    # [n*nd,1,3], [n*nd,1]
-        rgb_m = rgb.reshape(n, nd, 3).mean(1)                                          # :352-356
-        den_m = den.reshape(n, nd).mean(1)                                             # :357
-        alpha = torch.clip(1 - torch.exp(-delta * den_m), 0, 1)                        # :386
-        ctx.field, ctx.nd, ctx.delta, ctx.packed = field, nd, delta, packed
-        ctx.save_for_backward(oris, dd, z, cam, den, den_m, alpha)
-        return torch.cat([rgb_m.t(), alpha[None, :]], dim=0).contiguous()              # [4, n]
+        vals = torch.empty((4, n), dtype=torch.float32, device=coords.device)
+        _lib.check(lib.neraf_grid_refresh_vals(_lib.ctx(dev), rgb.data_ptr(), den.data_ptr(), n, nd, 1, delta, vals.data_ptr(),
+                                               _stream_ptr()), dev)                        # :352-357, :386
+        ctx.field, ctx.nd, ctx.delta, ctx.packed, ctx.dev = field, nd, delta, packed, dev
+        ctx.save_for_backward(oris, dd, z, cam, den)
+        return vals
 
     @staticmethod
     def backward(ctx, dvals: torch.Tensor):
-        oris, dd, z, cam, den, den_m, alpha = ctx.saved_tensors
+        oris, dd, z, cam, den = ctx.saved_tensors
         nd, delta = ctx.nd, ctx.delta
         n = oris.shape[0] // nd
-        dvals = dvals.float()
-        d_rgb = (dvals[:3].t() / nd).repeat_interleave(nd, dim=0).reshape(nd * n, 1, 3).contiguous()
-        inside = ((alpha > 0) & (alpha < 1)).float()
-        d_den_m = dvals[3] * delta * torch.exp(-delta * den_m) * inside
-        d_den = (d_den_m / nd).repeat_interleave(nd).reshape(nd * n, 1).contiguous()
+        lib = _lib.load()
+        dvals = dvals.float().contiguous()
+        d_rgb = torch.empty((nd * n, 1, 3), dtype=torch.float32, device=oris.device)
+        d_den = torch.empty((nd * n, 1), dtype=torch.float32, device=oris.device)
+        _lib.check(lib.neraf_grid_refresh_vals_bwd(_lib.ctx(ctx.dev), dvals.data_ptr(), den.data_ptr(), n, nd, 1, delta,
+                                                   d_rgb.data_ptr(), d_den.data_ptr(), _stream_ptr()), ctx.dev)
         grads = ctx.field.backward_query(ctx.packed, oris, dd, z, cam, den, d_rgb, d_den)
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 class NeRAFAudioModel(nn.Module):
@@ -177,29 +181,34 @@ class NeRAFAudioModel(nn.Module):
         module.spatial_distortion = None                                                # :302
         try:
             aabb = module.aabb
-            lengths = aabb[1] - aabb[0]
             n_cells = self.coordinates_to_render.shape[0]
             i = self.grid_batch_i
             if i + batch_size > n_cells:                                                # :308-309
                 batch_size = n_cells - i
             coords = self.coordinates_to_render[i:i + batch_size]
-            ori = coords * lengths + aabb[0]                                            # :315
-            dirs = self.view_dirs.to(ori.device) if self.view_dirs is not None else torch.tensor([[1.0, 0.0, 0.0]], device=ori.device)
+            if self.view_dirs is not None:
+                dirs = self.view_dirs.to(coords.device)
+            else:
+                if getattr(self, "_one_dir", None) is None or self._one_dir.device != coords.device:
+                    self._one_dir = torch.tensor([[1.0, 0.0, 0.0]], device=coords.device)
+                dirs = self._one_dir
             nd = dirs.shape[0]
-            oris = ori.repeat(nd, 1)                                                    # direction-major concat, :327-333
-            dd = dirs.repeat_interleave(batch_size, dim=0)
             nvox = self.grid.shape[1] * self.grid.shape[2] * self.grid.shape[3]
             differentiable = (self.training and torch.is_grad_enabled() and renderer_rgb is not None
                               and any(p.requires_grad for p in module.grad_params()))
             if differentiable:
                 # the grid is detached and the fresh values keep their graph (:395-400): vals is an autograd node over the
                 # radiance-field parameters, consumed by the ResNet3D node in scene_feature()
-                vals = _RefreshFn.apply(module, ori.contiguous(), dirs.contiguous(), nd, self._delta, *module.grad_params())
+                vals = _RefreshFn.apply(module, coords, aabb, dirs, nd, self._delta, self._refresh_consts(dirs, batch_size),
+                                        *module.grad_params())
                 with torch.no_grad():
                     self.grid.view(7, nvox)[0:4, i:i + batch_size] = vals
                 self._window = (i, batch_size, vals)
             else:
                 with torch.no_grad():
+                    ori = coords * (aabb[1] - aabb[0]) + aabb[0]                            # :315
+                    oris = ori.repeat(nd, 1)                                                # direction-major concat, :327-333
+                    dd = dirs.repeat_interleave(batch_size, dim=0)
                     z = torch.zeros((oris.shape[0], 1), device=ori.device)
                     rs = RaySamples(Frustums(oris, dd, z, z), torch.zeros((oris.shape[0], 1), dtype=torch.int32, device=ori.device))
                     was = module.training
@@ -221,6 +230,18 @@ class NeRAFAudioModel(nn.Module):
             self._feat_key = None
         finally:
             module.spatial_distortion = saved                                           # :407
+
+    def _refresh_consts(self, dirs, n):
+        """(directions [n*nd,3] cell-major, zero frustum extents [n*nd,2], camera index 0 [n*nd]) of a refresh window: constant
+        per (n, directions), built once."""
+        key = (n, dirs.data_ptr(), dirs._version, str(dirs.device))
+        c = getattr(self, "_refresh_const_cache", None)
+        if c is None or c[0] != key:
+            nd = dirs.shape[0]
+            c = (key, (dirs.repeat(n, 1).contiguous(), torch.zeros((n * nd, 2), device=dirs.device),
+                       torch.zeros(n * nd, dtype=torch.int32, device=dirs.device)))
+            self._refresh_const_cache = c
+        return c[1]
 
     # ---- A4: scene feature -----------------------------------------------------------------------
     def scene_feature(self) -> torch.Tensor:

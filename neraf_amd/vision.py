@@ -165,6 +165,13 @@ def _build_frag_index_bwd() -> np.ndarray:
 _FRAG_INDEX_BWD = _build_frag_index_bwd()
 
 
+def _param_key(params):
+    """Identity of a parameter state: the fused optimizer's update counter (its kernels write through raw pointers and do not
+    touch tensor version counters) plus storage pointer and version counter of every tensor (torch-side updates)."""
+    from . import optim
+    return (optim.UPDATE_EPOCH,) + tuple((p.data_ptr(), p._version) for p in params)
+
+
 class HashMLPDensityField(nn.Module):
     """Proposal network: 5-level hash grid + MLP(10 -> 16 -> 1), tcnn layout (bias-free, padded to 16)."""
 
@@ -179,7 +186,14 @@ class HashMLPDensityField(nn.Module):
         self.average_init_density = average_init_density
 
     def packed(self):
-        return self.table.detach().half().contiguous(), torch.cat([self.w0.detach().reshape(-1), self.w1.detach()[0]]).half().contiguous()
+        """fp16 copies for the kernels, cached until the parameters change (see ``_param_key``)."""
+        key = _param_key((self.table, self.w0, self.w1))
+        c = getattr(self, "_pack_cache", None)
+        if c is None or c[0] != key:
+            c = (key, (self.table.detach().half().contiguous(),
+                       torch.cat([self.w0.detach().reshape(-1), self.w1.detach()[0]]).half().contiguous()))
+            self._pack_cache = c
+        return c[1]
 
     def density(self, origins, directions, e_bins, packed=None):
         lib = _lib.load()
@@ -221,16 +235,38 @@ class NerfactoField(nn.Module):
                           self.head_w1.detach().reshape(-1), self.head_w2.detach().reshape(-1),
                           torch.zeros(1, device=self.table.device)])
 
+    def _cache(self):
+        """fp16 copies of the parameters are made once per parameter state: a training step queries the field three times
+        (render, grid refresh, backward) between two optimizer steps, and every conversion is a handful of small launches."""
+        key = _param_key(self.grad_params())
+        c = getattr(self, "_pack_cache", None)
+        if c is None or c["key"] != key:
+            c = {"key": key}
+            self._pack_cache = c
+        return c
+
+    def invalidate_packed(self):
+        """Drop the cached fp16 copies (needed only after a parameter edit that bypasses tensor version counters, e.g. ``p.data``)."""
+        self._pack_cache = None
+
     def packed(self, with_average: bool = True):
         """fp16 copies for the kernels: (table, 24 weight fragments, embedding rows).  ``with_average`` appends the mean embedding
         as an extra row (eval / camera-less queries use it); training queries index real rows only and skip the reduction."""
-        wfrag = self._flat_weights()[self._frag_index].half().contiguous()
-        e = self.embedding.detach()
-        emb = (torch.cat([e, e.mean(0, keepdim=True)], 0) if with_average else e).half().contiguous()
-        return self.table.detach().half().contiguous(), wfrag, emb
+        c = self._cache()
+        if "table" not in c:
+            c["table"] = self.table.detach().half().contiguous()
+            c["wfrag"] = self._flat_weights()[self._frag_index].half().contiguous()
+        k = "emb_avg" if with_average else "emb"
+        if k not in c:
+            e = self.embedding.detach()
+            c[k] = (torch.cat([e, e.mean(0, keepdim=True)], 0) if with_average else e).half().contiguous()
+        return c["table"], c["wfrag"], c[k]
 
     def packed_bwd(self):
-        return self._flat_weights()[self._frag_index_bwd].half().contiguous()
+        c = self._cache()
+        if "wfrag_bwd" not in c:
+            c["wfrag_bwd"] = self._flat_weights()[self._frag_index_bwd].half().contiguous()
+        return c["wfrag_bwd"]
 
     def dump_buffer(self, R: int, S: int, device) -> torch.Tensor:
         """Persistent (X, dY) scratch of the field backward, one per (R, S) shape; zeroed ONCE (padding rows stay zero)."""

@@ -159,7 +159,9 @@ def test_refresh_gradient_edge_vs_oracle(models):
     for p in f.parameters():
         p.grad = None
     try:
-        vals = _RefreshFn.apply(f, ori.to(dev).contiguous(), dirs.to(dev).contiguous(), 18, 1e-2, *f.grad_params())
+        dirs_d = dirs.to(dev).contiguous()
+        vals = _RefreshFn.apply(f, coords.float().to(dev).contiguous(), f.aabb, dirs_d, 18, 1e-2, am._refresh_consts(dirs_d, n),
+                                *f.grad_params())
         assert float((vals.detach().cpu() - vals_o.detach()).abs().max()) <= 4e-3
         (vals * dvals.to(dev)).sum().backward()
     finally:
