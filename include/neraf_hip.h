@@ -61,6 +61,9 @@ const char* neraf_last_error(neraf_ctx* ctx);
 int neraf_graph_stats(neraf_ctx* ctx, int* captures, int* launches);
 int neraf_prof_enable(neraf_ctx* ctx, int on);
 int neraf_prof_summary(neraf_ctx* ctx, int kernel_id, double* total_ms, int* launches, double* work);
+/* Median elapsed time (ms) of an empty HIP event pair on `stream` behind a 4-byte fill of `scratch_word` (device): the part of
+ * every profiled interval that is not the kernel; callers subtract it per launch. */
+int neraf_prof_event_overhead(neraf_ctx* ctx, void* scratch_word, neraf_stream_t stream, double* ms);
 const char* neraf_prof_kernel_name(int kernel_id);
 
 /* ------------------------------------------------------------------------------------

@@ -72,6 +72,7 @@ SIGNATURES = {
     "neraf_stft_loss_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "neraf_stft_loss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_prof_event_overhead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "neraf_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "neraf_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "neraf_prof_summary": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),

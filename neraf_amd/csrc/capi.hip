@@ -1,5 +1,6 @@
 // Context management for libneraf_hip (C ABI, include/neraf_hip.h).
 #include "common.h"
+#include <algorithm>
 #include <stdlib.h>
 
 __global__ void neraf_zero_kernel(unsigned* __restrict__ p, size_t n_words) {
@@ -52,6 +53,28 @@ extern "C" int neraf_prof_enable(neraf_ctx* ctx, int on) {
   return NERAF_OK;
 }
 
+// Elapsed time of an EMPTY event pair on `stream` (median of 64): what every ProfScope interval contains besides its kernel.
+// bench.py subtracts it per launch, so that intervals of few-microsecond kernels agree with rocprofv3's kernel durations.
+extern "C" int neraf_prof_event_overhead(neraf_ctx* ctx, void* scratch_word, neraf_stream_t stream, double* ms) {
+  if (!ctx || !ms || !scratch_word) return NERAF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  constexpr int N = 64;
+  hipEvent_t ev[2 * N];
+  for (int i = 0; i < 2 * N; ++i) NERAF_HIP_CHECK(ctx, hipEventCreate(&ev[i]));
+  for (int i = 0; i < N; ++i) {
+    neraf_zero_async(st, scratch_word, 4);                           // keeps the queue non-empty between pairs, as in a real step
+    NERAF_HIP_CHECK(ctx, hipEventRecord(ev[2 * i], st));
+    NERAF_HIP_CHECK(ctx, hipEventRecord(ev[2 * i + 1], st));
+  }
+  NERAF_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  float t[N];
+  for (int i = 0; i < N; ++i) NERAF_HIP_CHECK(ctx, hipEventElapsedTime(&t[i], ev[2 * i], ev[2 * i + 1]));
+  for (int i = 0; i < 2 * N; ++i) (void)hipEventDestroy(ev[i]);
+  std::sort(t, t + N);
+  *ms = t[N / 2];
+  return NERAF_OK;
+}
+
 extern "C" int neraf_prof_summary(neraf_ctx* ctx, int kernel_id, double* total_ms, int* launches, double* work) {
   if (!ctx || kernel_id < 0 || kernel_id >= PROF_NUM_KERNELS) return NERAF_EINVAL;
   double ms = 0.0, w = 0.0; int n = 0;
@@ -69,9 +92,14 @@ extern "C" int neraf_prof_summary(neraf_ctx* ctx, int kernel_id, double* total_m
 }
 
 extern "C" const char* neraf_prof_kernel_name(int kernel_id) {
-  static const char* names[PROF_NUM_KERNELS] = {"gemm_f16_nt_pipe_kernel<128, 128, 4, *>", "gemm_f16_nt_pipe_kernel<64|128x64, 4, *>",
+  // the rocprofv3 kernel-name prefix each scope covers (template arguments that vary inside a scope are written as *)
+  static const char* names[PROF_NUM_KERNELS] = {"gemm_f16_nt_pipe_kernel<128, 128, *, 0, 1, *>", "gemm_f16_nt_pipe_kernel<64, 64, 4, 0, 1, false>",
                                                       "proposal_density_kernel", "field_query_kernel",
-                                                      "gemm_f16_nt_pipe_kernel<*, 4, conv loader 1|2>", "proposal_backward_kernel",
-                                                      "field_backward_kernel", "field_scatter_kernel"};
+                                                      "gemm_f16_nt_pipe_kernel<64, 64, 4, 1, *, false>", "proposal_backward_kernel",
+                                                      "field_backward_kernel", "field_scatter_kernel | field_slice_ids_kernel + field_scatter_owner_kernel",
+                                                      "gemm_f16_nt_wide_kernel<160|128, 3, *>", "wgrad_grouped_tn_kernel",
+                                                      "gemm_f16_nt_pipe_kernel<64, 64, 4, 0, 1, true>", "gemm_f16_nt_pipe_kernel<128, 64, 3, 0, 1, *>",
+                                                      "gemm_f16_nt_pipe_kernel<64, 64, 4, 1, *, true>", "gemm_f16_nt_pipe_kernel<128, 64, 3, 1, *, *>",
+                                                      "gemm_f16_nt_pipe_kernel<128, 128, 2, 1, *, *>", "gemm_f16_nt_pipe_kernel<128, 64, 3, 2, 5, false>"};
   return (kernel_id >= 0 && kernel_id < PROF_NUM_KERNELS) ? names[kernel_id] : nullptr;
 }

@@ -19,7 +19,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_PROP_DENSITY = 2, PROF_FIELD_QUERY = 3, PROF_CONV = 4, PROF_PROP_BWD = 5, PROF_FIELD_BWD = 6, PROF_FIELD_SCATTER = 7, PROF_NUM_KERNELS = 8 };
+enum { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_PROP_DENSITY = 2, PROF_FIELD_QUERY = 3, PROF_CONV = 4, PROF_PROP_BWD = 5, PROF_FIELD_BWD = 6,
+       PROF_FIELD_SCATTER = 7, PROF_GEMM_WIDE = 8, PROF_WGRAD = 9, PROF_GEMM64_BF16 = 10, PROF_GEMM12864 = 11,
+       PROF_CONV64_BF16 = 12, PROF_CONV12864 = 13, PROF_CONV128 = 14, PROF_CONV_STEM = 15, PROF_NUM_KERNELS = 16 };
 
 struct ProfRec { hipEvent_t a, b; int kid; double work; };
 

@@ -652,7 +652,10 @@ int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
   const int ng = p.ngroups > 1 ? p.ngroups : 1;
   double flops = 2.0 * p.M * p.N * p.K;
   if (ng > 1) { flops = 0.0; for (int g = 0; g < ng; ++g) flops += 2.0 * p.grp[g].M * p.grp[g].N * p.K; }
-  ProfScope prof(ctx, stream, LOADER != 0 ? PROF_CONV : (BM * BN == 128 * 128 ? PROF_GEMM128 : PROF_GEMM64), flops);
+  constexpr int kid = LOADER == 2 ? PROF_CONV_STEM
+                      : LOADER == 1 ? (BM * BN == 128 * 128 ? PROF_CONV128 : (BM == 128 ? PROF_CONV12864 : (BF ? PROF_CONV64_BF16 : PROF_CONV)))
+                                    : (BM * BN == 128 * 128 ? PROF_GEMM128 : (BM == 128 ? PROF_GEMM12864 : (BF ? PROF_GEMM64_BF16 : PROF_GEMM64)));
+  ProfScope prof(ctx, stream, kid, flops);
   hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF>), dim3(ntiles * splits * ng), dim3(256), PT::LDS_BYTES,
                      stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
@@ -676,7 +679,7 @@ int launch_wide(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
     attr_set = true;
   }
   const int ntiles = (p.Mpad / 256) * (p.Npad / BN);
-  ProfScope prof(ctx, stream, PROF_GEMM128, 2.0 * p.M * p.N * p.K);
+  ProfScope prof(ctx, stream, PROF_GEMM_WIDE, 2.0 * p.M * p.N * p.K);
   hipLaunchKernelGGL((gemm_f16_nt_wide_kernel<BN, NST, BF>), dim3(ntiles * splits), dim3(512), LDS_BYTES, stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   if (splits > 1) {
@@ -1002,7 +1005,7 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
   t.total_blocks = blocks;
   r.n = nred; r.tile_begin[nred] = red_tiles;
   {
-    ProfScope prof(ctx, stream, PROF_GEMM64, flops);
+    ProfScope prof(ctx, stream, PROF_WGRAD, flops);
     hipLaunchKernelGGL(wgrad_grouped_tn_kernel, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
   }
   if (nred > 0) hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(red_tiles), dim3(256), 0, stream, t, r);

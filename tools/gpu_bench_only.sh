@@ -13,7 +13,8 @@ cd $GRAFT_REPO_ROOT; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | sort |
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("total GPU ms per step (35 steps):", tot / 35 / 1e6)
+steps = max(int(r["Calls"]) for r in rows if "grid_to_ndhwc8" in r["Name"])    # one launch per step (priming + warm-up + timed + replay)
+print(f"total GPU ms per step ({steps} steps):", tot / steps / 1e6)
 for r in rows[:28]:
-    print(f'{r["Name"][:90]:90s} calls/step {int(r["Calls"])/35:6.1f} avg {float(r["AverageNs"])/1e3:8.1f} us  {float(r["TotalDurationNs"])/35/1e6:6.3f} ms/step')
+    print(f'{r["Name"][:90]:90s} calls/step {int(r["Calls"])/steps:6.1f} avg {float(r["AverageNs"])/1e3:8.1f} us  {float(r["TotalDurationNs"])/steps/1e6:6.3f} ms/step')
 PY

@@ -16,13 +16,22 @@ def load(path, name):
 F = load(latest("gpurun_out/pmc/FETCH_SIZE/runc/*_counter_collection.csv"), "FETCH_SIZE")
 W = load(latest("gpurun_out/pmc/WRITE_SIZE/runc/*_counter_collection.csv"), "WRITE_SIZE")
 def fam(n):
-    m = re.search(r"gemm_f16_nt_pipe_kernel<(\d+), (\d+), 4, (\d), (\d), (true|false)>", n)
+    """rocprofv3 kernel name -> the bench.py profiling scope (neraf_prof_kernel_name) it is timed under"""
+    if "gemm_f16_nt_wide_kernel" in n: return "gemm_f16_nt_wide_kernel<160|128, 3, *>"
+    if "wgrad_grouped_tn_kernel" in n: return "wgrad_grouped_tn_kernel"
+    m = re.search(r"gemm_f16_nt_pipe_kernel<(\d+), (\d+), \d, (\d), (\d), (true|false)>", n)
     if m:
-        bm, bn, ld = int(m.group(1)), int(m.group(2)), int(m.group(3))
-        if ld != 0: return "gemm_f16_nt_pipe_kernel<*, 4, conv loader 1|2>"
-        return "gemm_f16_nt_pipe_kernel<128, 128, 4, *>" if bm * bn == 128 * 128 else "gemm_f16_nt_pipe_kernel<64|128x64, 4, *>"
-    if "gemm_bf16_tn_kernel" in n or "wgrad_grouped_tn_kernel" in n: return "gemm_f16_nt_pipe_kernel<64|128x64, 4, *>"
-    for k in ("proposal_density_kernel", "field_query_kernel", "proposal_backward_kernel", "field_backward_kernel", "field_scatter_kernel", "fused_adam_kernel"):
+        bm, bn, ld, bf = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(5) == "true"
+        if ld == 2: return "gemm_f16_nt_pipe_kernel<128, 64, 3, 2, 5, false>"
+        if ld == 1:
+            if bm * bn == 128 * 128: return "gemm_f16_nt_pipe_kernel<128, 128, 2, 1, *, *>"
+            if bm == 128: return "gemm_f16_nt_pipe_kernel<128, 64, 3, 1, *, *>"
+            return "gemm_f16_nt_pipe_kernel<64, 64, 4, 1, *, true>" if bf else "gemm_f16_nt_pipe_kernel<64, 64, 4, 1, *, false>"
+        if bm * bn == 128 * 128: return "gemm_f16_nt_pipe_kernel<128, 128, *, 0, 1, *>"
+        if bm == 128: return "gemm_f16_nt_pipe_kernel<128, 64, 3, 0, 1, *>"
+        return "gemm_f16_nt_pipe_kernel<64, 64, 4, 0, 1, true>" if bf else "gemm_f16_nt_pipe_kernel<64, 64, 4, 0, 1, false>"
+    if "field_scatter" in n or "field_slice_ids" in n: return "field_scatter_kernel | field_slice_ids_kernel + field_scatter_owner_kernel"
+    for k in ("proposal_density_kernel", "field_query_kernel", "proposal_backward_kernel", "field_backward_kernel", "fused_adam_kernel"):
         if k in n: return k
     return None
 fams = collections.defaultdict(lambda: [0.0, 0.0, 0, 0])
