@@ -720,8 +720,9 @@ __device__ __forceinline__ size_t wg_out_index(const WgDesc& d, int m, int n) { 
   return ((size_t)m * d.cin_real + c) * d.taps + tap;
 }
 
+template <int NST>
 __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
-  constexpr int BM = 64, BN = 64, NST = 4;
+  constexpr int BM = 64, BN = 64;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -815,8 +816,8 @@ __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const int after = nk - 1 - kt;
-    if (after >= 2) wait_vmcnt<8>();
-    else if (after >= 1) wait_vmcnt<4>();
+    if (NST >= 4 && after >= 2) wait_vmcnt<8>();
+    else if (NST >= 3 && after >= 1) wait_vmcnt<4>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (kt + NST - 1 < nk) {
@@ -950,11 +951,14 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
 int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const half_t* zero_page, float* slab_ws, size_t slab_bytes,
                          const float* alpha_dev, hipStream_t stream) {
   if (n <= 0 || n > kMaxWg || !items || !zero_page) return neraf_fail(ctx, NERAF_EINVAL, "wgrad_grouped: bad arguments");
-  constexpr int LDS_BYTES = 4 * 128 * 128;
+  static const int nst = [] { const char* e = getenv("NERAF_WGRAD_NST"); const int v = e ? atoi(e) : 3; return v < 2 ? 2 : (v > 4 ? 4 : v); }();   // 3 stages = 48 KiB: three workgroups per CU (5.42 -> 5.34 ms/step against 4 stages)
+  static const int rounds = [] { const char* e = getenv("NERAF_WGRAD_ROUNDS"); return e ? atoi(e) : 8; }();
+  const int LDS_BYTES = nst * 128 * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 128));
     attr_set = true;
   }
   const int cus = ctx ? ctx->num_cus : 256;
@@ -969,7 +973,7 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
     const int taps = it.ksize * it.ksize * it.ksize;
     total_steps += (double)(it.cout / 64) * (round_up(taps * it.cin, 64) / 64) * (it.K / 64);
   }
-  int target = (int)(total_steps / (cus * 8.0)) + 1;       // ~8 rounds of 2 workgroups per CU
+  int target = (int)(total_steps / (cus * (double)rounds)) + 1;       // ~8 rounds of 2 workgroups per CU
   if (target < 16) target = 16;
   size_t slab_off = 0; int blocks = 0, red_tiles = 0, nred = 0;
   double flops = 0.0;
@@ -1006,7 +1010,9 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
   r.n = nred; r.tile_begin[nred] = red_tiles;
   {
     ProfScope prof(ctx, stream, PROF_WGRAD, flops);
-    hipLaunchKernelGGL(wgrad_grouped_tn_kernel, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
+    if (nst == 2) hipLaunchKernelGGL(wgrad_grouped_tn_kernel<2>, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
+    else if (nst == 3) hipLaunchKernelGGL(wgrad_grouped_tn_kernel<3>, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
+    else hipLaunchKernelGGL(wgrad_grouped_tn_kernel<4>, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
   }
   if (nred > 0) hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(red_tiles), dim3(256), 0, stream, t, r);
   NERAF_HIP_CHECK(ctx, hipGetLastError());

@@ -8,6 +8,6 @@ for v in "$@"; do
 import sys, json
 d = json.loads(sys.stdin.read())
 fam = {k['kernel'][:44]: k['ms_per_step'] for k in d['roofline']['all_kernel_families']}
-print('  ms_per_step %.3f   ' % d['ms_per_step'] + '  '.join('%s=%.3f' % (k.split('<')[-1] if 'gemm' in k else k[:14], v) for k, v in fam.items()))
+print('  ms_per_step %.3f   ' % d['ms_per_step'] + '  '.join('%s=%.3f' % (k[24:44] if k.startswith('gemm_f16_nt_pipe') else k[:22], v) for k, v in fam.items()))
 "
 done
