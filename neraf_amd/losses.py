@@ -18,7 +18,10 @@ from .field import _dev_index, _stream_ptr
 
 class _StftLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_log: torch.Tensor, y_log: torch.Tensor, loss_type: int, group=None):
+    def forward(ctx, x_log: torch.Tensor, y_log: torch.Tensor, loss_type: int, group=None, weights=None):
+        """``weights``: optional device tensor [2] multiplied into (sc, mag) here -- the reference scales its two audio losses by
+        constants right after computing them (NeRAF_model.py:592-599); done inside the node that is one kernel forward and one
+        backward instead of four each."""
         lib = _lib.load()
         dev = _dev_index(x_log)
         x = x_log.contiguous().float()
@@ -36,8 +39,10 @@ class _StftLossFn(torch.autograd.Function):
             n_total = allreduce_loss_sums(sums, x.numel(), group=group if group is not True else None, uniform_shards=True)
         _lib.check(lib.neraf_stft_loss_finalize(_lib.ctx(dev), sums.data_ptr(), n_total, losses.data_ptr(),
                                                 _stream_ptr()), dev)
+        if weights is not None:
+            losses = losses * weights
         ctx.save_for_backward(x, y, sums)
-        ctx.loss_type, ctx.dev, ctx.n_total = loss_type, dev, n_total
+        ctx.loss_type, ctx.dev, ctx.n_total, ctx.weights = loss_type, dev, n_total, weights
         return losses[0], losses[1]
 
     @staticmethod
@@ -46,13 +51,15 @@ class _StftLossFn(torch.autograd.Function):
         lib = _lib.load()
         dx = torch.empty_like(x)
         # upstream scalars (loss weights x GradScaler scale) stay on the device: no host sync
-        zero = torch.zeros((), dtype=torch.float32, device=x.device)
+        zero = torch.zeros((), dtype=torch.float32, device=x.device) if (g_sc is None or g_mag is None) else None
         w = torch.stack([(g_sc if g_sc is not None else zero).float().reshape(()),
                          (g_mag if g_mag is not None else zero).float().reshape(())]).contiguous()
+        if ctx.weights is not None:
+            w = w * ctx.weights
         _lib.check(lib.neraf_stft_loss_bwd(_lib.ctx(ctx.dev), x.data_ptr(), y.data_ptr(), x.numel(), ctx.n_total,
                                            ctx.loss_type, sums.data_ptr(), w.data_ptr(), dx.data_ptr(), _stream_ptr()),
                    ctx.dev)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 class SpectralConvergenceLoss(nn.Module):
@@ -88,6 +95,7 @@ class STFTLoss(nn.Module):
         self.loss_type = loss_type
         self.process_group = process_group
 
-    def forward(self, x_log, y_log):
-        sc, mag = _StftLossFn.apply(x_log, y_log, 1 if self.loss_type == "l1" else 0, self.process_group)
+    def forward(self, x_log, y_log, weights=None):
+        """``weights`` (optional, device tensor [2]): factors applied to (sc, mag) inside the fused node."""
+        sc, mag = _StftLossFn.apply(x_log, y_log, 1 if self.loss_type == "l1" else 0, self.process_group, weights)
         return {"audio_sc_loss": sc, "audio_mag_loss": mag}

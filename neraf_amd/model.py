@@ -273,10 +273,13 @@ class NeRAFAudioModel(nn.Module):
         pred = outputs.float()
         if self.criterion_name == "MSE":
             return {"audio_mse": torch.nn.functional.mse_loss(pred, gt) * self.loss_factor}
-        loss = self.criterion(pred, gt)
-        loss["audio_sc_loss"] = loss["audio_sc_loss"] * 1e-1 * self.loss_factor
-        loss["audio_mag_loss"] = loss["audio_mag_loss"] * 1.0 * self.loss_factor
-        return loss
+        # sc * 1e-1 * loss_factor, mag * 1.0 * loss_factor (:592-599) -- the products of the constants are formed in fp32 like the
+        # reference's two successive multiplications only up to 1 ulp; applied inside the loss node (one kernel each way)
+        w = getattr(self, "_loss_w", None)
+        if w is None or w.device != pred.device:
+            w = torch.tensor([1e-1 * self.loss_factor, 1.0 * self.loss_factor], dtype=torch.float32, device=pred.device)
+            self._loss_w = w
+        return self.criterion(pred, gt, w)
 
     def set_eval_data(self, eval_source_pose, eval_mic_pose, eval_rot, eval_gt):        # :602-607
         self.eval_source_pose, self.eval_mic_pose, self.eval_rot, self.eval_gt = eval_source_pose, eval_mic_pose, eval_rot, eval_gt

@@ -47,6 +47,32 @@ class RIRBankDataManager:
         return {}
 
 
+class _ScaledLossSum(torch.autograd.Function):
+    """(scale * sum_i loss_i, sum_i loss_i) of 0-d device losses in three small launches (stack, sum, multiply) with a one-launch
+    backward, instead of the chain of scalar adds and multiplies the Trainer's two lines build."""
+
+    @staticmethod
+    def forward(ctx, scaler, *losses):
+        stacked = torch.stack([l.reshape(()).float() for l in losses])
+        total = stacked.sum()
+        if scaler is not None and scaler.is_enabled():
+            if scaler._scale is None:
+                scaler._lazy_init_scale_growth_tracker(total.device)
+            scale = scaler._scale.reshape(())
+            scaled = total * scale
+        else:
+            scale, scaled = None, total.clone()
+        ctx.scale = scale
+        ctx.n = len(losses)
+        ctx.mark_non_differentiable(total)
+        return scaled, total
+
+    @staticmethod
+    def backward(ctx, g, _g_total):
+        gi = g if ctx.scale is None else g * ctx.scale
+        return (None,) + (gi,) * ctx.n
+
+
 class NeRAFPipeline(nn.Module):
     """Joint radiance + acoustic pipeline (NeRAF_pipeline.py:64-222)."""
 
@@ -145,8 +171,9 @@ class NeRAFPipeline(nn.Module):
         for o in optimizers:
             o.zero_grad(set_to_none=True)
         _, loss_dict, _ = self.get_train_loss_dict(step)
-        loss = sum(loss_dict.values())
-        scaler.scale(loss).backward()
+        # Trainer.train_iteration: loss = reduce(add, loss_dict.values()); grad_scaler.scale(loss).backward() -- as one node
+        scaled, loss = _ScaledLossSum.apply(scaler, *loss_dict.values())
+        scaled.backward()
         if self._reducer is not None:
             self._reducer.finish()
         for o in optimizers:

@@ -20,6 +20,10 @@ def test_pipeline_train_iterations_and_checkpoint():
     from neraf_amd.pipeline import FixedBatchDataManager, NeRAFPipeline, RIRBankDataManager
     from neraf_amd.vision import NeRAFVisionModel, RayBundle
     dev = torch.device("cuda:0")
+    # seeded: with 512 rays the interlevel loss (~1e-6) has histogram violations -- hence non-zero proposal gradients -- for most
+    # random initialisations but not all (tools/proposal_grad_seed_sweep.py: 5 of 16 seeds give an exactly zero proposal gradient, a legitimate
+    # no-op for Adam); seed 0 has them
+    torch.manual_seed(0)
     vm = NeRAFVisionModel(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 210)
     am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 64), T(synth.audio_aabb()))
     am.field.load_state_dict({k: T(v) for k, v in synth.nacf_state_dict(1187, 512, 1, 513).items()})
