@@ -6,6 +6,7 @@
 // (NeRAF_model.py:557-558), so  z0 = q . W0[:,1024:]^T + (W0[:,:1024] . feat + b0) -- one
 // GEMV folded into the bias plus a K=163(->192) GEMM instead of a K=1187 GEMM.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -151,6 +152,58 @@ __global__ __launch_bounds__(256) void cvt_pad_transpose_kernel(
 __global__ void pad_copy_f32_kernel(const float* __restrict__ src, int n, float* __restrict__ dst, int npad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < npad) dst[i] = (i < n) ? src[i] : 0.f;
+}
+
+// ---- one-launch forms of the per-layer launches above (descriptor tables in the kernel arguments) ----------------------------
+// Weight packing runs every training step; eight small launches cost more than their 80 MB of traffic.
+struct CvtJob {
+  const float* src; half_t* dst; half_t* dstT;
+  int ld, R, Cc, ld_dst, Rpad, Cpad, ld_dstT, RpadT, CpadT;
+  int tiles_x, tile_begin;
+};
+constexpr int kMaxCvtJobs = 10;
+struct CvtTable { int n; int total; CvtJob j[kMaxCvtJobs]; };
+
+__global__ __launch_bounds__(256) void cvt_pad_transpose_grouped_kernel(CvtTable t) {
+  __shared__ float tile[32][33];
+  int ji = 0;
+  while (ji + 1 < t.n && (int)blockIdx.x >= t.j[ji + 1].tile_begin) ++ji;
+  const CvtJob& J = t.j[ji];
+  const int b = blockIdx.x - J.tile_begin;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = (b % J.tiles_x) * 32, r0 = (b / J.tiles_x) * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + i * 8, c = c0 + tx;
+    float v = 0.f;
+    if (r < J.R && c < J.Cc) v = J.src[(size_t)r * J.ld + c];
+    tile[ty + i * 8][tx] = v;
+    if (J.dst && r < J.Rpad && c < J.Cpad) J.dst[(size_t)r * J.ld_dst + c] = (half_t)v;
+  }
+  __syncthreads();
+  if (J.dstT) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + i * 8, r = r0 + tx;
+      if (c < J.CpadT && r < J.RpadT) J.dstT[(size_t)c * J.ld_dstT + r] = (half_t)tile[tx][ty + i * 8];
+    }
+  }
+}
+
+// up to 16 segments: dst[i] = i < n ? src[i] * (mul ? mul[0] : 1) : 0 for i < npad
+struct SegCopyTable { int n; int begin[17]; const float* src[16]; float* dst[16]; int len[16]; int npad[16]; const float* mul; };
+
+__global__ __launch_bounds__(256) void seg_copy_kernel(SegCopyTable t) {
+  int si = 0;
+  while (si + 1 < t.n && (int)blockIdx.x >= t.begin[si + 1]) ++si;
+  const int i = (blockIdx.x - t.begin[si]) * 256 + threadIdx.x;
+  if (i < t.npad[si]) t.dst[si][i] = i < t.len[si] ? t.src[si][i] * (t.mul ? t.mul[0] : 1.f) : 0.f;
+}
+
+static void seg_copy_add(SegCopyTable& t, float* dst, const float* src, int n, int npad) {
+  const int k = t.n++;
+  t.src[k] = src; t.dst[k] = dst; t.len[k] = n; t.npad[k] = npad;
+  t.begin[k + 1] = t.begin[k] + (npad + 255) / 256;
 }
 
 // bias0_eff[n] = b0[n] + sum_k W0[n][k] * feat[k]  (k < n_feat), one wave per output row.
@@ -395,43 +448,47 @@ static int check_desc(neraf_ctx* ctx, const neraf_nacf_desc* d) {
 extern "C" int neraf_nacf_pack_weights(neraf_ctx* ctx, const neraf_nacf_desc* d, const float* const* w, void* packed,
                                        neraf_stream_t stream) {
   if (int e = check_desc(ctx, d)) return e;
+  if (d->C + 6 > kMaxCvtJobs || d->C + 5 > 16) return neraf_fail(ctx, NERAF_EINVAL, "nacf_pack_weights: too many heads");
   hipStream_t st = (hipStream_t)stream;
   const Dims D = make_dims(d);
   const PackLayout L = make_pack_layout(d, D);
   char* P = (char*)packed;
   const int ld0 = D.kdense;
+  CvtTable t{};
+  auto add = [&](const float* src, int ld, int R, int Cc, half_t* dst, int ld_dst, int Rpad, int Cpad, half_t* dstT, int ld_dstT,
+                 int RpadT, int CpadT) {
+    CvtJob& J = t.j[t.n++];
+    J.src = src; J.dst = dst; J.dstT = dstT; J.ld = ld; J.R = R; J.Cc = Cc; J.ld_dst = ld_dst; J.Rpad = Rpad; J.Cpad = Cpad;
+    J.ld_dstT = ld_dstT; J.RpadT = RpadT; J.CpadT = CpadT;
+    const int rows = std::max(dst ? Rpad : 0, dstT ? RpadT : 0), cols = std::max(dst ? Cpad : 0, dstT ? CpadT : 0);
+    J.tiles_x = (cols + 31) / 32;
+    J.tile_begin = t.total;
+    t.total += J.tiles_x * ((rows + 31) / 32);
+  };
   // layer 0, query half: columns [n_feat, n_feat+163) of W0
-  if (int e = cvt_pad_transpose(ctx, st, Wptr(w, 0) + d->n_feat, nullptr, nullptr, ld0, D.n[0], D.k[0], 0, (half_t*)(P + L.w[0]),
-                                D.kp[0], D.np[0], D.kp[0], nullptr, 0, 0, 0, nullptr))
-    return e;
-  if (d->dense_l0) {
-    if (int e = cvt_pad_transpose(ctx, st, Wptr(w, 0), nullptr, nullptr, ld0, D.n[0], D.kdense, 0, (half_t*)(P + L.w0d), D.kdense_p,
-                                  D.np[0], D.kdense_p, (half_t*)(P + L.w0dt), D.np[0], D.np[0], D.kdense_p, nullptr))
-      return e;
-  }
-  for (int l = 1; l < 5; ++l) {
-    if (int e = cvt_pad_transpose(ctx, st, Wptr(w, l), nullptr, nullptr, D.k[l], D.n[l], D.k[l], 0, (half_t*)(P + L.w[l]), D.kp[l],
-                                  D.np[l], D.kp[l], (half_t*)(P + L.wt[l]), D.np[l], D.np[l], round_up(D.kp[l], 128), nullptr))
-      return e;
-  }
-  // heads: C tensors [F, W] stacked along rows; zero the blob first so padding rows are zero
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(P + L.w[5], 0, (size_t)D.np[5] * D.kp[5] * 2, st));
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(P + L.wt[5], 0, (size_t)round_up(D.kp[5], 128) * D.np[5] * 2, st));
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(P + L.bias[5], 0, (size_t)D.np[5] * 4, st));
+  add(Wptr(w, 0) + d->n_feat, ld0, D.n[0], D.k[0], (half_t*)(P + L.w[0]), D.kp[0], D.np[0], D.kp[0], nullptr, 0, 0, 0);
+  if (d->dense_l0)
+    add(Wptr(w, 0), ld0, D.n[0], D.kdense, (half_t*)(P + L.w0d), D.kdense_p, D.np[0], D.kdense_p, (half_t*)(P + L.w0dt), D.np[0], D.np[0],
+        D.kdense_p);
+  for (int l = 1; l < 5; ++l)
+    add(Wptr(w, l), D.k[l], D.n[l], D.k[l], (half_t*)(P + L.w[l]), D.kp[l], D.np[l], D.kp[l], (half_t*)(P + L.wt[l]), D.np[l], D.np[l],
+        round_up(D.kp[l], 128));
+  // heads: C tensors [F, W] stacked along rows; the last job also writes the zero rows / columns up to the padded extent
+  const int kt5 = round_up(D.kp[5], 128);
   for (int c = 0; c < d->C; ++c) {
-    const float* Wh = w[2 * (5 + c)];
-    const float* bh = w[2 * (5 + c) + 1];
-    half_t* dst = (half_t*)(P + L.w[5]) + (size_t)c * d->F * D.kp[5];
-    half_t* dstT = (half_t*)(P + L.wt[5]) + (size_t)c * d->F;
-    if (int e = cvt_pad_transpose(ctx, st, Wh, nullptr, nullptr, d->W, d->F, d->W, 0, dst, D.kp[5], d->F, D.kp[5], dstT, D.np[5],
-                                  d->F, D.kp[5], nullptr))
-      return e;
-    hipLaunchKernelGGL(pad_copy_f32_kernel, dim3((d->F + 255) / 256), dim3(256), 0, st, bh, d->F,
-                       (float*)(P + L.bias[5]) + (size_t)c * d->F, d->F);
+    const bool last = c == d->C - 1;
+    const int rows = last ? D.np[5] - c * d->F : d->F;
+    add(w[2 * (5 + c)], d->W, d->F, d->W, (half_t*)(P + L.w[5]) + (size_t)c * d->F * D.kp[5], D.kp[5], rows, D.kp[5],
+        (half_t*)(P + L.wt[5]) + (size_t)c * d->F, D.np[5], rows, kt5);
   }
-  for (int l = 0; l < 5; ++l)
-    hipLaunchKernelGGL(pad_copy_f32_kernel, dim3((D.np[l] + 255) / 256), dim3(256), 0, st, Bptr(w, l), D.n[l],
-                       (float*)(P + L.bias[l]), D.np[l]);
+  hipLaunchKernelGGL(cvt_pad_transpose_grouped_kernel, dim3(t.total), dim3(256), 0, st, t);
+  SegCopyTable sc{};
+  for (int c = 0; c < d->C; ++c) {
+    const bool last = c == d->C - 1;
+    seg_copy_add(sc, (float*)(P + L.bias[5]) + (size_t)c * d->F, w[2 * (5 + c) + 1], d->F, last ? D.np[5] - c * d->F : d->F);
+  }
+  for (int l = 0; l < 5; ++l) seg_copy_add(sc, (float*)(P + L.bias[l]), Bptr(w, l), D.n[l], D.np[l]);
+  hipLaunchKernelGGL(seg_copy_kernel, dim3(sc.begin[sc.n]), dim3(256), 0, st, sc);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
@@ -555,9 +612,10 @@ static int nacf_bwd_body(neraf_ctx* ctx, const neraf_nacf_desc* d, const Dims& D
     hipLaunchKernelGGL(amax_dz5_kernel, dim3(blocks), dim3(256), 0, st, dout, out, n, reinterpret_cast<unsigned*>(scale) + 2);
     hipLaunchKernelGGL(make_scale_kernel, dim3(1), dim3(64), 0, st, scale);
   }
-  auto copy_out = [&](float* dst, const float* src, int n) {
-    hipLaunchKernelGGL(scale_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, src, n, inv_scale);
-  };
+  // bias gradients = un-scaled column sums: collected here, copied out by ONE launch once the last sum is complete
+  SegCopyTable outs{};
+  outs.mul = inv_scale;
+  auto copy_out = [&](float* dst, const float* src, int n) { seg_copy_add(outs, dst, src, n, n); };
   int cur = 0;
   half_t* dz = (half_t*)(ws + WL.dz[cur]);
   half_t* dzT = (half_t*)(ws + WL.dzT[cur]);
@@ -603,6 +661,7 @@ static int nacf_bwd_body(neraf_ctx* ctx, const neraf_nacf_desc* d, const Dims& D
     }
   }
   copy_out(grads[1], (const float*)(ws + WL.colsum[0]), D.n[0]);
+  hipLaunchKernelGGL(seg_copy_kernel, dim3(outs.begin[outs.n]), dim3(256), 0, st, outs);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   *slot0 = cur;
   return NERAF_OK;
