@@ -703,7 +703,7 @@ struct WgDesc {                       // 64 bytes
   unsigned long long slab_off;        // floats, into the shared slab buffer (unused when splits == 1)
   int block_begin; int K;
   unsigned short cout, cin, cin_real, taps, din, tiles_n, splits;
-  unsigned char dl, stride, ksize, loader; signed char pad; unsigned char r0, r1, r2, r3, r4;
+  unsigned char dl, stride, ksize, loader; signed char pad; unsigned char mh, r1, r2, r3, r4;   // mh: wide kernel, 64-row halves of the M tile (1 | 2)
 };
 static_assert(sizeof(WgDesc) == 64, "descriptor table must fit the 4 KiB kernel-argument segment");
 constexpr int kMaxWg = 48;
@@ -875,6 +875,185 @@ __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
     }
 }
 
+// ---- wide form: (64*MH) x (64*NH) tiles built from 64-column HALF tiles -------------------------------------------------------
+// The 64x64 tile above stages 16 KiB per 0.52 MFLOP K-step and re-reads dY once per N tile (PMC: 1.57 GB fetched per step for
+// 0.45 GB of operands).  Here a workgroup stages MH + NH half tiles ([64 k][64 columns] each, the layout, swizzle and
+// transposed reads of the kernel above) and every wave owns one 64x64 block of the product -- (A half, B half) = (w >> 1, w & 1)
+// for MH = NH = 2 (cout >= 128) or (0, w) for MH = 1, NH = 4 (the 64-filter convolutions, half of the FLOPs): 32 / 40 KiB per
+// 2.1 MFLOP K-step, 16 transposed reads per 16 MFMAs instead of 16 per 8.
+template <int NST>
+__global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
+  constexpr int HALF = 64 * 128;
+  constexpr int STAGE_BYTES = 5 * HALF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gi = wg_find(t, blockIdx.x);
+  const WgDesc& D = t.d[gi];
+  const int MH = D.mh, NH = MH == 2 ? 2 : 4;
+  const int ha = MH == 2 ? (wave >> 1) : 0, hb = MH == 2 ? (wave & 1) : wave;
+  int bid = blockIdx.x - D.block_begin;
+  const int splits = D.splits, n64 = D.tiles_n, tiles_m = D.cout / (64 * MH);
+  const int split = bid % splits;
+  bid /= splits;
+  const int bm = bid % tiles_m, bnw = bid / tiles_m;
+  const int nk_total = D.K / BK;
+  const int per = (nk_total + splits - 1) / splits;
+  const int k_begin = split * per;
+  const int k_end = (k_begin + per) < nk_total ? (k_begin + per) : nk_total;
+  const int nk = k_end > k_begin ? k_end - k_begin : 0;
+
+  int lrow[2], lcs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + (tid >> 3);
+    lrow[i] = row;
+    lcs[i] = (tid & 7) ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1);
+  }
+  const int cout = D.cout, cin = D.cin, KS = D.ksize, loader = D.loader, din = D.din, stride = D.stride, pad = D.pad;
+  const bf16_t* Ab = D.dy + (size_t)bm * MH * 64;
+  const bf16_t* Bb = D.x;
+  const int dl = D.dl, dmask = (1 << dl) - 1;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(t.zero_page);
+  // per B half: filter tap and channel block of its 64 columns (loader 1), validity
+  int h_dz[4], h_dy[4], h_dx[4], h_cb[4];
+  bool h_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int b64 = bnw * NH + j;
+    h_ok[j] = j < NH && b64 < n64;
+    h_dz[j] = h_dy[j] = h_dx[j] = h_cb[j] = 0;
+    if (loader == 1 && h_ok[j]) {
+      const int n0 = b64 * 64;
+      const int tap = n0 / cin; h_cb[j] = n0 - tap * cin;
+      h_dz[j] = tap / (KS * KS); h_dy[j] = (tap / KS) % KS; h_dx[j] = tap % KS;
+    }
+  }
+
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int swz = (((q >> 1) & 1) | ((g & 1) << 1)) << 1;
+  int f_off[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int c = f * 16 + 4 * pp;
+    f_off[f] = (8 * g + q) * 128 + (((c >> 3) ^ swz) << 4) + ((pp & 1) << 3);
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((address_space(3))) bf16x4* lds_v4_t;
+
+  auto body = [&](auto mh_c) {
+    constexpr int MHc = decltype(mh_c)::value, NHc = MHc == 2 ? 2 : 4, NP = 2 * (MHc + NHc);   // LDS-DMA pieces per thread and stage
+    auto issue = [&](int kt, int stage) {
+      char* base = smem + stage * STAGE_BYTES + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = kt * BK + lrow[i];
+#pragma unroll
+        for (int h = 0; h < MHc; ++h)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ab + (size_t)m * cout + h * 64 + lcs[i] * 8), (lds_ptr_t)(base + h * HALF + i * 4096), 16, 0, 0);
+        int vz = 0, vy = 0, vx = 0;
+        if (loader != 0) { const int x = m & dmask, y = (m >> dl) & dmask, z = m >> (2 * dl); vz = z * stride - pad; vy = y * stride - pad; vx = x * stride - pad; }
+#pragma unroll
+        for (int j = 0; j < NHc; ++j) {
+          const bf16_t* src = zero;
+          if (h_ok[j]) {
+            if (loader == 0) {
+              src = Bb + (size_t)m * cin + (bnw * NHc + j) * 64 + lcs[i] * 8;
+            } else {
+              int dz = h_dz[j], dy = h_dy[j], dx = h_dx[j];
+              if (loader == 2) {
+                const int tap = (bnw * NHc + j) * 8 + lcs[i];
+                dz = tap / (KS * KS); dy = (tap / KS) % KS; dx = tap % KS;
+                if (tap >= KS * KS * KS) dz = 1 << 20;
+              }
+              const int iz = vz + dz, iy = vy + dy, ix = vx + dx;
+              const bool ok = (unsigned)iz < (unsigned)din && (unsigned)iy < (unsigned)din && (unsigned)ix < (unsigned)din;
+              const size_t vox = ((size_t)(iz * din + iy) * din + ix);
+              if (ok) src = loader == 2 ? Bb + vox * 8 : Bb + vox * cin + h_cb[j] + lcs[i] * 8;
+            }
+          }
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + (MHc + j) * HALF + i * 4096), 16, 0, 0);
+        }
+      }
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+      if (s0 < nk) issue(k_begin + s0, s0);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int after = nk - 1 - kt;
+      if (NST >= 3 && after >= 1) wait_vmcnt<NP>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (kt + NST - 1 < nk) {
+        int st2 = stage + NST - 1; if (st2 >= NST) st2 -= NST;
+        issue(k_begin + kt + NST - 1, st2);
+      }
+      char* sa = smem + stage * STAGE_BYTES + ha * HALF;
+      char* sb = smem + stage * STAGE_BYTES + (MHc + hb) * HALF;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sa + f_off[f] + ks * 4096));
+          const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sa + f_off[f] + ks * 4096 + 512));
+          const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sb + f_off[f] + ks * 4096));
+          const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sb + f_off[f] + ks * 4096 + 512));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { fa[f][e] = a0[e]; fa[f][4 + e] = a1[e]; fb[f][e] = b0[e]; fb[f][4 + e] = b1[e]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      }
+      if (++stage == NST) stage = 0;
+    }
+  };
+  static_assert(NST == 2 || NST == 3, "ring depths the waits are written for");
+  if (MH == 2) body(std::integral_constant<int, 2>{}); else body(std::integral_constant<int, 1>{});
+
+  const int b64 = bnw * NH + hb;
+  if (b64 >= n64) return;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int N = D.taps * cin, Npad = n64 * 64;
+  const int m_base = (bm * MH + ha) * 64, n_base = b64 * 64;
+  if (splits == 1) {
+    const float alpha = t.alpha_dev ? *t.alpha_dev : 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m_base + i * 16 + frow;
+        const int n0 = n_base + j * 16 + fq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + r;
+          if (n < N && (n % cin) < D.cin_real) D.out[wg_out_index(D, m, n)] = acc[i][j][r] * alpha;
+        }
+      }
+    return;
+  }
+  float* slab = t.slab + D.slab_off + (size_t)split * cout * Npad;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m_base + i * 16 + frow;
+      const int n0 = n_base + j * 16 + fq * 4;
+      *reinterpret_cast<f32x4*>(slab + (size_t)m * Npad + n0) = acc[i][j];
+    }
+}
+
 // one workgroup per 32x32 output tile of every split item: sums the slabs, scales, writes the PyTorch layout
 struct WgRedTable { int n; const float* alpha_dev; const float* slab; int tile_begin[kMaxWg + 1]; unsigned char item[kMaxWg]; };
 
@@ -953,12 +1132,17 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
   if (n <= 0 || n > kMaxWg || !items || !zero_page) return neraf_fail(ctx, NERAF_EINVAL, "wgrad_grouped: bad arguments");
   static const int nst = [] { const char* e = getenv("NERAF_WGRAD_NST"); const int v = e ? atoi(e) : 3; return v < 2 ? 2 : (v > 4 ? 4 : v); }();   // 3 stages = 48 KiB: three workgroups per CU (5.42 -> 5.34 ms/step against 4 stages)
   static const int rounds = [] { const char* e = getenv("NERAF_WGRAD_ROUNDS"); return e ? atoi(e) : 8; }();
+  static const int wide = [] { const char* e = getenv("NERAF_WGRAD_WIDE"); return e ? atoi(e) : 1; }();        // 0: 64x64 tiles only
+  static const int wide_nst = [] { const char* e = getenv("NERAF_WGRAD_WIDE_NST"); return (e && atoi(e) == 3) ? 3 : 2; }();
+  static const int wide_rounds = [] { const char* e = getenv("NERAF_WGRAD_WIDE_ROUNDS"); return e ? atoi(e) : 4; }();
   const int LDS_BYTES = nst * 128 * 128;
   static bool attr_set = false;
   if (!attr_set) {
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128));
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128));
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 128));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 5 * 8192));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 5 * 8192));
     attr_set = true;
   }
   const int cus = ctx ? ctx->num_cus : 256;
@@ -971,9 +1155,9 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
   for (int i = 0; i < n; ++i) {
     const WgradItem& it = items[i];
     const int taps = it.ksize * it.ksize * it.ksize;
-    total_steps += (double)(it.cout / 64) * (round_up(taps * it.cin, 64) / 64) * (it.K / 64);
+    total_steps += (double)(it.cout / 64) * (round_up(taps * it.cin, 64) / 64) * (it.K / 64) / (wide ? 4.0 : 1.0);   // wide tiles: 4 halves' products each
   }
-  int target = (int)(total_steps / (cus * (double)rounds)) + 1;       // ~8 rounds of 2 workgroups per CU
+  int target = (int)(total_steps / (cus * (double)(wide ? wide_rounds : rounds))) + 1;       // K-steps per workgroup: ~8 (4 wide) rounds of the chip
   if (target < 16) target = 16;
   size_t slab_off = 0; int blocks = 0, red_tiles = 0, nred = 0;
   double flops = 0.0;
@@ -996,7 +1180,9 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
     if (splits > 128) splits = 128;
     d.splits = (unsigned short)splits;
     d.block_begin = blocks;
-    blocks += tiles_m * tiles_n * splits;
+    d.mh = (unsigned char)(it.cout % 128 == 0 ? 2 : 1);
+    if (wide) blocks += (it.cout / (64 * d.mh)) * ((tiles_n + (d.mh == 2 ? 2 : 4) - 1) / (d.mh == 2 ? 2 : 4)) * splits;
+    else blocks += tiles_m * tiles_n * splits;
     d.slab_off = slab_off;
     if (splits > 1) {
       slab_off += (size_t)splits * it.cout * tiles_n * 64;
@@ -1010,7 +1196,9 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
   r.n = nred; r.tile_begin[nred] = red_tiles;
   {
     ProfScope prof(ctx, stream, PROF_WGRAD, flops);
-    if (nst == 2) hipLaunchKernelGGL(wgrad_grouped_tn_kernel<2>, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
+    if (wide && wide_nst == 2) hipLaunchKernelGGL(wgrad_wide_tn_kernel<2>, dim3(blocks), dim3(256), 2 * 5 * 8192, stream, t);
+    else if (wide) hipLaunchKernelGGL(wgrad_wide_tn_kernel<3>, dim3(blocks), dim3(256), 3 * 5 * 8192, stream, t);
+    else if (nst == 2) hipLaunchKernelGGL(wgrad_grouped_tn_kernel<2>, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
     else if (nst == 3) hipLaunchKernelGGL(wgrad_grouped_tn_kernel<3>, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
     else hipLaunchKernelGGL(wgrad_grouped_tn_kernel<4>, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
   }
