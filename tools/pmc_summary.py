@@ -18,7 +18,7 @@ W = load(latest("gpurun_out/pmc/WRITE_SIZE/runc/*_counter_collection.csv"), "WRI
 def fam(n):
     """rocprofv3 kernel name -> the bench.py profiling scope (neraf_prof_kernel_name) it is timed under"""
     if "gemm_f16_nt_wide_kernel" in n: return "gemm_f16_nt_wide_kernel<160|128, 3, *>"
-    if "wgrad_grouped_tn_kernel" in n: return "wgrad_grouped_tn_kernel"
+    if "wgrad_grouped_tn_kernel" in n or "wgrad_wide_tn_kernel" in n: return "wgrad_wide_tn_kernel | wgrad_grouped_tn_kernel"
     m = re.search(r"gemm_f16_nt_pipe_kernel<(\d+), (\d+), \d, (\d), (\d), (true|false)>", n)
     if m:
         bm, bn, ld, bf = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(5) == "true"
