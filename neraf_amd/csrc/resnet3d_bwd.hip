@@ -323,8 +323,10 @@ struct BwdLayout {
 
 // row blocks / accumulator replicas of the BN-backward reduction of conv ci
 inline int bwd_rows_per_block(const ConvSpec& c) {
+  static const int min_rows = [] { const char* e = getenv("NERAF_BN_BWD_MIN_ROWS"); return e ? atoi(e) : 32; }();
+  static const int max_blocks = [] { const char* e = getenv("NERAF_BN_BWD_MAX_BLOCKS"); return e ? atoi(e) : 512; }();
   const int M = (int)cube(c.dout);
-  return std::max(128, round_up((M + 511) / 512, 32));
+  return std::max(min_rows, round_up((M + max_blocks - 1) / max_blocks, 32));
 }
 inline int bwd_stat_rep(const ConvSpec& c) {
   if (2 * round_up(c.cout, 128) > kStatStride) return 1;
