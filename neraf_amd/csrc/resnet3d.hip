@@ -45,8 +45,10 @@ __global__ __launch_bounds__(256) void bn_update_running_all_kernel(RunTable t, 
 }
 
 // stem: out[32^3-like][64] = maxpool3(s2,p1)( relu(bn(x)) ), x pre-BN [din^3][64]
+// arg (training): tap index (dz+1)*9 + (dy+1)*3 + (dx+1) of the FIRST maximum of each window, 255 when the maximum is not > 0 --
+// the routing table of the backward (maxpool_bwd_gather_kernel)
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnSrc s, int din, int dout, size_t m_in, half_t* __restrict__ out,
-                                                             bf16_t* __restrict__ out_bf) {
+                                                             bf16_t* __restrict__ out_bf, unsigned char* __restrict__ arg) {
   __shared__ float sc[64], sh[64];
   if (threadIdx.x < 64) bn_scale_shift(s, threadIdx.x, 1.f / (float)m_in, sc[threadIdx.x], sh[threadIdx.x]);
   __syncthreads();
@@ -55,9 +57,9 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnSrc s, int din, 
   if (idx >= total) return;
   const size_t vox = idx >> 3; const int c0 = (int)(idx & 7) * 8;
   const int x = (int)(vox % dout), y = (int)((vox / dout) % dout), z = (int)(vox / ((size_t)dout * dout));
-  float best[8];
+  float best[8]; int at[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) best[j] = -3.0e38f;
+  for (int j = 0; j < 8; ++j) { best[j] = -3.0e38f; at[j] = 255; }
   for (int dz = -1; dz <= 1; ++dz) {
     const int iz = 2 * z + dz; if ((unsigned)iz >= (unsigned)din) continue;
     for (int dy = -1; dy <= 1; ++dy) {
@@ -65,10 +67,20 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnSrc s, int din, 
       for (int dx = -1; dx <= 1; ++dx) {
         const int ix = 2 * x + dx; if ((unsigned)ix >= (unsigned)din) continue;
         const half8 v = *reinterpret_cast<const half8*>(s.x + (((size_t)iz * din + iy) * din + ix) * 64 + c0);
+        const int tap = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], fmaxf(fmaf((float)v[j], sc[c0 + j], sh[c0 + j]), 0.f));
+        for (int j = 0; j < 8; ++j) {
+          const float a = fmaxf(fmaf((float)v[j], sc[c0 + j], sh[c0 + j]), 0.f);
+          if (a > best[j]) { best[j] = a; at[j] = tap; }
+        }
       }
     }
+  }
+  if (arg) {
+    unsigned long long packed = 0ull;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) packed |= (unsigned long long)(best[j] > 0.f ? at[j] : 255) << (8 * j);
+    *reinterpret_cast<unsigned long long*>(arg + vox * 64 + c0) = packed;
   }
   half8 o;
 #pragma unroll
@@ -185,7 +197,8 @@ static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     BnSrc s = bn_src_fwd(A, L, ws, bn, 0, use_batch_stats);
     const size_t total = cube(A.pooled) * 8;
     hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, c.dout, A.pooled,
-                       cube(c.dout), (half_t*)(ws + L.act_pool), shadow ? (bf16_t*)(ws + L.act_pool_bf) : nullptr);
+                       cube(c.dout), (half_t*)(ws + L.act_pool), shadow ? (bf16_t*)(ws + L.act_pool_bf) : nullptr,
+                       shadow ? (unsigned char*)(ws + L.pool_arg) : nullptr);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
   }
   const half_t* x = (const half_t*)(ws + L.act_pool);

@@ -69,6 +69,7 @@ struct Layout {
   size_t pre[64], stat[64];     // per conv: pre-BN output fp16 [rows_pad][cout], stats fp32 [rep][2][cpad] (replica stride kStatStride)
   size_t fin[64];               // per conv: finalised batch statistics fp32 [2][cpad] = mean, biased variance (written by the BN pass)
   size_t act_pool;              // stem: pooled activation
+  size_t pool_arg;              // stem: which of the 27 window taps held the maximum (uint8 [pooled^3][64], 255 = none > 0); training
   size_t a1[16], a2[16], out[16];   // per block post-activation tensors
   // bfloat16 shadows of every tensor a convolution reads (written by the same passes in training mode): the weight-gradient
   // GEMM pairs them with the bfloat16 gradient chain, and the MFMA wants both operands in one type
@@ -106,6 +107,7 @@ void make_layout(const Arch& A, Layout* L) {
   L->splitk = take(L->splitk_bytes);
   L->x0_bf = take(cube(A.S) * 8 * 2);
   L->act_pool_bf = take(rows_pad(A.pooled) * 64 * 2);
+  L->pool_arg = take(cube(A.pooled) * 64);
   for (int b = 0; b < A.nblock; ++b) {
     const ConvSpec& c0 = A.conv[A.block[b].conv[0]]; const ConvSpec& c1 = A.conv[A.block[b].conv[1]];
     const ConvSpec& c2 = A.conv[A.block[b].conv[2]];
