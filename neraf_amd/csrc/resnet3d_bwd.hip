@@ -145,16 +145,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs p) {
 // grid (Mpad / 64, C / 64)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
   __shared__ float mean[64], rstd[64], k1[64], k2[64], k3[64];
+  __shared__ float part[2][4][64];
   const int c_base = blockIdx.y * 64, m0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
   const float inv_m = 1.f / (float)p.M;
+  {
+    // the replicas of the two sums: four threads per channel take every fourth replica (a chain of rep loads otherwise)
+    const int c = c_base + (tid & 63), q = tid >> 6;
+    float db = 0.f, dg = 0.f;
+    for (int r = q; r < p.rep; r += 4) { db += p.sums[r * kStatStride + c]; dg += p.sums[r * kStatStride + p.s.cpad + c]; }
+    part[0][q][tid & 63] = db; part[1][q][tid & 63] = dg;
+  }
+  __syncthreads();
   if (tid < 64) {
     const int c = c_base + tid;
     float m, v;
     bn_mean_var(p.s, c, 0.f, m, v);
     const float rs = rsqrtf(v + 1e-5f);
-    float dbeta = 0.f, dgamma = 0.f;
-    for (int r = 0; r < p.rep; ++r) { dbeta += p.sums[r * kStatStride + c]; dgamma += p.sums[r * kStatStride + p.s.cpad + c]; }
+    const float dbeta = (part[0][0][tid] + part[0][1][tid]) + (part[0][2][tid] + part[0][3][tid]);
+    const float dgamma = (part[1][0][tid] + part[1][1][tid]) + (part[1][2][tid] + part[1][3][tid]);
     mean[tid] = m; rstd[tid] = rs;
     k1[tid] = p.s.gamma[c] * rs; k2[tid] = dbeta * inv_m; k3[tid] = dgamma * inv_m;
     if (blockIdx.x == 0 && p.dgamma) { p.dgamma[c] = dgamma * p.inv_scale[0]; p.dbeta[c] = dbeta * p.inv_scale[0]; }
