@@ -132,8 +132,17 @@ __device__ __forceinline__ void bn_mean_var(const BnSrc& s, int c, float inv_m, 
   if (s.fin_r) {
     mean = s.fin_r[c]; var = s.fin_r[s.cpad + c];
   } else if (s.stats) {
-    float a = 0.f, b = 0.f;
-    for (int r = 0; r < s.rep; ++r) { a += s.stats[r * kStatStride + c]; b += s.stats[r * kStatStride + s.cpad + c]; }
+    // four independent chains: the loop is a latency chain of 2 * rep loads otherwise (rep is 1, 2, 4, 8 or 16)
+    float a = 0.f, b = 0.f, a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, a3 = 0.f, b3 = 0.f;
+    int r = 0;
+    for (; r + 4 <= s.rep; r += 4) {
+      a += s.stats[r * kStatStride + c]; b += s.stats[r * kStatStride + s.cpad + c];
+      a1 += s.stats[(r + 1) * kStatStride + c]; b1 += s.stats[(r + 1) * kStatStride + s.cpad + c];
+      a2 += s.stats[(r + 2) * kStatStride + c]; b2 += s.stats[(r + 2) * kStatStride + s.cpad + c];
+      a3 += s.stats[(r + 3) * kStatStride + c]; b3 += s.stats[(r + 3) * kStatStride + s.cpad + c];
+    }
+    for (; r < s.rep; ++r) { a += s.stats[r * kStatStride + c]; b += s.stats[r * kStatStride + s.cpad + c]; }
+    a = (a + a1) + (a2 + a3); b = (b + b1) + (b2 + b3);
     mean = a * inv_m;
     var = fmaxf(b * inv_m - mean * mean, 0.f);    // biased variance, as nn.BatchNorm3d normalises with
   } else {
