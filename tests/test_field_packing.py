@@ -174,3 +174,39 @@ def test_fixed_point_level_scale_bound():
     # resolution: the quantised total matches the float total to ~1e-6 of the gradient mass
     tot = (w[:, :, None] * g[:, None, :]).sum(axis=(0, 1))
     np.testing.assert_allclose(q.sum(axis=(0, 1)) / F, tot, atol=1e-6 * T)
+
+
+def test_packed_copies_are_cached_per_parameter_state():
+    """NerfactoField.packed() / packed_bwd() / HashMLPDensityField.packed() make their fp16 copies once per parameter state: the
+    key is the fused optimizer's update counter (its kernels write through raw pointers) plus every parameter's storage pointer
+    and version counter (torch-side in-place updates)."""
+    import torch
+    from neraf_amd import optim
+    from neraf_amd.vision import HashMLPDensityField, NerfactoField
+    f = NerfactoField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=4)
+    a = f.packed(with_average=False)
+    b = f.packed(with_average=False)
+    assert all(x is y for x, y in zip(a, b))                      # same objects: nothing was converted again
+    c = f.packed(with_average=True)
+    assert c[0] is a[0] and c[1] is a[1] and c[2].shape[0] == a[2].shape[0] + 1     # only the embedding rows differ
+    wb = f.packed_bwd()
+    assert f.packed_bwd() is wb
+    with torch.no_grad():
+        f.base_w0.mul_(2.0)                                       # torch-side update: version counter
+    d = f.packed(with_average=False)
+    assert d[1] is not a[1] and not torch.equal(d[1], a[1]) and f.packed_bwd() is not wb
+    optim.UPDATE_EPOCH += 1                                       # what FusedAdam.step() does
+    e = f.packed(with_average=False)
+    assert e[0] is not d[0] and torch.equal(e[0], d[0])
+    f.invalidate_packed()
+    assert f.packed(with_average=False)[0] is not e[0]
+    p = HashMLPDensityField.__new__(HashMLPDensityField)
+    torch.nn.Module.__init__(p)
+    p.table = torch.nn.Parameter(torch.rand(64, 2))
+    p.w0 = torch.nn.Parameter(torch.rand(16, 16))
+    p.w1 = torch.nn.Parameter(torch.rand(16, 16))
+    t0 = p.packed()
+    assert p.packed()[0] is t0[0]
+    with torch.no_grad():
+        p.table.add_(1.0)
+    assert p.packed()[0] is not t0[0]
