@@ -427,9 +427,9 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
 // 128-wide tiles would leave a quarter-filled second round.
 // The stage image is (256 + BN) rows x 128 B (A rows, then B rows); one LDS-DMA wave-instruction fills 8 rows, wave w issues
 // instructions w, w+8, ... so some waves issue one more than the others -- each wave counts its own in s_waitcnt vmcnt.
-template <int BN, int NST, bool BF>
+template <int BM, int BN, int NST, bool BF>
 __global__ __launch_bounds__(512) void gemm_f16_nt_wide_kernel(GemmParams p, int splits) {
-  constexpr int BM = 256, WAVES_M = 4;
+  constexpr int WAVES_M = 4;
   using T = Tile<BM, BN, WAVES_M>;
   using E8 = typename ET<BF>::v8;
   constexpr int WM = T::WM, WN = T::WN, FM = T::FM, FN = T::FN;
@@ -667,20 +667,20 @@ int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
 }
 
 
-template <int BN, int NST, bool BF>
+template <int BM, int BN, int NST, bool BF>
 int launch_wide(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t stream) {
-  using T = Tile<256, BN, 4>;
+  using T = Tile<BM, BN, 4>;
   constexpr int LDS_BYTES = (NST * T::STAGE_BYTES > T::NWAVES * T::EPI_BYTES_WAVE) ? NST * T::STAGE_BYTES : T::NWAVES * T::EPI_BYTES_WAVE;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_nt_wide_kernel<BN, NST, BF>),
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_nt_wide_kernel<BM, BN, NST, BF>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
-  const int ntiles = (p.Mpad / 256) * (p.Npad / BN);
+  const int ntiles = (p.Mpad / BM) * (p.Npad / BN);
   ProfScope prof(ctx, stream, PROF_GEMM_WIDE, 2.0 * p.M * p.N * p.K);
-  hipLaunchKernelGGL((gemm_f16_nt_wide_kernel<BN, NST, BF>), dim3(ntiles * splits), dim3(512), LDS_BYTES, stream, p, splits);
+  hipLaunchKernelGGL((gemm_f16_nt_wide_kernel<BM, BN, NST, BF>), dim3(ntiles * splits), dim3(512), LDS_BYTES, stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   if (splits > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel<BF>, dim3(p.Npad / 32, p.Mpad / 32, 1), dim3(256), 0, stream, p, splits);
@@ -1116,9 +1116,13 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   }
   if (LOADER == 0 && ng == 1 && kWide && (p.Mpad % 256) == 0) {
     // wide body where its tiles fill the chip: 256x160 (the 5096-wide NAcF layers), else 256x128
-    if ((p.Npad % 160) == 0 && (p.Mpad / 256) * (p.Npad / 160) * 4 >= cus * 3) return launch_wide<160, 3, BF>(ctx, p, 1, stream);
-    if ((p.Npad % 128) == 0 && (p.Mpad / 256) * (p.Npad / 128) >= cus) return launch_wide<128, 3, BF>(ctx, p, 1, stream);
+    if ((p.Npad % 160) == 0 && (p.Mpad / 256) * (p.Npad / 160) * 4 >= cus * 3) return launch_wide<256, 160, 3, BF>(ctx, p, 1, stream);
+    if ((p.Npad % 128) == 0 && (p.Mpad / 256) * (p.Npad / 128) >= cus) return launch_wide<256, 128, 3, BF>(ctx, p, 1, stream);
   }
+  // 128x128 tiles, about one per CU (too few for two 4-wave workgroups per CU to overlap each other): the 8-wave ping-pong body
+  // on the same tile -- the dominant NAcF forward layer, 2048 x 2048 x 5120 = 256 tiles
+  if (LOADER == 0 && ng == 1 && kWide && bm == 128 && bn == 128 && splits == 1 && ntiles < 2 * cus)
+    return launch_wide<128, 128, 3, BF>(ctx, p, 1, stream);
   // staging depth: the 128-wide tiles run faster with two workgroups per CU (2 / 3 stages) than with one and a deep ring
   if (bm == 128 && bn == 128) return launch_pipe<128, 128, 2, LOADER, KS, BF>(ctx, p, splits, stream);
   if (bm == 128 && bn == 64) return launch_pipe<128, 64, 3, LOADER, KS, BF>(ctx, p, splits, stream);
