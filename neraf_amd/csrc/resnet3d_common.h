@@ -240,32 +240,39 @@ __global__ __launch_bounds__(256) void pack_bricks_kernel(BrickTable t, char* __
   for (int co_l = wave; co_l < 32; co_l += 4) {
     const float* row = src + (size_t)co_l * cin * taps;
     unsigned short* dst = brick16 + co_l * pitch;
-    for (int idx = lane; idx < run; idx += 64) {
-      const float v = row[idx];
+    auto put = [&](int idx, float v) {
       if (MODE == 0) { const half_t h = (half_t)v; dst[idx] = *reinterpret_cast<const unsigned short*>(&h); }
       else { const bf16_t h = (bf16_t)v; dst[idx] = *reinterpret_cast<const unsigned short*>(&h); }
+    };
+    int idx = lane;
+    for (; idx + 192 < run; idx += 256) {              // four loads in flight per lane: one per iteration is a latency chain
+      const float v0 = row[idx], v1 = row[idx + 64], v2 = row[idx + 128], v3 = row[idx + 192];
+      put(idx, v0); put(idx + 64, v1); put(idx + 128, v2); put(idx + 192, v3);
     }
+    for (; idx < run; idx += 64) put(idx, row[idx]);
   }
   __syncthreads();
-  unsigned short* out = reinterpret_cast<unsigned short*>(packed + t.dst_off[i]);
+  // destination runs are written two elements (4 bytes) per lane: cib, cin, cout, co0 and ci0 are all even
+  unsigned* out = reinterpret_cast<unsigned*>(packed + t.dst_off[i]);
   if (MODE == 0) {
     // runs of cib ci for every (co, tap)
-    const int lpr = cib < 256 ? cib : 256;             // lanes per run (cib is 32, 64, 128 or 256)
-    const int ci_l = threadIdx.x % lpr, rg = threadIdx.x / lpr, nrg = 256 / lpr;
+    const int lpr = (cib >> 1) < 256 ? (cib >> 1) : 256;      // lanes per run (cib is 32, 64, 128 or 256)
+    const int cp = threadIdx.x % lpr, rg = threadIdx.x / lpr, nrg = 256 / lpr;
     const size_t ld = (size_t)taps * cin;
     for (int co_l = rg; co_l < 32; co_l += nrg) {
-      const unsigned short* srow = brick16 + co_l * pitch + ci_l * taps;
-      unsigned short* drow = out + (size_t)(co0 + co_l) * ld + ci0 + ci_l;
-      for (int tap = 0; tap < taps; ++tap) drow[(size_t)tap * cin] = srow[tap];
+      const unsigned short* srow = brick16 + co_l * pitch + 2 * cp * taps;
+      unsigned* drow = out + (((size_t)(co0 + co_l) * ld + ci0) >> 1) + cp;
+      for (int tap = 0; tap < taps; ++tap) drow[((size_t)tap * cin) >> 1] = (unsigned)srow[tap] | ((unsigned)srow[taps + tap] << 16);
     }
   } else {
     // runs of 32 co for every (ci, tap)
-    const int co_l = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int cp = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const size_t ld = (size_t)taps * cout;
-    for (int ci_l = rg; ci_l < cib; ci_l += 8) {
-      const unsigned short* srow = brick16 + co_l * pitch + ci_l * taps;
-      unsigned short* drow = out + (size_t)(ci0 + ci_l) * ld + co0 + co_l;
-      for (int tap = 0; tap < taps; ++tap) drow[(size_t)tap * cout] = srow[tap];
+    for (int ci_l = rg; ci_l < cib; ci_l += 16) {
+      const unsigned short* s0 = brick16 + (2 * cp) * pitch + ci_l * taps;
+      const unsigned short* s1 = s0 + pitch;
+      unsigned* drow = out + (((size_t)(ci0 + ci_l) * ld + co0) >> 1) + cp;
+      for (int tap = 0; tap < taps; ++tap) drow[((size_t)tap * cout) >> 1] = (unsigned)s0[tap] | ((unsigned)s1[tap] << 16);
     }
   }
 }
