@@ -244,12 +244,21 @@ __global__ __launch_bounds__(256) void pack_bricks_kernel(BrickTable t, char* __
       if (MODE == 0) { const half_t h = (half_t)v; dst[idx] = *reinterpret_cast<const unsigned short*>(&h); }
       else { const bf16_t h = (bf16_t)v; dst[idx] = *reinterpret_cast<const unsigned short*>(&h); }
     };
-    int idx = lane;
-    for (; idx + 192 < run; idx += 256) {              // four loads in flight per lane: one per iteration is a latency chain
-      const float v0 = row[idx], v1 = row[idx + 64], v2 = row[idx + 128], v3 = row[idx + 192];
-      put(idx, v0); put(idx + 64, v1); put(idx + 128, v2); put(idx + 192, v3);
+    // 16-byte loads, two in flight per lane (run and every row offset are multiples of 4 floats): with 4-byte loads a wave kept
+    // 1 KiB in flight and the kernel ran at 1.6 TB/s
+    const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
+    const int run4 = run >> 2;
+    int i4 = lane;
+    for (; i4 + 64 < run4; i4 += 128) {
+      const f32x4 v0 = row4[i4], v1 = row4[i4 + 64];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { put(4 * i4 + e, v0[e]); put(4 * (i4 + 64) + e, v1[e]); }
     }
-    for (; idx < run; idx += 64) put(idx, row[idx]);
+    for (; i4 < run4; i4 += 64) {
+      const f32x4 v0 = row4[i4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) put(4 * i4 + e, v0[e]);
+    }
   }
   __syncthreads();
   // destination runs are written two elements (4 bytes) per lane: cib, cin, cout, co0 and ci0 are all even
