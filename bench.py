@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (NeRAF_config.py:87)")
     ap.add_argument("--slices", type=int, default=2048, help="RIR STFT slices per GPU per step (NeRAF_config.py:57)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dataset", choices=("raf", "soundspaces"), default="raf",
+                    help="audio head shape: raf = 1 x 513 bins, T = 60 (BASELINE configs[1..2], the default and the metric's config); "
+                         "soundspaces = 2 x 257 bins, T = 101 (configs[3]: per GPU 4096 rays + 808 slices)")
     return ap.parse_args()
 
 
@@ -64,7 +67,7 @@ class JointStep:
           proposal backward, fused field backward, weight-grad GEMMs) -> [RCCL all-reduce] -> GradScaler + fused Adam on
           the radiance parameters (lr 1e-2) and the audio parameters (NAcF + ResNet3D, lr 1e-4)."""
 
-    def __init__(self, dev, R, B, world):
+    def __init__(self, dev, R, B, world, dataset="raf"):
         from neraf_amd import synth
         from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
         from neraf_amd.vision import NeRAFVisionModel, RayBundle
@@ -75,8 +78,9 @@ class JointStep:
             g = torch.Generator(device="cpu").manual_seed(0)
             for p in [self.vm.field.module.table] + [pn.table for pn in self.vm.proposal_networks]:
                 p.copy_((torch.rand(p.shape, generator=g) - 0.5).to(dev))
-        self.am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 128), T(synth.audio_aabb()),
-                                  process_group=True if world > 1 else None)
+        cfg = (NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 128) if dataset == "raf" else
+               NeRAFAudioModelConfig(dataset="SoundSpaces", grid_step=1 / 128, max_len=T_, N_freq_stft=F_))
+        self.am = NeRAFAudioModel(cfg, T(synth.audio_aabb()), process_group=True if world > 1 else None)
         self.am.field.load_state_dict({k: T(v) for k, v in synth.nacf_state_dict(1187, 512, C_, F_).items()})
         self.am.resnet3d.backbone_net.load_state_dict({k: T(v) for k, v in synth.resnet3d_state_dict(7).items()})
         self.am.to(dev)
@@ -196,7 +200,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # RCCL
     from neraf_amd import _lib
 
-    st = JointStep(dev, a.rays, a.slices, world)
+    if a.dataset == "soundspaces":
+        global C_, F_, T_
+        C_, F_, T_ = 2, 257, 101
+    st = JointStep(dev, a.rays, a.slices, world, dataset=a.dataset)
     # Setup, before the W warm-up steps: the first steps of a run build the optimizer launch plans (the step with the first
     # proposal-network update builds a second one), capture the ResNet3D hipGraphs and grow the allocator pools --
     # tools/step_trace.py shows them as 10-400 ms steps -- and a full Python garbage collection over the module graph costs
@@ -265,7 +272,7 @@ def main():
         # tools/gpu_pmc.sh -> profiles/*_pmc_traffic.json (FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE)
         import glob
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-        pmc = json.load(open(pmc_files[-1]))["families"] if pmc_files and a.rays == 4096 and a.slices == 2048 else {}
+        pmc = json.load(open(pmc_files[-1]))["families"] if pmc_files and a.rays == 4096 and a.slices == 2048 and a.dataset == "raf" else {}
         for k in fams:
             t = pmc.get(k["kernel"])
             k["traffic"] = t["hbm_bytes_per_launch"] if t else None
@@ -285,14 +292,15 @@ def main():
             "dtype": "f16",
             "data": "synthetic",
             "config": {
-                "workload": ("RAF FurnishedRoom joint step (BASELINE configs[2] shape: %d rays + %d RIR slices x 513 bins per GPU): "
+                "workload": (("RAF FurnishedRoom joint step (BASELINE configs[2] shape: %d rays + %d RIR slices x 513 bins per GPU): " if a.dataset == "raf"
+                              else "SoundSpaces joint step (BASELINE configs[3] head shape: %d rays + %d RIR slices x 2 x 257 bins per GPU): ") +
                              "radiance forward (sampler, 2 proposal nets, 2 PDF resamplings, fused field query, composite) + rgb/"
                              "interlevel/distortion losses -> grid refresh (%d cells x 18 dirs) -> ResNet3D forward on the 7x128^3 "
                              "grid -> audio prologue + NAcF MLP -> STFT loss -> one backward (NAcF -> ResNet3D -> refreshed grid cells -> "
                              "field; radiance losses -> proposal nets + fused field backward + weight-grad GEMMs) -> %sGradScaler + "
                              "fused Adam: proposal_networks + fields (lr 1e-2), then audio_fields = NAcF + ResNet3D + fields again (lr 1e-4), as NeRAF_pipeline.py:487 groups them.  Not modelled: camera-pose optimizer "
-                             "(nerfstudio CameraOptimizer), data loading."
-                             % (a.rays, a.slices, a.rays, "RCCL all-reduce -> " if world > 1 else "")),
+                             "(nerfstudio CameraOptimizer), data loading.")
+                             % (a.rays, a.slices, a.rays, "RCCL all-reduce -> " if world > 1 else ""),
                 "rays_per_gpu": a.rays, "slices_per_gpu": a.slices, "parallelism": f"dp{world}",
             },
         }
