@@ -264,6 +264,16 @@ int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* t
                          float* table_grad, float* emb_grad, float* const* w_grads, void* dump, void* splitk_ws,
                          size_t splitk_bytes, neraf_stream_t stream);
 
+/* The same call for batches in which runs of `pos_run` consecutive rays share their single sample position (S must be 1, R a
+ * multiple of pos_run) -- the grid refresh queries every cell centre under 18 directions (NeRAF_model.py:327-339): the hash-grid
+ * gradient of a run is summed before it is scattered.  pos_run = 1 is neraf_field_backward. */
+int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                         const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
+                         const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
+                         float avg_density, int avg_row, const float* density, const float* d_rgb, const float* d_density,
+                         float* table_grad, float* emb_grad, float* const* w_grads, void* dump, void* splitk_ws,
+                         size_t splitk_bytes, int pos_run, neraf_stream_t stream);
+
 /* Grid refresh epilogue of query_grid_one_batch (NeRAF_model.py:352-357,386,395-400): mean over the ndirs
  * view directions of rgb [ndirs*n,3] / density [ndirs*n] (direction-major), alpha = clip(1-exp(-delta d)),
  * written to channels 0..3 of grid fp32 [7, nvox] at flat cells [start, start+n). */

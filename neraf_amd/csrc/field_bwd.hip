@@ -674,7 +674,24 @@ struct FieldScatterArgs {
   const float* lvl;                    // F_l [16], 1/F_l [16]
   unsigned long long* acc;             // [rows]: packed fixed-point sums (the table_grad buffer, zero on entry)
   int l_end;                           // levels [0, l_end) are scattered here (the rest by the owner kernels below)
+  const float2* d_red; int run;        // run > 1: rays [k*run, (k+1)*run) share their (single) sample position and d_red [16][npad_r]
+  long npad_r;                         // holds the gradients already summed over each run (the grid refresh: 18 directions per cell)
 };
+
+// sums the encoding gradient over runs of rays that share a position: d_red[l][k] = sum_j d_enc[l][k*run + j]
+__global__ __launch_bounds__(256) void field_runsum_kernel(const unsigned* __restrict__ d_enc, long npad, long nruns, int run,
+                                                          float2* __restrict__ d_red, long npad_r) {
+  const int l = blockIdx.y;
+  for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nruns; k += (long)gridDim.x * 256) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int j = 0; j < run; ++j) {
+      const unsigned raw = d_enc[(long)l * npad + k * run + j];
+      const half2v gh = *reinterpret_cast<const half2v*>(&raw);
+      s0 += (float)gh[0]; s1 += (float)gh[1];
+    }
+    d_red[(long)l * npad_r + k] = make_float2(s0, s1);
+  }
+}
 
 __device__ __forceinline__ long long shfl_up_i64(long long v, int o) {
   const int lo = __shfl_up((int)(v & 0xffffffffll), o), hi = __shfl_up((int)(v >> 32), o);
@@ -693,23 +710,32 @@ __global__ __launch_bounds__(256) void field_scatter_kernel(FieldScatterArgs a) 
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const long N = (long)a.R * a.S;
+  const long N = a.run > 1 ? (long)a.R / a.run : (long)a.R * a.S;      // runs of rays (S == 1) or samples
   const long nwave = (N + 63) / 64;
   for (long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < nwave; wv += (long)gridDim.x * 4) {
     long n = wv * 64 + lane;
     const bool valid = n < N;
     if (!valid) n = N - 1;
-    const int ray = (int)(n / a.S), sidx = (int)(n % a.S);
+    const int ray = a.run > 1 ? (int)(n * a.run) : (int)(n / a.S), sidx = a.run > 1 ? 0 : (int)(n % a.S);
     const float t = 0.5f * (a.e_bins[(size_t)ray * (a.S + 1) + sidx] + a.e_bins[(size_t)ray * (a.S + 1) + sidx + 1]);
     float x = fmaf(a.dirs[ray * 3 + 0], t, a.origins[ray * 3 + 0]);
     float y = fmaf(a.dirs[ray * 3 + 1], t, a.origins[ray * 3 + 1]);
     float z = fmaf(a.dirs[ray * 3 + 2], t, a.origins[ray * 3 + 2]);
     map_position(x, y, z, a.mode, a.aabb);
-    for (int l = 0; l < a.l_end; ++l) {
-      const unsigned raw = valid ? a.d_enc[(long)l * a.npad + n] : 0u;
-      const half2v gh = *reinterpret_cast<const half2v*>(&raw);
+    // grid.y > 1: one level per workgroup row (few runs, many levels: the refresh has 4096 positions -- 64 waves -- and a wave's
+    // 16 x 8 corner updates are a latency chain)
+    const int l_first = gridDim.y > 1 ? (int)blockIdx.y : 0, l_last = gridDim.y > 1 ? l_first + 1 : a.l_end;
+    for (int l = l_first; l < l_last; ++l) {
       const float F = l_fix[l];
-      const float g0 = (float)gh[0] * F, g1 = (float)gh[1] * F;
+      float g0, g1;
+      if (a.run > 1) {
+        const float2 gr = valid ? a.d_red[(long)l * a.npad_r + n] : make_float2(0.f, 0.f);
+        g0 = gr.x * F; g1 = gr.y * F;
+      } else {
+        const unsigned raw = valid ? a.d_enc[(long)l * a.npad + n] : 0u;
+        const half2v gh = *reinterpret_cast<const half2v*>(&raw);
+        g0 = (float)gh[0] * F; g1 = (float)gh[1] * F;
+      }
       const float scale = l_scale[l];
       const int res = l_res[l]; const unsigned size = l_size[l], offset = l_off[l]; const int hashed = l_hash[l];
       const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
@@ -1014,12 +1040,32 @@ extern "C" size_t neraf_field_backward_dump_bytes(int R, int S) {
   return (size_t)10 * 128 * npad * 2 + 256;
 }
 
+extern "C" int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                                         const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
+                                         const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
+                                         float avg_density, int avg_row, const float* density, const float* d_rgb,
+                                         const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
+                                         void* splitk_ws, size_t splitk_bytes, int pos_run, neraf_stream_t stream);
+
 extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
                                     const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
                                     const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
                                     float avg_density, int avg_row, const float* density, const float* d_rgb, const float* d_density,
                                     float* table_grad, float* emb_grad, float* const* w_grads, void* dump, void* splitk_ws,
                                     size_t splitk_bytes, neraf_stream_t stream) {
+  return neraf_field_backward_runs(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
+                                   aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
+                                   splitk_ws, splitk_bytes, 1, stream);
+}
+
+extern "C" int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                                         const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
+                                         const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
+                                         float avg_density, int avg_row, const float* density, const float* d_rgb,
+                                         const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
+                                         void* splitk_ws, size_t splitk_bytes, int pos_run, neraf_stream_t stream) {
+  if (pos_run < 1 || (pos_run > 1 && (S != 1 || R % pos_run != 0)))
+    return neraf_fail(ctx, NERAF_EINVAL, "field_backward_runs: pos_run > 1 needs S == 1 and R a multiple of pos_run");
   FieldBwdArgs a{};
   if (make_grid_layout(g, &a.g) || a.g.n_levels != 16) return neraf_fail(ctx, NERAF_EINVAL, "field_backward: grid must have 16 levels");
   if (R <= 0 || S <= 0 || !table_f16 || !wfrag_f16 || !wfrag_bwd_f16 || !emb_f16 || !origins || !dirs || !e_bins || !density ||
@@ -1046,7 +1092,7 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
   constexpr int kOwnLds = (1 << OWN_SLICE_LOG2) * 8 + (OWN_THREADS / 64) * OWN_QUEUE * 4;
   const char* own_e = getenv("NERAF_FIELD_OWNER_SCATTER");      // read per call: the parity test flips it between two runs
   const int own_env = own_e ? atoi(own_e) : 1;
-  bool use_owner = own_env && (N >= 131072 || own_env == 2) && N < (1l << 30);   // 2 = also for small batches (tests)
+  bool use_owner = own_env && pos_run == 1 && (N >= 131072 || own_env == 2) && N < (1l << 30);   // 2 = also for small batches (tests)
   int own_blk[MAX_LEVELS + 1] = {0};
   unsigned char own_rep[MAX_LEVELS] = {0};
   for (int l = 0; l < 16 && use_owner; ++l) {
@@ -1096,11 +1142,23 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
     for (int i = 0; i < 6; ++i) sa.aabb[i] = a.aabb[i];
     sa.d_enc = a.d_enc; sa.npad = npad; sa.lvl = lvl; sa.acc = reinterpret_cast<unsigned long long*>(table_grad);
     sa.l_end = 16;
+    sa.run = pos_run;
     long sblocks = ((N + 63) / 64 + 3) / 4;
+    if (pos_run > 1) {
+      // runs of rays sharing one position (the grid refresh: 18 directions per cell): sum their encoding gradients first, then
+      // scatter one update set per run -- 18x less index arithmetic and merging (scratch: slot 5, rows 64.. of the dump)
+      const long nruns = N / pos_run;
+      sa.npad_r = (nruns + 63) / 64 * 64;
+      float2* d_red = reinterpret_cast<float2*>((half_t*)dump + (size_t)5 * 128 * npad + (size_t)64 * npad);
+      sa.d_red = d_red;
+      long rb = (nruns + 255) / 256; if (rb > 256) rb = 256;
+      hipLaunchKernelGGL(field_runsum_kernel, dim3((unsigned)rb, 16), dim3(256), 0, st, a.d_enc, npad, nruns, pos_run, d_red, sa.npad_r);
+      sblocks = ((nruns + 63) / 64 + 3) / 4;
+    }
     if (sblocks > cap) sblocks = cap;
     {
       ProfScope prof(ctx, st, PROF_FIELD_SCATTER, (double)N * 16 * 8 * 8);   // one 8-byte update per (sample, level, corner) before merging
-      if (!use_owner) hipLaunchKernelGGL(field_scatter_kernel, dim3((unsigned)sblocks), dim3(256), 0, st, sa);
+      if (!use_owner) hipLaunchKernelGGL(field_scatter_kernel, dim3((unsigned)sblocks, pos_run > 1 ? 16 : 1), dim3(256), 0, st, sa);
       else {
         FieldOwnerArgs oa{};
         oa.g = a.g; oa.pos = a.pos; oa.npad = npad; oa.N = N; oa.d_enc = a.d_enc; oa.lvl = lvl; oa.acc = sa.acc;

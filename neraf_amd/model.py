@@ -94,7 +94,7 @@ class _RefreshFn(torch.autograd.Function):
         d_den = torch.empty((nd * n, 1), dtype=torch.float32, device=oris.device)
         _lib.check(lib.neraf_grid_refresh_vals_bwd(_lib.ctx(ctx.dev), dvals.data_ptr(), den.data_ptr(), n, nd, 1, delta,
                                                    d_rgb.data_ptr(), d_den.data_ptr(), _stream_ptr()), ctx.dev)
-        grads = ctx.field.backward_query(ctx.packed, oris, dd, z, cam, den, d_rgb, d_den)
+        grads = ctx.field.backward_query(ctx.packed, oris, dd, z, cam, den, d_rgb, d_den, pos_run=nd)   # cell-major: nd rays per position
         return (None, None, None, None, None, None, None, *grads)
 
 

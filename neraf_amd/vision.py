@@ -282,9 +282,10 @@ class NerfactoField(nn.Module):
             self._splitk = torch.empty(4 << 20, dtype=torch.float32, device=device)
         return self._splitk
 
-    def backward_query(self, packed, origins, directions, e_bins, camera_indices, density, d_rgb, d_density):
+    def backward_query(self, packed, origins, directions, e_bins, camera_indices, density, d_rgb, d_density, pos_run: int = 1):
         """Gradients of the field parameters for upstream d_rgb [R,S,3] / d_density [R,S] of a structured query.
-        Returns [d table, d base_w0, d base_w1, d head_w0, d head_w1, d head_w2, d embedding]."""
+        Returns [d table, d base_w0, d base_w1, d head_w0, d head_w1, d head_w2, d embedding].  ``pos_run`` > 1: runs of that many
+        consecutive rays share their single sample position (the grid refresh), see neraf_field_backward_runs."""
         lib = _lib.load()
         dev = _dev_index(origins)
         device = origins.device
@@ -299,13 +300,13 @@ class NerfactoField(nn.Module):
         cam = camera_indices.reshape(-1).to(torch.int32).contiguous() if camera_indices is not None else None
         mode = 0 if self.spatial_distortion is not None else 1
         ab = _lib.host_f32(self.aabb)
-        _lib.check(lib.neraf_field_backward(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), wfrag.data_ptr(), wfrag_b.data_ptr(),
+        _lib.check(lib.neraf_field_backward_runs(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), wfrag.data_ptr(), wfrag_b.data_ptr(),
                                             emb.data_ptr(), origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(),
                                             cam.data_ptr() if cam is not None else None, R, S, mode, ab, self.average_init_density,
                                             -1 if cam is not None else self.embedding.shape[0], density.data_ptr(),
                                             d_rgb.data_ptr(), d_density.data_ptr(), g_table.data_ptr(),
                                             g_emb.data_ptr() if cam is not None else None, _lib.ptr_array(g_w), dump.data_ptr(),
-                                            splitk.data_ptr(), splitk.numel() * 4, _stream_ptr()), dev)
+                                            splitk.data_ptr(), splitk.numel() * 4, int(pos_run), _stream_ptr()), dev)
         return [g_table] + g_w + [g_emb]
 
     def grad_params(self):
