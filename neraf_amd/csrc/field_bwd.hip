@@ -327,20 +327,26 @@ __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
   }
 }
 
-__global__ __launch_bounds__(64) void prop_wgrad_fold_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ w_grad) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= 272) return;
-  float t = 0.f;
-  int b = 0;
-  for (; b + 8 <= nblocks; b += 8) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u) * 272 + i];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) t += v[u];
+// w_grad[i] += sum over workgroups of part[b][i], i < 272: 34 workgroups of 8 outputs x 32 row slices (five 64-thread workgroups
+// walking 2048 rows each were a 60-80 us latency chain)
+__global__ __launch_bounds__(256) void prop_wgrad_fold_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ w_grad) {
+  __shared__ float red[32][9];
+  const int o = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + o;
+  float t = 0.f, t1 = 0.f;
+  if (i < 272) {
+    int b = sl;
+    for (; b + 32 < nblocks; b += 64) { t += part[(size_t)b * 272 + i]; t1 += part[(size_t)(b + 32) * 272 + i]; }
+    for (; b < nblocks; b += 32) t += part[(size_t)b * 272 + i];
   }
-  for (; b < nblocks; ++b) t += part[(size_t)b * 272 + i];
-  w_grad[i] += t;
+  red[sl][o] = t + t1;
+  __syncthreads();
+  if (threadIdx.x < 8 && i < 272) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
+    w_grad[blockIdx.x * 8 + threadIdx.x] += s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1030,7 +1036,7 @@ extern "C" int neraf_proposal_backward(neraf_ctx* ctx, const neraf_grid_desc* g,
     ProfScope prof(ctx, (hipStream_t)stream, PROF_PROP_BWD, (double)n * a.g.n_levels * 8 * 8);   // fp32x2 atomically added bytes
     hipLaunchKernelGGL(proposal_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   }
-  if (a.w_part) hipLaunchKernelGGL(prop_wgrad_fold_kernel, dim3(5), dim3(64), 0, (hipStream_t)stream, a.w_part, (int)blocks, w_grad);
+  if (a.w_part) hipLaunchKernelGGL(prop_wgrad_fold_kernel, dim3(34), dim3(256), 0, (hipStream_t)stream, a.w_part, (int)blocks, w_grad);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
