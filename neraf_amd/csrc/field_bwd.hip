@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256) void field_scatter_kernel(FieldScatterArgs a) 
   }
 }
 
-// ---- owner scatter for the hashed levels ----------------------------------------------------------------------------------
+// ---- owner scatter (all 16 levels of a large batch) ---------------------------------------------------------------------------
 // Scattered 8-byte atomics retire at ~21-24 G/s on this chip whatever their scope or footprint (tools/microbench/atomic_*), and a
 // hashed level gives consecutive samples nothing to merge: 10 hashed levels x 8 corners x 196,608 samples cost ~0.5 ms.  Here a
 // workgroup OWNS a 2^14-entry slice of one level's table in LDS (128 KiB of packed sums), finds the corner updates that fall
@@ -792,6 +792,8 @@ __global__ __launch_bounds__(256) void field_scatter_kernel(FieldScatterArgs a) 
 //   * a dense pre-pass ORs those 4 ids into a 32-bit slice mask per (level, sample); the owner's scan reads one dword per sample,
 //     tests one bit, and pushes hits into a per-wave LDS queue; every 64 queued samples are expanded with all lanes busy (the
 //     hit rate per lane is 1/8, expanding in place would run the expensive part at 8 of 64 lanes).
+//   * dense levels take the same path with the slice of the linear index (8 corners tested one by one); the coarsest ones, whose
+//     one or two slices every sample touches, are shared by rep[l] workgroups over sample ranges and flushed with global atomics.
 constexpr int OWN_SLICE_LOG2 = 14;
 constexpr int OWN_THREADS = 1024;
 constexpr int OWN_QUEUE = 128;

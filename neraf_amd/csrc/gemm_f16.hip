@@ -17,6 +17,9 @@
 // Implicit-GEMM convolution only changes where an A chunk comes from (a filter tap of an input voxel, or a
 // zero page for padding).  Under-filled grids (few tiles, long K) are split along K into fp32 partial slabs that
 // a second kernel reduces and finishes.
+// Bodies in this file: gemm_f16_nt_pipe_kernel (4 waves; 128x128 / 128x64 / 64x64 tiles, plain or implicit-conv loader),
+// gemm_f16_nt_wide_kernel (8 waves, ping-pong K loop; 256x160, 256x128, 128x128 tiles of plain GEMMs), the bf16 "TN" weight-gradient
+// kernels wgrad_grouped_tn_kernel / wgrad_wide_tn_kernel over all convolutions of a backward pass, and their reducers.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
