@@ -317,7 +317,7 @@ def main():
         g_cap, g_launch = C.c_int(), C.c_int()
         out["hip_graphs"] = {"enabled": bool(lib.neraf_graph_stats(h, C.byref(g_cap), C.byref(g_launch))), "captures": g_cap.value,
                              "launches": g_launch.value}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # the host baseline is reported by the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(a.rays, a.slices)
         print(json.dumps(out))
     if world > 1:
