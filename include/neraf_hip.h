@@ -341,6 +341,13 @@ int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_real, int co
                                    const void* x_f16, const float* w, const float* gamma, const float* beta, const float* g,
                                    void* y_f16, float* dx, float* dw, float* dgamma, float* dbeta, neraf_stream_t stream);
 
+/* Test aid: where a forward tensor lives inside the forward `workspace` (byte offset, logical rows x cols; rows are voxels in
+ * x-major / z-fastest order, i.e. torch's flattened [D,H,W]).  kind 0 / 1 / 2: fp16 post-activation a1 / a2 / block output of
+ * Bottleneck `index` (NeRAF_resnet3d.py:97, :101, :111); 3: fp16 pooled stem activation (:188); 4: uint8 arg-max tap table of
+ * the stem max-pool (tap = (dz+1)*9 + (dy+1)*3 + (dx+1), 255 = window maximum not > 0; training forward only); 5: fp16 pre-BN
+ * output of convolution `index`; 6: fp32 [2][cols] batch mean / biased variance of BatchNorm `index`. */
+int neraf_resnet3d_debug_locate(const neraf_resnet3d_desc* d, int kind, int index, size_t* offset, int* rows, int* cols);
+
 /* ------------------------------------------------------------------------------------
  * Optimizer step (SURVEY 8f "optimizer fusion"): torch.optim.Adam as nerfstudio's Optimizers apply it to the
  * `fields` and `audio_fields` groups (NeRAF_config.py:116-127), one launch per optimizer.  `table` is a device
@@ -349,8 +356,10 @@ int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_real, int co
  * g_ptrs (device uint64[n], may be NULL) overrides the records' gradient pointers -- autograd hands out new gradient
  * tensors every step, and this column can be refreshed with an asynchronous copy while the rest of the table stays;
  * workgroup b updates elements [blk_chunk[b]*chunk, +chunk) of tensor blk_tensor[b] (chunk =
- * neraf_fused_adam_chunk()).  step: device float[4] {t, 1/(1-b1^t), 1/sqrt(1-b2^t), -}, t incremented by the call; grad_scale / found_inf: the
- * GradScaler's device scalars (NULL = no scaling); when *found_inf != 0 nothing is modified.
+ * neraf_fused_adam_chunk()).  step: device float[8][4], one record {t, 1/(1-b1^t), 1/sqrt(1-b2^t), -} per parameter group; the call
+ * increments t of the groups whose bit is set in group_mask (the groups that hold gradients this step: torch.optim.Adam skips
+ * parameters without a gradient, so e.g. the proposal networks' bias correction only advances on their update steps);
+ * grad_scale / found_inf: the GradScaler's device scalars (NULL = no scaling); when *found_inf != 0 nothing is modified.
  * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), exactly torch's formula (no weight decay, no amsgrad).
  * ---------------------------------------------------------------------------------- */
 int neraf_fused_adam_chunk(void);
@@ -358,8 +367,8 @@ int neraf_fused_adam_chunk(void);
 int neraf_grads_nonfinite(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
                           int n_blocks, float* found_inf, neraf_stream_t stream);
 int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
-                     int n_blocks, const float* group_lr, int n_groups, double beta1, double beta2, double eps, float* step,
-                     const float* grad_scale, const float* found_inf, neraf_stream_t stream);
+                     int n_blocks, const float* group_lr, int n_groups, unsigned group_mask, double beta1, double beta2, double eps,
+                     float* step, const float* grad_scale, const float* found_inf, neraf_stream_t stream);
 
 #ifdef __cplusplus
 }

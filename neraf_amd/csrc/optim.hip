@@ -13,15 +13,19 @@ static_assert(sizeof(AdamTensor) == 48, "table layout is shared with neraf_amd/o
 
 constexpr int kAdamChunk = 4096;       // elements per workgroup
 
-// step[0] += 1 (unless a gradient was non-finite); step[1] = 1 / (1 - b1^t), step[2] = 1 / sqrt(1 - b2^t), in double as torch does
-// on the host (1 - 0.999^t cancels catastrophically in fp32 for small t)
-__global__ void adam_advance_step_kernel(float* __restrict__ step, const float* __restrict__ found_inf, double beta1, double beta2) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    if (!(found_inf && found_inf[0] != 0.f)) step[0] += 1.f;
-    const double t = (double)step[0];
-    step[1] = (float)(1.0 / (1.0 - pow(beta1, t)));
-    step[2] = (float)(1.0 / sqrt(1.0 - pow(beta2, t)));
-  }
+// One counter record {t, 1 / (1 - b1^t), 1 / sqrt(1 - b2^t), -} per parameter group (torch keeps a step per parameter and skips
+// parameters without a gradient; the groups here receive their gradients together -- the proposal networks only every few steps --
+// so a counter per group reproduces torch's bias correction).  Lane g advances group g if bit g of `mask` is set (unless a gradient
+// was non-finite); the corrections in double as torch computes them on the host (1 - 0.999^t cancels catastrophically in fp32).
+__global__ void adam_advance_step_kernel(float* __restrict__ step, const float* __restrict__ found_inf, double beta1, double beta2,
+                                         unsigned mask) {
+  const int g = threadIdx.x;
+  if (blockIdx.x != 0 || g >= 8 || !((mask >> g) & 1u)) return;
+  float* s = step + 4 * g;
+  if (!(found_inf && found_inf[0] != 0.f)) s[0] += 1.f;
+  const double t = (double)s[0];
+  s[1] = (float)(1.0 / (1.0 - pow(beta1, t)));
+  s[2] = (float)(1.0 / sqrt(1.0 - pow(beta2, t)));
 }
 
 __global__ __launch_bounds__(256) void fused_adam_kernel(const AdamTensor* __restrict__ table, const unsigned long long* __restrict__ g_ptrs,
@@ -35,7 +39,7 @@ __global__ __launch_bounds__(256) void fused_adam_kernel(const AdamTensor* __res
   if (g_ptrs) t.g = reinterpret_cast<const float*>(g_ptrs[blk_tensor[blockIdx.x]]);
   const long long base = (long long)blk_chunk[blockIdx.x] * kAdamChunk;
   const float inv_scale = grad_scale ? 1.f / grad_scale[0] : 1.f;
-  const float step_size = lrs.lr[t.group & 7] * step[1], inv_sqrt_bc2 = step[2];
+  const float step_size = lrs.lr[t.group & 7] * step[4 * (t.group & 7) + 1], inv_sqrt_bc2 = step[4 * (t.group & 7) + 2];
   const bool vec = ((reinterpret_cast<size_t>(t.p) | reinterpret_cast<size_t>(t.g) | reinterpret_cast<size_t>(t.m) |
                      reinterpret_cast<size_t>(t.v)) & 15) == 0;
 #pragma unroll
@@ -108,14 +112,14 @@ extern "C" int neraf_grads_nonfinite(neraf_ctx* ctx, const void* table, const vo
 extern "C" int neraf_fused_adam_chunk(void) { return kAdamChunk; }
 
 extern "C" int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
-                                int n_blocks, const float* group_lr, int n_groups, double beta1, double beta2, double eps, float* step,
-                                const float* grad_scale, const float* found_inf, neraf_stream_t stream) {
+                                int n_blocks, const float* group_lr, int n_groups, unsigned group_mask, double beta1, double beta2, double eps,
+                                float* step, const float* grad_scale, const float* found_inf, neraf_stream_t stream) {
   if (!table || !blk_tensor || !blk_chunk || n_blocks <= 0 || !step || !group_lr || n_groups < 1 || n_groups > 8)
     return neraf_fail(ctx, NERAF_EINVAL, "fused_adam: bad arguments (1..8 parameter groups)");
   AdamLrs lrs{};
   for (int i = 0; i < n_groups; ++i) lrs.lr[i] = group_lr[i];
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_advance_step_kernel, dim3(1), dim3(64), 0, st, step, found_inf, beta1, beta2);
+  hipLaunchKernelGGL(adam_advance_step_kernel, dim3(1), dim3(64), 0, st, step, found_inf, beta1, beta2, group_mask);
   hipLaunchKernelGGL(fused_adam_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, (const AdamTensor*)table, (const unsigned long long*)g_ptrs,
                      blk_tensor, blk_chunk, lrs, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, step,
                      grad_scale, found_inf);

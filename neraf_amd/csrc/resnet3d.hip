@@ -135,6 +135,31 @@ extern "C" size_t neraf_resnet3d_workspace_bytes(const neraf_resnet3d_desc* d) {
   return L.total;
 }
 
+// Test aid: byte offset / extent of a forward tensor inside the workspace (the gate-matched backward parity test reads the ReLU
+// gates and the max-pool routing the forward actually used).
+extern "C" int neraf_resnet3d_debug_locate(const neraf_resnet3d_desc* d, int kind, int index, size_t* offset, int* rows, int* cols) {
+  Arch A; Layout L;
+  if (make_arch(d, &A) || !offset || !rows || !cols) return NERAF_EINVAL;
+  make_layout(A, &L);
+  if (kind >= 0 && kind <= 2) {
+    if (index < 0 || index >= A.nblock) return NERAF_EINVAL;
+    const ConvSpec& c = A.conv[A.block[index].conv[kind]];
+    *offset = kind == 0 ? L.a1[index] : kind == 1 ? L.a2[index] : L.out[index];
+    *rows = (int)cube(c.dout); *cols = c.cout;
+    return NERAF_OK;
+  }
+  if (kind == 3) { *offset = L.act_pool; *rows = (int)cube(A.pooled); *cols = 64; return NERAF_OK; }
+  if (kind == 4) { *offset = L.pool_arg; *rows = (int)cube(A.pooled); *cols = 64; return NERAF_OK; }
+  if (kind == 5 || kind == 6) {
+    if (index < 0 || index >= A.nconv) return NERAF_EINVAL;
+    const ConvSpec& c = A.conv[index];
+    if (kind == 5) { *offset = L.pre[index]; *rows = (int)cube(c.dout); *cols = c.cout; }
+    else { *offset = L.fin[index]; *rows = 2; *cols = round_up(c.cout, 128); }
+    return NERAF_OK;
+  }
+  return NERAF_EINVAL;
+}
+
 extern "C" int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const float* const* conv_w, void* packed,
                                            neraf_stream_t stream) {
   Arch A; Layout L;

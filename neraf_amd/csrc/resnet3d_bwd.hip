@@ -614,8 +614,9 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
 
 // ------------------------------------------------------------------------------------------------------------------
 // Test entry: ONE conv + BatchNorm(train) + ReLU stage, forward statistics and backward, on caller data.  The full
-// encoder is chaotic under fp16 rounding (see oracle.audio.resnet3d_forward_fp16_storage), so the backward kernels are
-// verified stage by stage against autograd here (tests/test_gpu_resnet3d.py::test_conv_bn_relu_stage_backward).
+// encoder is chaotic under fp16 rounding through its ReLU gates, so besides the gate-matched full-chain test
+// (tests/test_gpu_resnet3d.py::test_resnet3d_backward_gate_matched) the backward kernels are verified stage by stage against
+// autograd here (::test_conv_bn_relu_stage_backward).
 //   x    fp16 [din^3][cin]          w fp32 [cout][cin_real][k^3]        gamma, beta fp32 [cout]
 //   g    fp32 [dout^3][cout]  upstream gradient w.r.t. relu(bn(conv(x)))
 //   out: y fp16 [dout^3][cout] (post ReLU), dx fp32 [din^3][cin] (skipped for the stem), dw fp32 like w, dgamma, dbeta

@@ -36,21 +36,70 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("FusedAdam: betas and eps must be the same in every group (the learning rate may differ)")
         self._plans = {}                       # ids of the parameters holding a gradient -> device tables (the proposal networks
                                                # only receive gradients every few steps: two plans alternate)
-        self._step_t = None
+        self._step_t = None                    # device float [8][4]: per-group step counter + bias corrections
         self._found = None
         self._fresh_plan = None
         self._flat = [(p, gi) for gi, group in enumerate(self.param_groups) for p in group["params"]]
         self._all_sig = tuple(id(e[0]) for e in self._flat)
 
-    def _state_for(self, p: torch.Tensor):
+    def _steps(self, device) -> torch.Tensor:
+        if self._step_t is None or self._step_t.device != device:
+            old = self._step_t
+            self._step_t = torch.zeros((8, 4), dtype=torch.float32, device=device)    # per group {t, 1/(1-b1^t), 1/sqrt(1-b2^t), -}
+            if old is not None:
+                self._step_t.copy_(old)
+        return self._step_t
+
+    def _state_for(self, p: torch.Tensor, gi: int):
         st = self.state[p]
         if not st:
-            if self._step_t is None:
-                self._step_t = torch.zeros(4, dtype=torch.float32, device=p.device)   # {t, 1/(1-b1^t), 1/sqrt(1-b2^t), -}
-            st["step"] = self._step_t[0]       # one device counter for the whole optimizer
+            st["step"] = self._steps(p.device)[gi, 0]     # one device counter per parameter group (see csrc/optim.hip)
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
+
+    def _adopt_loaded_state(self):
+        """After ``load_state_dict`` / unpickling: the loaded ``step`` values become the per-group device counters again (the
+        kernel advances those, and every parameter's ``state['step']`` is a view of its group's), moments move to the
+        parameter's device, and every cached launch plan -- which holds raw moment pointers -- is dropped."""
+        self._plans, self._fresh_plan = {}, None
+        self._step_t = None
+        self._flat = [(p, gi) for gi, group in enumerate(self.param_groups) for p in group["params"]]
+        self._all_sig = tuple(id(e[0]) for e in self._flat)
+        loaded = {}
+        for p, gi in self._flat:
+            st = self.state.get(p)
+            if not st:
+                continue
+            t = float(st["step"]) if "step" in st else 0.0
+            loaded[gi] = max(loaded.get(gi, 0.0), t)
+        if not loaded:
+            return
+        dev = next(p for p, _ in self._flat).device
+        steps = self._steps(dev)
+        b1, b2 = self.param_groups[0]["betas"]
+        for gi, t in loaded.items():
+            steps[gi, 0] = t
+            if t > 0:
+                steps[gi, 1] = 1.0 / (1.0 - b1 ** t)
+                steps[gi, 2] = 1.0 / (1.0 - b2 ** t) ** 0.5
+        for p, gi in self._flat:
+            st = self.state.get(p)
+            if not st:
+                continue
+            st["step"] = steps[gi, 0]
+            for k in ("exp_avg", "exp_avg_sq"):
+                st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._adopt_loaded_state()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        if not hasattr(self, "_plans"):
+            self._step_t = self._found = None
+        self._adopt_loaded_state()
 
     def _build(self, entries: List[tuple], device) -> dict:
         chunk = _lib.load().neraf_fused_adam_chunk()
@@ -61,12 +110,15 @@ class FusedAdam(torch.optim.Optimizer):
                 raise TypeError("FusedAdam: contiguous fp32 parameters and gradients only")
             if p.device != device:
                 raise ValueError("FusedAdam: all parameters on one device")
-            st = self._state_for(p)
+            st = self._state_for(p, gi)
             rec[i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi, 0)
             n = (p.numel() + chunk - 1) // chunk
             bt.append(np.full(n, i, np.int32)); bc.append(np.arange(n, dtype=np.int32))
         n = len(entries)
-        return dict(table=torch.from_numpy(rec.view(np.uint8).copy()).to(device),
+        mask = 0
+        for _, gi in entries:
+            mask |= 1 << gi
+        return dict(group_mask=mask, table=torch.from_numpy(rec.view(np.uint8).copy()).to(device),
                     blk_tensor=torch.from_numpy(np.concatenate(bt)).to(device),
                     blk_chunk=torch.from_numpy(np.concatenate(bc)).to(device),
                     # gradient-pointer column, refreshed asynchronously every step: (pinned, device, event, used) x 4
@@ -144,7 +196,7 @@ class FusedAdam(torch.optim.Optimizer):
         fi = getattr(self, "found_inf", None)
         _lib.check(lib.neraf_fused_adam(_lib.ctx(dev), plan["table"].data_ptr(), plan["gdev"].data_ptr(), plan["blk_tensor"].data_ptr(),
                                         plan["blk_chunk"].data_ptr(), int(plan["blk_tensor"].numel()), lrs, len(self.param_groups),
-                                        float(b1), float(b2), float(self.param_groups[0]["eps"]), self._step_t.data_ptr(),
+                                        plan["group_mask"], float(b1), float(b2), float(self.param_groups[0]["eps"]), self._step_t.data_ptr(),
                                         gs.data_ptr() if gs is not None else None, fi.data_ptr() if fi is not None else None,
                                         _stream_ptr()), dev)
         return loss

@@ -6,6 +6,8 @@ Tolerance: fp16 operands / fp16 stored activations with fp32 accumulation and fp
 conv+BN layers; against the reference's fp32 outputs we require the 1024-d feature within relative L2 1e-2 and
 every stage statistic (mean, abs-mean, rms) within 1e-2 relative.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -124,15 +126,109 @@ def test_conv_bn_relu_stage_backward(cin, cin_real, cout, k, stride, pad, din):
         assert rel_l2(dx, dxr) <= tol
 
 
-def test_resnet3d_backward_full_chain(golden):
-    """Whole encoder backward (G1, 64^3 grid).  The randomly initialised 43-layer BatchNorm network is chaotic under fp16
-    rounding: the REFERENCE module under its own fp16 autocast (NeRAF_config.py:79) deviates from its fp32 gradients by
-    0.41-0.71 relative L2 (tests/tools/amp_sensitivity_probe.py), because the pooled loss makes the last BatchNorm's input
-    gradient a pure function of the ReLU gates and ~5% of the gates flip.  So the full chain is held to
-      (a) the same gradient NORMS as the fp32 reference (within 10%), i.e. no lost / duplicated / mis-scaled branch,
-      (b) a deviation from the reference's fp32 gradients no larger than the reference's own fp16-autocast deviation (<= 0.75),
-      (c) exact structural facts (padding channel of the stem gets no gradient),
-    while the kernels themselves are verified tightly stage by stage (test above)."""
+def _ws_tensor(net_bb, kind, index, dtype):
+    """A forward tensor of the HIP encoder, read out of its workspace (neraf_resnet3d_debug_locate)."""
+    import ctypes as C
+    from neraf_amd import _lib
+    lib = _lib.load()
+    off, rows, cols = C.c_size_t(), C.c_int(), C.c_int()
+    assert lib.neraf_resnet3d_debug_locate(C.byref(net_bb._desc), kind, index, C.byref(off), C.byref(rows), C.byref(cols)) == 0
+    nbytes = rows.value * cols.value * torch.empty((), dtype=dtype).element_size()
+    return net_bb._ws[off.value:off.value + nbytes].view(dtype).reshape(rows.value, cols.value)
+
+
+def _hip_gates(bb):
+    """ReLU gates and max-pool routing the HIP forward used, in oracle.audio.resnet3d_forward_gated's format."""
+    gates = {"pool_arg": _ws_tensor(bb, 4, 0, torch.uint8).cpu()}
+    b = 0
+    for li, nblocks in zip((1, 2, 3), (3, 4, 6)):
+        for k in range(nblocks):
+            for kind, name in ((0, "a1"), (1, "a2"), (2, "out")):
+                t = _ws_tensor(bb, kind, b, torch.float16)
+                e = round(t.shape[0] ** (1 / 3))
+                gates[f"layer{li}.{k}.{name}"] = (t > 0).reshape(e, e, e, t.shape[1]).permute(3, 0, 1, 2).contiguous().cpu()
+            b += 1
+    return gates
+
+
+@pytest.mark.parametrize("S", [64, 128])
+def test_resnet3d_backward_gate_matched(S):
+    """A4 backward, tight: EVERY one of the 129 parameter gradients and the full grid gradient of the HIP encoder against autograd
+    through the pinned oracle with the network's discrete decisions (ReLU gates, max-pool routing) fixed to the ones the HIP
+    forward took -- oracle.audio.resnet3d_forward_gated, which with its own gates is bit-identical to the G1-pinned
+    resnet3d_forward (tests/test_oracle_golden.py) -- and the rounding points of the HIP forward emulated (fp16_storage=True:
+    with an exact backward on both sides the fp16 forward alone moves these gradients by 6e-2 ... 1.2e-1, a share the reference's
+    own fp16 autocast training has too).  What is left is the backward kernels and nothing else: residual joins, strided
+    downsample branches, max-pool gather, average-pool backward, stem grid gradient, BatchNorm backward through the batch
+    statistics, all 43 weight gradients.  Tolerance 5e-2 relative L2 per tensor (bf16 gradient chain through 43 layers)."""
+    from oracle import audio as O
+    dev = torch.device("cuda:0")
+    net = _model(dev, 1 / S)
+    net.train()
+    bb = net.backbone_net
+    x = T(synth.uniform(f"g1.grid{S}", (1, 7, S, S, S), 0.0, 1.0))
+    wsum = T(synth.uniform("g1.outw", (1024,), -1.0, 1.0))
+    got = {}
+    bb.grid_window = (0, S ** 3, 7)
+    bb.grid_grad_sink = lambda d: got.__setitem__("dx", d.clone())
+    y = net(x.to(dev))
+    (y.flatten() * wsum.to(dev)).sum().backward()
+    bb.grid_window, bb.grid_grad_sink = None, None
+    torch.cuda.synchronize()
+    gates = _hip_gates(bb)
+    sd = {k: T(v) for k, v in synth.resnet3d_state_dict(7).items()}
+    params = dict(bb.named_parameters())
+
+    def oracle_grads(fp16_storage):
+        sdg = {k: (v.clone().requires_grad_(True) if k.endswith("weight") or k.endswith("bias") else v) for k, v in sd.items()}
+        xg = x.clone().requires_grad_(True)
+        yo = O.resnet3d_forward_gated(xg, sdg, gates, fp16_storage=fp16_storage)
+        (yo.flatten() * wsum).sum().backward()
+        return yo.detach(), xg.grad[0], {k: v.grad for k, v in sdg.items() if v.requires_grad}
+
+    def compare(yo, dxo, go):
+        errs = {}
+        for k, gref in go.items():
+            if k == "bn1.bias":
+                # d beta of the stem BatchNorm is the residual of an (almost) exact cancellation: both consumers of the pooled
+                # activation are 1x1x1 convolutions followed by a train-mode BatchNorm, whose input gradient sums to zero over
+                # the voxels, so sum dL/d bn1-output = -(gradient of the few windows whose maximum is <= 0).  Its natural scale is
+                # the same BatchNorm's d gamma, not its own near-zero norm (observed |d beta| / |d gamma| = 0.02).
+                errs[k] = float((params[k].grad.double().cpu() - gref.double()).norm() / go["bn1.weight"].double().norm())
+            else:
+                errs[k] = rel_l2(params[k].grad, gref)
+        errs["d grid"] = rel_l2(got["dx"].reshape(7, S, S, S), dxo)
+        return errs
+
+    # (1) the parity target: the engine's rounding points emulated in the oracle's FORWARD, exact fp32 autograd backward
+    yo, dxo, go = oracle_grads(True)
+    assert len(go) == 129
+    assert rel_l2(y, yo) <= 2e-3
+    errs = compare(yo, dxo, go)
+    if os.environ.get("NERAF_TEST_VERBOSE"):
+        for k, v in errs.items():
+            print(f"  {k:40s} {v:.3e}")
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print(f"gate-matched backward S={S} vs fp16-storage oracle: worst {worst[0]} rel-L2 {worst[1]:.3e}; conv1.weight {errs['conv1.weight']:.3e}; "
+          f"d grid {errs['d grid']:.3e}; median {float(np.median(list(errs.values()))):.3e}")
+    assert worst[1] <= 5e-2, worst
+    # (2) against the all-fp32 forward with the same gates the distance is the fp16 FORWARD's share (measured on CPU with an
+    # exact backward on both sides: 6e-2 ... 1.2e-1, oracle/audio.py resnet3d_forward_gated): bounded, not the parity claim
+    yo32, dxo32, go32 = oracle_grads(False)
+    assert rel_l2(y, yo32) <= 1e-2
+    errs32 = compare(yo32, dxo32, go32)
+    worst32 = max(errs32.items(), key=lambda kv: kv[1])
+    print(f"  vs all-fp32 gated oracle: worst {worst32[0]} {worst32[1]:.3e}")
+    assert worst32[1] <= 0.2, worst32
+
+
+def test_resnet3d_backward_norms_vs_reference_fp32_golden(golden):
+    """Whole encoder backward against the REFERENCE's own fp32 gradients (G1, 64^3 grid), as far as those can be compared: the
+    randomly initialised 43-layer BatchNorm network is chaotic under fp16 rounding through its ReLU gates (the reference module
+    under its own fp16 autocast, NeRAF_config.py:79, deviates from its fp32 gradients by 0.41-0.71 relative L2,
+    tests/tools/amp_sensitivity_probe.py), so element-wise parity is established by test_resnet3d_backward_gate_matched above
+    (all 129 gradients + grid gradient <= 5e-2 with the gates fixed) and this test holds the ungated quantities that survive the
+    gate flips: gradient NORMS within 10 % of the reference's (no lost / duplicated / mis-scaled branch) and structural facts."""
     dev = torch.device("cuda:0")
     g = golden("g1_resnet3d_64")
     S = 64
@@ -159,12 +255,8 @@ def test_resnet3d_backward_full_chain(golden):
     assert 0.9 <= norm_ratio(bb.layer2[0].downsample[1].weight.grad, g["dgamma_l2_0_ds"]) <= 1.1
     np.testing.assert_allclose(bb.layer1[0].conv2.weight.grad.double().pow(2).mean().sqrt().item(), g["dw_l1_0_conv2_stats"][2], rtol=0.1)
     np.testing.assert_allclose(bb.layer3[5].conv3.weight.grad.double().pow(2).mean().sqrt().item(), g["dw_l3_5_conv3_stats"][2], rtol=0.1)
-    assert rel_l2(bb.conv1.weight.grad, T(g["dw_conv1"])) <= 0.75
-    assert rel_l2(bb.bn1.bias.grad, T(g["dbeta_bn1"])) <= 0.75
     dx = got["dx"].reshape(7, S, S, S).cpu()
     np.testing.assert_allclose(dx.double().pow(2).mean().sqrt().item(), g["dx_stats"][2], rtol=0.1)
-    pi = g["probe_idx"]
-    assert rel_l2(dx[pi[:, 0], pi[:, 1], pi[:, 2], pi[:, 3]], T(g["dx_probe"])) <= 0.75
 
 
 def test_graph_replay_after_interleaved_graph_matches_first_launch():

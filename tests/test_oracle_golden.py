@@ -181,3 +181,28 @@ def test_audio_prologue_layout_and_selector():
     assert torch.all(q[0, 21 + 60:21 + 63] == 0)
     assert torch.all(q[5, 21 + 60:21 + 63] != 0)
     np.testing.assert_allclose(q[:, 20].numpy(), b["time_query"] / 59.0, rtol=1e-6)
+
+
+def test_gated_resnet3d_with_own_gates_is_the_pinned_forward():
+    """oracle.audio.resnet3d_forward_gated (the parity target of the HIP backward) with the gates of its own forward reproduces the
+    G1-pinned resnet3d_forward: same feature, same gradient for every parameter and for the grid (32^3 grid, seconds on CPU)."""
+    from oracle import audio as O
+    sd = {k: torch.from_numpy(v) for k, v in synth.resnet3d_state_dict(7).items()}
+    S = 32
+    x = torch.from_numpy(synth.uniform("gated.grid", (1, 7, S, S, S), 0.0, 1.0))
+    w = torch.from_numpy(synth.uniform("g1.outw", (1024,), -1.0, 1.0))
+    gates = O.resnet3d_gates_from_forward(x, sd)
+    assert gates["pool_arg"].shape == (8 ** 3, 64) and gates["layer3.5.out"].shape == (1024, 2, 2, 2)
+    res = []
+    for gated in (True, False):
+        sdg = {k: (v.clone().requires_grad_(True) if k.endswith("weight") or k.endswith("bias") else v) for k, v in sd.items()}
+        xg = x.clone().requires_grad_(True)
+        y = O.resnet3d_forward_gated(xg, sdg, gates) if gated else O.resnet3d_forward(xg, sdg, train=True)
+        (y.flatten() * w).sum().backward()
+        res.append((y.detach(), xg.grad, {k: v.grad for k, v in sdg.items() if v.requires_grad}))
+    (ya, dxa, ga), (yb, dxb, gb) = res
+    assert len(ga) == 129
+    np.testing.assert_allclose(ya.numpy(), yb.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dxa.numpy(), dxb.numpy(), rtol=1e-5, atol=1e-9)
+    for k in ga:
+        np.testing.assert_allclose(ga[k].numpy(), gb[k].numpy(), rtol=1e-5, atol=1e-9, err_msg=k)

@@ -5,7 +5,7 @@ its own training precision (fp16 autocast, NeRAF_config.py:79) instead of fp32? 
 Measured here (64^3 grid, synthetic weights, CPU autocast): feature 4.7e-3; weight gradients 0.41 (layer3.5.conv3),
 0.55 (layer3.0.conv2), 0.60 (layer2.0.conv2), 0.61 (layer1.0.conv2), 0.61 (conv1), 0.71 (bn1.weight).  The HIP engine's
 deviations from the fp32 golden are the same figures, which is why tests/test_gpu_resnet3d.py checks gradients against the
-rounding-matched oracle (oracle.audio.resnet3d_forward_fp16_storage) instead."""
+rounding-matched oracle (oracle.audio.resnet3d_forward_gated(fp16_storage=True) with the engine's gates) instead."""
 import os
 import sys
 
