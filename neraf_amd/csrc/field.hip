@@ -283,6 +283,10 @@ struct CompArgs {
 };
 
 // global min / max of the sample mid-points (positive floats order like their bit patterns)
+// seeds the {min, max} pair of steps_minmax_kernel on the device (a host-side 8-byte copy would come from pageable memory:
+// host-synchronous, and not capturable into a graph)
+__global__ void minmax_seed_kernel(unsigned* __restrict__ mm) { if (threadIdx.x < 2 && blockIdx.x == 0) mm[threadIdx.x] = threadIdx.x ? 0u : 0x7f7fffffu; }
+
 __global__ __launch_bounds__(256) void steps_minmax_kernel(const float* __restrict__ e_bins, int R, int S, unsigned* __restrict__ mm) {
   const int ray = blockIdx.x * 256 + threadIdx.x;
   float lo = 3.0e38f, hi = 0.f;
@@ -536,8 +540,7 @@ extern "C" int neraf_composite(neraf_ctx* ctx, const float* density, const float
     return neraf_fail(ctx, NERAF_EINVAL, "composite: bad arguments (S <= 64; scratch8 needed for expected depth)");
   unsigned* mm = (unsigned*)scratch8;
   if (expected) {
-    const unsigned init[2] = {0x7f7fffffu, 0u};
-    NERAF_HIP_CHECK(ctx, hipMemcpyAsync(mm, init, 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+    hipLaunchKernelGGL(minmax_seed_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mm);
     hipLaunchKernelGGL(steps_minmax_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, e_bins, R, S, mm);
   }
   CompArgs a{density, rgb, e_bins, R, S, training, weights, rgb_out, depth, expected, acc, mm};

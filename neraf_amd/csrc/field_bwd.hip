@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
         out = fmaf(w1[j], fmaxf(h, 0.f), out);
       }
       // sigma = avg * trunc_exp(out) * sel  ->  d out = d sigma * avg * exp(min(out, 15)) * sel
-      gs = sel ? a.d_density[idx] * a.avg_density * __expf(fminf(out, 15.f)) : 0.f;
+      gs = sel ? a.d_density[idx] * a.avg_density * __expf(fminf(fmaxf(out, -15.f), 15.f)) : 0.f;
 #pragma unroll
       for (int j = 0; j < 16; ++j) dh[j] = hpre[j] > 0.f ? gs * w1[j] : 0.f;
     }
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
     }
     // base output gradient: geo part from the head, logit part from d sigma (sigma = avg * exp(logit) * sel)
     f32x4 dy2 = dbase;
-    if (q == 0) dy2[0] = (valid && sel) ? a.d_density[n] * a.avg_density * __expf(fminf(logit, 15.f)) * gscale : 0.f;
+    if (q == 0) dy2[0] = (valid && sel) ? a.d_density[n] * a.avg_density * __expf(fminf(fmaxf(logit, -15.f), 15.f)) * gscale : 0.f;
     // X_b1 = relu(d1), dY_b1 = dy2
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
@@ -965,11 +965,15 @@ __global__ __launch_bounds__(256) void field_unpack_grad_kernel(GridLayout g, co
 
 // amax of the upstream gradients entering the fp16 chain -> power-of-two scale {S, 1/S}
 __global__ __launch_bounds__(256) void field_amax_kernel(const float* __restrict__ d_rgb, const float* __restrict__ d_density,
-                                                        const float* __restrict__ density, long N, unsigned* __restrict__ amax_bits) {
+                                                        const float* __restrict__ density, long N, float avg_density,
+                                                        unsigned* __restrict__ amax_bits) {
+  // |d logit| = |d sigma| * avg * exp(clamp(logit, -15, 15)): the forward density with the trunc_exp clamp applied to it (an
+  // un-clamped density of 1e20 would push the scale so low that every clamped gradient underflows the fp16 chain)
+  const float dlo = avg_density * 3.0590232e-7f, dhi = avg_density * 3269017.4f;       // avg * e^-15, avg * e^15
   float m = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
     float v = fmaxf(fabsf(d_rgb[i * 3]), fmaxf(fabsf(d_rgb[i * 3 + 1]), fabsf(d_rgb[i * 3 + 2]))) * 0.25f;   // sigmoid' <= 1/4
-    v = fmaxf(v, fabsf(d_density[i] * density[i]));
+    v = fmaxf(v, fabsf(d_density[i]) * fminf(fmaxf(density[i], dlo), dhi));
     m = (v == v && v > m) ? v : m;
   }
 #pragma unroll
@@ -1126,7 +1130,7 @@ extern "C" int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* 
   NERAF_HIP_CHECK(ctx, hipMemsetAsync(scale, 0, 16, st));
   {
     long blocks = (N + 1023) / 1024; if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(field_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_rgb, d_density, density, N,
+    hipLaunchKernelGGL(field_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_rgb, d_density, density, N, avg_density,
                        reinterpret_cast<unsigned*>(scale) + 2);
     hipLaunchKernelGGL(field_make_scale_kernel, dim3(1), dim3(64), 0, st, scale);
   }

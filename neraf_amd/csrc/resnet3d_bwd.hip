@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_gather_kernel(const unsigned 
   *reinterpret_cast<bf16x8*>(dpost + vox * 64 + c0) = o;
 }
 
+__global__ void set_f32x2_kernel(float* p, float a, float b) { if (threadIdx.x == 0 && blockIdx.x == 0) { p[0] = a; p[1] = b; } }
 __global__ void set_u64_kernel(unsigned long long* p, unsigned long long v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
 
 // stem input gradient for a window of cells: dgrid[c][cell] = sum_taps sum_co dY[(z+2-dz)/2,...][co] W[co][c][tap] / S.
@@ -664,8 +665,7 @@ extern "C" int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_r
   NERAF_HIP_CHECK(ctx, hipMemcpyAsync(y_f16, yact, cube(dout) * cout * 2, hipMemcpyDeviceToDevice, st));
   // backward
   float* scale = (float*)(bws + B.scale);
-  const float one[2] = {1.f, 1.f};
-  NERAF_HIP_CHECK(ctx, hipMemcpyAsync(scale, one, 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(set_f32x2_kernel, dim3(1), dim3(64), 0, st, scale, 1.f, 1.f);
   if (dx && cin % 64 == 0) {
     PackTTable t{};
     const int nrows = cin == 64 || cin == 8 ? 64 : round_up(cin, 128);

@@ -1,0 +1,214 @@
+"""Data-manager objects with the surface ``NeRAFPipeline`` reads from nerfstudio's / the reference's managers
+(NeRAF_pipeline.py:104-149, :175, :187, :243, :276, :310-325, :360): ``train_dataset`` / ``eval_dataset`` (with ``scene_box``,
+``metadata``, ``__len__``), ``next_train`` / ``next_eval`` / ``next_eval_image``, ``fixed_indices_eval_dataloader``,
+``train_num_rays_per_batch``, ``get_param_groups``, ``to``.
+
+File decoding, COLMAP / transforms.json parsing and the 16-worker loaders of NeRAF_datamanager.py / NeRAF_dataset.py are out of
+scope: these managers serve DEVICE-RESIDENT data -- synthetic (tests, bench) or handed in by the caller
+-- and never touch the host inside a step."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import synth
+from .cameras import Cameras
+from .config import SceneBox
+from .vision import RayBundle
+
+
+class FixedBatchDataManager:
+    """``next_train`` returns the same resident (ray_bundle, batch) pair every step."""
+
+    def __init__(self, ray_bundle, batch: Dict[str, torch.Tensor], train_num_rays_per_batch: Optional[int] = None):
+        self.ray_bundle, self.batch = ray_bundle, batch
+        if train_num_rays_per_batch is None:
+            train_num_rays_per_batch = len(ray_bundle) if ray_bundle is not None else 4096
+        self.train_num_rays_per_batch = train_num_rays_per_batch
+
+    def next_train(self, step: int):
+        return self.ray_bundle, self.batch
+
+    next_eval = next_train
+
+    def get_param_groups(self):
+        return {}
+
+
+class RIRBankDataManager:
+    """Audio batches sampled on the device from a ``DeviceRIRBank`` (neraf_amd/data.py); the ray bundle slot is None as in
+    NeRAFDataManager.next_train (the audio model needs no rays, NeRAF_pipeline.py:187)."""
+
+    def __init__(self, bank, batch_size: int = 2048, generator: Optional[torch.Generator] = None):
+        self.bank, self.batch_size, self.generator = bank, batch_size, generator
+
+    def next_train(self, step: int):
+        return None, self.bank.next_train(self.batch_size, generator=self.generator)
+
+    next_eval = next_train
+
+    def get_param_groups(self):
+        return {}
+
+
+# ---- synthetic scene: cameras + images ------------------------------------------------------------------------------------------
+def _look_at(eye: np.ndarray, target: np.ndarray) -> np.ndarray:
+    """camera_to_world [3,4], OpenGL convention (camera looks along -z, +y up)."""
+    fwd = target - eye
+    fwd = fwd / np.linalg.norm(fwd)
+    up = np.array([0.0, 0.0, 1.0])
+    right = np.cross(fwd, up)
+    right = right / max(np.linalg.norm(right), 1e-9)
+    up2 = np.cross(right, fwd)
+    return np.concatenate([np.stack([right, up2, -fwd], axis=1), eye[:, None]], axis=1).astype(np.float32)
+
+
+def synthetic_cameras(n: int, width: int = 684, height: int = 1024, tag: str = "cams", distortion: bool = True) -> Cameras:
+    """n cameras with the RAF intrinsics (data/RAF/FurnishedRoom/transforms.json: 684 x 1024, fl 350.41, OPENCV distortion) on a
+    ring inside the unit scene, looking at jittered targets near the centre."""
+    ang = synth.uniform(tag + ".ang", (n,), 0.0, 2 * math.pi).astype(np.float64)
+    rad = synth.uniform(tag + ".rad", (n,), 0.25, 0.6).astype(np.float64)
+    hz = synth.uniform(tag + ".h", (n,), -0.2, 0.2).astype(np.float64)
+    tgt = synth.uniform(tag + ".tgt", (n, 3), -0.15, 0.15).astype(np.float64)
+    c2w = np.stack([_look_at(np.array([rad[i] * math.cos(ang[i]), rad[i] * math.sin(ang[i]), hz[i]]), tgt[i]) for i in range(n)])
+    sx, sy = width / 684.0, height / 1024.0
+    dist = torch.tensor([-0.03364928460212668, 0.008088314216939308, -0.00032575844569464275, 0.0,
+                         0.00013248765042335402, -0.00043094049868545956]) if distortion else None
+    return Cameras(torch.from_numpy(c2w), 350.41100113602533 * sx, 350.41100113602533 * sy, 342.5683121123288 * sx,
+                   511.3341668407641 * sy, width, height, dist)
+
+
+class _VisionDataset:
+    def __init__(self, cameras: Cameras, images: torch.Tensor, scene_box: SceneBox):
+        self.cameras, self.images, self.scene_box, self.metadata = cameras, images, scene_box, {}
+
+    def __len__(self):
+        return self.cameras.size
+
+
+class SyntheticVisionDataManager:
+    """Pixel-sampling vision manager over device-resident images [N,H,W,3]: ``next_train`` draws ``train_num_rays_per_batch``
+    random (camera, row, col) triples and returns (RayBundle, {"image": rgb [R,3], "indices": [R,3]}) like nerfstudio's
+    ParallelDataManager (NeRAF_config.py:83-91); ``fixed_indices_eval_dataloader`` yields (camera, {"image": [H,W,3]})."""
+
+    def __init__(self, n_train: int = 8, n_eval: int = 2, width: int = 64, height: int = 96, train_num_rays_per_batch: int = 4096,
+                 device="cpu", seed: int = 0, world_size: int = 1, local_rank: int = 0):
+        box = SceneBox(torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]))
+
+        def images(n, tag):
+            return torch.from_numpy(synth.uniform(tag, (n, height, width, 3), 0.0, 1.0))
+        self.train_dataset = _VisionDataset(synthetic_cameras(n_train, width, height, "dm.train"), images(n_train, "dm.train.img"), box)
+        self.eval_dataset = _VisionDataset(synthetic_cameras(n_eval, width, height, "dm.eval"), images(n_eval, "dm.eval.img"), box)
+        self.train_num_rays_per_batch = train_num_rays_per_batch
+        self.eval_num_rays_per_batch = train_num_rays_per_batch
+        self.device = torch.device(device)
+        self.generator = torch.Generator(device="cpu").manual_seed(seed + 7919 * local_rank)
+        self._eval_i = 0
+        self.to(device)
+
+    def to(self, device):
+        self.device = torch.device(device)
+        for ds in (self.train_dataset, self.eval_dataset):
+            ds.cameras, ds.images = ds.cameras.to(device), ds.images.to(device)
+        return self
+
+    def _sample(self, ds: _VisionDataset, n: int):
+        N, H, W = ds.images.shape[:3]
+        idx = torch.stack([torch.randint(0, N, (n,), generator=self.generator), torch.randint(0, H, (n,), generator=self.generator),
+                           torch.randint(0, W, (n,), generator=self.generator)], dim=-1).to(self.device)
+        coords = idx[:, 1:].float() + 0.5
+        rb = ds.cameras.generate_rays(idx[:, 0], coords)
+        return rb, {"image": ds.images[idx[:, 0], idx[:, 1], idx[:, 2]], "indices": idx}
+
+    def next_train(self, step: int):
+        return self._sample(self.train_dataset, self.train_num_rays_per_batch)
+
+    def next_eval(self, step: int):
+        return self._sample(self.eval_dataset, self.eval_num_rays_per_batch)
+
+    def next_eval_image(self, step: int):
+        i = self._eval_i % len(self.eval_dataset)
+        self._eval_i += 1
+        return self.eval_dataset.cameras[i], {"image": self.eval_dataset.images[i]}
+
+    @property
+    def fixed_indices_eval_dataloader(self):
+        return [(self.eval_dataset.cameras[i], {"image": self.eval_dataset.images[i]}) for i in range(len(self.eval_dataset))]
+
+    def get_param_groups(self):
+        return {}
+
+
+# ---- synthetic RIR set ------------------------------------------------------------------------------------------------------------
+class _AudioDataset:
+    """Indexable like the reference's eval datasets: mode 'eval' -> one time slice per index (NeRAF_dataset.py:129-130), mode
+    'eval_image' -> one whole RIR per index with 'data' [C,F,T] and 'waveform' [C,n] (:180-181, :352-353)."""
+
+    def __init__(self, bank, waveforms: torch.Tensor, scene_box: SceneBox):
+        self.bank, self.waveforms, self.scene_box, self.mode = bank, waveforms, scene_box, "eval"
+
+    def __len__(self):
+        return self.bank.n_rir if self.mode in ("eval_image", "inference") else len(self.bank)
+
+    def __getitem__(self, i: int):
+        if self.mode in ("eval_image", "inference"):
+            d = self.bank.get_data_eval(int(i))
+            d["waveform"] = self.waveforms[int(i)]
+            return d
+        return self.bank.get_data(int(i))
+
+
+class SyntheticAudioDataManager:
+    """Exponentially decaying noise RIRs in a RAF-like room, tokenised once into a DeviceRIRBank (neraf_amd/data.py)."""
+
+    def __init__(self, n_train: int = 6, n_eval: int = 2, dataset: str = "RAF", batch_size: int = 2048, device="cpu", seed: int = 0,
+                 world_size: int = 1, local_rank: int = 0):
+        from .data import DeviceRIRBank
+        self.batch_size = batch_size
+        fs, max_len, hop = (48000, 60, 256) if dataset == "RAF" else (16000, 60, 128)
+        n = hop * (max_len - 1)
+        aabb = torch.from_numpy(synth.audio_aabb())
+        box = SceneBox(aabb)
+
+        def make(nr, tag):
+            t = np.arange(n) / fs
+            tau = synth.uniform(tag + ".tau", (nr, 1), 0.03, 0.08).astype(np.float64)
+            w = synth.normal(tag + ".wave", (nr, n)).astype(np.float64) * np.exp(-t[None, :] / tau)
+            lo, hi = np.array([-3.0, -1.5, -4.0]), np.array([3.0, 1.5, 4.0])
+            mic = synth.uniform(tag + ".mic", (nr, 3), 0, 1, np.float64) * (hi - lo) + lo
+            src = synth.uniform(tag + ".src", (nr, 3), 0, 1, np.float64) * (hi - lo) + lo
+            ang = np.deg2rad(synth.integers(tag + ".rot", (nr,), 0, 360).astype(np.float64))
+            rot = (np.stack([np.cos(ang), np.zeros_like(ang), np.sin(ang)], -1) + 1.0) / 2.0
+            waves = torch.from_numpy(w.astype(np.float32))
+            bank = DeviceRIRBank.from_waveforms(waves, fs, max_len, torch.from_numpy(mic), torch.from_numpy(src), torch.from_numpy(rot))
+            return _AudioDataset(bank, waves[:, None, :], box)
+        self.train_dataset, self.eval_dataset = make(n_train, "adm.train"), make(n_eval, "adm.eval")
+        self.generator = None
+        self._eval_i = 0
+        self.to(device)
+
+    def to(self, device):
+        for ds in (self.train_dataset, self.eval_dataset):
+            b = ds.bank
+            b.log_mag, b.mic_pose, b.source_pose, b.rot = b.log_mag.to(device), b.mic_pose.to(device), b.source_pose.to(device), b.rot.to(device)
+            ds.waveforms = ds.waveforms.to(device)
+        return self
+
+    def next_train(self, step: int):
+        return None, self.train_dataset.bank.next_train(self.batch_size, generator=self.generator)
+
+    def next_eval(self, step: int):
+        return None, self.eval_dataset.bank.next_train(self.batch_size, generator=self.generator)
+
+    def next_eval_image(self, step: int):
+        i = self._eval_i % self.eval_dataset.bank.n_rir
+        self._eval_i += 1
+        d = self.eval_dataset.bank.get_data_eval(i)
+        d["waveform"] = self.eval_dataset.waveforms[i]
+        return None, d
+
+    def get_param_groups(self):
+        return {}

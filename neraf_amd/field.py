@@ -132,7 +132,9 @@ class NeRAFAudioSoundField(nn.Module):
         parameters in place without bumping ``_version``, so a version-keyed cache would silently go
         stale.  Inference re-packs only when a parameter's (data_ptr, _version) changed; call
         ``invalidate_packed()`` after out-of-band weight edits."""
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        from . import optim
+        # UPDATE_EPOCH: FusedAdam writes parameters through raw pointers without bumping tensor versions
+        key = (optim.UPDATE_EPOCH,) + tuple((p.data_ptr(), p._version) for p in params)
         dev = params[0].device
         desc = self._desc_dense if dense else self._desc
         cur = self._packed_buf[dense]

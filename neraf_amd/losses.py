@@ -31,18 +31,21 @@ class _StftLossFn(torch.autograd.Function):
         sums = torch.empty(4, dtype=torch.float32, device=x.device)
         losses = torch.empty(2, dtype=torch.float32, device=x.device)
         n_total = x.numel()
+        world = 1
         _lib.check(lib.neraf_stft_loss_sums(_lib.ctx(dev), x.data_ptr(), y.data_ptr(), x.numel(), loss_type,
                                             sums.data_ptr(), _stream_ptr()), dev)
         if group is not None:
             # data parallel: the Frobenius ratio / mean are over the GLOBAL batch (NeRAF_evaluator.py:26)
             from .parallel import allreduce_loss_sums
+            import torch.distributed as dist
             n_total = allreduce_loss_sums(sums, x.numel(), group=group if group is not True else None, uniform_shards=True)
+            world = dist.get_world_size(group if group is not True else None)
         _lib.check(lib.neraf_stft_loss_finalize(_lib.ctx(dev), sums.data_ptr(), n_total, losses.data_ptr(),
                                                 _stream_ptr()), dev)
         if weights is not None:
             losses = losses * weights
         ctx.save_for_backward(x, y, sums)
-        ctx.loss_type, ctx.dev, ctx.n_total, ctx.weights = loss_type, dev, n_total, weights
+        ctx.loss_type, ctx.dev, ctx.n_total, ctx.weights, ctx.world = loss_type, dev, n_total, weights, world
         return losses[0], losses[1]
 
     @staticmethod
@@ -56,6 +59,12 @@ class _StftLossFn(torch.autograd.Function):
                          (g_mag if g_mag is not None else zero).float().reshape(())]).contiguous()
         if ctx.weights is not None:
             w = w * ctx.weights
+        if ctx.world > 1:
+            # Data parallel: the loss value is already the GLOBAL one (sums all-reduced above), so this rank's dx is
+            # dL_global/dx_local, and the sum over ranks of the resulting parameter gradients is dL_global/dtheta.  The gradient
+            # reducer AVERAGES over ranks (right for the per-rank-mean radiance losses): pre-multiply by the world size so that the
+            # averaged gradient of the audio loss is the single-process global-batch gradient, not 1/world of it.
+            w = w * float(ctx.world)
         _lib.check(lib.neraf_stft_loss_bwd(_lib.ctx(ctx.dev), x.data_ptr(), y.data_ptr(), x.numel(), ctx.n_total,
                                            ctx.loss_type, sums.data_ptr(), w.data_ptr(), dx.data_ptr(), _stream_ptr()),
                    ctx.dev)

@@ -32,6 +32,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .config import InstantiateConfig
 from .evaluator import GriffinLim, RAFEvaluator, SoundSpacesEvaluator
 from .field import NeRAFAudioSoundField, _dev_index, _stream_ptr
 from .losses import STFTLoss
@@ -40,8 +41,9 @@ from .vision import FieldHeadNames, Frustums, RaySamples
 
 
 @dataclass
-class NeRAFAudioModelConfig:
-    """Fields and defaults of the reference config (NeRAF_model.py:88-101)."""
+class NeRAFAudioModelConfig(InstantiateConfig):
+    """Fields and defaults of the reference config (NeRAF_model.py:88-101); ``setup(scene_box=..., num_train_data=..., device=...)``
+    instantiates the model as NeRAF_pipeline.py:135-139 does."""
     dataset: str = "SoundSpaces"
     use_grid: bool = True
     grid_step: float = 1 / 128
@@ -55,6 +57,10 @@ class NeRAFAudioModelConfig:
     N_freq_stft: int = 257
     hop_len: int = 128
     win_len: int = 512
+
+    def __post_init__(self):
+        if self._target is None:
+            self._target = NeRAFAudioModel
 
 
 class _RefreshFn(torch.autograd.Function):
@@ -99,11 +105,19 @@ class _RefreshFn(torch.autograd.Function):
 
 
 class NeRAFAudioModel(nn.Module):
-    def __init__(self, config: NeRAFAudioModelConfig, aabb: torch.Tensor, process_group=None):
-        """``aabb`` [2,3] is the audio scene box (mic bounding box +- 1 m, NeRAF_dataparser.py:155-161)."""
+    def __init__(self, config: NeRAFAudioModelConfig, aabb: torch.Tensor = None, process_group=None, scene_box=None,
+                 num_train_data: int = 0, device=None, **kwargs):
+        """``aabb`` [2,3] (or ``scene_box.aabb``, the nerfstudio ``Model.__init__(config, scene_box, num_train_data, **kwargs)``
+        form used by ``config.setup``, NeRAF_pipeline.py:135-139) is the audio scene box: mic bounding box +- 1 m
+        (NeRAF_dataparser.py:155-161)."""
         super().__init__()
         self.config = config
-        self.register_buffer("aabb", aabb.float())
+        if aabb is None:
+            if scene_box is None:
+                raise ValueError("NeRAFAudioModel needs the audio scene box (aabb=... or scene_box=...)")
+            aabb = scene_box.aabb
+        self.scene_box, self.num_train_data = scene_box, num_train_data
+        self.register_buffer("aabb", torch.as_tensor(aabb).float())
         self.dataset = config.dataset
         if self.dataset == "RAF":                                   # default_RAF_config, :109-119, :126-129
             config.fs, config.max_len = 48000, 0.32
@@ -335,6 +349,14 @@ class NeRAFAudioModel(nn.Module):
             wav_istft_prd = self.istft_transform(mag_prd.to(dev), generator=generator).cpu().numpy()
             return self.evaluator.get_full_metrics(mag_prd.numpy(), mag_gt.numpy(), wav_gt, wav_istft_prd, wav_istft_gt,
                                                    stft.numpy(), data.numpy())
+
+    def get_image_metrics_and_images(self, outputs: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], generator=None):
+        """NeRAF_model.py:738-803 as its callers use it (NeRAF_pipeline.py:278, :364): (metrics_dict, images_dict).  The metric
+        half is ``get_audio_metrics``; the image half returns the raw log-magnitude panels the forward already produced (the
+        reference colour-maps them with matplotlib for tensorboard -- presentation code, not built)."""
+        metrics = self.get_audio_metrics(outputs, batch, generator=generator)
+        images = {k: v for k, v in outputs.items() if k.startswith(("stft_ch_", "gt_ch_", "comparison_ch_"))}
+        return metrics, images
 
     def get_param_groups(self):                                                         # :730-737
         params = list(self.field.parameters())

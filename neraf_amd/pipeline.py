@@ -17,34 +17,7 @@ from .checkpoint import load_pipeline as _load_pipeline
 from .checkpoint import pipeline_state_dict
 
 
-class FixedBatchDataManager:
-    """``next_train`` returns the same resident (ray_bundle, batch) pair every step."""
-
-    def __init__(self, ray_bundle, batch: Dict[str, torch.Tensor], train_num_rays_per_batch: Optional[int] = None):
-        self.ray_bundle, self.batch = ray_bundle, batch
-        if train_num_rays_per_batch is None:
-            train_num_rays_per_batch = len(ray_bundle) if ray_bundle is not None else 4096
-        self.train_num_rays_per_batch = train_num_rays_per_batch
-
-    def next_train(self, step: int):
-        return self.ray_bundle, self.batch
-
-    def get_param_groups(self):
-        return {}
-
-
-class RIRBankDataManager:
-    """Audio batches sampled on the device from a ``DeviceRIRBank`` (neraf_amd/data.py); the ray bundle slot is None as in
-    NeRAFDataManager.next_train (the audio model needs no rays, NeRAF_pipeline.py:187)."""
-
-    def __init__(self, bank, batch_size: int = 2048, generator: Optional[torch.Generator] = None):
-        self.bank, self.batch_size, self.generator = bank, batch_size, generator
-
-    def next_train(self, step: int):
-        return None, self.bank.next_train(self.batch_size, generator=self.generator)
-
-    def get_param_groups(self):
-        return {}
+from .datamanagers import FixedBatchDataManager, RIRBankDataManager  # noqa: F401  (re-exported)
 
 
 class _ScaledLossSum(torch.autograd.Function):
@@ -77,15 +50,54 @@ class NeRAFPipeline(nn.Module):
     """Joint radiance + acoustic pipeline (NeRAF_pipeline.py:64-222)."""
 
     def __init__(self, model: nn.Module, audio_model: nn.Module, datamanager=None, audio_datamanager=None,
-                 start_step_audio: int = 2000, world_size: int = 1):
+                 start_step_audio: int = 2000, world_size: int = 1, local_rank: int = 0, config=None):
         super().__init__()
+        self.config = config
         self._model = model                                   # nerfstudio names the (possibly DDP-wrapped) vision model `_model`
         self.audio_model = audio_model
         self.datamanager, self.audio_datamanager = datamanager, audio_datamanager
         self.start_step_audio = start_step_audio               # NeRAF_config.py:66
-        self.world_size = world_size
+        self.world_size, self.local_rank = world_size, local_rank
+        self.save_eval_audio_path = getattr(config, "save_eval_audio_path", None)
         self.audio_model.spatial_distortion = self.model.field.module.spatial_distortion        # :143
+        self.model.audio_model = self.audio_model                                                # :152 (viewer hand-off)
         self._reducer = None
+
+    @classmethod
+    def from_config(cls, config, device="cuda", test_mode: str = "val", world_size: int = 1, local_rank: int = 0, grad_scaler=None):
+        """``NeRAFPipeline.__init__(config, device, test_mode, world_size, local_rank, grad_scaler)`` (NeRAF_pipeline.py:86-159), i.e.
+        what ``NeRAFPipelineConfig.setup(...)`` runs: set up both data managers, instantiate both models through their configs'
+        ``setup`` with the reference's keyword arguments, link spatial distortion / eval data / audio model.  Where the reference
+        raises for ``world_size > 1`` (:153-157) this pipeline shards (neraf_amd/parallel.py)."""
+        def build(dm):
+            return dm.setup(device=device, test_mode=test_mode, world_size=world_size, local_rank=local_rank) if hasattr(dm, "setup") else dm
+        datamanager, audio_datamanager = build(config.datamanager), build(config.audio_datamanager)             # :104-109
+        seed_pts = None
+        tdo = getattr(datamanager, "train_dataparser_outputs", None)
+        if tdo is not None and "points3D_xyz" in tdo.metadata:                                                   # :111-118
+            seed_pts = (tdo.metadata["points3D_xyz"], tdo.metadata["points3D_rgb"])
+        datamanager.to(device)
+        audio_datamanager.to(device)
+        assert datamanager.train_dataset is not None, "Missing input dataset"                                    # :123
+        model = config.vision_model.setup(scene_box=datamanager.train_dataset.scene_box, num_train_data=len(datamanager.train_dataset),
+                                          metadata=datamanager.train_dataset.metadata, device=device, grad_scaler=grad_scaler,
+                                          seed_points=seed_pts)                                                  # :125-132
+        model.to(device)
+        audio_kw = dict(scene_box=audio_datamanager.train_dataset.scene_box, num_train_data=len(audio_datamanager.train_dataset),
+                        device=device)
+        if world_size > 1:
+            audio_kw["process_group"] = True
+        audio_model = config.audio_model.setup(**audio_kw)                                                       # :135-139
+        audio_model.to(device)
+        pipe = cls(model, audio_model, datamanager, audio_datamanager, start_step_audio=config.start_step_audio, world_size=world_size,
+                   local_rank=local_rank, config=config)
+        ev = audio_datamanager.eval_dataset
+        if ev is not None and len(ev) > 0:                                                                        # :147
+            e0 = ev[0]
+            audio_model.set_eval_data(e0["source_pose"], e0["mic_pose"], e0["rot"], e0["data"])
+        if world_size > 1:
+            pipe.attach_gradient_reducer()
+        return pipe
 
     @property
     def model(self):
@@ -115,38 +127,156 @@ class NeRAFPipeline(nn.Module):
 
     @torch.no_grad()
     def get_eval_loss_dict(self, step: int):
-        """Eval-mode losses on the next training batch of each manager (the reference evaluates its eval split the same way)."""
+        """NeRAF_pipeline.py:231-259: eval-mode outputs, losses and metrics on the next eval batch of each manager."""
         was = self.training
         self.eval()
         try:
-            ray_bundle, batch = self.datamanager.next_train(step)
-            out = self.model.get_outputs(ray_bundle)
-            res = {"rgb_mse": torch.mean((out["rgb"] - batch["image"].to(out["rgb"].device)) ** 2)}
+            nxt = getattr(self.datamanager, "next_eval", None) or self.datamanager.next_train
+            ray_bundle, batch = nxt(step)
+            model_outputs = self.model(ray_bundle)
+            metrics_dict = self.model.get_metrics_dict(model_outputs, batch)
+            gt = (batch["image"] if "image" in batch else batch["rgb"]).to(model_outputs["rgb"].device)
+            # NerfactoModel.get_loss_dict outside training: the rgb loss only (interlevel / distortion need the sample lists)
+            loss_dict = {"rgb_loss": torch.mean((model_outputs["rgb"] - gt) ** 2)}
             if step > self.start_step_audio:
-                _, ba = self.audio_datamanager.next_train(step)
-                res.update(self.audio_model.get_loss_dict(self.audio_model.get_outputs(ba), ba))
-            return res
+                nxt_a = getattr(self.audio_datamanager, "next_eval", None) or self.audio_datamanager.next_train
+                _, ba = nxt_a(step)
+                out_a = self.audio_model.get_outputs(ba)
+                metrics_dict.update(self.audio_model.get_metrics_dict(out_a, ba))
+                loss_dict.update(self.audio_model.get_loss_dict(out_a, ba, metrics_dict))
+            return model_outputs, loss_dict, metrics_dict
+        finally:
+            self.train(was)
+
+    @torch.no_grad()
+    def get_eval_image_metrics_and_images(self, step: int):
+        """NeRAF_pipeline.py:261-289: one eval frame (and, once the audio branch runs, one eval RIR)."""
+        was = self.training
+        self.eval()
+        try:
+            camera, batch = self.datamanager.next_eval_image(step)
+            outputs = self.model.get_outputs_for_camera(camera, None, eval=True)
+            metrics_dict, images_dict = self.model.get_image_metrics_and_images(outputs, batch)
+            assert "num_rays" not in metrics_dict
+            metrics_dict["num_rays"] = camera.height * camera.width * camera.size
+            if step > self.start_step_audio:
+                _, batch_audio = self.audio_datamanager.next_eval_image(step)
+                outputs_audio = self.audio_model.get_outputs_for_camera(None, None, batch_audio=batch_audio)
+                m_a, im_a = self.audio_model.get_image_metrics_and_images(outputs_audio, batch_audio)
+                metrics_dict.update(m_a)
+                images_dict.update(im_a)
+            return metrics_dict, images_dict
+        finally:
+            self.train(was)
+
+    @torch.no_grad()
+    def get_average_eval_image_metrics(self, step: Optional[int] = None, output_path=None, get_std: bool = False):
+        """NeRAF_pipeline.py:291-436: every eval frame through ``get_outputs_for_camera`` + image metrics, then (when
+        ``step > start_step_audio``, or always when an output path is given, :353-354) every eval RIR through the audio model's eval
+        branch + audio metrics; means (and stds) over items, throughput keys as the reference names them.
+
+        Data parallel (SURVEY 8e "Eval"): frames and RIRs are dealt round-robin over the ranks (item i -> rank i % world), every
+        rank evaluates its share without any collective inside the loop, and the per-item metric rows are all-gathered once at the
+        end so that every rank returns the same averages as a single process would."""
+        import os
+        from time import time
+        import numpy as np
+        was = self.training
+        self.eval()
+        try:
+            rank, world = (self.local_rank, self.world_size) if self.world_size > 1 else (0, 1)
+            rows_v: List[Dict[str, float]] = []
+            for i, (camera, batch) in enumerate(self.datamanager.fixed_indices_eval_dataloader):           # :323
+                if i % world != rank:
+                    continue
+                t0 = time()
+                outputs = self.model.get_outputs_for_camera(camera=camera, obb_box=None, eval=True)         # :325
+                num_rays = camera.height * camera.width
+                metrics_dict, im = self.model.get_image_metrics_and_images(outputs, batch)                  # :328
+                if output_path is not None:                                                                # :329-338 (cv2.imwrite)
+                    arr = (im["img"].detach().cpu().numpy() * 255).astype(np.uint8)
+                    np.save(os.path.join(output_path, f"eval_{str(i).zfill(5)}.npy"), arr)
+                torch.cuda.synchronize() if torch.cuda.is_available() else None
+                metrics_dict["num_rays_per_sec"] = num_rays / (time() - t0)                                 # :341
+                metrics_dict["fps"] = metrics_dict["num_rays_per_sec"] / num_rays                           # :343-344
+                rows_v.append({k: float(v) for k, v in metrics_dict.items()})
+            if output_path is not None:                                                                    # :353-354
+                step = self.start_step_audio + 1
+            rows_a: List[Dict[str, float]] = []
+            if step is not None and step > self.start_step_audio:
+                ev = self.audio_datamanager.eval_dataset
+                old_mode = getattr(ev, "mode", None)
+                if old_mode != "inference":
+                    ev.mode = "eval_image"                                                                 # :310-311
+                try:
+                    for i in range(len(ev)):                                                               # :355
+                        if i % world != rank:
+                            continue
+                        t0 = time()
+                        batch = ev[i]                                                                      # :360
+                        outputs = self.audio_model.get_outputs_for_camera(None, None, batch_audio=batch)  # :362
+                        metrics_dict, _ = self.audio_model.get_image_metrics_and_images(outputs, batch)   # :364
+                        if self.save_eval_audio_path is not None:                                          # :366-372
+                            d = os.path.join(self.save_eval_audio_path, str(step))
+                            os.makedirs(d, exist_ok=True)
+                            np.save(os.path.join(d, f"eval_{i}.npy"), {"pred": outputs["raw_output"].detach().cpu().numpy(),
+                                                                       **{k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in batch.items()}})
+                        if output_path is not None:                                                        # :374-380
+                            np.save(os.path.join(output_path, f"eval_{str(i).zfill(5)}.npy"),
+                                    outputs["raw_output"].permute(1, 2, 0).detach().cpu().numpy())
+                        num_rays = batch["data"].shape[-1]                                                 # :382
+                        metrics_dict["num_rays_per_sec_audio"] = num_rays / (time() - t0)                  # :384
+                        metrics_dict["fps_audio"] = metrics_dict["num_rays_per_sec_audio"] / num_rays       # :386-387
+                        rows_a.append({k: float(v) for k, v in metrics_dict.items()})
+                finally:
+                    if old_mode != "inference":
+                        ev.mode = "eval"                                                                   # :398-399
+            if world > 1:
+                import torch.distributed as dist
+                gathered: List = [None] * world
+                dist.all_gather_object(gathered, (rows_v, rows_a))
+                rows_v = [r for part in gathered for r in part[0]]
+                rows_a = [r for part in gathered for r in part[1]]
+            out: Dict[str, float] = {}
+            for rows in (rows_v, rows_a):                                                                  # :402-432
+                if not rows:
+                    continue
+                for key in rows[0].keys():
+                    vals = torch.tensor([r[key] for r in rows], dtype=torch.float64)
+                    if get_std:
+                        std, mean = torch.std_mean(vals) if len(rows) > 1 else (torch.zeros(()), vals.mean())
+                        out[key], out[f"{key}_std"] = float(mean), float(std)
+                    else:
+                        out[key] = float(vals.mean())
+            return out
         finally:
             self.train(was)
 
     # ---- optimisation ------------------------------------------------------------------------------------------------
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
-        """nerfacto's groups plus the audio group, with the field parameters appended to the audio group as well
-        ("Backprop on vision too", NeRAF_pipeline.py:487): they are stepped by both optimizers."""
-        fields = list(self.model.field.parameters())
-        groups = {"proposal_networks": [p for pn in self.model.proposal_networks for p in pn.parameters()], "fields": fields}
+        """NeRAF_pipeline.py:477-490: data-manager groups, the vision model's groups (nerfacto's "proposal_networks", "fields",
+        "camera_opt") and the audio group with the field parameters appended to it as well ("Backprop on vision too", :487): they
+        are stepped by both optimizers."""
+        groups: Dict[str, List[nn.Parameter]] = {}
+        for dm in (self.datamanager, self.audio_datamanager):
+            if dm is not None and hasattr(dm, "get_param_groups"):
+                groups.update(dm.get_param_groups())
+        groups.update(self.model.get_param_groups())
         audio = self.audio_model.get_param_groups()
-        audio["audio_fields"] = list(audio["audio_fields"]) + fields
+        audio["audio_fields"] = list(audio["audio_fields"]) + list(groups["fields"])
         return {**groups, **audio}
 
-    def make_optimizers(self, init_scale: float = 65536.0):
-        """FusedAdam equivalents of NeRAF_config.py:115-127 (Adam eps 1e-15; lr 1e-2 / 1e-2 / 1e-4) and the GradScaler.  The
-        first two optimizers share hyper-parameters and run as two groups of one launch."""
-        from .optim import FusedAdam, GradScaler
-        g = self.get_param_groups()
-        opt = FusedAdam([{"params": g["proposal_networks"], "lr": 1e-2}, {"params": g["fields"], "lr": 1e-2}], eps=1e-15)
-        opt_audio = FusedAdam([{"params": g["audio_fields"], "lr": 1e-4}], eps=1e-15)
-        return [opt, opt_audio], GradScaler("cuda", init_scale=init_scale)
+    def make_optimizers(self, init_scale: float = 65536.0, optimizers_config=None, with_schedulers: bool = False):
+        """nerfstudio's ``Optimizers`` for NeRAF_config.py:115-132 (Adam eps 1e-15; lr 1e-2 / 1e-2 / 1e-4 / 1e-3, exponential-decay
+        schedulers) over ``get_param_groups()`` and the GradScaler (mixed_precision=True, :79).  Returns ([optimizers in step
+        order], scaler); ``with_schedulers`` returns the ``neraf_amd.config.Optimizers`` wrapper instead of the bare list (its
+        ``scheduler_step_all`` is what the Trainer calls after every iteration)."""
+        from .config import Optimizers, default_optimizers
+        from .optim import GradScaler
+        cfg = optimizers_config if optimizers_config is not None else default_optimizers(self.start_step_audio)
+        opts = Optimizers(cfg, self.get_param_groups())
+        scaler = GradScaler("cuda", init_scale=init_scale)
+        return (opts if with_schedulers else opts.steppers), scaler
 
     def attach_gradient_reducer(self, group=None):
         """Data parallel: average gradients over the ranks, overlapped with the backward pass (neraf_amd/parallel.py)."""
@@ -168,6 +298,9 @@ class NeRAFPipeline(nn.Module):
     def train_iteration(self, step: int, optimizers, scaler) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         """One Trainer.train_iteration: zero_grad, forward, summed loss, scaled backward, (gradient averaging), optimizer steps."""
         self.model.update_to_step(step)
+        wrapper = optimizers if hasattr(optimizers, "scheduler_step_all") else None
+        if wrapper is not None:
+            optimizers = wrapper.steppers
         for o in optimizers:
             o.zero_grad(set_to_none=True)
         _, loss_dict, _ = self.get_train_loss_dict(step)
@@ -179,6 +312,8 @@ class NeRAFPipeline(nn.Module):
         for o in optimizers:
             scaler.step(o)
         scaler.update()
+        if wrapper is not None:
+            wrapper.scheduler_step_all(step)            # Trainer.train_iteration [NS-recall]: schedulers after the optimizer steps
         return loss, loss_dict
 
     # ---- checkpoints -------------------------------------------------------------------------------------------------

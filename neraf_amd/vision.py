@@ -8,9 +8,10 @@ piecewise sampler -> proposal density x2 -> PDF resampling x2 -> fused field que
 Training: ``get_outputs`` (forward) + ``get_loss_dict`` (rgb MSE, interlevel x1.0, distortion x0.002 -- the
 nerfacto loss dict, V4) are differentiable end to end: the three losses come out of one autograd node
 (``_VisionLossFn``) whose backward runs the HIP loss-gradient, proposal-backward and fused field-backward
-kernels and returns gradients for the hash tables, the MLP weights and the appearance embedding.  Not yet
-differentiable: the camera optimizer (pose deltas) and the audio-loss path into the field through the voxel
-grid (NeRAF_model.py:395-400).
+kernels and returns gradients for the hash tables, the MLP weights and the appearance embedding.  The audio
+loss reaches the same parameters through the voxel grid (``model._RefreshFn``, NeRAF_model.py:395-400).  The
+camera optimizer (neraf_amd/cameras.py) is applied to the ray bundle and regularised; the kernels do not return
+a gradient w.r.t. ray origins / directions, so the photometric loss does not move the poses.
 
 No fallback: every method raises if the HIP library or the GPU is missing.
 """
@@ -439,13 +440,39 @@ class NeRAFVisionModel(nn.Module):
     proposal_weights_anneal_slope, proposal_weights_anneal_max_num_iters = 10.0, 1000
     proposal_update_every, proposal_warmup = 5, 5000          # nerfacto defaults [NS-recall]
 
-    def __init__(self, aabb: torch.Tensor, num_train_data: int, average_init_density: float = 0.01):
+    def __init__(self, aabb=None, num_train_data: int = None, average_init_density: float = 0.01, *, scene_box=None, config=None,
+                 **kwargs):
+        """Two call forms: ``NeRAFVisionModel(aabb [2,3], num_train_data)`` and nerfstudio's ``Model.__init__(config, scene_box,
+        num_train_data, **kwargs)`` as ``NeRAFVisionModelConfig.setup`` calls it (NeRAF_pipeline.py:125-132; metadata, device,
+        grad_scaler and seed_points are accepted and unused, as in NerfactoModel)."""
         super().__init__()
         from .field import NeRAFVisionFieldValue
+        if aabb is not None and not isinstance(aabb, torch.Tensor) and hasattr(aabb, "eval_num_rays_per_chunk"):
+            config, aabb = aabb, None                             # positional (config, scene_box, num_train_data)
+            if num_train_data is not None and not isinstance(num_train_data, int):
+                scene_box, num_train_data = num_train_data, kwargs.pop("num_train_data", None)
+        if aabb is None:
+            if scene_box is None:
+                raise ValueError("NeRAFVisionModel needs the scene box (aabb=... or scene_box=...)")
+            aabb = scene_box.aabb
+        if num_train_data is None:
+            raise ValueError("NeRAFVisionModel needs num_train_data (size of the appearance embedding)")
+        self.config, self.scene_box, self.num_train_data = config, scene_box, num_train_data
+        if config is not None:                                    # NeRAF_config.py:94-98 + nerfacto defaults
+            for k in ("num_proposal_samples_per_ray", "num_nerf_samples_per_ray", "near_plane", "far_plane", "eval_num_rays_per_chunk",
+                      "proposal_weights_anneal_slope", "proposal_weights_anneal_max_num_iters", "proposal_update_every",
+                      "proposal_warmup", "interlevel_loss_mult", "distortion_loss_mult"):
+                setattr(self, k, getattr(config, k))
+            average_init_density = config.average_init_density
+        aabb = torch.as_tensor(aabb).float()
         self.field = NeRAFVisionFieldValue(NerfactoField(aabb, num_train_data, average_init_density))   # NeRAF_model.py:61
         self.proposal_networks = nn.ModuleList([HashMLPDensityField(128, average_init_density=average_init_density),
                                                 HashMLPDensityField(256, average_init_density=average_init_density)])
         self.renderer_rgb = RGBRenderer()
+        from .cameras import CameraOptimizer
+        cam_cfg = getattr(config, "camera_optimizer", None) if config is not None else None
+        self.camera_optimizer = (cam_cfg.setup(num_cameras=num_train_data) if cam_cfg is not None
+                                 else CameraOptimizer(num_train_data, mode="off"))
         self.audio_model = None
         self.step = 0
         self._steps_since_update = 0
@@ -480,8 +507,10 @@ class NeRAFVisionModel(nn.Module):
         """NerfactoModel.get_outputs + rgb clip (NeRAF_model.py:65-68).  ``jitters`` (3 tensors [R]) override the
         training-time single jitter of the three sampling stages (tests pass the oracle's values)."""
         lib = _lib.load()
-        o = ray_bundle.origins.float().contiguous()
-        d = ray_bundle.directions.float().contiguous()
+        if self.training:
+            ray_bundle = self.camera_optimizer.apply_to_raybundle(ray_bundle)     # NerfactoModel.get_outputs [NS-recall]
+        o = ray_bundle.origins.detach().float().contiguous()
+        d = ray_bundle.directions.detach().float().contiguous()
         dev = _dev_index(o)
         h, st = _lib.ctx(dev), _stream_ptr()
         R = o.shape[0]
@@ -547,15 +576,36 @@ class NeRAFVisionModel(nn.Module):
         return ps
 
     def get_metrics_dict(self, outputs, batch):
-        return {}
+        """NerfactoModel.get_metrics_dict [NS-recall]: psnr of the batch (+ camera-optimizer norms in training)."""
+        m: Dict[str, torch.Tensor] = {}
+        if batch is not None and ("image" in batch or "rgb" in batch):
+            gt = (batch["image"] if "image" in batch else batch["rgb"]).to(outputs["rgb"].device).float()
+            m["psnr"] = psnr(outputs["rgb"].detach(), gt)
+        if self.training:
+            self.camera_optimizer.get_metrics_dict(m)
+        return m
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
-        """NerfactoModel.get_loss_dict: rgb MSE (on the clipped colour, NeRAF_model.py:67) + interlevel + distortion."""
+        """NerfactoModel.get_loss_dict: rgb MSE (on the clipped colour, NeRAF_model.py:67) + interlevel + distortion
+        (+ the camera-optimizer regulariser)."""
         if "_state" not in outputs:
             raise RuntimeError("get_loss_dict needs the outputs of a training-mode get_outputs call")
         gt = (batch["image"] if "image" in batch else batch["rgb"]).to(outputs["rgb"].device).float().contiguous()
         rgb_l, inter, dist = _VisionLossFn.apply(self, outputs["_state"], gt, *self.loss_params())
-        return {"rgb_loss": rgb_l, "interlevel_loss": inter, "distortion_loss": dist}
+        d = {"rgb_loss": rgb_l, "interlevel_loss": inter, "distortion_loss": dist}
+        self.camera_optimizer.get_loss_dict(d)
+        return d
+
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        """NerfactoModel.get_param_groups [NS-recall]: {"proposal_networks", "fields", "camera_opt"}."""
+        g = {"proposal_networks": list(self.proposal_networks.parameters()), "fields": list(self.field.parameters())}
+        self.camera_optimizer.get_param_groups(g)
+        return g
+
+    def get_training_callbacks(self, training_callback_attributes=None):
+        """nerfacto registers the proposal sampler's step callbacks (anneal, update schedule) [NS-recall]; here the Trainer calls
+        ``update_to_step(step)`` once per iteration instead (neraf_amd/pipeline.py::train_iteration)."""
+        return []
 
     forward = get_outputs
 
@@ -568,12 +618,67 @@ class NeRAFVisionModel(nn.Module):
         outs: Dict[str, List[torch.Tensor]] = {}
         was = self.training
         self.eval()
-        for i in range(0, R, self.eval_num_rays_per_chunk):
-            sl = slice(i, min(R, i + self.eval_num_rays_per_chunk))
-            rb = RayBundle(ray_bundle.origins[sl], ray_bundle.directions[sl],
-                           ray_bundle.camera_indices[sl] if ray_bundle.camera_indices is not None else None)
-            o = self.get_outputs(rb)
-            for k in ("rgb", "accumulation", "depth", "expected_depth"):
-                outs.setdefault(k, []).append(o[k])
-        self.train(was)
+        try:
+            for i in range(0, R, self.eval_num_rays_per_chunk):
+                sl = slice(i, min(R, i + self.eval_num_rays_per_chunk))
+                rb = RayBundle(ray_bundle.origins[sl], ray_bundle.directions[sl],
+                               ray_bundle.camera_indices[sl] if ray_bundle.camera_indices is not None else None)
+                o = self.get_outputs(rb)
+                for k in ("rgb", "accumulation", "depth", "expected_depth"):
+                    outs.setdefault(k, []).append(o[k])
+        finally:
+            self.train(was)
         return {k: torch.cat(v, 0) for k, v in outs.items()}
+
+    @torch.no_grad()
+    def get_outputs_for_camera(self, camera, obb_box=None, eval: bool = False):
+        """NeRAFVisionModel.get_outputs_for_camera(camera, obb_box, eval) (NeRAF_model.py:70-79): rays of every pixel of ``camera``
+        (a one-camera ``neraf_amd.cameras.Cameras``) -> chunked render -> image-shaped outputs [H,W,.], rgb clipped to [0,1].
+        ``eval=False`` is the viewer branch that additionally renders the audio model's outputs (:73-77): UI code, out of scope."""
+        if obb_box is not None:
+            raise NotImplementedError("oriented-box cropping is viewer functionality (the reference always passes None)")
+        if not eval and self.audio_model is not None and getattr(self.audio_model, "viewer_enabled", False):
+            raise NotImplementedError("viewer branch (NeRAF_model.py:73-77) is UI code, out of scope (SURVEY.md row 15)")
+        cam = camera.to(self.device)
+        rb = cam.generate_rays(0)
+        out = self.get_outputs_for_camera_ray_bundle(rb)
+        H, W = cam.height, cam.width
+        img = {k: v.reshape(H, W, -1) for k, v in out.items()}
+        img["rgb"] = torch.clip(img["rgb"], 0.0, 1.0)                                        # :78
+        return img
+
+    @torch.no_grad()
+    def get_image_metrics_and_images(self, outputs, batch):
+        """NerfactoModel.get_image_metrics_and_images [NS-recall]: PSNR and SSIM of the rendered frame against ``batch['image']``
+        [H,W,3], and the side-by-side image.  LPIPS needs pretrained network weights that cannot be obtained offline: omitted."""
+        gt = batch["image"].to(outputs["rgb"].device).float()
+        pred = outputs["rgb"]
+        metrics = {"psnr": float(psnr(pred, gt)), "ssim": float(ssim(pred, gt))}
+        images = {"img": torch.cat([gt, pred], dim=1), "accumulation": outputs["accumulation"], "depth": outputs["depth"]}
+        return metrics, images
+
+
+def psnr(pred: torch.Tensor, gt: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
+    """10 log10(range^2 / MSE) over all elements (torchmetrics PeakSignalNoiseRatio(data_range=1.0) as nerfacto builds it)."""
+    mse = torch.mean((pred.float() - gt.float()) ** 2)
+    return 10.0 * torch.log10(data_range ** 2 / mse)
+
+
+def ssim(pred: torch.Tensor, gt: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
+    """Structural similarity with torchmetrics' defaults (11x11 gaussian window, sigma 1.5, k1 0.01, k2 0.03), images [H,W,3]."""
+    import torch.nn.functional as F
+    x = pred.float().permute(2, 0, 1)[None]
+    y = gt.float().permute(2, 0, 1)[None]
+    ax = torch.arange(11, dtype=torch.float32, device=x.device) - 5
+    g = torch.exp(-(ax ** 2) / (2 * 1.5 ** 2))
+    g = (g / g.sum())
+    win = (g[:, None] * g[None, :])[None, None].expand(3, 1, 11, 11)
+    pad = 5
+    xp, yp = F.pad(x, (pad,) * 4, mode="reflect"), F.pad(y, (pad,) * 4, mode="reflect")
+    mu_x, mu_y = F.conv2d(xp, win, groups=3), F.conv2d(yp, win, groups=3)
+    sxx = F.conv2d(xp * xp, win, groups=3) - mu_x ** 2
+    syy = F.conv2d(yp * yp, win, groups=3) - mu_y ** 2
+    sxy = F.conv2d(xp * yp, win, groups=3) - mu_x * mu_y
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    s = ((2 * mu_x * mu_y + c1) * (2 * sxy + c2)) / ((mu_x ** 2 + mu_y ** 2 + c1) * (sxx + syy + c2))
+    return s[..., pad:-pad, pad:-pad].mean() if min(s.shape[-2:]) > 2 * pad else s.mean()

@@ -231,6 +231,25 @@ class NerfactoSpec:
     distortion_mult: float = 0.002
 
 
+class _TruncExp(torch.autograd.Function):
+    """nerfstudio's ``trunc_exp`` [NS-recall: field_components/activations.py]: forward ``exp(x)``, backward
+    ``g * exp(clamp(x, -15, 15))`` -- the density activation of NerfactoField and HashMLPDensityField."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(x.clamp(-15, 15))
+
+
+def trunc_exp(x: Tensor) -> Tensor:
+    return _TruncExp.apply(x)
+
+
 def anneal_value(step: int, spec: NerfactoSpec) -> float:
     x = float(np.clip(step / spec.anneal_iters, 0, 1))
     b = spec.anneal_slope
@@ -246,7 +265,7 @@ def proposal_density(pos: Tensor, P: Dict[str, Tensor], i: int, spec: NerfactoSp
     x = x * sel[:, None]
     enc = hash_encode(x, P[f"prop{i}.table"], spec.prop_grids[i])
     out = tcnn_mlp(enc, [P[f"prop{i}.w0"], P[f"prop{i}.w1"]])[:, :1]
-    dens = spec.average_init_density * torch.exp(out) * sel[:, None]
+    dens = spec.average_init_density * trunc_exp(out) * sel[:, None]
     return dens.reshape(*shp)
 
 
@@ -264,7 +283,7 @@ def field_forward(pos: Tensor, dirs: Tensor, cam_idx: Optional[Tensor], P: Dict[
     x = x * sel[:, None]
     enc = hash_encode(x, P["field.table"], spec.main_grid)
     h = tcnn_mlp(enc, [P["field.base_w0"], P["field.base_w1"]])          # [N,16]
-    density = spec.average_init_density * torch.exp(h[:, :1]) * sel[:, None]
+    density = spec.average_init_density * trunc_exp(h[:, :1]) * sel[:, None]
     geo = h[:, 1:1 + spec.geo_feat_dim]
     d = sh4_encoding((dirs.reshape(-1, 3) + 1.0) / 2.0)
     if training:

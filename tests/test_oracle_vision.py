@@ -79,3 +79,58 @@ def test_interlevel_loss_zero_when_proposal_bounds_fine_weights():
     w = torch.full((1, 8), 0.1)
     assert float(V.lossfun_outer(t, w, t, w).sum()) == 0.0
     assert float(V.lossfun_outer(t, w, t, w * 0.5).sum()) > 0.0
+
+
+def test_trunc_exp_backward_is_clamped_to_pm15():
+    """nerfstudio's trunc_exp [NS-recall]: forward exp(x), backward g * exp(clamp(x, -15, 15)) -- the three places it lives (this
+    oracle, field_bwd.hip's field and proposal backward) agree; test_gpu_vision_train drives logits past +-15 on the GPU."""
+    x = torch.tensor([-40.0, -15.0, -3.0, 0.0, 3.0, 15.0, 20.0], dtype=torch.float64, requires_grad=True)
+    y = V.trunc_exp(x)
+    np.testing.assert_allclose(y.detach().numpy(), np.exp(x.detach().numpy()))
+    y.sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), np.exp(np.clip(x.detach().numpy(), -15, 15)))
+
+
+def test_gradcheck_fp64_of_the_differentiable_pieces():
+    """fp64 finite-difference check (torch.autograd.gradcheck) of every differentiable piece of the unpinned oracle that the
+    HIP backward kernels are compared with: trilinear hash encode w.r.t. the table, the bias-free MLP, get_weights, the
+    composite, the distortion and interlevel ("outer") losses w.r.t. weights."""
+    torch.manual_seed(0)
+    g = V.GridSpec(3, 4, 16, 8)                       # tiny grid: 2 dense levels + 1 hashed one
+    assert g.sizes[-1] < g.resolutions[-1] ** 3
+    x = torch.rand(5, 3, dtype=torch.float64)
+    table = torch.randn(g.total, 2, dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda t: V.hash_encode(x, t, g), (table,), eps=1e-6, atol=1e-6)
+    ws = [torch.randn(8, 6, dtype=torch.float64, requires_grad=True), torch.randn(3, 8, dtype=torch.float64, requires_grad=True)]
+    xin = torch.randn(4, 6, dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda a, b, c: V.tcnn_mlp(a, [b, c]), (xin, ws[0], ws[1]), eps=1e-6, atol=1e-6)
+    dens = (torch.rand(3, 7, dtype=torch.float64) * 3).requires_grad_(True)
+    deltas = torch.rand(3, 7, dtype=torch.float64) + 0.05
+    assert torch.autograd.gradcheck(lambda d: V.get_weights(d, deltas), (dens,), eps=1e-6, atol=1e-6)
+    # losses on a 2-level toy sample hierarchy
+    R, S0, S1 = 2, 6, 4
+    e0 = torch.sort(torch.rand(R, S0 + 1, dtype=torch.float64), -1).values
+    e1 = torch.sort(torch.rand(R, S1 + 1, dtype=torch.float64), -1).values
+    z = torch.zeros(R, 3, dtype=torch.float64)
+    r0, r1 = V.RaySamples(z, z, e0, e0), V.RaySamples(z, z, e1, e1)
+    w0 = torch.rand(R, S0, dtype=torch.float64).requires_grad_(True)
+    w1 = torch.rand(R, S1, dtype=torch.float64).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a: V.distortion_loss([a], [r1]), (w1,), eps=1e-6, atol=1e-6)
+    assert torch.autograd.gradcheck(lambda a: V.interlevel_loss([a, w1.detach()], [r0, r1]), (w0,),
+                                    eps=1e-6, atol=1e-6)
+    rgb = torch.rand(R, S1, 3, dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda c, w: V.render(r1, c, w, True)[0], (rgb, w1), eps=1e-6, atol=1e-6)
+
+
+def test_hash_index_stays_inside_its_level_at_the_2pow19_boundary():
+    """Hashed levels of the main grid (T = 2^19): every corner index is < 2^19 for coordinates at the extreme corners of the
+    unit cube and for the finest level's largest integer coordinates; dense levels index below res^3 (rounded up to 8)."""
+    g = V.GridSpec(16, 16, 2048, 19)
+    marks = torch.zeros(g.total, 2)
+    x = torch.cat([torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1.0, 0.0, 1.0], [0.999999, 0.999999, 0.999999]]), torch.rand(4096, 3)])
+    # a table whose value is the level number: if any index left its level the encoded value would mix levels
+    for l in range(16):
+        marks[g.offsets[l]:g.offsets[l + 1]] = float(l)
+    enc = V.hash_encode(x, marks, g)
+    np.testing.assert_allclose(enc[:, ::2].numpy(), np.arange(16)[None, :].repeat(x.shape[0], 0), atol=2e-4)
+    assert max(g.sizes) == 1 << 19 and g.sizes[-1] == 1 << 19 and g.resolutions[-1] ** 3 > 1 << 19
