@@ -1,24 +1,28 @@
 #!/usr/bin/env python3
 """NeRAF hot-path benchmark on MI355X (contract: see the task brief / DESIGN.md "Measurement").
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--dataset raf|soundspaces] [--rays R --slices B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-A *step* is one pass of NeRAFPipeline.get_train_loss_dict (NeRAF_pipeline.py:166-222) over one synthetic
-batch already resident in HBM, at the RAF FurnishedRoom training shape (4096 rays + 2048 RIR STFT slices of
-513 bins, NeRAF_config.py:57,87); ``config.workload`` states exactly which stages are inside the timed region.
-One process per GPU; for N > 1 every rank owns its own shard of rays and slices (weak scaling) and gradients
-and loss sums are all-reduced over RCCL.
+A *step* is one pass of NeRAFPipeline.get_train_loss_dict (NeRAF_pipeline.py:166-222) + backward + optimizer steps over one
+synthetic batch already resident in HBM, at the RAF FurnishedRoom training shape (4096 rays + 2048 RIR STFT slices of 513 bins,
+NeRAF_config.py:57,87); ``config.workload`` states exactly which stages are inside the timed region.  One process per GPU; with
+``--gpus N`` and no launcher in the environment the script starts the N ranks itself (before anything touches the GPU).
+``--scaling weak`` (default): every rank owns --rays / --slices of its own; ``--scaling strong``: --rays / --slices are the GLOBAL
+batch, split contiguously over the ranks.  Gradients and STFT-loss sums are all-reduced over RCCL.
 
-Rank 0 prints ONE JSON line: whole-job field-samples/s, plus ``roofline`` for the dominant kernel family
-(HIP-event durations recorded inside the library over an instrumented replay of the same steps) and
-``cpu_baseline`` (the CPU oracle on this host, bounded sample of the same workload).
+Rank 0 prints ONE JSON line: whole-job field-samples/s (and rays/s, bins/s), ``roofline`` for the kernel family with the largest
+share of the step (HIP-event durations recorded inside the library over an instrumented replay of the same steps; every family
+with its own fraction of the gfx950 peak), and ``cpu_baseline`` (the CPU oracle on this host, bounded sample of the same workload).
 """
 import argparse
 import ctypes as C
 import gc
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,12 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
-PRIME_STEPS = 8             # untimed set-up steps before the --warmup steps (see main)
 HBM_PEAK_GBS = 8000.0       # HBM3E spec, same guide
+PRIME_STEPS = 8             # untimed set-up steps before the --warmup steps (see main)
 NACF_DENSE_FLOP_PER_SLICE_FWD = 40_836_464  # SURVEY.md 8(d), RAF head (C*F = 513)
 RESNET_FWD_GFLOP = 94.72
 C_, F_, T_ = 1, 513, 60
@@ -42,16 +43,33 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (NeRAF_config.py:87)")
-    ap.add_argument("--slices", type=int, default=2048, help="RIR STFT slices per GPU per step (NeRAF_config.py:57)")
+    ap.add_argument("--rays", type=int, default=4096, help="rays per step: per GPU (weak) or global (strong) (NeRAF_config.py:87)")
+    ap.add_argument("--slices", type=int, default=2048, help="RIR STFT slices per step: per GPU (weak) or global (strong) (NeRAF_config.py:57)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dataset", choices=("raf", "soundspaces"), default="raf",
                     help="audio head shape: raf = 1 x 513 bins, T = 60 (BASELINE configs[1..2], the default and the metric's config); "
-                         "soundspaces = 2 x 257 bins, T = 101 (configs[3]: per GPU 4096 rays + 808 slices)")
+                         "soundspaces = 2 x 257 bins, T = 101 (configs[3]: globally 32768 rays + 6464 slices, i.e. per GPU 4096 + 808)")
     return ap.parse_args()
 
 
+def _spawn_ranks(a):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks with torch.distributed.run as a CHILD process (nothing in
+    this process has touched the GPU yet -- only argparse and the standard library are loaded) and relay its output and exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def T(a):
+    import numpy as np
+    import torch
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
@@ -59,15 +77,19 @@ class JointStep:
     """cfg3 (RAF FurnishedRoom joint) training step, NeRAFPipeline.get_train_loss_dict order (NeRAF_pipeline.py:175-199):
        1. NeRAFVisionModel.get_outputs on the ray batch (sampler, 2 proposal nets, 2 PDF resamplings, fused field
           query, composite) + get_loss_dict (rgb MSE, interlevel, distortion)
-       2. audio_model.query_grid_one_batch: 4096 cells x 18 directions through the field, mean, slab write
+       2. audio_model.query_grid_one_batch: 4096 cells x 18 directions through the field, mean, slab write (data parallel: every
+          rank queries 1/world of the cells and the shares are assembled)
        3. ResNet3D(7x128^3 grid) -> 1024 feature (train-mode BatchNorm)
        4. audio get_outputs (GPU prologue + NAcF MLP) -> STFT loss
        5. ONE backward over the summed loss dict: NAcF (all grads + d/d feature) -> ResNet3D backward (dgrad/wgrad GEMMs,
           BatchNorm backward) -> grid-window gradient -> refresh backward into the field; radiance half (loss grads,
           proposal backward, fused field backward, weight-grad GEMMs) -> [RCCL all-reduce] -> GradScaler + fused Adam on
-          the radiance parameters (lr 1e-2) and the audio parameters (NAcF + ResNet3D, lr 1e-4)."""
+          the radiance parameters (lr 1e-2) and the audio parameters (NAcF + ResNet3D + field, lr 1e-4) -> scheduler steps.
 
-    def __init__(self, dev, R, B, world, dataset="raf"):
+    ``R`` / ``B`` are THIS rank's rays / slices; ``tag_rank`` selects which synthetic shard it holds."""
+
+    def __init__(self, dev, R, B, world, dataset="raf", start_step=20000):
+        import torch
         from neraf_amd import synth
         from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
         from neraf_amd.vision import NeRAFVisionModel, RayBundle
@@ -90,99 +112,197 @@ class JointStep:
         self.batch = {k: T(v).to(dev) for k, v in synth.audio_batch(B, C_, F_, T_, tag=f"bench.r{rank}").items()}
         self.gt = {"image": T(rb["rgb"]).to(dev)}
         # the reference's pipeline object: get_train_loss_dict (NeRAF_pipeline.py:166-222) inside Trainer.train_iteration, with its
-        # parameter groups / optimizers (NeRAF_config.py:115-127; the field parameters are in "fields" AND "audio_fields", :487)
+        # parameter groups / optimizers / schedulers (NeRAF_config.py:115-132; the field parameters are in "fields" AND
+        # "audio_fields", :487)
         from neraf_amd.pipeline import FixedBatchDataManager, NeRAFPipeline
         self.pipe = NeRAFPipeline(self.vm, self.am, datamanager=FixedBatchDataManager(self.bundle, self.gt, R),
-                                  audio_datamanager=FixedBatchDataManager(None, self.batch), start_step_audio=2000, world_size=world)
-        self.optimizers, self.scaler = self.pipe.make_optimizers(init_scale=65536.0)
+                                  audio_datamanager=FixedBatchDataManager(None, self.batch), start_step_audio=2000, world_size=world,
+                                  local_rank=rank)
+        self.opt_wrapper, self.scaler = self.pipe.make_optimizers(init_scale=65536.0, with_schedulers=True)
+        self.optimizers = self.opt_wrapper.steppers
         if world > 1:
-            # gradient averaging overlapped with the backward pass; every group is all-reduced, the ResNet3D's too (its forward
-            # accumulates BatchNorm statistics with fp32 atomics, so per-rank gradients differ in the last bits and the chaotic
-            # encoder amplifies that: only an all-reduce keeps the replicas identical)
+            # gradient averaging overlapped with the backward pass; every group is all-reduced, the ResNet3D's too: that keeps the
+            # replicas bit-identical although BatchNorm statistics are summed with order-dependent fp32 atomics
             self.pipe.attach_gradient_reducer()
-        self.i = 20000      # steady-state regime of the 400k-iteration schedule: anneal done, proposal nets updated every 6th step
+        self.i = start_step   # 20000: steady-state regime of the 400k-iteration schedule (anneal done, proposal nets every 6th step)
 
     def samples_per_step(self):
         return self.R + self.B * C_ * F_
 
     def step(self):
         self.i += 1
-        loss, _ = self.pipe.train_iteration(self.i, self.optimizers, self.scaler)
+        loss, _ = self.pipe.train_iteration(self.i, self.opt_wrapper, self.scaler)
         return loss
 
 
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
 def cpu_baseline(R, B):
-    """The CPU oracle (torch fp32; audio half pinned to the reference on G1-G5, radiance half unpinned) timed on this
-    host for the SAME stages.  A full step costs ~1 min of CPU, so the ray/slice-proportional stages are timed on a
-    1/8 sample and scaled by 8 while the per-step-constant ResNet3D forward is timed in full; the figure reported is
-    samples_per_step / extrapolated step time."""
+    """The CPU oracle (torch fp32; audio half pinned to the reference on G1-G5, radiance half unpinned) timed on this host, stage by
+    stage, for the stages the GPU step contains.  A complete CPU step is minutes, so each ray / cell / slice-proportional stage is
+    timed at TWO sample sizes (1/32 and 1/16 of the batch: 1 warm-up + 2-3 timed runs each, median) and extrapolated linearly to the
+    full batch -- t(N) = t(n2) + (t(n2) - t(n1)) / (n2 - n1) * (N - n2) -- which keeps the per-step fixed costs (dense hash-table
+    gradients, Adam over 13 M radiance parameters) counted once instead of multiplied by the sampling ratio; the per-step-constant
+    ResNet3D forward + backward runs on the full 7 x 128^3 grid.  Forward-only and forward+backward are reported separately, rays/s and
+    bins/s separately (the promised 3 + 10 repetitions do not fit the ~20 s budget of a default run)."""
+    import torch
     from neraf_amd import synth
     from oracle import audio as O
     from oracle import vision as V
     ncores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(ncores)
-    frac = 8
-    r, b = R // frac, B // frac
     spec = V.NerfactoSpec()
     tot = (spec.prop_grids[0].total, spec.prop_grids[1].total, spec.main_grid.total)
-    P = {k: T(v) for k, v in synth.vision_params(tot, num_train_data=210, table_scale=0.5).items()}
-    rb = synth.ray_batch(r, tag="bench.rays.r0")
+    P = {k: T(v).requires_grad_(True) for k, v in synth.vision_params(tot, num_train_data=210, table_scale=0.5).items()}
     sdn = {k: T(v).requires_grad_(True) for k, v in synth.nacf_state_dict(1187, 512, C_, F_).items()}
-    sdr = {k: T(v) for k, v in synth.resnet3d_state_dict(7).items()}
-    ab = {k: T(v) for k, v in synth.audio_batch(b, C_, F_, T_, tag="bench.r0").items()}
+    sdr = {k: (T(v).requires_grad_(True) if k.endswith("weight") or k.endswith("bias") else T(v)) for k, v in synth.resnet3d_state_dict(7).items()}
     aabb = T(synth.audio_aabb())
     grid = O.reset_grid(1 / 128)
-    coords = O.coordinates_to_render(1 / 128)[:r]
     dirs = O.fixed_viewing_directions()
     vaabb = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
-    opt = torch.optim.Adam(list(sdn.values()), lr=1e-4, eps=1e-15)
-    t = {}
-    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    t0 = time.perf_counter()
-    ov = V.nerfacto_forward(T(rb["origins"]), T(rb["directions"]), T(rb["camera_indices"]), Pg, spec, training=True,
-                            jitters=[T(j) for j in rb["jitters"]])
-    lv = V.vision_loss_dict(ov, T(rb["rgb"]), spec)
-    (lv["rgb_loss"] + lv["interlevel_loss"] + lv["distortion_loss"]).backward()
-    t["vision_train"] = (time.perf_counter() - t0) * frac
-    del Pg, ov, lv
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        ori = O.refresh_world_positions(coords, vaabb)
-        rg, dn = [], []
-        for j in range(18):
-            a, d_ = V.field_forward(ori, dirs[j].expand(r, -1), torch.zeros(r, dtype=torch.long), P, spec, contract=False, aabb=vaabb)
-            rg.append(a); dn.append(d_[:, None])
-        grid = O.grid_refresh_scatter(grid, coords, torch.stack(rg).mean(0), torch.stack(dn).mean(0), 1 / 128)
-        t["refresh"] = (time.perf_counter() - t0) * frac
-        O.resnet3d_forward(grid.unsqueeze(0), sdr, train=True)   # warm-up
-        t0 = time.perf_counter()
-        feat = O.resnet3d_forward(grid.unsqueeze(0), sdr, train=True).flatten()
-        t["resnet3d_fwd"] = time.perf_counter() - t0
+    opt_v = torch.optim.Adam([v for v in P.values()], lr=1e-2, eps=1e-15)
+    opt_a = torch.optim.Adam(list(sdn.values()) + [v for v in sdr.values() if v.requires_grad], lr=1e-4, eps=1e-15)
 
-    def audio():
-        opt.zero_grad(set_to_none=True)
-        f = feat.clone().requires_grad_(True)
-        y = O.audio_get_outputs(ab, f, sdn, aabb, T_)
-        l = O.audio_loss_dict(y, ab["data"])
-        (l["audio_sc_loss"] + l["audio_mag_loss"]).backward()
-        opt.step()
-    audio()
-    t0 = time.perf_counter()
-    audio()
-    t["audio_train"] = (time.perf_counter() - t0) * frac
-    step_s = sum(t.values())
-    return {"value": (R + B * C_ * F_) / step_s, "unit": "field-samples/s", "cores": ncores, "kind": "port",
-            "sample": ("1/8 sample (%d rays, %d refresh cells, %d slices) scaled x8 + one full ResNet3D forward; extrapolated "
-                       "step %.1f s = %s; torch-CPU fp32 oracle") % (r, r, b, step_s, {k: round(v, 2) for k, v in t.items()})}
+    def timed(fn, reps, warm=True):
+        if warm:
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return _median(ts)
+
+    def vision(n, train):
+        rb = synth.ray_batch(n, tag="bench.rays.r0")
+
+        def run():
+            with torch.set_grad_enabled(train):
+                ov = V.nerfacto_forward(T(rb["origins"]), T(rb["directions"]), T(rb["camera_indices"]), P, spec, training=True,
+                                        jitters=[T(j) for j in rb["jitters"]])
+                lv = V.vision_loss_dict(ov, T(rb["rgb"]), spec)
+                if train:
+                    opt_v.zero_grad(set_to_none=True)
+                    (lv["rgb_loss"] + lv["interlevel_loss"] + lv["distortion_loss"]).backward()
+                    opt_v.step()
+        return run
+
+    def refresh(n, train):
+        coords = O.coordinates_to_render(1 / 128)[:n]
+
+        def run():
+            with torch.set_grad_enabled(train):
+                ori = O.refresh_world_positions(coords, vaabb)
+                # the 18 directions of every cell in ONE batched field call (direction-major, NeRAF_model.py:327-333)
+                a, d_ = V.field_forward(ori.repeat(18, 1), dirs.repeat_interleave(n, dim=0), torch.zeros(18 * n, dtype=torch.long), P, spec,
+                                        contract=False, aabb=vaabb)
+                rgb_m, den_m = a.reshape(18, n, 3).mean(0), d_.reshape(18, n, 1).mean(0)
+                O.grid_refresh_scatter(grid, coords, rgb_m.detach(), den_m.detach(), 1 / 128)
+                if train:      # the audio loss reaches the field through these cells (NeRAF_model.py:395-400); unit upstream gradient
+                    opt_v.zero_grad(set_to_none=True)
+                    (rgb_m.sum() + den_m.sum()).backward()
+        return run
+
+    feat_box = {}
+
+    def resnet(train):
+        def run():
+            with torch.set_grad_enabled(train):
+                f = O.resnet3d_forward(grid.unsqueeze(0), sdr, train=True).flatten()
+                feat_box["feat"] = f.detach()
+                if train:
+                    opt_a.zero_grad(set_to_none=True)
+                    f.sum().backward()
+        return run
+
+    def audio(n, train):
+        ab = {k: T(v) for k, v in synth.audio_batch(n, C_, F_, T_, tag="bench.r0").items()}
+
+        def run():
+            with torch.set_grad_enabled(train):
+                f = feat_box["feat"].clone().requires_grad_(train)
+                y = O.audio_get_outputs(ab, f, sdn, aabb, T_)
+                l = O.audio_loss_dict(y, ab["data"])
+                if train:
+                    opt_a.zero_grad(set_to_none=True)
+                    (l["audio_sc_loss"] + l["audio_mag_loss"]).backward()
+                    opt_a.step()
+        return run
+
+    def extrapolated(make, n_full, reps):
+        n1, n2 = max(n_full // 32, 8), max(n_full // 16, 16)
+        out = {}
+        for train in (False, True):
+            t1, t2 = timed(make(n1, train), reps), timed(make(n2, train), reps, warm=False)
+            slope = max((t2 - t1) / (n2 - n1), 0.0)
+            out["train" if train else "fwd"] = t2 + slope * (n_full - n2)
+        return out, (n1, n2)
+
+    t = {}
+    v, nv = extrapolated(vision, R, 2)
+    rf, nr = extrapolated(refresh, R, 2)
+    t["resnet3d_fwd"], t["resnet3d_train"] = timed(resnet(False), 2), timed(resnet(True), 2)
+    au, na = extrapolated(audio, B, 3)
+    t.update({"vision_fwd": v["fwd"], "vision_train": v["train"], "refresh_fwd": rf["fwd"], "refresh_train": rf["train"],
+              "audio_fwd": au["fwd"], "audio_train": au["train"]})
+    step_train = t["vision_train"] + t["refresh_train"] + t["resnet3d_train"] + t["audio_train"]
+    step_fwd = t["vision_fwd"] + t["refresh_fwd"] + t["resnet3d_fwd"] + t["audio_fwd"]
+    bins = B * C_ * F_
+    return {"value": (R + bins) / step_train, "unit": "field-samples/s", "cores": ncores, "kind": "port",
+            "rays_per_s_train": R / (t["vision_train"] + t["refresh_train"]), "rays_per_s_fwd": R / (t["vision_fwd"] + t["refresh_fwd"]),
+            "bins_per_s_train": bins / (t["resnet3d_train"] + t["audio_train"]), "bins_per_s_fwd": bins / (t["resnet3d_fwd"] + t["audio_fwd"]),
+            "field_samples_per_s_fwd": (R + bins) / step_fwd,
+            "stage_seconds_full_step": {k: round(v_, 3) for k, v_ in t.items()},
+            "sample": ("per stage 1 warm-up (at the smaller sample) + 2-3 timed runs per sample size, median; radiance step at %d and %d rays, grid refresh at %d and %d cells x 18 "
+                       "directions, NAcF + STFT loss at %d and %d slices, each extrapolated linearly to the full batch (%d rays / cells, %d "
+                       "slices); ResNet3D forward + backward on the full 7x128^3 grid; train = forward + backward + torch Adam (radiance "
+                       "parameters lr 1e-2; NAcF + ResNet3D lr 1e-4); the refresh backward uses a unit upstream gradient; extrapolated full "
+                       "step %.1f s train / %.1f s forward; torch-CPU fp32 oracle, %d threads")
+                      % (nv[0], nv[1], nr[0], nr[1], na[0], na[1], R, B, step_train, step_fwd, ncores)}
+
+
+def _rocprof_reference():
+    """Average kernel durations from the newest committed rocprofv3 --kernel-trace --stats summary of this command (profiles/), so
+    that the HIP-event durations in ``roofline`` can be cross-checked without re-running the profiler."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_joint_step_kernel_stats.csv")))
+    if not files:
+        return None, {}
+    rows = {}
+    with open(files[-1]) as f:
+        for r in csv.DictReader(f):
+            rows[r["Name"]] = (int(r["Calls"]), float(r["TotalDurationNs"]))
+    return os.path.basename(files[-1]), rows
+
+
+def _family_regex(pattern: str):
+    """neraf_prof_kernel_name patterns ('a<64, 64, *, 160|128> | b + c') -> regex over rocprof kernel names."""
+    alts = []
+    for part in re.split(r"\s*[|+]\s*(?![^<]*>)", pattern):
+        part = part.strip()
+        if not part:
+            continue
+        rx = re.escape(part).replace(r"\*", r"[^,>]+").replace(r"\|", "|")
+        rx = re.sub(r"(\d+)\|(\d+)", r"(?:\1|\2)", rx)
+        alts.append(rx)
+    return re.compile("(?:" + "|".join(alts) + ")")
 
 
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_spawn_ranks(a))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    import numpy as np  # noqa: F401
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     # NERAF_BENCH_SHARE_GPU=1 (test aid): several ranks share the visible GPUs and talk over gloo -- exercises the multi-rank
     # code path (sharding, overlapped gradient reducer, global loss sums) on a 1-GPU box; never a measurement.
@@ -199,11 +319,21 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)   # RCCL
     from neraf_amd import _lib
+    from neraf_amd.parallel import shard_range
 
     if a.dataset == "soundspaces":
         global C_, F_, T_
         C_, F_, T_ = 2, 257, 101
-    st = JointStep(dev, a.rays, a.slices, world, dataset=a.dataset)
+    if a.scaling == "strong":
+        lo, hi = shard_range(a.rays, rank, world)
+        R_local = hi - lo
+        lo, hi = shard_range(a.slices, rank, world)
+        B_local = hi - lo
+        R_global, B_global = a.rays, a.slices
+    else:
+        R_local, B_local = a.rays, a.slices
+        R_global, B_global = a.rays * world, a.slices * world
+    st = JointStep(dev, R_local, B_local, world, dataset=a.dataset)
     # Setup, before the W warm-up steps: the first steps of a run build the optimizer launch plans (the step with the first
     # proposal-network update builds a second one), capture the ResNet3D hipGraphs and grow the allocator pools --
     # tools/step_trace.py shows them as 10-400 ms steps -- and a full Python garbage collection over the module graph costs
@@ -224,59 +354,97 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        st.step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_steps(k):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            st.step()
+        sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
 
-    # ---- instrumented replay (not timed): per-kernel-family HIP-event durations
+    elapsed = timed_steps(a.steps)
+
+    # ---- the other proposal-update regime (not the headline value): the first 5000 iterations back-propagate through the proposal
+    # networks on EVERY step (ProposalNetworkSampler's warm-up schedule); the steady state above does so every 6th step
+    steady_i = st.i
+    st.i = 2500          # audio branch running (start_step_audio = 2000), proposal warm-up not over (5000)
+    for _ in range(3):
+        st.step()
+    early = timed_steps(min(a.steps, 12))
+    early_ms = early / min(a.steps, 12) * 1e3
+    st.i = steady_i
+    for _ in range(2):
+        st.step()
+
+    # ---- the per-rank REPLICATED part of a data-parallel step: ResNet3D forward + backward on the (replicated) grid
+    torch.cuda.synchronize()
+    net = st.am.resnet3d
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    w1024 = torch.ones(1024, device=dev)
+    for it in range(6):
+        if it == 1:
+            ev0.record()
+        f = net(st.am.grid.unsqueeze(0)).flatten()
+        (f * w1024).sum().backward()
+    ev1.record()
+    torch.cuda.synchronize()
+    resnet_ms = ev0.elapsed_time(ev1) / 5
+
+    # ---- instrumented replay (not timed): per-kernel-family HIP-event durations, as recorded (no overhead subtraction: an event
+    # pair around a few-microsecond kernel reads ~3 us more than rocprofv3's kernel duration, so small kernels are UNDER-stated)
     lib = _lib.load()
     h = _lib.ctx(local)
-    # what an event pair measures around nothing: subtracted per launch below (a 10 us kernel would read 13 us otherwise)
-    ov = C.c_double()
-    word = torch.zeros(1, dtype=torch.int32, device=dev)
-    _lib.check(lib.neraf_prof_event_overhead(h, word.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(ov)), local)
     lib.neraf_prof_enable(h, 1)
-    nprof = min(a.steps, 10)
+    nprof = min(a.steps, 12)
     for _ in range(nprof):
         st.step()
     torch.cuda.synchronize()
+    ref_name, ref_rows = _rocprof_reference()
     fams = []
     kid = 0
     while lib.neraf_prof_kernel_name(kid):
         ms, n, w = C.c_double(), C.c_int(), C.c_double()
         _lib.check(lib.neraf_prof_summary(h, kid, C.byref(ms), C.byref(n), C.byref(w)), local)
         if n.value:
-            raw_ms = ms.value
-            ms.value = max(raw_ms - n.value * ov.value, 0.25 * raw_ms)
+            name = lib.neraf_prof_kernel_name(kid).decode()
             is_bytes = kid in (2, 3, 5, 6, 7)     # gather / scatter kernels are priced in bytes against HBM (ids: csrc/common.h PROF_*)
+            peak = HBM_PEAK_GBS if is_bytes else MFMA_PEAK_TFLOPS
             rate = w.value / (ms.value * 1e-3) / (1e9 if is_bytes else 1e12) if ms.value > 0 else 0.0
-            fams.append({"kernel": lib.neraf_prof_kernel_name(kid).decode(), "bound": "hbm" if is_bytes else "mfma",
-                         "launches_per_step": n.value / nprof, "avg_us": ms.value * 1e3 / n.value,
-                         "ms_per_step": ms.value / nprof, "achieved": rate, "unit": "GB/s" if is_bytes else "TFLOP/s",
-                         "work_per_launch": w.value / n.value, "avg_us_with_event_overhead": raw_ms * 1e3 / n.value})
+            fam = {"kernel": name, "bound": "hbm" if is_bytes else "mfma", "launches_per_step": n.value / nprof,
+                   "avg_us": ms.value * 1e3 / n.value, "ms_per_step": ms.value / nprof, "achieved": rate,
+                   "unit": "GB/s" if is_bytes else "TFLOP/s", "peak": peak, "frac": rate / peak, "work_per_launch": w.value / n.value}
+            if ref_rows:
+                rx = _family_regex(name)
+                calls = sum(c for k, (c, _) in ref_rows.items() if rx.search(k))
+                tot = sum(t for k, (_, t) in ref_rows.items() if rx.search(k))
+                if calls:
+                    fam["rocprof_avg_us"] = tot / calls / 1e3
+                    fam["rocprof_frac"] = (w.value / n.value) / (tot / calls * 1e-9) / (1e9 if is_bytes else 1e12) / peak
+            fams.append(fam)
         kid += 1
     lib.neraf_prof_enable(h, 0)
     sync()
 
     if rank == 0:
-        samples = st.samples_per_step() * world * a.steps
+        bins = B_global * C_ * F_
+        samples = (R_global + bins) * a.steps
         # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot wrap itself from inside):
         # tools/gpu_pmc.sh -> profiles/*_pmc_traffic.json (FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE)
         import glob
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-        pmc = json.load(open(pmc_files[-1]))["families"] if pmc_files and a.rays == 4096 and a.slices == 2048 and a.dataset == "raf" else {}
+        default_shape = a.rays == 4096 and a.slices == 2048 and a.dataset == "raf" and world == 1
+        pmc = json.load(open(pmc_files[-1]))["families"] if pmc_files and default_shape else {}
         for k in fams:
             t = pmc.get(k["kernel"])
             k["traffic"] = t["hbm_bytes_per_launch"] if t else None
         dom = max(fams, key=lambda k: k["ms_per_step"]) if fams else None
+        ms_step = elapsed / a.steps * 1e3
         out = {
             "metric": "field-samples/sec (rays + RIR STFT bins)",
             "value": samples / elapsed,
@@ -285,35 +453,52 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "priming_steps": PRIME_STEPS,
-            "ms_per_step": elapsed / a.steps * 1e3,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
+            "rays_per_s": R_global * a.steps / elapsed,
+            "bins_per_s": bins * a.steps / elapsed,
+            "steps_per_s": a.steps / elapsed,
+            "regimes": {"steady_state_ms_per_step": ms_step,
+                        "iterations_2000_to_5000_ms_per_step": early_ms,
+                        "note": "value is the steady state of the 400k-iteration schedule (step 20000: proposal networks back-propagated every "
+                                "6th step, nerfacto's schedule); before iteration 5000 they are back-propagated (almost) every step; before iteration 2000 the audio branch is off"},
+            "replicated_per_rank": {"resnet3d_fwd_bwd_ms": resnet_ms,
+                                    "note": "data parallel: the ResNet3D forward + backward runs on every rank (the grid and its weights are "
+                                            "replicated); rays, RIR slices and the grid-refresh cells are sharded"},
             "config": {
                 "workload": (("RAF FurnishedRoom joint step (BASELINE configs[2] shape: %d rays + %d RIR slices x 513 bins per GPU): " if a.dataset == "raf"
                               else "SoundSpaces joint step (BASELINE configs[3] head shape: %d rays + %d RIR slices x 2 x 257 bins per GPU): ") +
-                             "radiance forward (sampler, 2 proposal nets, 2 PDF resamplings, fused field query, composite) + rgb/"
-                             "interlevel/distortion losses -> grid refresh (%d cells x 18 dirs) -> ResNet3D forward on the 7x128^3 "
+                             "radiance forward (camera-optimizer hook, sampler, 2 proposal nets, 2 PDF resamplings, fused field query, composite) + rgb/"
+                             "interlevel/distortion losses -> grid refresh (%d cells x 18 dirs%s) -> ResNet3D forward on the 7x128^3 "
                              "grid -> audio prologue + NAcF MLP -> STFT loss -> one backward (NAcF -> ResNet3D -> refreshed grid cells -> "
                              "field; radiance losses -> proposal nets + fused field backward + weight-grad GEMMs) -> %sGradScaler + "
-                             "fused Adam: proposal_networks + fields (lr 1e-2), then audio_fields = NAcF + ResNet3D + fields again (lr 1e-4), as NeRAF_pipeline.py:487 groups them.  Not modelled: camera-pose optimizer "
-                             "(nerfstudio CameraOptimizer), data loading.")
-                             % (a.rays, a.slices, a.rays, "RCCL all-reduce -> " if world > 1 else ""),
-                "rays_per_gpu": a.rays, "slices_per_gpu": a.slices, "parallelism": f"dp{world}",
+                             "fused Adam: proposal_networks + fields (lr 1e-2 -> 1e-4 @200k), then audio_fields = NAcF + ResNet3D + fields again "
+                             "(lr 1e-4 -> 1e-8, 2000 warm-up), as NeRAF_pipeline.py:487 / NeRAF_config.py:115-132 group and schedule them -> "
+                             "scheduler steps.  Not inside: data loading (batches are resident), camera-pose refinement (the bench bundle "
+                             "carries no trainable poses).")
+                             % (R_local, B_local, 4096, ", sharded over the ranks" if world > 1 else "", "RCCL all-reduce -> " if world > 1 else ""),
+                "rays_per_gpu": R_local, "slices_per_gpu": B_local, "global_rays": R_global, "global_slices": B_global,
+                "parallelism": f"dp{world}",
             },
         }
         if dom:
-            peak = HBM_PEAK_GBS if dom["bound"] == "hbm" else MFMA_PEAK_TFLOPS
-            out["roofline"] = {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": peak,
-                               "unit": dom["unit"], "frac": dom["achieved"] / peak, "traffic": dom["traffic"],
+            out["roofline"] = {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
+                               "unit": dom["unit"], "frac": dom["frac"], "traffic": dom["traffic"],
                                "traffic_source": os.path.basename(pmc_files[-1]) if pmc and dom["traffic"] is not None else None,
                                "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                                "algorithmic_work_per_launch": dom["work_per_launch"],
-                               "dense_equiv_gflop_per_step": {"nacf_fwd_bwd": 3 * NACF_DENSE_FLOP_PER_SLICE_FWD * a.slices / 1e9,
-                                                              "resnet3d_fwd": RESNET_FWD_GFLOP},
-                               "event_pair_overhead_us": ov.value * 1e3, "all_kernel_families": fams}
+                               "selection": "family with the largest share of the step (ms_per_step) among the instrumented families",
+                               "durations": "HIP events on the launch stream, as recorded (no overhead subtraction)",
+                               "rocprof_reference": ref_name,
+                               "dense_equiv_gflop_per_step": {"nacf_fwd_bwd": 3 * NACF_DENSE_FLOP_PER_SLICE_FWD * B_local / 1e9,
+                                                              "resnet3d_fwd_bwd": 3 * RESNET_FWD_GFLOP},
+                               "whole_step_mfma_frac": ((3 * NACF_DENSE_FLOP_PER_SLICE_FWD * B_local / 1e9 + 3 * RESNET_FWD_GFLOP) / 1e3)
+                                                       / (ms_step * 1e-3) / MFMA_PEAK_TFLOPS,
+                               "all_kernel_families": fams}
         g_cap, g_launch = C.c_int(), C.c_int()
         out["hip_graphs"] = {"enabled": bool(lib.neraf_graph_stats(h, C.byref(g_cap), C.byref(g_launch))), "captures": g_cap.value,
                              "launches": g_launch.value}

@@ -133,6 +133,7 @@ class NeRAFAudioModel(nn.Module):
                                           power=1)                  # :139
         self.use_grid = config.use_grid
         self.loss_factor = config.loss_factor
+        self.process_group = process_group
         self.criterion_name = config.criterion
         if self.criterion_name == "MSE":                            # :141-149
             self.criterion = None
@@ -210,11 +211,24 @@ class NeRAFAudioModel(nn.Module):
             nvox = self.grid.shape[1] * self.grid.shape[2] * self.grid.shape[3]
             differentiable = (self.training and torch.is_grad_enabled() and renderer_rgb is not None
                               and any(p.requires_grad for p in module.grad_params()))
+            dp = self._dp_world()
             if differentiable:
                 # the grid is detached and the fresh values keep their graph (:395-400): vals is an autograd node over the
                 # radiance-field parameters, consumed by the ResNet3D node in scene_feature()
-                vals = _RefreshFn.apply(module, coords, aabb, dirs, nd, self._delta, self._refresh_consts(dirs, batch_size),
-                                        *module.grad_params())
+                if dp is None:
+                    vals = _RefreshFn.apply(module, coords, aabb, dirs, nd, self._delta, self._refresh_consts(dirs, batch_size),
+                                            *module.grad_params())
+                else:
+                    # data parallel (SURVEY 8e "Partitioning"): every rank holds the same field, so rank r queries only its
+                    # share of the window's cells (and back-propagates only through those); the shares are assembled into the
+                    # same [4, n] values on every rank -- the grid stays bit-identical across replicas (the field query has no
+                    # atomics) at 1/world of the refresh work per rank
+                    from .parallel import gather_shards, shard_range
+                    group, rank, world = dp
+                    lo, hi = shard_range(batch_size, rank, world)
+                    local = _RefreshFn.apply(module, coords[lo:hi], aabb, dirs, nd, self._delta, self._refresh_consts(dirs, hi - lo),
+                                             *module.grad_params()) if hi > lo else torch.zeros((4, 0), device=coords.device)
+                    vals = gather_shards(local, lo, hi, batch_size, group)
                 with torch.no_grad():
                     self.grid.view(7, nvox)[0:4, i:i + batch_size] = vals
                 self._window = (i, batch_size, vals)
@@ -244,6 +258,18 @@ class NeRAFAudioModel(nn.Module):
             self._feat_key = None
         finally:
             module.spatial_distortion = saved                                           # :407
+
+    def _dp_world(self):
+        """(group, rank, world) when the model was built with a process group of more than one rank, else None."""
+        pg = getattr(self, "process_group", None)
+        if pg is None:
+            return None
+        import torch.distributed as dist
+        if not dist.is_available() or not dist.is_initialized():
+            return None
+        group = None if pg is True else pg
+        world = dist.get_world_size(group)
+        return (group, dist.get_rank(group), world) if world > 1 else None
 
     def _refresh_consts(self, dirs, n):
         """(directions [n*nd,3] cell-major, zero frustum extents [n*nd,2], camera index 0 [n*nd]) of a refresh window: constant

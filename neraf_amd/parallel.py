@@ -182,3 +182,34 @@ def allreduce_loss_sums(sums: torch.Tensor, n_local: int, group=None, uniform_sh
 def finalize_stft_loss(sums: torch.Tensor, n_total: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """{sc, mag} from (global) sums -- the arithmetic of neraf_stft_loss_finalize, for host-side checks."""
     return torch.sqrt(sums[0]) / torch.sqrt(sums[1]), sums[2] / n_total
+
+
+class _GatherShards(torch.autograd.Function):
+    """Differentiable assembly of a tensor whose LAST dimension is sharded over the ranks: rank r holds ``local`` = full[..., lo:hi].
+
+    Forward: every rank writes its shard into zeros and the buffers are summed (x + 0 = x exactly, so the result is bit-identical
+    on every rank whatever the reduction order -- an all-gather that tolerates uneven shards).
+
+    Backward, under this package's data-parallel convention (``GradientReducer`` AVERAGES parameter gradients over ranks, and every
+    rank's upstream gradient is world x its share of the global one, see ``_StftLossFn.backward``): the parameters behind
+    ``local`` receive on rank r ``sum_over_ranks(d)[..., lo:hi]``, so that the average over ranks of the resulting parameter
+    gradients equals the single-process gradient through the full tensor."""
+
+    @staticmethod
+    def forward(ctx, local: torch.Tensor, lo: int, hi: int, total: int, group):
+        full = torch.zeros(local.shape[:-1] + (total,), dtype=local.dtype, device=local.device)
+        full[..., lo:hi] = local
+        dist.all_reduce(full, group=group)
+        ctx.lo, ctx.hi, ctx.group = lo, hi, group
+        return full
+
+    @staticmethod
+    def backward(ctx, d: torch.Tensor):
+        d = d.contiguous().clone()
+        dist.all_reduce(d, group=ctx.group)
+        return d[..., ctx.lo:ctx.hi].contiguous(), None, None, None, None
+
+
+def gather_shards(local: torch.Tensor, lo: int, hi: int, total: int, group=None) -> torch.Tensor:
+    """See ``_GatherShards``: full[..., total] from per-rank shards [..., lo:hi]; differentiable; identical on every rank."""
+    return _GatherShards.apply(local, lo, hi, total, group)

@@ -116,3 +116,51 @@ def test_world2_gloo_loss_and_gradients():
         np.testing.assert_allclose(g0, [1.5, 3.0, 4.5])          # mean over ranks of (rank+1)*(i+1)
     assert abs(res[0][6] - res[0][4]) > 1e-6 or abs(res[1][6] - res[1][4]) > 1e-6
     assert res[0][9] == (0, 32) and res[1][9] == (32, 64)
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 7                                               # uneven shards: 4 + 3 cells
+        theta = torch.nn.Parameter(torch.linspace(0.3, 1.1, 4))
+        w = [torch.from_numpy(synth.normal(f"dp.gather.w{r}", (4, n))) for r in range(world)]     # rank r's share of the global loss
+        cells = torch.arange(1, n + 1, dtype=torch.float32)
+
+        def vals_of(c):                                      # the "refresh": values of cells c as a function of the shared parameters
+            return torch.sin(theta[:, None] * c[None, :])
+        lo, hi = parallel.shard_range(n, rank, world)
+        full = parallel.gather_shards(vals_of(cells[lo:hi]), lo, hi, n)
+        # package convention: every rank back-propagates world x its share of the global loss, parameter gradients are then AVERAGED
+        (world * (full * w[rank]).sum()).backward()
+        g = theta.grad.clone()
+        dist.all_reduce(g)
+        g /= world
+        # single process: all cells, the whole loss
+        theta2 = theta.detach().clone().requires_grad_(True)
+        ref_full = torch.sin(theta2[:, None] * cells[None, :])
+        sum((ref_full * w[r]).sum() for r in range(world)).backward()
+        q.put((rank, full.detach().numpy(), ref_full.detach().numpy(), g.numpy(), theta2.grad.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gather_shards_forward_identical_and_gradient_equals_single_process():
+    """The data-parallel grid refresh (each rank queries its share of the window, neraf_amd/model.py) assembles the shares with
+    parallel.gather_shards: bit-identical values on every rank, and -- under the package's convention (world x local share of the
+    loss, averaged parameter gradients) -- the single-process gradient for the parameters behind the shares."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1])                      # identical on both ranks, bit for bit
+    for _, full, ref_full, g, g_ref in res:
+        np.testing.assert_array_equal(full, ref_full)
+        np.testing.assert_allclose(g, g_ref, rtol=1e-6)

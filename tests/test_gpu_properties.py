@@ -131,6 +131,6 @@ def test_bad_arguments_return_einval_with_message():
     assert rc != 0 and len(lib.neraf_last_error(h)) > 0
     d = _lib.ResnetDesc(96, 7, 1024)                                  # unsupported grid size
     assert lib.neraf_resnet3d_workspace_bytes(C.byref(d)) == 0 and lib.neraf_resnet3d_num_convs(C.byref(d)) == -1
-    rc = lib.neraf_fused_adam(h, None, None, None, None, 0, None, 0, 0.9, 0.999, 1e-8, None, None, None, st)
+    rc = lib.neraf_fused_adam(h, None, None, None, None, 0, None, 0, 0, 0.9, 0.999, 1e-8, None, None, None, st)
     assert rc != 0
     torch.cuda.synchronize()

@@ -1,0 +1,85 @@
+"""Worker of tests/test_gpu_dp2.py: one of two ranks that SHARE the single GPU of the test box and talk over gloo -- the
+multi-rank code path (ray / slice sharding, sharded grid refresh + assembly, global STFT-loss sums, overlapped gradient reducer,
+fused optimizers) on the real HIP pipeline.  Started as a fresh process (nothing has touched the GPU before the imports below).
+
+    python tests/tools/dp2_worker.py <out.json>      with RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT in the environment
+"""
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def digest(tensors):
+    h = hashlib.sha256()
+    for t in tensors:
+        h.update(t.detach().contiguous().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def main():
+    out_path = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import bench
+    from neraf_amd import synth
+    from neraf_amd.losses import STFTLoss
+    res = {"rank": rank}
+    torch.manual_seed(0)                                  # identical initial weights on every rank
+    js = bench.JointStep(dev, 512, 256, world)            # 64^3 would be faster, but the bench object is the product configuration
+    names = [n for n, _ in list(js.vm.named_parameters()) + list(js.am.named_parameters())]
+    params = [p for _, p in list(js.vm.named_parameters()) + list(js.am.named_parameters())]
+    res["init"] = digest(params)
+    losses = []
+    for _ in range(5):
+        js.i += 1
+        loss, ld = js.pipe.train_iteration(js.i, js.optimizers, js.scaler)
+        losses.append(float(loss))
+        assert js.am._dp_world() is not None
+    torch.cuda.synchronize()
+    res["losses"] = losses
+    res["params"] = digest(params)
+    res["per_param"] = {n: digest([p]) for n, p in zip(names, params)}
+    res["grid"] = digest([js.am.grid])
+    res["scale"] = js.scaler.get_scale()
+
+    # ---- averaged data-parallel gradient of the audio loss == single-process gradient on the concatenated batch
+    C_, F_, T_ = 1, 513, 60
+    B = 192
+    full = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in synth.audio_batch(B, C_, F_, T_, tag="dp2.audio").items()}
+    feat = torch.from_numpy(synth.uniform("dp2.feat", (1024,), 0.0, 2.0)).to(dev)
+    field = js.am.field
+    aabb = js.am.aabb
+
+    def grads(batch, group):
+        for p in field.parameters():
+            p.grad = None
+        y = field.forward_queries(feat, batch["time_query"], batch["mic_pose"], batch["source_pose"], batch["rot"], aabb, T_)
+        l = STFTLoss("mse", process_group=group)(y, batch["data"])
+        (l["audio_sc_loss"] * 1e-4 + l["audio_mag_loss"] * 1e-3).backward()
+        return [p.grad.detach().clone() for p in field.parameters()], float(l["audio_sc_loss"]), float(l["audio_mag_loss"])
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    g_dp, sc_dp, mag_dp = grads({k: v[lo:hi] for k, v in full.items()}, True)
+    for g in g_dp:                                        # what GradientReducer does on gloo: sum, then divide
+        dist.all_reduce(g)
+        g /= world
+    g_ref, sc_ref, mag_ref = grads(full, None)
+    rel = [float((a - b).norm() / (b.norm() + 1e-30)) for a, b in zip(g_dp, g_ref)]
+    res["audio_grad_rel"] = rel
+    res["audio_loss"] = [sc_dp, sc_ref, mag_dp, mag_ref]
+    json.dump(res, open(out_path, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
