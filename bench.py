@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--slices", type=int, default=2048, help="RIR STFT slices per step: per GPU (weak) or global (strong) (NeRAF_config.py:57)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plain", action="store_true",
+                    help="priming + warm-up + timed steps only (no second regime, no instrumented replay, no CPU baseline): the form that "
+                         "runs under rocprofv3, so that its per-kernel totals divide by exactly PRIME_STEPS + warmup + steps")
     ap.add_argument("--dataset", choices=("raf", "soundspaces"), default="raf",
                     help="audio head shape: raf = 1 x 513 bins, T = 60 (BASELINE configs[1..2], the default and the metric's config); "
                          "soundspaces = 2 x 257 bins, T = 101 (configs[3]: globally 32768 rays + 6464 slices, i.e. per GPU 4096 + 808)")
@@ -369,6 +372,17 @@ def main():
         return el
 
     elapsed = timed_steps(a.steps)
+
+    if a.plain:
+        if rank == 0:
+            print(json.dumps({"metric": "field-samples/sec (rays + RIR STFT bins)", "value": (R_global + B_global * C_ * F_) * a.steps / elapsed,
+                              "unit": "field-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "priming_steps": PRIME_STEPS,
+                              "ms_per_step": elapsed / a.steps * 1e3, "scaling": a.scaling, "plain": True,
+                              "steps_executed_in_process": PRIME_STEPS + a.warmup + a.steps}))
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
 
     # ---- the other proposal-update regime (not the headline value): the first 5000 iterations back-propagate through the proposal
     # networks on EVERY step (ProposalNetworkSampler's warm-up schedule); the steady state above does so every 6th step

@@ -97,7 +97,7 @@ extern "C" const char* neraf_prof_kernel_name(int kernel_id) {
                                                       "proposal_density_kernel", "field_query_kernel",
                                                       "gemm_f16_nt_pipe_kernel<64, 64, 4, 1, *, false>", "proposal_backward_kernel",
                                                       "field_backward_kernel", "field_scatter_kernel | field_slice_ids_kernel + field_scatter_owner_kernel",
-                                                      "gemm_f16_nt_wide_kernel<160|128, 3, *>", "wgrad_wide_tn_kernel | wgrad_grouped_tn_kernel",
+                                                      "gemm_f16_nt_wide_kernel<*, 160|128, 3, *>", "wgrad_wide_tn_kernel | wgrad_grouped_tn_kernel",
                                                       "gemm_f16_nt_pipe_kernel<64, 64, 4, 0, 1, true>", "gemm_f16_nt_pipe_kernel<128, 64, 3, 0, 1, *>",
                                                       "gemm_f16_nt_pipe_kernel<64, 64, 4, 1, *, true>", "gemm_f16_nt_pipe_kernel<128, 64, 3, 1, *, *>",
                                                       "gemm_f16_nt_pipe_kernel<128, 128, 2, 1, *, *>", "gemm_f16_nt_pipe_kernel<128, 64, 3, 2, 5, false>"};

@@ -302,7 +302,7 @@ struct BnApplyArgs {
 };
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
-  extern __shared__ float sm[];            // scale[C] shift[C] (+ scale_r[C] shift_r[C])
+  extern __shared__ __attribute__((aligned(16))) float sm[];            // scale[C] shift[C] (+ scale_r[C] shift_r[C])
   float* sc = sm; float* sh = sm + p.C; float* scr = sm + 2 * p.C; float* shr = sm + 3 * p.C;
   const float inv_m = 1.f / (float)p.M;
   for (int c = threadIdx.x; c < p.C; c += 256) {
@@ -320,10 +320,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
       half8 rr;
       if (p.r.x) rr = *reinterpret_cast<const half8*>(p.r.x + row * p.C + c0);
       else if (p.res) rr = *reinterpret_cast<const half8*>(p.res + row * p.C + c0);
+      // the 8 scale / shift values of this thread as two 16-byte LDS reads each: element-wise reads put the lanes of a wave 32 bytes
+      // apart on every access, an 8-way bank conflict (SQ_LDS_BANK_CONFLICT was 83 % of the kernel's LDS cycles)
+      float scv[8], shv[8], scrv[8], shrv[8];
+      *reinterpret_cast<f32x4*>(scv) = *reinterpret_cast<const f32x4*>(sc + c0); *reinterpret_cast<f32x4*>(scv + 4) = *reinterpret_cast<const f32x4*>(sc + c0 + 4);
+      *reinterpret_cast<f32x4*>(shv) = *reinterpret_cast<const f32x4*>(sh + c0); *reinterpret_cast<f32x4*>(shv + 4) = *reinterpret_cast<const f32x4*>(sh + c0 + 4);
+      if (p.r.x) {
+        *reinterpret_cast<f32x4*>(scrv) = *reinterpret_cast<const f32x4*>(scr + c0); *reinterpret_cast<f32x4*>(scrv + 4) = *reinterpret_cast<const f32x4*>(scr + c0 + 4);
+        *reinterpret_cast<f32x4*>(shrv) = *reinterpret_cast<const f32x4*>(shr + c0); *reinterpret_cast<f32x4*>(shrv + 4) = *reinterpret_cast<const f32x4*>(shr + c0 + 4);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float v = fmaf((float)x[j], sc[c0 + j], sh[c0 + j]);
-        if (p.r.x) v += fmaf((float)rr[j], scr[c0 + j], shr[c0 + j]);
+        float v = fmaf((float)x[j], scv[j], shv[j]);
+        if (p.r.x) v += fmaf((float)rr[j], scrv[j], shrv[j]);
         else if (p.res) v += (float)rr[j];
         if (p.relu) v = fmaxf(v, 0.f);
         o[j] = (half_t)v;

@@ -1,0 +1,126 @@
+"""The pipeline built the way nerfstudio's Trainer builds it -- ``NeRAF_method.config.pipeline.setup(device=...)``
+(neraf_amd/config.py, NeRAF_pipeline.py:86-159) -- driven through training iterations with the scheduled optimizers and through
+the three eval entry points (NeRAF_pipeline.py:231-436), on synthetic device-resident data managers."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    from neraf_amd import config as C
+    from neraf_amd.datamanagers import SyntheticAudioDataManager, SyntheticVisionDataManager
+    torch.manual_seed(0)
+    m = C.make_method("RAF", "FurnishedRoom", datamanager=SyntheticVisionDataManager(6, 3, 96, 128, 1024),
+                      audio_datamanager=SyntheticAudioDataManager(4, 3, batch_size=256))
+    m.config.pipeline.audio_model.grid_step = 1 / 64          # 64^3 grid: same code, 8x less ResNet3D work for a unit test
+    m.config.pipeline.start_step_audio = 3
+    p = m.config.pipeline.setup(device="cuda:0", test_mode="val", world_size=1, local_rank=0, grad_scaler=None)
+    return p, m
+
+
+def test_train_iterations_with_scheduled_optimizers(pipe):
+    from neraf_amd import config as C
+    p, m = pipe
+    p.train()
+    opts, scaler = p.make_optimizers(init_scale=1024.0, optimizers_config=C.default_optimizers(p.start_step_audio), with_schedulers=True)
+    assert set(opts.optimizers) == {"proposal_networks", "fields", "camera_opt", "audio_fields"}
+    # proposal_networks, fields and camera_opt share one fused launch (three groups); audio_fields (which contains the field
+    # parameters too) is the second optimizer
+    assert len(opts.steppers) == 2 and opts.optimizers["fields"] is opts.optimizers["proposal_networks"] is opts.optimizers["camera_opt"]
+    losses = []
+    for step in range(1, 9):
+        loss, ld = p.train_iteration(step, opts, scaler)
+        losses.append(float(loss))
+        if step > p.start_step_audio:
+            assert {"audio_sc_loss", "audio_mag_loss", "camera_opt_regularizer"} <= set(ld)
+    assert all(np.isfinite(losses))
+    cfg = C.default_optimizers(p.start_step_audio)
+    for name, lr0 in (("fields", 1e-2), ("proposal_networks", 1e-2), ("audio_fields", 1e-4), ("camera_opt", 1e-3)):
+        np.testing.assert_allclose(opts.get_lr(name), cfg[name]["scheduler"].lr_at(8, lr0), rtol=1e-6)
+    # audio_fields is in its 3-step cosine warm-up ramp from 1e-8: at scheduler step 8 it is past it and decaying
+    assert opts.get_lr("audio_fields") < 1e-4 and opts.get_lr("audio_fields") > 0.99e-4
+    assert bool(torch.isfinite(p.model.camera_optimizer.pose_adjustment).all())
+
+
+def test_eval_loss_dict_and_image_metrics(pipe):
+    p, _ = pipe
+    outs, ld, md = p.get_eval_loss_dict(10)
+    assert {"rgb_loss", "audio_sc_loss", "audio_mag_loss"} <= set(ld) and "psnr" in md and p.training
+    np.testing.assert_allclose(float(md["psnr"]), -10 * math.log10(float(ld["rgb_loss"])), rtol=1e-4)
+    met, img = p.get_eval_image_metrics_and_images(10)
+    assert met["num_rays"] == 96 * 128 and {"psnr", "ssim", "t60_error", "edt_error", "c50_error"} <= set(met) or \
+        {"psnr", "ssim"} <= set(met)
+    assert img["img"].shape == (128, 2 * 96, 3)
+    assert any(k.startswith("stft_ch_") for k in img)
+
+
+def test_average_eval_image_metrics_matches_manual_loop(pipe, tmp_path):
+    """get_average_eval_image_metrics (NeRAF_pipeline.py:291-436): means (and stds) over all eval frames and all eval RIRs, with the
+    reference's throughput keys; the image part equals a manual loop over get_outputs_for_camera + PSNR."""
+    from neraf_amd.vision import psnr
+    p, _ = pipe
+    res = p.get_average_eval_image_metrics(step=10, get_std=True)
+    for k in ("psnr", "ssim", "num_rays_per_sec", "fps", "num_rays_per_sec_audio", "fps_audio", "psnr_std"):
+        assert k in res, k
+    manual = []
+    for cam, batch in p.datamanager.fixed_indices_eval_dataloader:
+        out = p.model.get_outputs_for_camera(cam, None, eval=True)
+        manual.append(float(psnr(out["rgb"], batch["image"])))
+    np.testing.assert_allclose(res["psnr"], np.mean(manual), rtol=1e-5)
+    assert len(manual) == 3 and p.audio_datamanager.eval_dataset.mode == "eval" and p.training
+    audio_keys = [k for k in res if k not in ("psnr", "ssim", "num_rays_per_sec", "fps") and not k.endswith("_std")]
+    assert len(audio_keys) >= 4, audio_keys                 # audio metrics (T60 / EDT / C50 / ...) + the two throughput keys
+    # saving predictions (the reference writes eval_XXXXX.npy for every RIR, :374-380)
+    p.get_average_eval_image_metrics(step=None, output_path=str(tmp_path))
+    import os
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".npy")]) >= 3
+
+
+def test_fused_adam_state_dict_save_load_continue_matches_torch_adam():
+    """Resume: FusedAdam.state_dict() -> fresh FusedAdam.load_state_dict() continues exactly like torch.optim.Adam does through its
+    own save / load (advisor finding of round 1: the loaded state used to be ignored or dangling)."""
+    from neraf_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    shapes = [(513, 64), (17,), (4096 * 2 + 3,)]
+    pa = [torch.randn(s, generator=g).to(dev).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+
+    def grads(step):
+        gg = torch.Generator().manual_seed(100 + step)
+        return [torch.randn(s, generator=gg).to(dev) for s in shapes]
+    oa = FusedAdam([{"params": pa[:1], "lr": 1e-2}, {"params": pa[1:], "lr": 1e-3}], eps=1e-15)
+    ob = torch.optim.Adam([{"params": pb[:1], "lr": 1e-2}, {"params": pb[1:], "lr": 1e-3}], eps=1e-15)
+    for step in range(3):
+        for x, y, gr in zip(pa, pb, grads(step)):
+            x.grad, y.grad = gr.clone(), gr.clone()
+        if step == 1:                      # group 1 without gradients on this step: its bias correction must not advance
+            pa[1].grad = pa[2].grad = pb[1].grad = pb[2].grad = None
+        oa.step(); ob.step()
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert float(sa["state"][0]["step"]) == 3.0 and float(sa["state"][1]["step"]) == 2.0
+    import copy
+    sa = copy.deepcopy(sa)
+    pa2 = [p.detach().clone().requires_grad_(True) for p in pa]
+    pb2 = [p.detach().clone().requires_grad_(True) for p in pb]
+    oa2 = FusedAdam([{"params": pa2[:1], "lr": 1e-2}, {"params": pa2[1:], "lr": 1e-3}], eps=1e-15)
+    ob2 = torch.optim.Adam([{"params": pb2[:1], "lr": 1e-2}, {"params": pb2[1:], "lr": 1e-3}], eps=1e-15)
+    oa2.load_state_dict(sa); ob2.load_state_dict(sb)
+    for step in range(3, 6):
+        for x, y, gr in zip(pa2, pb2, grads(step)):
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa2.step(); ob2.step()
+    for x, y in zip(pa2, pb2):
+        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+    assert float(oa2.state[pa2[0]]["step"]) == 6.0 and float(oa2.state[pa2[1]]["step"]) == 5.0
+    # loading into an optimizer that has already stepped (plans cached) must not keep stale moment pointers
+    oa2.load_state_dict(copy.deepcopy(oa.state_dict()))
+    for x, gr in zip(pa2, grads(9)):
+        x.grad = gr
+    oa2.step()
+    assert float(oa2.state[pa2[0]]["step"]) == 4.0

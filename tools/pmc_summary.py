@@ -17,7 +17,7 @@ F = load(latest("gpurun_out/pmc/FETCH_SIZE/runc/*_counter_collection.csv"), "FET
 W = load(latest("gpurun_out/pmc/WRITE_SIZE/runc/*_counter_collection.csv"), "WRITE_SIZE")
 def fam(n):
     """rocprofv3 kernel name -> the bench.py profiling scope (neraf_prof_kernel_name) it is timed under"""
-    if "gemm_f16_nt_wide_kernel" in n: return "gemm_f16_nt_wide_kernel<160|128, 3, *>"
+    if "gemm_f16_nt_wide_kernel" in n: return "gemm_f16_nt_wide_kernel<*, 160|128, 3, *>"
     if "wgrad_grouped_tn_kernel" in n or "wgrad_wide_tn_kernel" in n: return "wgrad_wide_tn_kernel | wgrad_grouped_tn_kernel"
     m = re.search(r"gemm_f16_nt_pipe_kernel<(\d+), (\d+), \d, (\d), (\d), (true|false)>", n)
     if m:
@@ -46,7 +46,7 @@ for f, (fb, wb, nf, nw) in sorted(fams.items()):
               "launches_write_pass": nw, "hbm_bytes_per_launch": fb / max(nf, 1) + wb / max(nw, 1)}
     print(f"{f:52s} fetch {fb/max(nf,1)/1e6:9.2f} MB  write {wb/max(nw,1)/1e6:9.2f} MB per launch  ({nf} launches)")
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes, --kernel-trace only) over `bench.py --steps 4 --warmup 2 "
-                     "--no-cpu-baseline` (tools/gpu_pmc.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md; counters are KiB; Infinity-Cache hits included",
+                     "--plain` (tools/gpu_pmc.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md; counters are KiB; Infinity-Cache hits included",
            "families": out}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 for name, d in (("FETCH_SIZE", F), ("WRITE_SIZE", W)):
     with open(f"profiles/{tag}_pmc_{name}_by_kernel.csv", "w") as fh:
