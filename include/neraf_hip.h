@@ -341,6 +341,19 @@ int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_real, int co
                                    const void* x_f16, const float* w, const float* gamma, const float* beta, const float* g,
                                    void* y_f16, float* dx, float* dw, float* dgamma, float* dbeta, neraf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * fp16 working copies of the radiance parameters (tiny-cuda-nn keeps fp32 masters + fp16 copies inside its optimizer; the
+ * reference reaches them through nerfstudio's NerfactoField / HashMLPDensityField).  neraf_cvt_f16_segments converts up to 12
+ * contiguous fp32 tensors (hash tables, embedding, proposal MLP weights) to fp16 in ONE launch: src / dst / len are HOST arrays
+ * of device pointers and element counts.  neraf_gather_f16 builds the MFMA weight fragments: dst[i] = fp16(flat[index[i]]) where
+ * flat is the concatenation of nsrc (<= 8) fp32 tensors (src_len elements each; an index past the end reads 0) and index a device
+ * int64 array (the fragment permutation built once by the host layer).
+ * ---------------------------------------------------------------------------------- */
+int neraf_cvt_f16_segments(neraf_ctx* ctx, const float* const* src, void* const* dst, const long long* len, int n,
+                           neraf_stream_t stream);
+int neraf_gather_f16(neraf_ctx* ctx, const float* const* src, const long long* src_len, int nsrc, const long long* index, void* dst,
+                     long long n, neraf_stream_t stream);
+
 /* Test aid: where a forward tensor lives inside the forward `workspace` (byte offset, logical rows x cols; rows are voxels in
  * x-major / z-fastest order, i.e. torch's flattened [D,H,W]).  kind 0 / 1 / 2: fp16 post-activation a1 / a2 / block output of
  * Bottleneck `index` (NeRAF_resnet3d.py:97, :101, :111); 3: fp16 pooled stem activation (:188); 4: uint8 arg-max tap table of

@@ -382,10 +382,14 @@ class _VisionLossFn(torch.autograd.Function):
                                                  None, None, sums.data_ptr(), stream), dev)
         ctx.model, ctx.st, ctx.gt, ctx.dev = model, st, gt, dev
         ctx.n_params = len(params)
-        rgb_loss = sums[0] / (3.0 * R)
-        dist = sums[1] * (model.distortion_loss_mult / R)
-        inter = sums[2] * (model.interlevel_loss_mult / (R * S2))
-        return rgb_loss, inter, dist
+        # {sum (rgb-gt)^2, sum distortion, sum outer} -> the three means in one launch
+        key = (R, S2, model.distortion_loss_mult, model.interlevel_loss_mult, str(gt.device))
+        sc = getattr(model, "_loss_scale", None)
+        if sc is None or sc[0] != key:
+            sc = (key, torch.tensor([1.0 / (3.0 * R), model.distortion_loss_mult / R, model.interlevel_loss_mult / (R * S2)], **f32))
+            model._loss_scale = sc
+        losses = sums[:3] * sc[1]
+        return losses[0], losses[2], losses[1]
 
     @staticmethod
     def backward(ctx, g_rgb, g_inter, g_dist):
@@ -486,6 +490,46 @@ class NeRAFVisionModel(nn.Module):
         self.step = step
         self._steps_since_update += 1
 
+    def _refresh_packs(self):
+        """fp16 working copies of EVERY radiance parameter in two launches (csrc/pack.hip) when the parameter state changed since
+        the last call -- i.e. once per optimizer step -- stored in the per-module caches that ``packed()`` / ``packed_bwd()`` consult.
+        (The per-module paths they fall back to do the same with ~15 small torch launches.)"""
+        f = self.field.module
+        fkey = _param_key(f.grad_params())
+        pkeys = [_param_key((pn.table, pn.w0, pn.w1)) for pn in self.proposal_networks]
+        fc = getattr(f, "_pack_cache", None)
+        if fc is not None and fc.get("key") == fkey and "wfrag_bwd" in fc and "emb" in fc and \
+                all(getattr(pn, "_pack_cache", None) is not None and pn._pack_cache[0] == k for pn, k in zip(self.proposal_networks, pkeys)):
+            return
+        lib = _lib.load()
+        dev_t = f.table.device
+        dev = _dev_index(f.table)
+        h16 = dict(dtype=torch.float16, device=dev_t)
+        table16 = torch.empty(f.table.shape, **h16)
+        emb16 = torch.empty(f.embedding.shape, **h16)
+        srcs, dsts, lens = [f.table, f.embedding], [table16, emb16], [f.table.numel(), f.embedding.numel()]
+        prop = []
+        for pn in self.proposal_networks:
+            t16 = torch.empty(pn.table.shape, **h16)
+            w16 = torch.empty(16 * 16 + 16, **h16)
+            prop.append((t16, w16))
+            srcs += [pn.table, pn.w0, pn.w1]                      # w1: only its first row (the used output) follows w0
+            dsts += [t16, w16, w16[256:]]
+            lens += [pn.table.numel(), 256, 16]
+        n = len(srcs)
+        _lib.check(lib.neraf_cvt_f16_segments(_lib.ctx(dev), _lib.ptr_array([s_.detach() for s_ in srcs]), _lib.ptr_array(dsts),
+                                              (C.c_longlong * n)(*lens), n, _stream_ptr()), dev)
+        ws = [f.base_w0, f.base_w1, f.head_w0, f.head_w1, f.head_w2]
+        if getattr(f, "_frag_index_all", None) is None or f._frag_index_all.device != dev_t:
+            f._frag_index_all = torch.cat([f._frag_index, f._frag_index_bwd]).contiguous()
+        nf, nb = f._frag_index.numel(), f._frag_index_bwd.numel()
+        frag = torch.empty(nf + nb, **h16)
+        _lib.check(lib.neraf_gather_f16(_lib.ctx(dev), _lib.ptr_array([w.detach() for w in ws]), (C.c_longlong * 5)(*[w.numel() for w in ws]), 5,
+                                        f._frag_index_all.data_ptr(), frag.data_ptr(), nf + nb, _stream_ptr()), dev)
+        f._pack_cache = {"key": fkey, "table": table16, "wfrag": frag[:nf], "wfrag_bwd": frag[nf:], "emb": emb16}
+        for pn, k, pk in zip(self.proposal_networks, pkeys, prop):
+            pn._pack_cache = (k, pk)
+
     def _proposal_updated(self) -> bool:
         """ProposalNetworkSampler's schedule [NS-recall]: the proposal networks receive gradients on every step during
         warm-up and then only when more than ``update_sched(step)`` (-> proposal_update_every) steps have passed."""
@@ -528,6 +572,8 @@ class NeRAFVisionModel(nn.Module):
         prop_updated = self._proposal_updated() if self.training else False
         weights_list, samples_list = [], []
         s_prev, e_prev = s0, e0
+        if self.training:
+            self._refresh_packs()
         prop_packed = [pn.packed() for pn in self.proposal_networks]
         prop_dens = []
         for i, S_next in enumerate((S1, S2)):
