@@ -253,7 +253,7 @@ int neraf_proposal_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void
  * atomic per table entry instead of two fp32 ones, unpacked in place before returning; the result is
  * bit-reproducible), emb_grad fp32 [n_emb,32] (ACCUMULATED, caller zeroes) and the five MLP weight gradients
  * w_grads (HOST array of device pointers {base_w0 [64,32], base_w1 [16,64], head_w0 [64,64], head_w1
- * [64,64], head_w2 [16,64]}, overwritten).  wfrag_bwd_f16: 26 transposed-weight MFMA fragments packed by
+ * [64,64], head_w2 [16,64]}, overwritten).  wfrag_bwd_f16: 28 transposed-weight MFMA fragments packed by
  * the host layer.  dump: scratch of neraf_field_backward_dump_bytes(R,S) bytes that the caller ZEROES ONCE
  * at allocation (its padding rows must stay zero); splitk_ws: >= 8 MB fp32 scratch. */
 size_t neraf_field_backward_dump_bytes(int R, int S);
@@ -273,6 +273,22 @@ int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* g, const vo
                          float avg_density, int avg_row, const float* density, const float* d_rgb, const float* d_density,
                          float* table_grad, float* emb_grad, float* const* w_grads, void* dump, void* splitk_ws,
                          size_t splitk_bytes, int pos_run, neraf_stream_t stream);
+
+/* The two backward calls with the camera-pose edge: additionally ACCUMULATE d loss / d (ray origin, ray direction) into d_rays
+ * fp32 [R,6] (caller zeroes) -- the gradient nerfstudio's CameraOptimizer (NeRAF_config.py:97, SO3xR3) receives through
+ * RaySamples.frustums.get_positions() / the SH direction encoding: hash-grid input gradient (tiny-cuda-nn computes it on request),
+ * L-inf contraction Jacobian, sum over the ray's samples (sample distances are constants: the PDF sampler detaches its bins), and
+ * for the main field the SH input gradient.  wfrag_bwd_f16 holds 28 fragments (the last two: head layer 0's SH columns). */
+int neraf_field_backward_rays(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                              const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
+                              const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
+                              float avg_density, int avg_row, const float* density, const float* d_rgb, const float* d_density,
+                              float* table_grad, float* emb_grad, float* const* w_grads, void* dump, void* splitk_ws,
+                              size_t splitk_bytes, float* d_rays, neraf_stream_t stream);
+int neraf_proposal_backward_rays(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
+                                 const float* origins, const float* dirs, const float* e_bins, const float* d_density, int R,
+                                 int S, float avg_density, float* table_grad, float* w_grad, void* scratch, size_t scratch_bytes,
+                                 float* d_rays, neraf_stream_t stream);
 
 /* Grid refresh epilogue of query_grid_one_batch (NeRAF_model.py:352-357,386,395-400): mean over the ndirs
  * view directions of rgb [ndirs*n,3] / density [ndirs*n] (direction-major), alpha = clip(1-exp(-delta d)),

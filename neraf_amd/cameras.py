@@ -168,9 +168,10 @@ class CameraOptimizer(nn.Module):
     ``mean |t| * trans_l2_penalty + mean |r| * rot_l2_penalty`` (1e-2, 1e-3).  The parameter lives in the ``camera_opt`` group
     (NeRAF_config.py:128-131: Adam lr 1e-3 -> 1e-4 over 5000 steps).
 
-    What reaches ``pose_adjustment`` here is the regulariser's gradient and whatever gradient the caller provides for the ray
-    bundle: the HIP radiance kernels do not return d loss / d (origin, direction) -- tiny-cuda-nn's hash-grid input gradient has no
-    counterpart in csrc/field_bwd.hip yet -- so the photometric term does not move the poses."""
+    ``pose_adjustment`` receives the regulariser's gradient and the photometric one: the vision loss node returns d loss / d (ray
+    origin, ray direction) from the HIP backward kernels (neraf_field_backward_rays / neraf_proposal_backward_rays: hash-grid input
+    gradient through the contraction, SH input gradient), and autograd carries it through ``apply_to_raybundle`` into the pose
+    deltas."""
 
     def __init__(self, num_cameras: int, mode: str = "SO3xR3", trans_l2_penalty: float = 1e-2, rot_l2_penalty: float = 1e-3):
         super().__init__()

@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int NFRAG = 24;     // forward fragments (see field.hip)
-constexpr int NFRAG_B = 26;   // backward: Th2 0-3, Th1 4-11 (ib*2+s), Th0a 12-13, Th0b 14-17 (ib*2+s), Tb1 18-21, Tb0 22-25 (rb*2+s)
+constexpr int NFRAG_B = 28;   // backward: Th2 0-3, Th1 4-11 (ib*2+s), Th0a 12-13, Th0b 14-17 (ib*2+s), Tb1 18-21, Tb0 22-25 (rb*2+s), Th0sh 26-27 (SH inputs, ray gradient)
 
 // ------------------------------------------------------------------------------------------------------------
 struct RenderLossArgs {
@@ -241,6 +241,7 @@ struct PropBwdArgs {
   float* w_grad;          // fp32 [16*16 + 16], accumulated
   float* w_part;          // optional fp32 [blocks][272]: per-workgroup partials (folded by prop_wgrad_fold_kernel) instead of
                           // 272 atomics per workgroup on nine cache lines (~220 us of same-line serialisation at 2048 workgroups)
+  float* d_ray;           // optional fp32 [R][6], ACCUMULATED: d loss / d (ray origin, ray direction)
 };
 
 __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
@@ -261,13 +262,17 @@ __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) { enc[k] = 0.f; dh[k] = 0.f; hpre[k] = 0.f; }
     float x = 0.f, y = 0.f, z = 0.f, gs = 0.f;
+    float xr = 0.f, yr = 0.f, zr = 0.f, tmid = 0.f; int ray_id = -1; bool sel_pt = false;
+    float rgx = 0.f, rgy = 0.f, rgz = 0.f;                 // ray gradient: d loss / d mapped position
     if (valid) {
       const int ray = (int)(idx / a.S), s = (int)(idx % a.S);
       const float t = 0.5f * (a.e_bins[(size_t)ray * (a.S + 1) + s] + a.e_bins[(size_t)ray * (a.S + 1) + s + 1]);
       x = fmaf(a.dirs[ray * 3 + 0], t, a.origins[ray * 3 + 0]);
       y = fmaf(a.dirs[ray * 3 + 1], t, a.origins[ray * 3 + 1]);
       z = fmaf(a.dirs[ray * 3 + 2], t, a.origins[ray * 3 + 2]);
+      xr = x; yr = y; zr = z; tmid = t; ray_id = ray;
       const bool sel = map_position(x, y, z, 0, nullptr);
+      sel_pt = sel;
 #pragma unroll
       for (int l = 0; l < 8; ++l)
         if (l < a.g.n_levels) {
@@ -296,8 +301,29 @@ __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
         float g0 = 0.f, g1 = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) { g0 = fmaf(dh[j], w0[j][2 * l], g0); g1 = fmaf(dh[j], w0[j][2 * l + 1], g1); }
+        if (a.d_ray && valid && sel_pt)
+          encode_level_dpos(a.table, x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.offset[l], a.g.hashed[l], g0, g1, rgx, rgy, rgz);
         scatter_level_seg<64>(a.table_grad, x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.offset[l], a.g.hashed[l], g0, g1, lane);
       }
+    if (a.d_ray) {
+      // camera-pose edge: the position gradient of this sample -> d (origin, direction) of its ray; the 64 samples of a wave lie
+      // on one ray unless a ray boundary falls inside it (S = 256 / 96 samples per ray)
+      map_position_jt(xr, yr, zr, rgx, rgy, rgz);
+      float g6[6] = {rgx, rgy, rgz, tmid * rgx, tmid * rgy, tmid * rgz};
+      const int ray0 = __shfl(ray_id, 0);
+      if (__all(ray_id == ray0 || !valid)) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          float v = valid ? g6[k] : 0.f;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+          if (lane == 0 && v != 0.f && ray0 >= 0) atomicAdd(a.d_ray + (size_t)ray0 * 6 + k, v);
+        }
+      } else if (valid) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (g6[k] != 0.f) atomicAdd(a.d_ray + (size_t)ray_id * 6 + k, g6[k]);
+      }
+    }
     // weight gradients: dW0[j][k] = sum_p dh[p][j] enc[p][k] ; dW1[j] = sum_p gs[p] relu(h[p][j]) -- per-wave LDS staging
 #pragma unroll
     for (int k = 0; k < 16; ++k) { s_dh[wv][lane][k] = dh[k]; s_enc[wv][lane][k] = enc[k]; s_hr[wv][lane][k] = gs * fmaxf(hpre[k], 0.f); }
@@ -364,6 +390,7 @@ struct FieldBwdArgs {
   float* e_part; int* e_part_row;                  // fp32 [blocks][32] + row: per-workgroup appearance-embedding gradient of the
                                                    // workgroup's leading embedding row (rows 64.. of slots 2 / 3)
   float* pos;                                      // optional fp32 [3][npad]: mapped sample positions for the owner scatter (slot 4, rows 64..)
+  float* d_ray;                                    // optional fp32 [R][6], ACCUMULATED: d loss / d (ray origin, ray direction) -- the camera-pose optimizer's edge
 };
 
 __device__ __forceinline__ void dump_block(half_t* base, long npad, long n, int row0, const f32x4& v, float m) {
@@ -372,6 +399,7 @@ __device__ __forceinline__ void dump_block(half_t* base, long npad, long n, int 
   for (int r = 0; r < 4; ++r) base[(long)(row0 + r) * npad + n] = (half_t)(v[r] * m);
 }
 
+template <bool RAYGRAD>
 __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
   __shared__ float l_scale[MAX_LEVELS];
   __shared__ int l_res[MAX_LEVELS];
@@ -423,6 +451,7 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
     float x = fmaf(dx, t, a.origins[ray * 3 + 0]);
     float y = fmaf(dy, t, a.origins[ray * 3 + 1]);
     float z = fmaf(dz, t, a.origins[ray * 3 + 2]);
+    const float xr = x, yr = y, zr = z;            // un-mapped position (ray gradient)
     const bool sel = map_position(x, y, z, a.mode, a.aabb);
     if (a.pos && q == 0) { a.pos[ncol] = x; a.pos[a.npad + ncol] = y; a.pos[2 * a.npad + ncol] = z; }
     // ---------------- forward recompute (identical to field_query_kernel) ----------------
@@ -522,11 +551,15 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
 #pragma unroll
       for (int ob = 0; ob < 4; ++ob) dump_block(D + 5 * MAT, a.npad, ncol, 16 * ob + 4 * q, dy3[ob], 1.f);
     }
-    f32x4 dbase, demb[2];
+    f32x4 dbase, demb[2], dsh = zero;
     {
       const half8 b0 = pack_relu(dy3[0], dy3[1], false), b1 = pack_relu(dy3[2], dy3[3], false);
       dbase = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[12 * 64], b0, zero, 0, 0, 0);
       dbase = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[13 * 64], b1, dbase, 0, 0, 0);
+      if (RAYGRAD) {                               // d loss / d SH inputs 4q..4q+3 of this point
+        dsh = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[26 * 64], b0, zero, 0, 0, 0);
+        dsh = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[27 * 64], b1, dsh, 0, 0, 0);
+      }
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib) {
         demb[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[(14 + ib * 2) * 64], b0, zero, 0, 0, 0);
@@ -599,6 +632,50 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
       gh[1] = (half_t)(valid ? de[li >> 1][2 * (li & 1) + 1] : 0.f);
       a.d_enc[(long)l * a.npad + ncol] = *reinterpret_cast<const unsigned*>(&gh);
       tl[li] += fmaxf(fabsf((float)gh[0]), fabsf((float)gh[1]));
+    }
+    if (RAYGRAD) {
+      // d loss / d (origin, direction) of this sample's ray: hash-grid input gradient of this lane's four levels (a second
+      // gather of the 32 entries the forward recompute just touched), through the position map, plus the SH input gradient;
+      // summed over the four lanes of a point and, when the 16 points of the group lie on one ray, over the group
+      float px = 0.f, py = 0.f, pz = 0.f;
+      if (valid && sel && a.mode == 0) {
+#pragma unroll
+        for (int li = 0; li < 4; ++li) {
+          const int l = 4 * q + li;
+          encode_level_dpos(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l],
+                            de[li >> 1][2 * (li & 1)], de[li >> 1][2 * (li & 1) + 1], px, py, pz);
+        }
+      }
+      px += __shfl_xor(px, 16); py += __shfl_xor(py, 16); pz += __shfl_xor(pz, 16);
+      px += __shfl_xor(px, 32); py += __shfl_xor(py, 32); pz += __shfl_xor(pz, 32);
+      map_position_jt(xr, yr, zr, px, py, pz);
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      if (valid) {
+        const float g4[4] = {dsh[0], dsh[1], dsh[2], dsh[3]};
+        sh4_quarter_dpos(q, dx, dy, dz, g4, sx, sy, sz);
+      }
+      sx += __shfl_xor(sx, 16); sy += __shfl_xor(sy, 16); sz += __shfl_xor(sz, 16);
+      sx += __shfl_xor(sx, 32); sy += __shfl_xor(sy, 32); sz += __shfl_xor(sz, 32);
+      float g6[6] = {px * inv_gscale, py * inv_gscale, pz * inv_gscale,
+                     fmaf(t, px, sx) * inv_gscale, fmaf(t, py, sy) * inv_gscale, fmaf(t, pz, sz) * inv_gscale};
+      const int ray0 = __shfl(ray, lane & 48);
+      const bool one_ray = __all(ray == ray0 || !valid);
+      if (one_ray) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          float v = valid ? g6[k] : 0.f;
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+          g6[k] = v;
+        }
+        if (p == 0 && q == 0) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) if (g6[k] != 0.f) atomicAdd(a.d_ray + (size_t)ray0 * 6 + k, g6[k]);
+        }
+      } else if (valid && q == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (g6[k] != 0.f) atomicAdd(a.d_ray + (size_t)ray * 6 + k, g6[k]);
+      }
     }
   }
   // per-level gradient mass of this workgroup (bounds every table entry's sum: the trilinear weights of a sample add to 1)
@@ -1024,16 +1101,38 @@ extern "C" int neraf_interlevel_loss(neraf_ctx* ctx, const float* c_bins, const 
   return NERAF_OK;
 }
 
+static int proposal_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
+                                  const float* origins, const float* dirs, const float* e_bins, const float* d_density,
+                                  int R, int S, float avg_density, float* table_grad, float* w_grad, void* scratch,
+                                  size_t scratch_bytes, float* d_rays, neraf_stream_t stream);
+
 extern "C" int neraf_proposal_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                                        const float* origins, const float* dirs, const float* e_bins, const float* d_density,
                                        int R, int S, float avg_density, float* table_grad, float* w_grad, void* scratch,
                                        size_t scratch_bytes, neraf_stream_t stream) {
+  return proposal_backward_impl(ctx, g, table_f16, mlp_f16, origins, dirs, e_bins, d_density, R, S, avg_density, table_grad, w_grad,
+                                scratch, scratch_bytes, nullptr, stream);
+}
+
+extern "C" int neraf_proposal_backward_rays(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
+                                            const float* origins, const float* dirs, const float* e_bins, const float* d_density,
+                                            int R, int S, float avg_density, float* table_grad, float* w_grad, void* scratch,
+                                            size_t scratch_bytes, float* d_rays, neraf_stream_t stream) {
+  if (!d_rays) return neraf_fail(ctx, NERAF_EINVAL, "proposal_backward_rays: d_rays required");
+  return proposal_backward_impl(ctx, g, table_f16, mlp_f16, origins, dirs, e_bins, d_density, R, S, avg_density, table_grad, w_grad,
+                                scratch, scratch_bytes, d_rays, stream);
+}
+
+static int proposal_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
+                                  const float* origins, const float* dirs, const float* e_bins, const float* d_density,
+                                  int R, int S, float avg_density, float* table_grad, float* w_grad, void* scratch,
+                                  size_t scratch_bytes, float* d_rays, neraf_stream_t stream) {
   PropBwdArgs a{};
   if (make_grid_layout(g, &a.g) || a.g.n_levels > 8) return neraf_fail(ctx, NERAF_EINVAL, "proposal_backward: bad grid (<= 8 levels)");
   if (R <= 0 || S <= 0 || !table_f16 || !mlp_f16 || !origins || !dirs || !e_bins || !d_density || !table_grad || !w_grad)
     return neraf_fail(ctx, NERAF_EINVAL, "proposal_backward: bad arguments");
   a.table = (const unsigned*)table_f16; a.w = (const half_t*)mlp_f16; a.origins = origins; a.dirs = dirs; a.e_bins = e_bins;
-  a.d_density = d_density; a.R = R; a.S = S; a.avg_density = avg_density; a.table_grad = table_grad; a.w_grad = w_grad;
+  a.d_density = d_density; a.R = R; a.S = S; a.avg_density = avg_density; a.table_grad = table_grad; a.w_grad = w_grad; a.d_ray = d_rays;
   const long n = (long)R * S;
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -1052,12 +1151,12 @@ extern "C" size_t neraf_field_backward_dump_bytes(int R, int S) {
   return (size_t)10 * 128 * npad * 2 + 256;
 }
 
-extern "C" int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
-                                         const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
-                                         const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
-                                         float avg_density, int avg_row, const float* density, const float* d_rgb,
-                                         const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
-                                         void* splitk_ws, size_t splitk_bytes, int pos_run, neraf_stream_t stream);
+static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                               const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
+                               const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
+                               float avg_density, int avg_row, const float* density, const float* d_rgb,
+                               const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
+                               void* splitk_ws, size_t splitk_bytes, int pos_run, float* d_rays, neraf_stream_t stream);
 
 extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
                                     const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
@@ -1065,9 +1164,9 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
                                     float avg_density, int avg_row, const float* density, const float* d_rgb, const float* d_density,
                                     float* table_grad, float* emb_grad, float* const* w_grads, void* dump, void* splitk_ws,
                                     size_t splitk_bytes, neraf_stream_t stream) {
-  return neraf_field_backward_runs(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
-                                   aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
-                                   splitk_ws, splitk_bytes, 1, stream);
+  return field_backward_impl(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
+                             aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
+                             splitk_ws, splitk_bytes, 1, nullptr, stream);
 }
 
 extern "C" int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
@@ -1076,6 +1175,29 @@ extern "C" int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* 
                                          float avg_density, int avg_row, const float* density, const float* d_rgb,
                                          const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
                                          void* splitk_ws, size_t splitk_bytes, int pos_run, neraf_stream_t stream) {
+  return field_backward_impl(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
+                             aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
+                             splitk_ws, splitk_bytes, pos_run, nullptr, stream);
+}
+
+extern "C" int neraf_field_backward_rays(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                                         const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
+                                         const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
+                                         float avg_density, int avg_row, const float* density, const float* d_rgb,
+                                         const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
+                                         void* splitk_ws, size_t splitk_bytes, float* d_rays, neraf_stream_t stream) {
+  if (!d_rays) return neraf_fail(ctx, NERAF_EINVAL, "field_backward_rays: d_rays required");
+  return field_backward_impl(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
+                             aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
+                             splitk_ws, splitk_bytes, 1, d_rays, stream);
+}
+
+static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                               const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
+                               const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
+                               float avg_density, int avg_row, const float* density, const float* d_rgb,
+                               const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
+                               void* splitk_ws, size_t splitk_bytes, int pos_run, float* d_rays, neraf_stream_t stream) {
   if (pos_run < 1 || (pos_run > 1 && (S != 1 || R % pos_run != 0)))
     return neraf_fail(ctx, NERAF_EINVAL, "field_backward_runs: pos_run > 1 needs S == 1 and R a multiple of pos_run");
   FieldBwdArgs a{};
@@ -1141,7 +1263,9 @@ extern "C" int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* 
     if (blocks > cap) blocks = cap;
     {
       ProfScope prof(ctx, st, PROF_FIELD_BWD, (double)N * 16 * 8 * 4);       // gathered fp16x2 bytes
-      hipLaunchKernelGGL(field_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+      a.d_ray = d_rays;
+      if (d_rays) hipLaunchKernelGGL(field_backward_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(field_backward_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     }
     NERAF_HIP_CHECK(ctx, hipGetLastError());
     // hash-grid gradient: per-level fixed-point scale from the gradient mass, packed 64-bit scatter, in-place unpack

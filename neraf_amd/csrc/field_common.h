@@ -86,6 +86,78 @@ __device__ __forceinline__ void encode_level(const unsigned* __restrict__ table,
   }
 }
 
+// d/d(x,y,z) of  g0 * f0 + g1 * f1  for one level (f = the trilinear interpolation of encode_level), ACCUMULATED into (dx,dy,dz):
+// the hash-grid input gradient (tiny-cuda-nn computes it for its inputs; here it feeds the camera-pose optimizer).  The weights
+// are products of (w | 1-w) per axis, so the derivative along an axis replaces that axis' factor by (+1 | -1) * scale.
+__device__ __forceinline__ void encode_level_dpos(const unsigned* __restrict__ table, float x, float y, float z, float scale, int res,
+                                                  unsigned size, unsigned offset, int hashed, float g0, float g1,
+                                                  float& dx, float& dy, float& dz) {
+  const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+  const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+  const float wx = px - flx, wy = py - fly, wz = pz - flz;
+  const unsigned ix = (unsigned)(int)flx, iy = (unsigned)(int)fly, iz = (unsigned)(int)flz;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned cx = ix + (c & 1), cy = iy + ((c >> 1) & 1), cz = iz + ((c >> 2) & 1);
+    unsigned idx;
+    if (hashed) idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1u);
+    else {
+      idx = cx + cy * (unsigned)res + cz * (unsigned)res * (unsigned)res;
+      if (idx >= size) idx -= size;
+    }
+    const unsigned raw = table[offset + idx];
+    const half2v v = *reinterpret_cast<const half2v*>(&raw);
+    const float val = g0 * (float)v[0] + g1 * (float)v[1];
+    const float fx = (c & 1) ? wx : 1.f - wx, fy = (c & 2) ? wy : 1.f - wy, fz = (c & 4) ? wz : 1.f - wz;
+    ax = fmaf(((c & 1) ? 1.f : -1.f) * fy * fz, val, ax);
+    ay = fmaf(((c & 2) ? 1.f : -1.f) * fx * fz, val, ay);
+    az = fmaf(((c & 4) ? 1.f : -1.f) * fx * fy, val, az);
+  }
+  dx = fmaf(scale, ax, dx); dy = fmaf(scale, ay, dy); dz = fmaf(scale, az, dz);
+}
+
+// transpose-Jacobian of map_position (mode 0: L-inf contraction, then (x+2)/4) applied to (gx,gy,gz), at the UNMAPPED point (x,y,z)
+__device__ __forceinline__ void map_position_jt(float x, float y, float z, float& gx, float& gy, float& gz) {
+  const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+  const float mag = fmaxf(ax, fmaxf(ay, az));
+  if (mag >= 1.f) {
+    const float inv = 1.f / mag;
+    const float c = (2.f - inv) * inv;                       // (2 - 1/m) / m
+    const float dc = (-2.f + 2.f * inv) * inv * inv;         // d c / d m = -2/m^2 + 2/m^3
+    const float dot = x * gx + y * gy + z * gz;
+    const int k = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    const float sk = (k == 0 ? x : (k == 1 ? y : z)) >= 0.f ? 1.f : -1.f;
+    gx *= c; gy *= c; gz *= c;
+    const float extra = sk * dc * dot;
+    if (k == 0) gx += extra; else if (k == 1) gy += extra; else gz += extra;
+  }
+  gx *= 0.25f; gy *= 0.25f; gz *= 0.25f;
+}
+
+// d/d(dx,dy,dz) of  sum_r g[r] * sh[r]  for the four SH components of sh4_quarter(q, ...), ACCUMULATED into (ox,oy,oz)
+__device__ __forceinline__ void sh4_quarter_dpos(int q, float dx, float dy, float dz, const float (&g)[4], float& ox, float& oy, float& oz) {
+  const float x2 = dx * dx, y2 = dy * dy, z2 = dz * dz;
+  if (q == 0) {
+    oy += -0.48860251190291987f * g[1]; oz += 0.48860251190291987f * g[2]; ox += -0.48860251190291987f * g[3];
+  } else if (q == 1) {
+    ox += 1.0925484305920792f * dy * g[0];                 oy += 1.0925484305920792f * dx * g[0];
+    oy += -1.0925484305920792f * dz * g[1];                oz += -1.0925484305920792f * dy * g[1];
+    oz += 2.f * 0.94617469575755997f * dz * g[2];
+    ox += -1.0925484305920792f * dz * g[3];                oz += -1.0925484305920792f * dx * g[3];
+  } else if (q == 2) {
+    ox += 2.f * 0.54627421529603959f * dx * g[0];          oy += -2.f * 0.54627421529603959f * dy * g[0];
+    ox += 0.59004358992664352f * dy * (-6.f * dx) * g[1];  oy += 0.59004358992664352f * (-3.f * x2 + 3.f * y2) * g[1];
+    ox += 2.8906114426405538f * dy * dz * g[2];            oy += 2.8906114426405538f * dx * dz * g[2];   oz += 2.8906114426405538f * dx * dy * g[2];
+    oy += 0.45704579946446572f * (1.f - 5.f * z2) * g[3];  oz += 0.45704579946446572f * dy * (-10.f * dz) * g[3];
+  } else {
+    oz += 0.3731763325901154f * (15.f * z2 - 3.f) * g[0];
+    ox += 0.45704579946446572f * (1.f - 5.f * z2) * g[1];  oz += 0.45704579946446572f * dx * (-10.f * dz) * g[1];
+    ox += 1.4453057213202769f * dz * 2.f * dx * g[2];      oy += -1.4453057213202769f * dz * 2.f * dy * g[2];   oz += 1.4453057213202769f * (x2 - y2) * g[2];
+    ox += 0.59004358992664352f * (-3.f * x2 + 3.f * y2) * g[3];   oy += 0.59004358992664352f * dx * 6.f * dy * g[3];
+  }
+}
+
 __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {

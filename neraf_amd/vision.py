@@ -9,9 +9,10 @@ Training: ``get_outputs`` (forward) + ``get_loss_dict`` (rgb MSE, interlevel x1.
 nerfacto loss dict, V4) are differentiable end to end: the three losses come out of one autograd node
 (``_VisionLossFn``) whose backward runs the HIP loss-gradient, proposal-backward and fused field-backward
 kernels and returns gradients for the hash tables, the MLP weights and the appearance embedding.  The audio
-loss reaches the same parameters through the voxel grid (``model._RefreshFn``, NeRAF_model.py:395-400).  The
-camera optimizer (neraf_amd/cameras.py) is applied to the ray bundle and regularised; the kernels do not return
-a gradient w.r.t. ray origins / directions, so the photometric loss does not move the poses.
+loss reaches the same parameters through the voxel grid (``model._RefreshFn``, NeRAF_model.py:395-400).  With the
+camera optimizer on (neraf_amd/cameras.py, NeRAF_config.py:97) the same node also returns d loss / d (ray origin,
+ray direction) -- hash-grid input gradient through the contraction, SH input gradient -- which autograd carries
+into the SO3xR3 pose deltas.
 
 No fallback: every method raises if the HIP library or the GPU is missing.
 """
@@ -138,7 +139,7 @@ def _build_frag_index_bwd() -> np.ndarray:
         base[k] = off
         off += o * i
     ZERO = off
-    idx = np.full((26, 64, 8), ZERO, np.int64)
+    idx = np.full((28, 64, 8), ZERO, np.int64)
 
     def W(name, out, col):
         return base[name] + out * sizes[name][1] + col
@@ -160,6 +161,7 @@ def _build_frag_index_bwd() -> np.ndarray:
                 for rb in range(2):                          # rows permuted: lane quarter q' = rho>>2 receives features 8q'..8q'+7
                     feat = 8 * (rho >> 2) + 4 * rb + (rho & 3)
                     idx[22 + rb * 2 + s, l, j] = W("b0", _dperm(s, q, j), feat)
+                idx[26 + s, l, j] = W("h0", _dperm(s, q, j), rho)   # SH input columns 0..15 of head layer 0 (ray-direction gradient)
     return idx.reshape(-1)
 
 
@@ -283,7 +285,8 @@ class NerfactoField(nn.Module):
             self._splitk = torch.empty(4 << 20, dtype=torch.float32, device=device)
         return self._splitk
 
-    def backward_query(self, packed, origins, directions, e_bins, camera_indices, density, d_rgb, d_density, pos_run: int = 1):
+    def backward_query(self, packed, origins, directions, e_bins, camera_indices, density, d_rgb, d_density, pos_run: int = 1,
+                       d_rays: Optional[torch.Tensor] = None):
         """Gradients of the field parameters for upstream d_rgb [R,S,3] / d_density [R,S] of a structured query.
         Returns [d table, d base_w0, d base_w1, d head_w0, d head_w1, d head_w2, d embedding].  ``pos_run`` > 1: runs of that many
         consecutive rays share their single sample position (the grid refresh), see neraf_field_backward_runs."""
@@ -301,13 +304,19 @@ class NerfactoField(nn.Module):
         cam = camera_indices.reshape(-1).to(torch.int32).contiguous() if camera_indices is not None else None
         mode = 0 if self.spatial_distortion is not None else 1
         ab = _lib.host_f32(self.aabb)
-        _lib.check(lib.neraf_field_backward_runs(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), wfrag.data_ptr(), wfrag_b.data_ptr(),
-                                            emb.data_ptr(), origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(),
-                                            cam.data_ptr() if cam is not None else None, R, S, mode, ab, self.average_init_density,
-                                            -1 if cam is not None else self.embedding.shape[0], density.data_ptr(),
-                                            d_rgb.data_ptr(), d_density.data_ptr(), g_table.data_ptr(),
-                                            g_emb.data_ptr() if cam is not None else None, _lib.ptr_array(g_w), dump.data_ptr(),
-                                            splitk.data_ptr(), splitk.numel() * 4, int(pos_run), _stream_ptr()), dev)
+        common = (_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), wfrag.data_ptr(), wfrag_b.data_ptr(),
+                  emb.data_ptr(), origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(),
+                  cam.data_ptr() if cam is not None else None, R, S, mode, ab, self.average_init_density,
+                  -1 if cam is not None else self.embedding.shape[0], density.data_ptr(),
+                  d_rgb.data_ptr(), d_density.data_ptr(), g_table.data_ptr(),
+                  g_emb.data_ptr() if cam is not None else None, _lib.ptr_array(g_w), dump.data_ptr(),
+                  splitk.data_ptr(), splitk.numel() * 4)
+        if d_rays is not None:       # camera-pose edge: also accumulate d loss / d (origin, direction) per ray, fp32 [R,6]
+            if pos_run != 1:
+                raise ValueError("ray gradients are for structured ray batches (pos_run == 1)")
+            _lib.check(lib.neraf_field_backward_rays(*common, d_rays.data_ptr(), _stream_ptr()), dev)
+        else:
+            _lib.check(lib.neraf_field_backward_runs(*common, int(pos_run), _stream_ptr()), dev)
         return [g_table] + g_w + [g_emb]
 
     def grad_params(self):
@@ -358,7 +367,10 @@ class _VisionLossFn(torch.autograd.Function):
     """{rgb_loss, interlevel_loss, distortion_loss} as one autograd node over the radiance parameters."""
 
     @staticmethod
-    def forward(ctx, model: "NeRAFVisionModel", st: dict, gt: torch.Tensor, *params: torch.Tensor):
+    def forward(ctx, model: "NeRAFVisionModel", st: dict, gt: torch.Tensor, ray_o: torch.Tensor, ray_d: torch.Tensor,
+                *params: torch.Tensor):
+        """``ray_o`` / ``ray_d`` are the bundle's origins / directions as the camera optimizer produced them: when they carry a graph
+        (pose refinement on) the backward also returns d loss / d (origin, direction) per ray."""
         lib = _lib.load()
         dev = _dev_index(gt)
         h, stream = _lib.ctx(dev), _stream_ptr()
@@ -382,6 +394,7 @@ class _VisionLossFn(torch.autograd.Function):
                                                  None, None, sums.data_ptr(), stream), dev)
         ctx.model, ctx.st, ctx.gt, ctx.dev = model, st, gt, dev
         ctx.n_params = len(params)
+        ctx.need_rays = bool(ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
         # {sum (rgb-gt)^2, sum distortion, sum outer} -> the three means in one launch
         key = (R, S2, model.distortion_loss_mult, model.interlevel_loss_mult, str(gt.device))
         sc = getattr(model, "_loss_scale", None)
@@ -407,11 +420,14 @@ class _VisionLossFn(torch.autograd.Function):
         u_rgb, u_dens, u_dens_dist = ctx.unit
         d_rgb_s = u_rgb * up[0]
         d_dens = torch.addcmul(u_dens * up[0], u_dens_dist, up[2])
-        # ---- main field
-        grads = field.backward_query(st["field_packed"], st["o"], st["d"], fine.e_bins, st["cam"], st["dens"], d_rgb_s, d_dens)
+        # ---- main field (+ the camera-pose edge: d loss / d (origin, direction) per ray)
+        d_rays = torch.zeros((R, 6), **f32) if ctx.need_rays else None
+        grads = field.backward_query(st["field_packed"], st["o"], st["d"], fine.e_bins, st["cam"], st["dens"], d_rgb_s, d_dens,
+                                     d_rays=d_rays)
+        ray_grads = (d_rays[:, :3], d_rays[:, 3:]) if ctx.need_rays else (None, None)
         # ---- proposal networks (interlevel loss); densities were computed under no_grad when not `updated`
         if not st["prop_updated"]:
-            return (None, None, None, *grads, *([None] * (3 * len(model.proposal_networks))))
+            return (None, None, None, *ray_grads, *grads, *([None] * (3 * len(model.proposal_networks))))
         for i, pn in enumerate(model.proposal_networks):
             ps = st["samples"][i]
             Sp = ps.e_bins.shape[1] - 1
@@ -423,14 +439,17 @@ class _VisionLossFn(torch.autograd.Function):
             g_pt = torch.zeros_like(pn.table)
             g_pw = torch.zeros(16 * 16 + 16, **f32)
             scratch = torch.empty(2048 * 272, **f32)           # per-workgroup weight-gradient partials
-            _lib.check(lib.neraf_proposal_backward(h, C.byref(pn.desc), ptab.data_ptr(), pw.data_ptr(), st["o"].data_ptr(),
-                                                   st["d"].data_ptr(), ps.e_bins.data_ptr(), d_pd.data_ptr(), R, Sp,
-                                                   pn.average_init_density, g_pt.data_ptr(), g_pw.data_ptr(), scratch.data_ptr(),
-                                                   scratch.numel() * 4, stream), dev)
+            pargs = (h, C.byref(pn.desc), ptab.data_ptr(), pw.data_ptr(), st["o"].data_ptr(), st["d"].data_ptr(), ps.e_bins.data_ptr(),
+                     d_pd.data_ptr(), R, Sp, pn.average_init_density, g_pt.data_ptr(), g_pw.data_ptr(), scratch.data_ptr(),
+                     scratch.numel() * 4)
+            if ctx.need_rays:
+                _lib.check(lib.neraf_proposal_backward_rays(*pargs, d_rays.data_ptr(), stream), dev)
+            else:
+                _lib.check(lib.neraf_proposal_backward(*pargs, stream), dev)
             g_w1 = torch.zeros_like(pn.w1)
             g_w1[0] = g_pw[256:]
             grads += [g_pt, g_pw[:256].reshape(16, 16), g_w1]
-        return (None, None, None, *grads)
+        return (None, None, None, *ray_grads, *grads)
 
 
 class NeRAFVisionModel(nn.Module):
@@ -553,8 +572,9 @@ class NeRAFVisionModel(nn.Module):
         lib = _lib.load()
         if self.training:
             ray_bundle = self.camera_optimizer.apply_to_raybundle(ray_bundle)     # NerfactoModel.get_outputs [NS-recall]
-        o = ray_bundle.origins.detach().float().contiguous()
-        d = ray_bundle.directions.detach().float().contiguous()
+        ray_o, ray_d = ray_bundle.origins, ray_bundle.directions      # carry the camera optimizer's graph when it is on
+        o = ray_o.detach().float().contiguous()
+        d = ray_d.detach().float().contiguous()
         dev = _dev_index(o)
         h, st = _lib.ctx(dev), _stream_ptr()
         R = o.shape[0]
@@ -605,7 +625,7 @@ class NeRAFVisionModel(nn.Module):
             out["weights_list"] = weights_list
             out["ray_samples_list"] = samples_list
             # everything the fused loss/backward node needs (same packed fp16 parameter copies as the forward used)
-            out["_state"] = dict(o=o, d=d, cam=ray_bundle.camera_indices, samples=samples_list, prop_dens=prop_dens,
+            out["_state"] = dict(o=o, d=d, ray_o=ray_o, ray_d=ray_d, cam=ray_bundle.camera_indices, samples=samples_list, prop_dens=prop_dens,
                                  prop_packed=prop_packed, field_packed=field_packed, rgb_s=rgb_s, dens=dens, w_fine=w,
                                  prop_updated=prop_updated)
         out["rgb_samples"], out["density"] = rgb_s, dens
@@ -637,7 +657,8 @@ class NeRAFVisionModel(nn.Module):
         if "_state" not in outputs:
             raise RuntimeError("get_loss_dict needs the outputs of a training-mode get_outputs call")
         gt = (batch["image"] if "image" in batch else batch["rgb"]).to(outputs["rgb"].device).float().contiguous()
-        rgb_l, inter, dist = _VisionLossFn.apply(self, outputs["_state"], gt, *self.loss_params())
+        st = outputs["_state"]
+        rgb_l, inter, dist = _VisionLossFn.apply(self, st, gt, st["ray_o"], st["ray_d"], *self.loss_params())
         d = {"rgb_loss": rgb_l, "interlevel_loss": inter, "distortion_loss": dist}
         self.camera_optimizer.get_loss_dict(d)
         return d

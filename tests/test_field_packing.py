@@ -75,7 +75,7 @@ def test_field_backward_fragment_dataflow_matches_autograd():
     flat = np.concatenate([Wn["base_w0"].ravel(), Wn["base_w1"].ravel(), Wn["head_w0"].ravel(), Wn["head_w1"].ravel(),
                            Wn["head_w2"].ravel(), np.zeros(1)])
     wf = flat[_FRAG_INDEX].reshape(24, 64, 8)
-    wb = flat[_FRAG_INDEX_BWD].reshape(26, 64, 8)
+    wb = flat[_FRAG_INDEX_BWD].reshape(28, 64, 8)
     rng = np.random.default_rng(1)
     enc = rng.normal(size=(16, 32)); sh = rng.normal(size=(16, 16)); emb = rng.normal(size=(16, 32))
     g_rgb = rng.normal(size=(16, 3)); g_logit = rng.normal(size=(16,))
