@@ -91,14 +91,19 @@ class JointStep:
 
     ``R`` / ``B`` are THIS rank's rays / slices; ``tag_rank`` selects which synthetic shard it holds."""
 
-    def __init__(self, dev, R, B, world, dataset="raf", start_step=20000):
+    def __init__(self, dev, R, B, world, dataset="raf", start_step=20000, camera_opt=True):
         import torch
         from neraf_amd import synth
+        from neraf_amd.config import NeRAFVisionModelConfig, CameraOptimizerConfig, SceneBox
         from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
-        from neraf_amd.vision import NeRAFVisionModel, RayBundle
+        from neraf_amd.vision import RayBundle
         self.dev, self.R, self.B, self.world = dev, R, B, world
         rank = int(os.environ.get("RANK", "0"))
-        self.vm = NeRAFVisionModel(torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]), 210).to(dev)
+        # the vision model as NeRAF_config.py:94-98 configures it: nerfacto defaults, 32768-ray eval chunks, average_init_density 0.01,
+        # camera_optimizer SO3xR3 (pose deltas of the 210 training cameras are applied to every ray bundle and trained)
+        vcfg = NeRAFVisionModelConfig(camera_optimizer=CameraOptimizerConfig(mode="SO3xR3" if camera_opt else "off"))
+        self.vm = vcfg.setup(scene_box=SceneBox(torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])), num_train_data=210, metadata={},
+                             device=dev, grad_scaler=None, seed_points=None).to(dev)
         with torch.no_grad():      # trained-like table magnitudes (synthetic, same on every rank)
             g = torch.Generator(device="cpu").manual_seed(0)
             for p in [self.vm.field.module.table] + [pn.table for pn in self.vm.proposal_networks]:
@@ -486,14 +491,15 @@ def main():
             "config": {
                 "workload": (("RAF FurnishedRoom joint step (BASELINE configs[2] shape: %d rays + %d RIR slices x 513 bins per GPU): " if a.dataset == "raf"
                               else "SoundSpaces joint step (BASELINE configs[3] head shape: %d rays + %d RIR slices x 2 x 257 bins per GPU): ") +
-                             "radiance forward (camera-optimizer hook, sampler, 2 proposal nets, 2 PDF resamplings, fused field query, composite) + rgb/"
+                             "radiance forward (camera-pose deltas, sampler, 2 proposal nets, 2 PDF resamplings, fused field query, composite) + rgb/"
                              "interlevel/distortion losses -> grid refresh (%d cells x 18 dirs%s) -> ResNet3D forward on the 7x128^3 "
                              "grid -> audio prologue + NAcF MLP -> STFT loss -> one backward (NAcF -> ResNet3D -> refreshed grid cells -> "
                              "field; radiance losses -> proposal nets + fused field backward + weight-grad GEMMs) -> %sGradScaler + "
                              "fused Adam: proposal_networks + fields (lr 1e-2 -> 1e-4 @200k), then audio_fields = NAcF + ResNet3D + fields again "
                              "(lr 1e-4 -> 1e-8, 2000 warm-up), as NeRAF_pipeline.py:487 / NeRAF_config.py:115-132 group and schedule them -> "
-                             "scheduler steps.  Not inside: data loading (batches are resident), camera-pose refinement (the bench bundle "
-                             "carries no trainable poses).")
+                             "scheduler steps; the camera optimizer (SO3xR3, NeRAF_config.py:97) is on: pose deltas applied to the ray bundle, "
+                             "their photometric + regulariser gradients computed, camera_opt Adam group stepped (lr 1e-3 -> 1e-4 @5k).  "
+                             "Not inside: data loading (batches are resident).")
                              % (R_local, B_local, 4096, ", sharded over the ranks" if world > 1 else "", "RCCL all-reduce -> " if world > 1 else ""),
                 "rays_per_gpu": R_local, "slices_per_gpu": B_local, "global_rays": R_global, "global_slices": B_global,
                 "parallelism": f"dp{world}",

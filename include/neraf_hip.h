@@ -358,6 +358,17 @@ int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_real, int co
                                    void* y_f16, float* dx, float* dw, float* dgamma, float* dbeta, neraf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Camera-pose refinement on a ray bundle (nerfstudio CameraOptimizer(mode="SO3xR3").apply_to_raybundle, NeRAF_config.py:97):
+ * pose_adjustment fp32 [n_cameras, 6] = (translation | so(3) log); per ray origins_out = origins + t[cam], dirs_out = exp(w[cam]) dirs
+ * (Rodrigues, squared angle clamped at 1e-4 as nerfstudio does).  The backward ACCUMULATES d pose [n_cameras, 6] (caller zeroes)
+ * from d origins_out / d dirs_out [R,3] (e.g. the d_rays halves of neraf_field_backward_rays).
+ * ---------------------------------------------------------------------------------- */
+int neraf_camera_apply(neraf_ctx* ctx, const float* pose_adjustment, const int32_t* cam_idx, const float* origins, const float* dirs,
+                       int R, float* origins_out, float* dirs_out, neraf_stream_t stream);
+int neraf_camera_apply_bwd(neraf_ctx* ctx, const float* pose_adjustment, const int32_t* cam_idx, const float* dirs,
+                           const float* d_origins, const float* d_dirs, int R, float* d_pose, neraf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * fp16 working copies of the radiance parameters (tiny-cuda-nn keeps fp32 masters + fp16 copies inside its optimizer; the
  * reference reaches them through nerfstudio's NerfactoField / HashMLPDensityField).  neraf_cvt_f16_segments converts up to 12
  * contiguous fp32 tensors (hash tables, embedding, proposal MLP weights) to fp16 in ONE launch: src / dst / len are HOST arrays

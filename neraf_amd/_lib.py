@@ -132,6 +132,8 @@ SIGNATURES = {
     "neraf_resnet3d_pack_weights_bwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), c_fpp, C.c_void_p, C.c_void_p]),
     "neraf_resnet3d_bwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, c_fpp, C.c_void_p, C.c_void_p,
                                      C.c_void_p, c_fpp, c_fpp, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "neraf_camera_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_camera_apply_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "neraf_cvt_f16_segments": (C.c_int, [C.c_void_p, c_fpp, c_fpp, C.POINTER(C.c_longlong), C.c_int, C.c_void_p]),
     "neraf_gather_f16": (C.c_int, [C.c_void_p, c_fpp, C.POINTER(C.c_longlong), C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "neraf_resnet3d_debug_locate": (C.c_int, [C.POINTER(ResnetDesc), C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int),

@@ -160,6 +160,39 @@ def exp_map_SO3xR3(tangent: torch.Tensor) -> torch.Tensor:
     return torch.cat([R, tangent[:, :3, None]], dim=-1)
 
 
+class _CameraApplyFn(torch.autograd.Function):
+    """``apply_to_raybundle`` on the device as ONE launch each way (csrc/camera.hip) instead of the ~35 small launches the PyTorch
+    expression below costs per training step once autograd has replayed it.  Inputs: pose_adjustment [n,6], camera index [R] int32,
+    origins / directions [R,3] fp32 (constants: the data manager's rays)."""
+
+    @staticmethod
+    def forward(ctx, pose: torch.Tensor, cam: torch.Tensor, o: torch.Tensor, d: torch.Tensor):
+        from . import _lib
+        from .field import _dev_index, _stream_ptr
+        lib = _lib.load()
+        dev = _dev_index(o)
+        R = o.shape[0]
+        o_out, d_out = torch.empty_like(o), torch.empty_like(d)
+        _lib.check(lib.neraf_camera_apply(_lib.ctx(dev), pose.data_ptr(), cam.data_ptr(), o.data_ptr(), d.data_ptr(), R, o_out.data_ptr(),
+                                          d_out.data_ptr(), _stream_ptr()), dev)
+        ctx.save_for_backward(pose, cam, d)
+        ctx.dev = dev
+        return o_out, d_out
+
+    @staticmethod
+    def backward(ctx, g_o: torch.Tensor, g_d: torch.Tensor):
+        from . import _lib
+        from .field import _stream_ptr
+        pose, cam, d = ctx.saved_tensors
+        lib = _lib.load()
+        g_pose = torch.zeros_like(pose)
+        g_o = g_o.contiguous().float() if g_o is not None else torch.zeros_like(d)
+        g_d = g_d.contiguous().float() if g_d is not None else torch.zeros_like(d)
+        _lib.check(lib.neraf_camera_apply_bwd(_lib.ctx(ctx.dev), pose.data_ptr(), cam.data_ptr(), d.data_ptr(), g_o.data_ptr(), g_d.data_ptr(),
+                                              d.shape[0], g_pose.data_ptr(), _stream_ptr()), ctx.dev)
+        return g_pose, None, None, None
+
+
 class CameraOptimizer(nn.Module):
     """``CameraOptimizerConfig(mode="SO3xR3")`` (NeRAF_config.py:97) [NS-recall: cameras/camera_optimizers.py].
 
@@ -193,6 +226,11 @@ class CameraOptimizer(nn.Module):
     def apply_to_raybundle(self, ray_bundle: RayBundle) -> RayBundle:
         if self.mode == "off" or ray_bundle.camera_indices is None:
             return ray_bundle
+        if ray_bundle.origins.is_cuda and not ray_bundle.origins.requires_grad and not ray_bundle.directions.requires_grad:
+            cam = ray_bundle.camera_indices.reshape(-1).to(torch.int32).contiguous()
+            o, d = _CameraApplyFn.apply(self.pose_adjustment, cam, ray_bundle.origins.float().contiguous(),
+                                        ray_bundle.directions.float().contiguous())
+            return RayBundle(o, d, ray_bundle.camera_indices, ray_bundle.nears, ray_bundle.fars)
         corr = self(ray_bundle.camera_indices)
         origins = ray_bundle.origins + corr[:, :3, 3]
         directions = torch.bmm(corr[:, :3, :3], ray_bundle.directions[..., None]).squeeze(-1)
@@ -200,8 +238,14 @@ class CameraOptimizer(nn.Module):
 
     def get_loss_dict(self, loss_dict: Dict[str, torch.Tensor]) -> None:
         if self.mode != "off":
-            loss_dict["camera_opt_regularizer"] = (self.pose_adjustment[:, :3].norm(dim=-1).mean() * self.trans_l2_penalty
-                                                   + self.pose_adjustment[:, 3:].norm(dim=-1).mean() * self.rot_l2_penalty)
+            # mean |t| * trans_l2_penalty + mean |w| * rot_l2_penalty, as three launches: norms of the [n, 2, 3] view, weights, sum
+            w = getattr(self, "_reg_w", None)
+            if w is None or w.device != self.pose_adjustment.device:
+                w = torch.tensor([self.trans_l2_penalty / self.num_cameras, self.rot_l2_penalty / self.num_cameras],
+                                 device=self.pose_adjustment.device)
+                self._reg_w = w
+            n = torch.linalg.vector_norm(self.pose_adjustment.view(-1, 2, 3), dim=-1)
+            loss_dict["camera_opt_regularizer"] = (n * w).sum()
 
     def get_metrics_dict(self, metrics_dict: Dict[str, torch.Tensor]) -> None:
         if self.mode != "off":

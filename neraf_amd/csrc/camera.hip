@@ -1,0 +1,125 @@
+// SO3xR3 camera-pose refinement applied to a ray bundle (nerfstudio CameraOptimizer.apply_to_raybundle, configured at
+// NeRAF_config.py:97): per ray  o' = o + t[cam],  d' = exp(w[cam]) d  with pose_adjustment[cam] = (t | w), exp by Rodrigues' formula
+// with nerfstudio's small-angle guard (the squared angle is clamped at 1e-4 before the square root).  Forward and backward are one
+// launch each; the PyTorch expression they replace (neraf_amd/cameras.py, kept as the reference of the tests) is ~35 small launches
+// per training step once autograd has replayed it.
+#include "common.h"
+
+namespace {
+
+struct Rod { float f1, f2, df1, df2, a; bool clamped; };
+
+__device__ __forceinline__ Rod rodrigues(float wx, float wy, float wz) {
+  Rod r;
+  const float n = wx * wx + wy * wy + wz * wz;
+  r.clamped = n < 1e-4f;
+  const float a2 = r.clamped ? 1e-4f : n;
+  const float a = sqrtf(a2), inv = 1.f / a;
+  const float s = sinf(a), c = cosf(a);
+  r.a = a;
+  r.f1 = inv * s;
+  r.f2 = inv * inv * (1.f - c);
+  r.df1 = (c * a - s) * inv * inv;                          // d/da sin(a)/a
+  r.df2 = (s * a - 2.f * (1.f - c)) * inv * inv * inv;      // d/da (1 - cos a)/a^2
+  return r;
+}
+
+__device__ __forceinline__ void cross(float ax, float ay, float az, float bx, float by, float bz, float& cx, float& cy, float& cz) {
+  cx = ay * bz - az * by; cy = az * bx - ax * bz; cz = ax * by - ay * bx;
+}
+
+__global__ __launch_bounds__(256) void camera_apply_kernel(const float* __restrict__ pose, const int* __restrict__ cam, const float* __restrict__ o,
+                                                          const float* __restrict__ d, int R, float* __restrict__ o_out, float* __restrict__ d_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R) return;
+  const float* p = pose + (size_t)cam[i] * 6;
+  const float wx = p[3], wy = p[4], wz = p[5];
+  const Rod r = rodrigues(wx, wy, wz);
+  const float dx = d[i * 3], dy = d[i * 3 + 1], dz = d[i * 3 + 2];
+  float kx, ky, kz, k2x, k2y, k2z;
+  cross(wx, wy, wz, dx, dy, dz, kx, ky, kz);                // K d
+  cross(wx, wy, wz, kx, ky, kz, k2x, k2y, k2z);             // K^2 d
+  d_out[i * 3] = dx + r.f1 * kx + r.f2 * k2x;
+  d_out[i * 3 + 1] = dy + r.f1 * ky + r.f2 * k2y;
+  d_out[i * 3 + 2] = dz + r.f1 * kz + r.f2 * k2z;
+  o_out[i * 3] = o[i * 3] + p[0]; o_out[i * 3 + 1] = o[i * 3 + 1] + p[1]; o_out[i * 3 + 2] = o[i * 3 + 2] + p[2];
+}
+
+// d pose[cam] += (d_o | J_w^T d_d); runs of rays with the same camera inside a wave are summed first (the sampler draws rays image
+// by image or at random: either way one atomic per run instead of one per ray)
+__global__ __launch_bounds__(256) void camera_apply_bwd_kernel(const float* __restrict__ pose, const int* __restrict__ cam, const float* __restrict__ d,
+                                                              const float* __restrict__ g_o, const float* __restrict__ g_d, int R,
+                                                              float* __restrict__ g_pose) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool valid = i < R;
+  const int c = valid ? cam[i] : -1;
+  float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    const float* p = pose + (size_t)c * 6;
+    const float wx = p[3], wy = p[4], wz = p[5];
+    const Rod r = rodrigues(wx, wy, wz);
+    const float dx = d[i * 3], dy = d[i * 3 + 1], dz = d[i * 3 + 2];
+    const float ux = g_d[i * 3], uy = g_d[i * 3 + 1], uz = g_d[i * 3 + 2];
+    g[0] = g_o[i * 3]; g[1] = g_o[i * 3 + 1]; g[2] = g_o[i * 3 + 2];
+    float kx, ky, kz, k2x, k2y, k2z;
+    cross(wx, wy, wz, dx, dy, dz, kx, ky, kz);
+    cross(wx, wy, wz, kx, ky, kz, k2x, k2y, k2z);
+    // radial term: (df1 K d + df2 K^2 d) . u * w_i / a   (zero inside the small-angle guard, where a is constant)
+    const float radial = r.clamped ? 0.f : ((r.df1 * kx + r.df2 * k2x) * ux + (r.df1 * ky + r.df2 * k2y) * uy + (r.df1 * kz + r.df2 * k2z) * uz) / r.a;
+    const float w[3] = {wx, wy, wz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float ex = a == 0 ? 1.f : 0.f, ey = a == 1 ? 1.f : 0.f, ez = a == 2 ? 1.f : 0.f;
+      float t1x, t1y, t1z, t2x, t2y, t2z, t3x, t3y, t3z;
+      cross(ex, ey, ez, dx, dy, dz, t1x, t1y, t1z);          // e_a x d
+      cross(ex, ey, ez, kx, ky, kz, t2x, t2y, t2z);          // e_a x (w x d)
+      cross(wx, wy, wz, t1x, t1y, t1z, t3x, t3y, t3z);       // w x (e_a x d)
+      g[3 + a] = r.f1 * (t1x * ux + t1y * uy + t1z * uz) + r.f2 * ((t2x + t3x) * ux + (t2y + t3y) * uy + (t2z + t3z) * uz) + radial * w[a];
+    }
+  }
+  // segmented sum over runs of equal camera index among consecutive lanes
+  const int prev = __shfl_up(c, 1), next = __shfl_down(c, 1);
+  int head = (lane == 0 || prev != c) ? 1 : 0;
+  const bool tail = (lane == 63) || next != c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float up[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) up[k] = __shfl_up(g[k], o);
+    const int hu = __shfl_up(head, o);
+    if (lane >= o) {
+      if (!head) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[k] += up[k];
+      }
+      head |= hu;
+    }
+  }
+  if (valid && tail) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (g[k] != 0.f) atomicAdd(g_pose + (size_t)c * 6 + k, g[k]);
+  }
+}
+
+}  // namespace
+
+extern "C" int neraf_camera_apply(neraf_ctx* ctx, const float* pose_adjustment, const int32_t* cam_idx, const float* origins,
+                                  const float* dirs, int R, float* origins_out, float* dirs_out, neraf_stream_t stream) {
+  if (!pose_adjustment || !cam_idx || !origins || !dirs || R <= 0 || !origins_out || !dirs_out)
+    return neraf_fail(ctx, NERAF_EINVAL, "camera_apply: bad arguments");
+  hipLaunchKernelGGL(camera_apply_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose_adjustment, cam_idx, origins, dirs, R,
+                     origins_out, dirs_out);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" int neraf_camera_apply_bwd(neraf_ctx* ctx, const float* pose_adjustment, const int32_t* cam_idx, const float* dirs,
+                                      const float* d_origins, const float* d_dirs, int R, float* d_pose, neraf_stream_t stream) {
+  if (!pose_adjustment || !cam_idx || !dirs || !d_origins || !d_dirs || R <= 0 || !d_pose)
+    return neraf_fail(ctx, NERAF_EINVAL, "camera_apply_bwd: bad arguments");
+  hipLaunchKernelGGL(camera_apply_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose_adjustment, cam_idx, dirs, d_origins,
+                     d_dirs, R, d_pose);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}

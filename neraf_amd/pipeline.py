@@ -282,7 +282,8 @@ class NeRAFPipeline(nn.Module):
         """Data parallel: average gradients over the ranks, overlapped with the backward pass (neraf_amd/parallel.py)."""
         from .parallel import GradientReducer
         groups = [list(self.audio_model.field.parameters()), list(self.audio_model.resnet3d.parameters()) if self.audio_model.use_grid else [],
-                  list(self.model.field.parameters()), [p for pn in self.model.proposal_networks for p in pn.parameters()]]
+                  list(self.model.field.parameters()), [p for pn in self.model.proposal_networks for p in pn.parameters()],
+                  list(self.model.camera_optimizer.parameters()) if hasattr(self.model, "camera_optimizer") else []]
         groups = [g for g in groups if g]
         self._reducer = GradientReducer(groups, group=group)
         if self.audio_model.use_grid:

@@ -642,13 +642,15 @@ class NeRAFVisionModel(nn.Module):
         return ps
 
     def get_metrics_dict(self, outputs, batch):
-        """NerfactoModel.get_metrics_dict [NS-recall]: psnr of the batch (+ camera-optimizer norms in training)."""
+        """NerfactoModel.get_metrics_dict [NS-recall]: psnr of the batch (+ camera-optimizer norms in training).  In training the
+        psnr is filled in by ``get_loss_dict`` from the rgb loss it computes anyway (psnr = -10 log10(mse): two launches instead of
+        a second pass over the batch); outside training it is computed here."""
         m: Dict[str, torch.Tensor] = {}
-        if batch is not None and ("image" in batch or "rgb" in batch):
-            gt = (batch["image"] if "image" in batch else batch["rgb"]).to(outputs["rgb"].device).float()
-            m["psnr"] = psnr(outputs["rgb"].detach(), gt)
         if self.training:
             self.camera_optimizer.get_metrics_dict(m)
+        elif batch is not None and ("image" in batch or "rgb" in batch):
+            gt = (batch["image"] if "image" in batch else batch["rgb"]).to(outputs["rgb"].device).float()
+            m["psnr"] = psnr(outputs["rgb"].detach(), gt)
         return m
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
@@ -661,6 +663,8 @@ class NeRAFVisionModel(nn.Module):
         rgb_l, inter, dist = _VisionLossFn.apply(self, st, gt, st["ray_o"], st["ray_d"], *self.loss_params())
         d = {"rgb_loss": rgb_l, "interlevel_loss": inter, "distortion_loss": dist}
         self.camera_optimizer.get_loss_dict(d)
+        if metrics_dict is not None and "psnr" not in metrics_dict:
+            metrics_dict["psnr"] = torch.log10(rgb_l.detach()) * -10.0
         return d
 
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:

@@ -187,3 +187,36 @@ def test_ray_gradients_vs_oracle_and_reach_the_camera_optimizer(setup):
     used = torch.zeros(210, dtype=torch.bool, device=dev)
     used[cam.long()] = True
     assert float(g[~used].abs().max()) == 0.0                          # cameras without rays in the batch get no photometric gradient
+
+
+def test_fused_camera_apply_matches_the_pytorch_expression():
+    """csrc/camera.hip (one launch forward, one backward) against the PyTorch restatement of CameraOptimizer.apply_to_raybundle
+    (exp_map_SO3xR3 + bmm, neraf_amd/cameras.py) and its autograd gradient, for poses inside and outside the small-angle guard."""
+    from neraf_amd.cameras import CameraOptimizer, exp_map_SO3xR3
+    from neraf_amd.vision import RayBundle
+    dev = torch.device("cuda:0")
+    n_cam, R = 37, 5000
+    pose = T(synth.normal("t.cam.pose", (n_cam, 6), 0.2))
+    pose[:5, 3:] *= 1e-3                                    # inside the guard (|w|^2 < 1e-4)
+    pose[5] = 0.0
+    cam = T(synth.integers("t.cam.idx", (R,), 0, n_cam))
+    o = T(synth.uniform("t.cam.o", (R, 3), -1, 1))
+    d = torch.nn.functional.normalize(T(synth.normal("t.cam.d", (R, 3))), dim=-1)
+    wo, wd = T(synth.normal("t.cam.wo", (R, 3))), T(synth.normal("t.cam.wd", (R, 3)))
+    # PyTorch expression (fp64 reference)
+    pr = pose.double().clone().requires_grad_(True)
+    corr = exp_map_SO3xR3(pr[cam])
+    o_ref = o.double() + corr[:, :3, 3]
+    d_ref = torch.bmm(corr[:, :3, :3], d.double()[..., None]).squeeze(-1)
+    ((o_ref * wo.double()).sum() + (d_ref * wd.double()).sum()).backward()
+    # fused
+    co = CameraOptimizer(n_cam, mode="SO3xR3").to(dev)
+    with torch.no_grad():
+        co.pose_adjustment.copy_(pose.to(dev))
+    out = co.apply_to_raybundle(RayBundle(o.to(dev), d.to(dev), cam.to(dev)[:, None]))
+    np.testing.assert_allclose(out.origins.detach().cpu().numpy(), o_ref.detach().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(out.directions.detach().cpu().numpy(), d_ref.detach().numpy(), rtol=1e-5, atol=2e-6)
+    ((out.origins * wo.to(dev)).sum() + (out.directions * wd.to(dev)).sum()).backward()
+    g, g_ref = co.pose_adjustment.grad.cpu().double(), pr.grad
+    assert float((g - g_ref).norm() / g_ref.norm()) <= 1e-4, float((g - g_ref).norm() / g_ref.norm())
+    np.testing.assert_allclose(g[:6].numpy(), g_ref[:6].numpy(), rtol=2e-3, atol=1e-3)       # guarded rows
