@@ -456,11 +456,13 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
     if (a.pos && q == 0) { a.pos[ncol] = x; a.pos[a.npad + ncol] = y; a.pos[2 * a.npad + ncol] = z; }
     // ---------------- forward recompute (identical to field_query_kernel) ----------------
     half8 xin;
+    float dfe[RAYGRAD ? 4 : 1][2][3];                // RAYGRAD: d enc / d mapped position of this lane's four levels
 #pragma unroll
     for (int li = 0; li < 4; ++li) {
       const int l = 4 * q + li;
       float f0, f1;
-      encode_level(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1);
+      if (RAYGRAD) encode_level_grad(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1, dfe[RAYGRAD ? li : 0][0], dfe[RAYGRAD ? li : 0][1]);
+      else encode_level(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1);
       xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
     }
     f32x4 d1[4];
@@ -634,16 +636,17 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
       tl[li] += fmaxf(fabsf((float)gh[0]), fabsf((float)gh[1]));
     }
     if (RAYGRAD) {
-      // d loss / d (origin, direction) of this sample's ray: hash-grid input gradient of this lane's four levels (a second
-      // gather of the 32 entries the forward recompute just touched), through the position map, plus the SH input gradient;
-      // summed over the four lanes of a point and, when the 16 points of the group lie on one ray, over the group
+      // d loss / d (origin, direction) of this sample's ray: hash-grid input gradient of this lane's four levels (their
+      // derivatives came out of the forward recompute's gathers), through the position map, plus the SH input gradient; summed over
+      // the four lanes of a point and, when the 16 points of the group lie on one ray, over the group
       float px = 0.f, py = 0.f, pz = 0.f;
       if (valid && sel && a.mode == 0) {
 #pragma unroll
         for (int li = 0; li < 4; ++li) {
-          const int l = 4 * q + li;
-          encode_level_dpos(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l],
-                            de[li >> 1][2 * (li & 1)], de[li >> 1][2 * (li & 1) + 1], px, py, pz);
+          const float g0 = de[li >> 1][2 * (li & 1)], g1 = de[li >> 1][2 * (li & 1) + 1];
+          px = fmaf(g0, dfe[RAYGRAD ? li : 0][0][0], fmaf(g1, dfe[RAYGRAD ? li : 0][1][0], px));
+          py = fmaf(g0, dfe[RAYGRAD ? li : 0][0][1], fmaf(g1, dfe[RAYGRAD ? li : 0][1][1], py));
+          pz = fmaf(g0, dfe[RAYGRAD ? li : 0][0][2], fmaf(g1, dfe[RAYGRAD ? li : 0][1][2], pz));
         }
       }
       px += __shfl_xor(px, 16); py += __shfl_xor(py, 16); pz += __shfl_xor(pz, 16);
