@@ -218,6 +218,14 @@ int neraf_field_query(neraf_ctx* ctx, const neraf_grid_desc* g, const void* tabl
                       const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host, float avg_density,
                       int avg_row, float* rgb, float* density, neraf_stream_t stream);
 
+/* Training form of the query: additionally stores the interpolated encoding enc_out fp16 [R*S, 32] (required) and, when denc_out is
+ * not NULL, its derivatives w.r.t. the mapped sample position denc_out fp16 [R*S, 4, 24] (lane quarter, then level x feature x axis).
+ * neraf_field_backward_ex reads them back instead of walking the hash table a second time (and a third for the camera-pose edge). */
+int neraf_field_query_train(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                            const void* emb_f16, const float* origins, const float* dirs, const float* e_bins,
+                            const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host, float avg_density,
+                            int avg_row, float* rgb, float* density, void* enc_out, void* denc_out, neraf_stream_t stream);
+
 /* Weights + composite for S <= 64 samples per ray: rgb = sum w c + c_last (1 - sum w) (clipped to
  * [0,1], NeRAF_model.py:67), median depth, expected depth (needs scratch8: 8 bytes), accumulation. */
 int neraf_composite(neraf_ctx* ctx, const float* density, const float* rgb, const float* e_bins, int R, int S,
@@ -285,6 +293,16 @@ int neraf_field_backward_rays(neraf_ctx* ctx, const neraf_grid_desc* g, const vo
                               float avg_density, int avg_row, const float* density, const float* d_rgb, const float* d_density,
                               float* table_grad, float* emb_grad, float* const* w_grads, void* dump, void* splitk_ws,
                               size_t splitk_bytes, float* d_rays, neraf_stream_t stream);
+/* The general form of the three calls above: pos_run as neraf_field_backward_runs, d_rays as neraf_field_backward_rays (NULL = none),
+ * enc_saved / denc_saved = the buffers neraf_field_query_train filled for the SAME batch and parameters (NULL = recompute from the table;
+ * denc_saved is only read together with d_rays). */
+int neraf_field_backward_ex(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                            const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
+                            const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
+                            float avg_density, int avg_row, const float* density, const float* d_rgb, const float* d_density,
+                            float* table_grad, float* emb_grad, float* const* w_grads, void* dump, void* splitk_ws,
+                            size_t splitk_bytes, int pos_run, float* d_rays, const void* enc_saved, const void* denc_saved,
+                            neraf_stream_t stream);
 int neraf_proposal_backward_rays(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                                  const float* origins, const float* dirs, const float* e_bins, const float* d_density, int R,
                                  int S, float avg_density, float* table_grad, float* w_grad, void* scratch, size_t scratch_bytes,

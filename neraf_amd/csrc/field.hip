@@ -192,10 +192,15 @@ struct FieldArgs {
   const float* origins; const float* dirs; const float* e_bins; const int* cam_idx;
   int R, S; int mode; float aabb[6]; float avg_density; int avg_row;
   float* rgb; float* density;
+  half_t* enc_out;               // optional fp16 [N][32]: the interpolated encoding, lane order (sample, quarter, 8) -- the backward reads
+                                 // it back instead of walking the hash table again at one wave per SIMD
+  half_t* denc_out;              // optional fp16 [N][4][24]: d enc / d mapped position of each lane's 4 levels x 2 features x 3 axes
+                                 // (the camera-pose edge of the backward)
 };
 
 constexpr int NFRAG = 24;   // base0: 0-3, base1: 4-5, head0: 6-13 (ob*2+s), head1: 14-21, head2: 22-23
 
+template <int SAVE>   // 0: outputs only; 1: also the encoding; 2: the encoding and its position derivatives
 __global__ __launch_bounds__(256) void field_query_kernel(FieldArgs a) {
   __shared__ float l_scale[MAX_LEVELS];
   __shared__ int l_res[MAX_LEVELS];
@@ -228,13 +233,32 @@ __global__ __launch_bounds__(256) void field_query_kernel(FieldArgs a) {
     const bool sel = map_position(x, y, z, a.mode, a.aabb);
     // --- hash encode: this lane's 4 levels -> B fragment of the first layer (k = 8q + 2*li + f)
     half8 xin;
+    if (SAVE == 2) {
+      half8 dh[3];                                 // [li][feature][axis] = 24 halfs
+      half_t* dp = reinterpret_cast<half_t*>(dh);
 #pragma unroll
-    for (int li = 0; li < 4; ++li) {
-      const int l = 4 * q + li;
-      float f0, f1;
-      encode_level(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1);
-      xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
+      for (int li = 0; li < 4; ++li) {
+        const int l = 4 * q + li;
+        float f0, f1, d0[3], d1_[3];
+        encode_level_grad(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1, d0, d1_);
+        xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dp[li * 6 + k] = (half_t)(sel ? d0[k] : 0.f); dp[li * 6 + 3 + k] = (half_t)(sel ? d1_[k] : 0.f); }
+      }
+      if (valid) {
+        half8* dst = reinterpret_cast<half8*>(a.denc_out + ((size_t)n * 4 + q) * 24);
+        dst[0] = dh[0]; dst[1] = dh[1]; dst[2] = dh[2];
+      }
+    } else {
+#pragma unroll
+      for (int li = 0; li < 4; ++li) {
+        const int l = 4 * q + li;
+        float f0, f1;
+        encode_level(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1);
+        xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
+      }
     }
+    if (SAVE >= 1 && valid) *reinterpret_cast<half8*>(a.enc_out + ((size_t)n * 4 + q) * 8) = xin;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     // --- base MLP 32 -> 64 (ReLU) -> 16
     f32x4 d1[4];
@@ -509,10 +533,32 @@ extern "C" int neraf_pdf_resample(neraf_ctx* ctx, const float* density, const fl
   return NERAF_OK;
 }
 
+static int field_query_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                            const void* emb_f16, const float* origins, const float* dirs, const float* e_bins,
+                            const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host, float avg_density,
+                            int avg_row, float* rgb, float* density, void* enc_out, void* denc_out, neraf_stream_t stream);
+
 extern "C" int neraf_field_query(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
                                  const void* emb_f16, const float* origins, const float* dirs, const float* e_bins,
                                  const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host, float avg_density,
                                  int avg_row, float* rgb, float* density, neraf_stream_t stream) {
+  return field_query_impl(ctx, g, table_f16, wfrag_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode, aabb_host, avg_density,
+                          avg_row, rgb, density, nullptr, nullptr, stream);
+}
+
+extern "C" int neraf_field_query_train(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                                       const void* emb_f16, const float* origins, const float* dirs, const float* e_bins,
+                                       const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host, float avg_density,
+                                       int avg_row, float* rgb, float* density, void* enc_out, void* denc_out, neraf_stream_t stream) {
+  if (!enc_out) return neraf_fail(ctx, NERAF_EINVAL, "field_query_train: enc_out required");
+  return field_query_impl(ctx, g, table_f16, wfrag_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode, aabb_host, avg_density,
+                          avg_row, rgb, density, enc_out, denc_out, stream);
+}
+
+static int field_query_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                            const void* emb_f16, const float* origins, const float* dirs, const float* e_bins,
+                            const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host, float avg_density,
+                            int avg_row, float* rgb, float* density, void* enc_out, void* denc_out, neraf_stream_t stream) {
   FieldArgs a{};
   if (make_grid_layout(g, &a.g) || a.g.n_levels != 16) return neraf_fail(ctx, NERAF_EINVAL, "field_query: grid must have 16 levels");
   if (R <= 0 || S <= 0 || !table_f16 || !wfrag_f16 || !emb_f16 || !origins || !dirs || !e_bins || !rgb || !density ||
@@ -528,7 +574,10 @@ extern "C" int neraf_field_query(neraf_ctx* ctx, const neraf_grid_desc* g, const
   const long cap = (long)(ctx ? ctx->num_cus : 256) * 8;
   if (blocks > cap) blocks = cap;
   ProfScope prof(ctx, (hipStream_t)stream, PROF_FIELD_QUERY, (double)n * 16 * 8 * 4);   // gathered table bytes
-  hipLaunchKernelGGL(field_query_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  a.enc_out = (half_t*)enc_out; a.denc_out = (half_t*)denc_out;
+  if (denc_out) hipLaunchKernelGGL(field_query_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else if (enc_out) hipLaunchKernelGGL(field_query_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(field_query_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }

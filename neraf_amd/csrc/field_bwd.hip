@@ -391,6 +391,8 @@ struct FieldBwdArgs {
                                                    // workgroup's leading embedding row (rows 64.. of slots 2 / 3)
   float* pos;                                      // optional fp32 [3][npad]: mapped sample positions for the owner scatter (slot 4, rows 64..)
   float* d_ray;                                    // optional fp32 [R][6], ACCUMULATED: d loss / d (ray origin, ray direction) -- the camera-pose optimizer's edge
+  const half_t* enc_in;                            // optional fp16 [N][32] saved by the forward (neraf_field_query_train): no table walk here
+  const half_t* denc_in;                           // optional fp16 [N][4][24]: saved d enc / d position (with d_ray)
 };
 
 __device__ __forceinline__ void dump_block(half_t* base, long npad, long n, int row0, const f32x4& v, float m) {
@@ -399,7 +401,7 @@ __device__ __forceinline__ void dump_block(half_t* base, long npad, long n, int 
   for (int r = 0; r < 4; ++r) base[(long)(row0 + r) * npad + n] = (half_t)(v[r] * m);
 }
 
-template <bool RAYGRAD>
+template <bool RAYGRAD, bool SAVED>
 __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
   __shared__ float l_scale[MAX_LEVELS];
   __shared__ int l_res[MAX_LEVELS];
@@ -457,13 +459,29 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
     // ---------------- forward recompute (identical to field_query_kernel) ----------------
     half8 xin;
     float dfe[RAYGRAD ? 4 : 1][2][3];                // RAYGRAD: d enc / d mapped position of this lane's four levels
+    if (SAVED) {
+      // the forward stored the encoding (and its position derivatives): two to five coalesced 16-byte loads instead of 32 gathers
+      // whose latency a one-wave-per-SIMD kernel cannot hide (render batch: 210 -> see DESIGN.md)
+      xin = *reinterpret_cast<const half8*>(a.enc_in + ((size_t)n * 4 + q) * 8);
+      if (RAYGRAD) {
+        half8 dh[3];
+        const half8* src = reinterpret_cast<const half8*>(a.denc_in + ((size_t)n * 4 + q) * 24);
+        dh[0] = src[0]; dh[1] = src[1]; dh[2] = src[2];
+        const half_t* dp = reinterpret_cast<const half_t*>(dh);
 #pragma unroll
-    for (int li = 0; li < 4; ++li) {
-      const int l = 4 * q + li;
-      float f0, f1;
-      if (RAYGRAD) encode_level_grad(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1, dfe[RAYGRAD ? li : 0][0], dfe[RAYGRAD ? li : 0][1]);
-      else encode_level(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1);
-      xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
+        for (int li = 0; li < 4; ++li)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { dfe[RAYGRAD ? li : 0][0][k] = (float)dp[li * 6 + k]; dfe[RAYGRAD ? li : 0][1][k] = (float)dp[li * 6 + 3 + k]; }
+      }
+    } else {
+#pragma unroll
+      for (int li = 0; li < 4; ++li) {
+        const int l = 4 * q + li;
+        float f0, f1;
+        if (RAYGRAD) encode_level_grad(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1, dfe[RAYGRAD ? li : 0][0], dfe[RAYGRAD ? li : 0][1]);
+        else encode_level(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1);
+        xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
+      }
     }
     f32x4 d1[4];
 #pragma unroll
@@ -1159,7 +1177,8 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
                                const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
                                float avg_density, int avg_row, const float* density, const float* d_rgb,
                                const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
-                               void* splitk_ws, size_t splitk_bytes, int pos_run, float* d_rays, neraf_stream_t stream);
+                               void* splitk_ws, size_t splitk_bytes, int pos_run, float* d_rays, const void* enc_in, const void* denc_in,
+                               neraf_stream_t stream);
 
 extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
                                     const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
@@ -1169,7 +1188,7 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
                                     size_t splitk_bytes, neraf_stream_t stream) {
   return field_backward_impl(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
                              aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
-                             splitk_ws, splitk_bytes, 1, nullptr, stream);
+                             splitk_ws, splitk_bytes, 1, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
@@ -1180,7 +1199,7 @@ extern "C" int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* 
                                          void* splitk_ws, size_t splitk_bytes, int pos_run, neraf_stream_t stream) {
   return field_backward_impl(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
                              aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
-                             splitk_ws, splitk_bytes, pos_run, nullptr, stream);
+                             splitk_ws, splitk_bytes, pos_run, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int neraf_field_backward_rays(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
@@ -1192,7 +1211,20 @@ extern "C" int neraf_field_backward_rays(neraf_ctx* ctx, const neraf_grid_desc* 
   if (!d_rays) return neraf_fail(ctx, NERAF_EINVAL, "field_backward_rays: d_rays required");
   return field_backward_impl(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
                              aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
-                             splitk_ws, splitk_bytes, 1, d_rays, stream);
+                             splitk_ws, splitk_bytes, 1, d_rays, nullptr, nullptr, stream);
+}
+
+extern "C" int neraf_field_backward_ex(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
+                                      const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
+                                      const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
+                                      float avg_density, int avg_row, const float* density, const float* d_rgb,
+                                      const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
+                                      void* splitk_ws, size_t splitk_bytes, int pos_run, float* d_rays, const void* enc_saved,
+                                      const void* denc_saved, neraf_stream_t stream) {
+  if (d_rays && pos_run != 1) return neraf_fail(ctx, NERAF_EINVAL, "field_backward_ex: ray gradients need pos_run == 1");
+  return field_backward_impl(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
+                             aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
+                             splitk_ws, splitk_bytes, pos_run, d_rays, enc_saved, denc_saved, stream);
 }
 
 static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
@@ -1200,7 +1232,8 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
                                const float* e_bins, const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host,
                                float avg_density, int avg_row, const float* density, const float* d_rgb,
                                const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
-                               void* splitk_ws, size_t splitk_bytes, int pos_run, float* d_rays, neraf_stream_t stream) {
+                               void* splitk_ws, size_t splitk_bytes, int pos_run, float* d_rays, const void* enc_in, const void* denc_in,
+                               neraf_stream_t stream) {
   if (pos_run < 1 || (pos_run > 1 && (S != 1 || R % pos_run != 0)))
     return neraf_fail(ctx, NERAF_EINVAL, "field_backward_runs: pos_run > 1 needs S == 1 and R a multiple of pos_run");
   FieldBwdArgs a{};
@@ -1266,9 +1299,11 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
     if (blocks > cap) blocks = cap;
     {
       ProfScope prof(ctx, st, PROF_FIELD_BWD, (double)N * 16 * 8 * 4);       // gathered fp16x2 bytes
-      a.d_ray = d_rays;
-      if (d_rays) hipLaunchKernelGGL(field_backward_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL(field_backward_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+      a.d_ray = d_rays; a.enc_in = (const half_t*)enc_in; a.denc_in = (const half_t*)denc_in;
+      if (d_rays && enc_in && denc_in) hipLaunchKernelGGL((field_backward_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+      else if (d_rays) hipLaunchKernelGGL((field_backward_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+      else if (enc_in) hipLaunchKernelGGL((field_backward_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((field_backward_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     }
     NERAF_HIP_CHECK(ctx, hipGetLastError());
     // hash-grid gradient: per-level fixed-point scale from the gradient mass, packed 64-bit scatter, in-place unpack

@@ -81,11 +81,11 @@ class _RefreshFn(torch.autograd.Function):
         _lib.check(lib.neraf_refresh_origins(_lib.ctx(dev), coords.data_ptr(), n, nd, _lib.host_f32(aabb), oris.data_ptr(),
                                              _stream_ptr()), dev)                          # :315, :327-333
         packed = field.packed(with_average=False)       # the refresh queries with camera index 0's embedding (:334)
-        rgb, den = field.query(oris, dd, z, cam, use_average_embedding=False, packed=packed)    # [n*nd,1,3], [n*nd,1]
+        rgb, den, saved = field.query(oris, dd, z, cam, use_average_embedding=False, packed=packed, save=1)    # [n*nd,1,3], [n*nd,1]
         vals = torch.empty((4, n), dtype=torch.float32, device=coords.device)
         _lib.check(lib.neraf_grid_refresh_vals(_lib.ctx(dev), rgb.data_ptr(), den.data_ptr(), n, nd, 1, delta, vals.data_ptr(),
                                                _stream_ptr()), dev)                        # :352-357, :386
-        ctx.field, ctx.nd, ctx.delta, ctx.packed, ctx.dev = field, nd, delta, packed, dev
+        ctx.field, ctx.nd, ctx.delta, ctx.packed, ctx.dev, ctx.saved = field, nd, delta, packed, dev, saved
         ctx.save_for_backward(oris, dd, z, cam, den)
         return vals
 
@@ -100,7 +100,7 @@ class _RefreshFn(torch.autograd.Function):
         d_den = torch.empty((nd * n, 1), dtype=torch.float32, device=oris.device)
         _lib.check(lib.neraf_grid_refresh_vals_bwd(_lib.ctx(ctx.dev), dvals.data_ptr(), den.data_ptr(), n, nd, 1, delta,
                                                    d_rgb.data_ptr(), d_den.data_ptr(), _stream_ptr()), ctx.dev)
-        grads = ctx.field.backward_query(ctx.packed, oris, dd, z, cam, den, d_rgb, d_den, pos_run=nd)   # cell-major: nd rays per position
+        grads = ctx.field.backward_query(ctx.packed, oris, dd, z, cam, den, d_rgb, d_den, pos_run=nd, saved=ctx.saved)   # cell-major: nd rays per position
         return (None, None, None, None, None, None, None, *grads)
 
 

@@ -286,7 +286,7 @@ class NerfactoField(nn.Module):
         return self._splitk
 
     def backward_query(self, packed, origins, directions, e_bins, camera_indices, density, d_rgb, d_density, pos_run: int = 1,
-                       d_rays: Optional[torch.Tensor] = None):
+                       d_rays: Optional[torch.Tensor] = None, saved=None):
         """Gradients of the field parameters for upstream d_rgb [R,S,3] / d_density [R,S] of a structured query.
         Returns [d table, d base_w0, d base_w1, d head_w0, d head_w1, d head_w2, d embedding].  ``pos_run`` > 1: runs of that many
         consecutive rays share their single sample position (the grid refresh), see neraf_field_backward_runs."""
@@ -311,19 +311,23 @@ class NerfactoField(nn.Module):
                   d_rgb.data_ptr(), d_density.data_ptr(), g_table.data_ptr(),
                   g_emb.data_ptr() if cam is not None else None, _lib.ptr_array(g_w), dump.data_ptr(),
                   splitk.data_ptr(), splitk.numel() * 4)
-        if d_rays is not None:       # camera-pose edge: also accumulate d loss / d (origin, direction) per ray, fp32 [R,6]
-            if pos_run != 1:
-                raise ValueError("ray gradients are for structured ray batches (pos_run == 1)")
-            _lib.check(lib.neraf_field_backward_rays(*common, d_rays.data_ptr(), _stream_ptr()), dev)
-        else:
-            _lib.check(lib.neraf_field_backward_runs(*common, int(pos_run), _stream_ptr()), dev)
+        # d_rays: camera-pose edge, also accumulate d loss / d (origin, direction) per ray (fp32 [R,6]); saved = (enc, denc | None) as
+        # stored by query(save=...) for this batch and parameter state: no second walk of the hash table
+        if d_rays is not None and pos_run != 1:
+            raise ValueError("ray gradients are for structured ray batches (pos_run == 1)")
+        enc, denc = saved if saved is not None else (None, None)
+        _lib.check(lib.neraf_field_backward_ex(*common, int(pos_run), d_rays.data_ptr() if d_rays is not None else None,
+                                               enc.data_ptr() if enc is not None else None,
+                                               denc.data_ptr() if (denc is not None and d_rays is not None) else None, _stream_ptr()), dev)
         return [g_table] + g_w + [g_emb]
 
     def grad_params(self):
         return [self.table, self.base_w0, self.base_w1, self.head_w0, self.head_w1, self.head_w2, self.embedding]
 
-    def query(self, origins, directions, e_bins, camera_indices=None, use_average_embedding: bool = False, packed=None):
-        """Structured query: R rays x S samples.  Returns (rgb [R,S,3], density [R,S])."""
+    def query(self, origins, directions, e_bins, camera_indices=None, use_average_embedding: bool = False, packed=None, save: int = 0):
+        """Structured query: R rays x S samples.  Returns (rgb [R,S,3], density [R,S]); with ``save`` = 1 / 2 also
+        ``(enc fp16 [R*S,32], denc fp16 [R*S,4,24] | None)``: the interpolated encoding (and its position derivatives) for
+        ``backward_query(saved=...)``."""
         lib = _lib.load()
         dev = _dev_index(origins)
         R, S = e_bins.shape[0], e_bins.shape[1] - 1
@@ -336,10 +340,16 @@ class NerfactoField(nn.Module):
         cam = camera_indices.reshape(-1).to(torch.int32).contiguous() if camera_indices is not None else None
         mode = 0 if self.spatial_distortion is not None else 1
         ab = _lib.host_f32(self.aabb)
-        _lib.check(lib.neraf_field_query(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), wfrag.data_ptr(), emb.data_ptr(),
-                                         origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(),
-                                         cam.data_ptr() if cam is not None else None, R, S, mode, ab,
-                                         self.average_init_density, avg_row, rgb.data_ptr(), den.data_ptr(), _stream_ptr()), dev)
+        args = (_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), wfrag.data_ptr(), emb.data_ptr(),
+                origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(),
+                cam.data_ptr() if cam is not None else None, R, S, mode, ab,
+                self.average_init_density, avg_row, rgb.data_ptr(), den.data_ptr())
+        if save:
+            enc = torch.empty((R * S, 32), dtype=torch.float16, device=origins.device)
+            denc = torch.empty((R * S, 4, 24), dtype=torch.float16, device=origins.device) if save >= 2 else None
+            _lib.check(lib.neraf_field_query_train(*args, enc.data_ptr(), denc.data_ptr() if denc is not None else None, _stream_ptr()), dev)
+            return rgb, den, (enc, denc)
+        _lib.check(lib.neraf_field_query(*args, _stream_ptr()), dev)
         return rgb, den
 
     def forward(self, ray_samples: RaySamples, compute_normals: bool = False) -> Dict[str, torch.Tensor]:
@@ -423,7 +433,7 @@ class _VisionLossFn(torch.autograd.Function):
         # ---- main field (+ the camera-pose edge: d loss / d (origin, direction) per ray)
         d_rays = torch.zeros((R, 6), **f32) if ctx.need_rays else None
         grads = field.backward_query(st["field_packed"], st["o"], st["d"], fine.e_bins, st["cam"], st["dens"], d_rgb_s, d_dens,
-                                     d_rays=d_rays)
+                                     d_rays=d_rays, saved=st.get("field_saved"))
         ray_grads = (d_rays[:, :3], d_rays[:, 3:]) if ctx.need_rays else (None, None)
         # ---- proposal networks (interlevel loss); densities were computed under no_grad when not `updated`
         if not st["prop_updated"]:
@@ -609,8 +619,14 @@ class NeRAFVisionModel(nn.Module):
             s_prev, e_prev = s_n, e_n
         field = self.field.module
         field_packed = field.packed(with_average=not self.training or ray_bundle.camera_indices is None)
-        rgb_s, dens = field.query(o, d, e_prev, ray_bundle.camera_indices, use_average_embedding=not self.training,
-                                  packed=field_packed)
+        saved = None
+        if self.training and torch.is_grad_enabled():
+            # keep the encoding for the backward; with trainable poses (the rays carry the camera optimizer's graph) its derivatives too
+            rgb_s, dens, saved = field.query(o, d, e_prev, ray_bundle.camera_indices, use_average_embedding=False, packed=field_packed,
+                                             save=2 if (ray_o.requires_grad or ray_d.requires_grad) else 1)
+        else:
+            rgb_s, dens = field.query(o, d, e_prev, ray_bundle.camera_indices, use_average_embedding=not self.training,
+                                      packed=field_packed)
         w = torch.empty((R, S2), **f32)
         rgb, depth = torch.empty((R, 3), **f32), torch.empty((R, 1), **f32)
         expd, acc = torch.empty((R, 1), **f32), torch.empty((R, 1), **f32)
@@ -626,7 +642,7 @@ class NeRAFVisionModel(nn.Module):
             out["ray_samples_list"] = samples_list
             # everything the fused loss/backward node needs (same packed fp16 parameter copies as the forward used)
             out["_state"] = dict(o=o, d=d, ray_o=ray_o, ray_d=ray_d, cam=ray_bundle.camera_indices, samples=samples_list, prop_dens=prop_dens,
-                                 prop_packed=prop_packed, field_packed=field_packed, rgb_s=rgb_s, dens=dens, w_fine=w,
+                                 prop_packed=prop_packed, field_packed=field_packed, field_saved=saved, rgb_s=rgb_s, dens=dens, w_fine=w,
                                  prop_updated=prop_updated)
         out["rgb_samples"], out["density"] = rgb_s, dens
         return out
