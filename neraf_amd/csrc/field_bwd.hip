@@ -425,9 +425,11 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
   const int e_blk = e_blk_s;
   const int lane = threadIdx.x & 63;
   const int p = lane & 15, q = lane >> 4;
-  half8 wf[NFRAG];
-#pragma unroll
-  for (int f = 0; f < NFRAG; ++f) wf[f] = a.wfrag[f * 64 + lane];
+  // forward fragments in LDS too (24 KiB): held in registers they cost 96 VGPRs of a kernel that then fits one wave per SIMD only
+  __shared__ half8 wf_s[NFRAG * 64];
+  for (int i = threadIdx.x; i < NFRAG * 64; i += 256) wf_s[i] = a.wfrag[i];
+  const half8* wfp = wf_s + lane;
+#define wf(f) wfp[(f) * 64]
   // the 26 backward fragments live in LDS (26 KiB): each is read once per 16-point group, and a global (L1/L2) load in front
   // of every MFMA of the chain is a ~500-cycle dependency where the LDS read is ~64
   __shared__ half8 wb_s[NFRAG_B * 64];
@@ -485,9 +487,9 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
     }
     f32x4 d1[4];
 #pragma unroll
-    for (int ob = 0; ob < 4; ++ob) d1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ob], xin, zero, 0, 0, 0);
-    f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[4], pack_relu(d1[0], d1[1], true), zero, 0, 0, 0);
-    d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[5], pack_relu(d1[2], d1[3], true), d2, 0, 0, 0);
+    for (int ob = 0; ob < 4; ++ob) d1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(ob), xin, zero, 0, 0, 0);
+    f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(4), pack_relu(d1[0], d1[1], true), zero, 0, 0, 0);
+    d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(5), pack_relu(d1[2], d1[3], true), d2, 0, 0, 0);
     float sh[4];
     sh4_quarter(q, dx, dy, dz, sh);
     half8 h0;
@@ -500,17 +502,17 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
     f32x4 d3[4], d4[4];
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
-      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[6 + ob * 2], h0, zero, 0, 0, 0);
-      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[7 + ob * 2], h1, d3[ob], 0, 0, 0);
+      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(6 + ob * 2), h0, zero, 0, 0, 0);
+      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(7 + ob * 2), h1, d3[ob], 0, 0, 0);
     }
     const half8 a0 = pack_relu(d3[0], d3[1], true), a1 = pack_relu(d3[2], d3[3], true);
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
-      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[14 + ob * 2], a0, zero, 0, 0, 0);
-      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[15 + ob * 2], a1, d4[ob], 0, 0, 0);
+      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(14 + ob * 2), a0, zero, 0, 0, 0);
+      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(15 + ob * 2), a1, d4[ob], 0, 0, 0);
     }
-    f32x4 d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[22], pack_relu(d4[0], d4[1], true), zero, 0, 0, 0);
-    d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[23], pack_relu(d4[2], d4[3], true), d5, 0, 0, 0);
+    f32x4 d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(22), pack_relu(d4[0], d4[1], true), zero, 0, 0, 0);
+    d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(23), pack_relu(d4[2], d4[3], true), d5, 0, 0, 0);
     // ---------------- backward ----------------
     f32x4 dy5 = zero;
     if (q == 0 && valid) {
@@ -712,6 +714,7 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
     a.t_part[(long)blockIdx.x * 16 + threadIdx.x] = t_sum[0][threadIdx.x] + t_sum[1][threadIdx.x] + t_sum[2][threadIdx.x] + t_sum[3][threadIdx.x];
   if (threadIdx.x < 32) a.e_part[(long)blockIdx.x * 32 + threadIdx.x] = e_acc[threadIdx.x];
   if (threadIdx.x == 0) a.e_part_row[blockIdx.x] = e_blk;
+#undef wf
 }
 
 // ---- hash-grid gradient scatter in packed fixed point ---------------------------------------------------------------------
