@@ -201,7 +201,7 @@ struct FieldArgs {
 constexpr int NFRAG = 24;   // base0: 0-3, base1: 4-5, head0: 6-13 (ob*2+s), head1: 14-21, head2: 22-23
 
 template <int SAVE>   // 0: outputs only; 1: also the encoding; 2: the encoding and its position derivatives
-__global__ __launch_bounds__(256) void field_query_kernel(FieldArgs a) {
+__global__ __launch_bounds__(256, SAVE == 2 ? 2 : 3) void field_query_kernel(FieldArgs a) {
   __shared__ float l_scale[MAX_LEVELS];
   __shared__ int l_res[MAX_LEVELS];
   __shared__ unsigned l_size[MAX_LEVELS], l_off[MAX_LEVELS];
@@ -213,9 +213,13 @@ __global__ __launch_bounds__(256) void field_query_kernel(FieldArgs a) {
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int p = lane & 15, q = lane >> 4;
-  half8 wf[NFRAG];
-#pragma unroll
-  for (int f = 0; f < NFRAG; ++f) wf[f] = a.wfrag[f * 64 + lane];
+  // the 24 weight fragments live in LDS (24 KiB per workgroup), not in 96 VGPRs: the kernel is bound by the latency of its 32
+  // table gathers per lane, and what hides that is waves per SIMD (202 VGPRs allowed two; now four)
+  __shared__ half8 wf_s[NFRAG * 64];
+  for (int i = threadIdx.x; i < NFRAG * 64; i += 256) wf_s[i] = a.wfrag[i];
+  __syncthreads();
+  const half8* wfp = wf_s + lane;
+#define wf(f) wfp[(f) * 64]
 
   const long N = (long)a.R * a.S;
   const long ngroups = (N + 15) / 16;
@@ -263,9 +267,9 @@ __global__ __launch_bounds__(256) void field_query_kernel(FieldArgs a) {
     // --- base MLP 32 -> 64 (ReLU) -> 16
     f32x4 d1[4];
 #pragma unroll
-    for (int ob = 0; ob < 4; ++ob) d1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ob], xin, zero, 0, 0, 0);
-    f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[4], pack_relu(d1[0], d1[1], true), zero, 0, 0, 0);
-    d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[5], pack_relu(d1[2], d1[3], true), d2, 0, 0, 0);
+    for (int ob = 0; ob < 4; ++ob) d1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(ob), xin, zero, 0, 0, 0);
+    f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(4), pack_relu(d1[0], d1[1], true), zero, 0, 0, 0);
+    d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(5), pack_relu(d1[2], d1[3], true), d2, 0, 0, 0);
     // density = avg * trunc_exp(logit) * selector ; logit = base output 0 -> lane q == 0, register 0
     if (q == 0 && valid) a.density[n] = sel ? a.avg_density * __expf(d2[0]) : 0.f;
     // --- colour head input: k-step 0 = [base out 4q..4q+3 | SH 4q..4q+3], k-step 1 = appearance embedding 8q..8q+7
@@ -280,23 +284,24 @@ __global__ __launch_bounds__(256) void field_query_kernel(FieldArgs a) {
     f32x4 d3[4], d4[4];
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
-      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[6 + ob * 2], h0, zero, 0, 0, 0);
-      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[7 + ob * 2], h1, d3[ob], 0, 0, 0);
+      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(6 + ob * 2), h0, zero, 0, 0, 0);
+      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(7 + ob * 2), h1, d3[ob], 0, 0, 0);
     }
     const half8 a0 = pack_relu(d3[0], d3[1], true), a1 = pack_relu(d3[2], d3[3], true);
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
-      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[14 + ob * 2], a0, zero, 0, 0, 0);
-      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[15 + ob * 2], a1, d4[ob], 0, 0, 0);
+      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(14 + ob * 2), a0, zero, 0, 0, 0);
+      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(15 + ob * 2), a1, d4[ob], 0, 0, 0);
     }
-    f32x4 d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[22], pack_relu(d4[0], d4[1], true), zero, 0, 0, 0);
-    d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[23], pack_relu(d4[2], d4[3], true), d5, 0, 0, 0);
+    f32x4 d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(22), pack_relu(d4[0], d4[1], true), zero, 0, 0, 0);
+    d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(23), pack_relu(d4[2], d4[3], true), d5, 0, 0, 0);
     if (q == 0 && valid) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) a.rgb[(size_t)n * 3 + c] = 1.f / (1.f + __expf(-d5[c]));
     }
   }
 }
+#undef wf
 
 // ---- weights + composite, one wavefront per ray (S <= 64) ---------------------------------------------------
 struct CompArgs {
