@@ -57,3 +57,39 @@ def test_native_checkpoint_round_trips():
     assert rep["skipped_tcnn"] == [] and rep["missing"] == []
     for (k, a), (_, b) in zip(sorted(pipeline_state_dict(vm, am).items()), sorted(pipeline_state_dict(vm2, am2).items())):
         assert torch.equal(a, b), k
+
+
+def test_tcnn_blob_converter_round_trips_under_the_documented_layout():
+    """tcnn's flat parameter blobs [TCNN-recall: MLP matrices [out, in] row-major padded to 16, then the grid levels]: blobs built
+    from a model under that layout load back into a fresh model exactly, in both key styles nerfstudio has used; a blob whose element
+    count does not match is skipped, not guessed.  (The layout itself cannot be validated offline: no tcnn, no released checkpoint.)"""
+    from neraf_amd.checkpoint import join_tcnn_mlp, tcnn_blobs_to_native
+    vm, am = _models()
+    with torch.no_grad():
+        for p in vm.parameters():
+            p.uniform_(-0.5, 0.5)
+    f = vm.field.module
+
+    def pad(m, rows, cols):
+        out = torch.zeros(rows, cols)
+        out[:m.shape[0], :m.shape[1]] = m
+        return out
+    state = {"_model.field.module.mlp_base.params": torch.cat([join_tcnn_mlp([f.base_w0.detach(), f.base_w1.detach()]), f.table.detach().reshape(-1)]).half(),
+             "_model.field.module.mlp_head.params": join_tcnn_mlp([f.head_w0.detach(), f.head_w1.detach(), f.head_w2.detach()]),
+             "_model.field.module.embedding_appearance.embedding.weight": f.embedding.detach().clone(),
+             "_model.proposal_networks.0.mlp_base_grid.tcnn_encoding.params": vm.proposal_networks[0].table.detach().reshape(-1).clone(),
+             "_model.proposal_networks.0.mlp_base_mlp.tcnn_encoding.params": join_tcnn_mlp([vm.proposal_networks[0].w0.detach(), vm.proposal_networks[0].w1.detach()]),
+             "_model.proposal_networks.1.mlp_base.params": torch.zeros(12345)}            # wrong size: must be skipped
+    vm2, am2 = _models()
+    rep = load_pipeline(dict(state), vm2, am2)
+    assert "_model.proposal_networks.1.mlp_base.params" in rep["skipped_tcnn"]
+    assert len(rep["converted_tcnn"]) == 5
+    f2 = vm2.field.module
+    np.testing.assert_allclose(f2.table.detach().numpy(), f.table.detach().half().float().numpy())
+    for a, b in ((f2.base_w0, f.base_w0), (f2.base_w1, f.base_w1)):
+        np.testing.assert_allclose(a.detach().numpy(), b.detach().half().float().numpy())
+    for a, b in ((f2.head_w0, f.head_w0), (f2.head_w2, f.head_w2), (f2.embedding, f.embedding), (vm2.proposal_networks[0].table, vm.proposal_networks[0].table),
+                 (vm2.proposal_networks[0].w1, vm.proposal_networks[0].w1)):
+        assert torch.equal(a.detach(), b.detach())
+    rep2 = tcnn_blobs_to_native({"_model.field.mlp_head.tcnn_encoding.params": state["_model.field.module.mlp_head.params"]}, vm2)
+    assert rep2["converted"] == ["_model.field.mlp_head.tcnn_encoding.params"]

@@ -227,3 +227,31 @@ def test_metric_chain_recovers_t60_of_a_synthetic_exponential_rir():
     rec_slow = gl(mag_slow, generator=torch.Generator(device=dev).manual_seed(0)).cpu().numpy()
     met2 = ev.get_full_metrics(mag_slow.cpu().numpy(), mag_gt.cpu().numpy(), wav_gt, rec_slow, wav_rec, torch.log(mag_slow + 1e-3).cpu().numpy(), log_gt)
     assert met2["audio_T60"] > 30.0, met2
+
+
+def test_device_rir_bank_equals_cpu_tokenisation_and_reference_item_semantics():
+    """SURVEY 8f rank 2 on the device: DeviceRIRBank built ON the GPU (rocFFT) equals the same tokenisation on the CPU
+    (log(|STFT| + 1e-3), slice-major), and a sampled batch has the reference's item semantics (NeRAF_dataset.py:85-86, :127-130:
+    flat index -> (rir, time slice), 'data' [B, C, F] = that slice of that RIR, poses / rot of that RIR, int64 time_query)."""
+    from neraf_amd.data import DeviceRIRBank
+    dev = torch.device("cuda:0")
+    n_rir, n = 5, 256 * 59
+    waves = T(np.stack([synth.normal(f"bank.rir{i}", (n,), 1.0, np.float64) * np.exp(-np.arange(n) / 48000.0 / 0.04) for i in range(n_rir)])).float()
+    mic, src = T(synth.uniform("bank.mic", (n_rir, 3), -2, 2)).double(), T(synth.uniform("bank.src", (n_rir, 3), -2, 2)).double()
+    rot = T(synth.uniform("bank.rot", (n_rir, 3), 0, 1)).double()
+    cpu = DeviceRIRBank.from_waveforms(waves, 48000, 60, mic, src, rot)
+    gpu = DeviceRIRBank.from_waveforms(waves, 48000, 60, mic, src, rot, device=dev)
+    assert gpu.log_mag.device.type == "cuda" and tuple(gpu.log_mag.shape) == (n_rir, 60, 1, 513)
+    np.testing.assert_allclose(gpu.log_mag.cpu().numpy(), cpu.log_mag.numpy(), rtol=0, atol=2e-3)
+    assert float((gpu.log_mag.cpu() - cpu.log_mag).abs().mean()) < 1e-5
+    g = torch.Generator(device=dev).manual_seed(3)
+    b = gpu.next_train(512, generator=g)
+    assert b["data"].shape == (512, 1, 513) and b["time_query"].dtype == torch.int64 and b["mic_pose"].dtype == torch.float64
+    r, t = b["audio_idx"].cpu(), b["time_query"].cpu()
+    assert int(t.max()) < 60 and int(r.max()) < n_rir
+    np.testing.assert_array_equal(b["data"].cpu().numpy(), gpu.log_mag.cpu()[r, t].numpy())
+    np.testing.assert_array_equal(b["mic_pose"].cpu().numpy(), mic[r].numpy())
+    item = gpu.get_data(3 * 60 + 7)                                    # flat index -> (3, 7)
+    assert item["audio_idx"] == 3 and item["time_query"] == 7 and torch.equal(item["data"], gpu.log_mag[3, 7])
+    ev = gpu.get_data_eval(2)
+    assert tuple(ev["data"].shape) == (1, 513, 60) and torch.equal(ev["data"][:, :, 11], gpu.log_mag[2, 11])
