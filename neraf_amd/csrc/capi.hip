@@ -10,6 +10,15 @@ __global__ void neraf_zero_kernel(unsigned* __restrict__ p, size_t n_words) {
   if (blockIdx.x == 0 && threadIdx.x < (n_words & 3)) p[n4 * 4 + threadIdx.x] = 0u;
 }
 
+__global__ void neraf_zero3_kernel(unsigned* __restrict__ p0, size_t n0, unsigned* __restrict__ p1, size_t n1, unsigned* __restrict__ p2, size_t n2) {
+  const size_t total = n0 + n1 + n2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    if (i < n0) p0[i] = 0u;
+    else if (i < n0 + n1) p1[i - n0] = 0u;
+    else p2[i - n0 - n1] = 0u;
+  }
+}
+
 extern "C" int neraf_abi_version(void) { return NERAF_ABI_VERSION; }
 
 extern "C" int neraf_ctx_create(neraf_ctx** out, int device) {

@@ -208,9 +208,7 @@ extern "C" int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_
 
 static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, const char* packed, const float* const* bn, const float* grid,
                              char* ws, float* feat, int use_batch_stats, hipStream_t st) {
-  neraf_zero_async(st, ws + L.zero_page, 256);
-  neraf_zero_async(st, ws + L.stats_begin, L.stats_bytes);
-  neraf_zero_async(st, feat, 1024 * sizeof(float));
+  neraf_zero3_async(st, ws + L.zero_page, 256, ws + L.stats_begin, L.stats_bytes, feat, 1024 * sizeof(float));
   const size_t nvox = cube(A.S);
   const bool shadow = use_batch_stats != 0;      // training forward: keep bfloat16 copies for the weight-gradient GEMMs
   hipLaunchKernelGGL(grid_to_ndhwc8_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, grid, nvox, (half_t*)(ws + L.x0),

@@ -195,12 +195,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
 }
 
 // ---- pools --------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dfeat, const float* __restrict__ scale, int M, int Mpad,
-                                                         int C, bf16_t* __restrict__ g) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)Mpad * C) return;
-  const int row = (int)(idx / C), c = (int)(idx % C);
-  g[idx] = (bf16_t)(row < M ? dfeat[c] * scale[0] / (float)M : 0.f);
+// Backward prologue in ONE launch: the power-of-two chain scale from max |d feat| (every workgroup derives the same value from the
+// 1024 inputs; workgroup 0 publishes {S, 1/S} for the kernels that follow) and the average-pool backward
+// g[row][c] = d feat[c] * S / M.  Replaces amax + make_scale + avgpool_bwd (three dependent launches of ~4.7 us each).
+__global__ __launch_bounds__(256) void bwd_prologue_kernel(const float* __restrict__ dfeat, float* __restrict__ scale, int target_log2, int M,
+                                                          int Mpad, int C, bf16_t* __restrict__ g) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < C; i += 256) { const float a = fabsf(dfeat[i]); m = (a == a && a > m) ? a : m; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  const float amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float S = 1.f;
+  if (amax > 0.f && amax < 3.0e38f) {
+    int e = target_log2 - (int)floorf(log2f(amax));
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    S = exp2f((float)e);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scale[0] = S; scale[1] = 1.f / S; }
+  const float k = S / (float)M;
+  const size_t total = (size_t)Mpad * C;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int row = (int)(idx / C), c = (int)(idx % C);
+    g[idx] = (bf16_t)(row < M ? dfeat[c] * k : 0.f);
+  }
 }
 
 // maxpool(3,2,1) of relu(bn(x)) backward: g[out voxel] goes to the arg-max input (first maximum), nothing if the max is <= 0.
@@ -297,27 +317,6 @@ __global__ void f16_to_bf16_kernel(const half_t* __restrict__ a, size_t n, bf16_
 __global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ a, size_t n, float* __restrict__ o) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = (float)a[i];
-}
-
-__global__ __launch_bounds__(256) void amax_f32_kernel(const float* __restrict__ v, int n, unsigned* __restrict__ amax_bits) {
-  float m = 0.f;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const float a = fabsf(v[i]); m = (a == a && a > m) ? a : m; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
-}
-
-__global__ void make_scale_kernel(float* __restrict__ scale, int target_log2) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const float amax = __uint_as_float(reinterpret_cast<unsigned*>(scale)[2]);
-    float S = 1.f;
-    if (amax > 0.f && amax < 3.0e38f) {
-      int e = target_log2 - (int)floorf(log2f(amax));
-      e = e > 100 ? 100 : (e < -100 ? -100 : e);
-      S = exp2f((float)e);
-    }
-    scale[0] = S; scale[1] = 1.f / S;
-  }
 }
 
 // ---- backward workspace ---------------------------------------------------------------------------------------------
@@ -519,19 +518,18 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
                              const float* const* conv_w, const float* const* bn, char* ws, char* bws, const float* dfeat,
                              float* const* w_grads, float* const* bn_grads, int n_cells, int n_ch, float* dgrid_cells, hipStream_t st) {
   float* scale = (float*)(bws + B.scale);
-  neraf_zero_async(st, scale, 16);
   neraf_zero_async(st, bws + B.sums_begin, B.sums_bytes);
-  hipLaunchKernelGGL(amax_f32_kernel, dim3(4), dim3(256), 0, st, dfeat, 1024, reinterpret_cast<unsigned*>(scale) + 2);
   // d feat is spread over M voxels by the average pool; aim the per-voxel gradient at ~2^4
   const int Mlast = (int)cube(A.final_edge);
-  hipLaunchKernelGGL(make_scale_kernel, dim3(1), dim3(64), 0, st, scale, 4 + (int)ceilf(log2f((float)Mlast)));
   Ctx c{ctx, st, &A, &L, &B, (const char*)packed_t, ws, bws, bn, w_grads, bn_grads, scale + 1};
   bf16_t* g = (bf16_t*)(bws + B.g[0]);
   bf16_t* g_next = (bf16_t*)(bws + B.g[1]);
   {
     const int Mpad = (int)rows_pad(A.final_edge);
     const size_t n = (size_t)Mpad * 1024;
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dfeat, scale, Mlast, Mpad, 1024, g);
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(bwd_prologue_kernel, dim3(blocks), dim3(256), 0, st, dfeat, scale, 4 + (int)ceilf(log2f((float)Mlast)), Mlast, Mpad, 1024, g);
   }
   bf16_t* gm = (bf16_t*)(bws + B.gm); bf16_t* da = (bf16_t*)(bws + B.da);
   WgradItem items[64]; int n_items = 0;     // every weight gradient is computed by ONE grouped launch at the end
