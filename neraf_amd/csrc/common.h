@@ -85,6 +85,9 @@ static inline int neraf_fail(neraf_ctx* ctx, int code, const char* what) {
 template <class Body>
 int neraf_run_graphed(neraf_ctx* ctx, hipStream_t user, uint64_t key, Body body) {
   if (!ctx || !ctx->graphs_enabled || ctx->prof) return body(user);
+  const char* tr = getenv("NERAF_GRAPH_TRUNC");      // measurement only: replay just a prefix of the captured sequence
+  const int trunc = tr ? atoi(tr) : -1;
+  if (trunc >= 0) key = key * 1099511628211ull + (uint64_t)(trunc + 1);
   GraphEntry* hit = nullptr;
   for (auto& e : ctx->graphs) if (e.key == key) { hit = &e; break; }
   if (!hit) {
@@ -100,6 +103,14 @@ int neraf_run_graphed(neraf_ctx* ctx, hipStream_t user, uint64_t key, Body body)
     hipGraph_t g = nullptr;
     const hipError_t ee = hipStreamEndCapture(ctx->capture_stream, &g);
     hipGraphExec_t ex = nullptr;
+    if (trunc >= 0 && ee == hipSuccess && g) {       // measurement only (tools/graph_prefix_times.py): keep the first `trunc` nodes
+      size_t n = 0;
+      if (hipGraphGetNodes(g, nullptr, &n) == hipSuccess && n > (size_t)trunc) {
+        std::vector<hipGraphNode_t> nodes(n);
+        if (hipGraphGetNodes(g, nodes.data(), &n) == hipSuccess)
+          for (size_t i = n; i-- > (size_t)trunc;) (void)hipGraphDestroyNode(nodes[i]);
+      }
+    }
     if (rc != NERAF_OK || ee != hipSuccess || !g || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) {
       if (g) (void)hipGraphDestroy(g);
       (void)hipGetLastError();
@@ -164,6 +175,9 @@ struct ConvGeom {
   int din, dout, stride, pad, ksize, cin;   // din = edge of the SOURCE tensor, dout = edge of the result
   int tflip;     // transposed convolution (dgrad): source offset is -tap instead of +tap
   int tstride;   // transposed convolution of a stride-2 conv: a tap contributes only where (z + pad - tap) is even
+  int tclass;    // (set by the dispatcher) tstride == 2 with PARITY-CLASS row order: M-tile t holds 64 result voxels of parity class
+                 // t & 7 = (z&1, y&1, x&1), so the tile walks only the taps that reach that class (27 -> 1, 2, 4 or 8 of a 3x3x3 filter;
+                 // 27/8 on average instead of 27 with 7/8 of the rows fed from the zero page); the epilogue maps rows back to voxels
   const half_t* zero_page;   // >= 16 bytes of zeros: source of every out-of-bounds / padding-tap chunk
 };
 

@@ -62,6 +62,24 @@ struct Tile {
   static constexpr int EPI_BYTES_WAVE = cmax(cmax(WM / C32_PASSES * IMG32_LD * 4, WM * IMG16_LD * 2), WN * IMG16T_LD * 2);
 };
 
+// Parity-class row order of a stride-2 transposed convolution (ConvGeom::tclass): GEMM row m -> (class, voxel coordinates).
+// Tile t = m / BM holds rows of class t & 7; within a class the voxels (z>>1, y>>1, x>>1) run in raster order.
+template <int BM>
+__device__ __forceinline__ void tclass_coords(const ConvGeom& g, int m, int& z, int& y, int& x) {
+  const int t = m / BM, cls = t & 7;
+  const int r = (t >> 3) * BM + (m - t * BM);
+  const int h = g.dout >> 1;
+  const int x2 = r % h, y2 = (r / h) % h, z2 = r / (h * h);
+  z = 2 * z2 + ((cls >> 2) & 1); y = 2 * y2 + ((cls >> 1) & 1); x = 2 * x2 + (cls & 1);
+}
+template <int BM>
+__device__ __forceinline__ int out_row(const GemmParams& p, int m) {
+  if (!p.conv.tclass) return m;
+  int z, y, x;
+  tclass_coords<BM>(p.conv, m, z, y, x);
+  return (z * p.conv.dout + y) * p.conv.dout + x;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Epilogue of the GEMM kernel (the split-K reducer applies the same operations element-wise).
 template <int BM, int BN, bool BF, int WAVES_M = 2>
@@ -97,7 +115,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         for (int r = 0; r < 4; ++r) v[r] *= ((float)mk[r] > 0.f) ? 1.f : p.mask_slope;
       }
       if (p.add16) {
-        const E4 ad = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.add16) + (size_t)m * p.ldadd + n0);
+        const E4 ad = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.add16) + (size_t)out_row<BM>(p, m) * p.ldadd + n0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)ad[r];
       }
@@ -165,7 +183,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     for (int it = 0; it < WM * CPR / 64; ++it) {
       const int idx = it * 64 + lane, row = idx / CPR, ch = idx - row * CPR;
       const uint4 d = *reinterpret_cast<const uint4*>(im + row * T::IMG16_LD + ch * 8);
-      *reinterpret_cast<uint4*>(p.C16 + (size_t)(m_w0 + row) * p.ldc16 + n_w0 + ch * 8) = d;
+      *reinterpret_cast<uint4*>(p.C16 + (size_t)out_row<BM>(p, m_w0 + row) * p.ldc16 + n_w0 + ch * 8) = d;
     }
     __syncthreads();
   }
@@ -280,7 +298,19 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
   const int bm = first_m + in_group % gsz;
   const int bn = in_group / gsz;
 
-  const int nk_total = p.K / BK;
+  // parity-class rows of a stride-2 transposed convolution: this tile's class walks taps t0 + 2i per axis only
+  const bool tclass = LOADER == 1 && p.conv.tclass;
+  int t0z = 0, t0y = 0, t0x = 0, cy = KS, cx = KS;
+  int nk_total = p.K / BK;
+  if (tclass) {
+    const int cls = bm & 7, padc = -p.conv.pad;
+    t0z = (((cls >> 2) & 1) + padc) & 1; t0y = (((cls >> 1) & 1) + padc) & 1; t0x = ((cls & 1) + padc) & 1;
+    const int cz = t0z < KS ? (KS - t0z + 1) >> 1 : 0;
+    cy = t0y < KS ? (KS - t0y + 1) >> 1 : 0; cx = t0x < KS ? (KS - t0x + 1) >> 1 : 0;
+    nk_total = cz * cy * cx * (p.conv.cin >> 6);
+    // a class no tap reaches (strided 1x1x1): the result is add16 itself -- nothing to do when that is the destination
+    if (nk_total == 0 && p.add16 == p.C16 && !p.C16T && !p.C32 && !p.colsum && !p.colsumsq && splits == 1) return;
+  }
   const int per = (nk_total + splits - 1) / splits;
   const int k_begin = split * per;
   const int k_end = (k_begin + per) < nk_total ? (k_begin + per) : nk_total;
@@ -307,7 +337,8 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
     } else {
       const int m = bm * BM + row;
       const int d = p.conv.dout;
-      const int x = m % d, y = (m / d) % d, z = m / (d * d);
+      int x = m % d, y = (m / d) % d, z = m / (d * d);
+      if (LOADER == 1 && p.conv.tclass) tclass_coords<BM>(p.conv, m, z, y, x);
       az[i] = z * p.conv.stride - p.conv.pad; ay[i] = y * p.conv.stride - p.conv.pad; ax[i] = x * p.conv.stride - p.conv.pad;
     }
   }
@@ -317,14 +348,21 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
   auto issue = [&](int kt, int stage) {
     char* sa = smem + stage * T::STAGE_BYTES + wave * 1024;   // wave-uniform base; HW adds lane*16
     char* sb = sa + BM * 128;
+    int kb = kt;                                               // K-step of the B panel (differs from kt for parity-class tiles)
     if (LOADER == 0) {
 #pragma unroll
       for (int i = 0; i < T::A_CH; ++i)
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + (size_t)kt * BK), (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
     } else if (LOADER == 1) {
       const int cpb = p.conv.cin >> 6;
-      const int tap = kt / cpb, cb = kt - tap * cpb;
-      const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+      int tap = kt / cpb;
+      const int cb = kt - tap * cpb;
+      int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+      if (tclass) {                       // tap = index into this class' list of contributing taps
+        dx = t0x + 2 * (tap % cx); dy = t0y + 2 * ((tap / cx) % cy); dz = t0z + 2 * (tap / (cx * cy));
+        tap = (dz * KS + dy) * KS + dx;
+        kb = tap * cpb + cb;
+      }
       const int din = p.conv.din;
       const int sdz = p.conv.tflip ? -dz : dz, sdy = p.conv.tflip ? -dy : dy, sdx = p.conv.tflip ? -dx : dx;
       const bool half_grid = p.conv.tstride == 2;
@@ -351,7 +389,7 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
     }
 #pragma unroll
     for (int i = 0; i < T::B_CH; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[i] + (size_t)kt * BK), (lds_ptr_t)(sb + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[i] + (size_t)kb * BK), (lds_ptr_t)(sb + i * 4096), 16, 0, 0);
   };
 
   const int frow = lane & 15, fq = lane >> 4;
@@ -1098,8 +1136,19 @@ static const int kWide = [] { const char* e = getenv("NERAF_GEMM_WIDE"); return 
 static const int kSplitMinK = [] { const char* e = getenv("NERAF_SPLIT_MIN_K"); return e ? atoi(e) : 32; }();
 
 template <int LOADER, int KS, bool BF>
-int dispatch_tile(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
+int dispatch_tile(neraf_ctx* ctx, const GemmParams& p_in, hipStream_t stream) {
+  GemmParams p = p_in;
   const int cus = ctx ? ctx->num_cus : 256;
+  // stride-2 transposed convolution: parity-class row order on 64x64 tiles (see ConvGeom::tclass); heavy and light classes
+  // alternate tile by tile, so every XCD's share of the grid holds the same mix
+  static const int kTclass = [] { const char* e = getenv("NERAF_DGRAD_TCLASS"); return e ? atoi(e) : 1; }();
+  p.conv.tclass = 0;
+  if (LOADER == 1 && kTclass && p.conv.tstride == 2 && p.conv.tflip && (p.conv.dout & 1) == 0 && p.ngroups <= 1 &&
+      p.Mpad == p.conv.dout * p.conv.dout * p.conv.dout && (p.Mpad % 512) == 0 && (p.Npad % 64) == 0 && !p.lmask && !p.C16T && !p.C32 &&
+      !p.colsum && !p.colsumsq) {
+    p.conv.tclass = 1;
+    return launch_pipe<64, 64, 4, LOADER, KS, BF>(ctx, p, 1, stream);
+  }
   const int nk = p.K / BK;
   // tile choice: 128x128 when it fills the chip; 128x64 for 64-wide outputs; otherwise 64x64 (4x the workgroups)
   int bm = 128, bn = 128;

@@ -556,8 +556,10 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     if (Bk.ds >= 0) {
       if (int e = bn_backward(c, Bk.ds, g, nullptr, out, dyds, nullptr)) return e;
       items[n_items++] = wgrad_item(c, Bk.ds, dyds, x_in_bf);
-      if (int e = conv_dgrad(c, Bk.ds, dyds, nullptr, da)) return e;           // residual-branch gradient w.r.t. x_in
-      if (int e = conv_dgrad(c, i0, dy0, da, g_next)) return e;
+      // the residual branch's gradient w.r.t. x_in is ADDED IN PLACE: a strided 1x1x1 branch reaches one voxel in eight, and the
+      // parity-class dgrad (ConvGeom::tclass) then skips the other seven classes' tiles altogether
+      if (int e = conv_dgrad(c, i0, dy0, nullptr, g_next)) return e;
+      if (int e = conv_dgrad(c, Bk.ds, dyds, g_next, g_next)) return e;
     } else {
       if (int e = conv_dgrad(c, i0, dy0, gm, g_next)) return e;                // identity residual
     }
