@@ -153,9 +153,11 @@ int neraf_nacf_bwd_dense(neraf_ctx* ctx, const neraf_nacf_desc* d, const void* p
  * STFT loss (STFTLoss.forward, NeRAF_evaluator.py:88-108; scaling NeRAF_model.py:584-600).
  * loss_type: 0 = 'mse' (SC+SLMSE), 1 = 'l1' (SC+SLL1).  sums (fp32[4], device, zeroed by the
  * call): sum (ymag-xmag)^2, sum ymag^2, sum |x-y|^p, unused.  losses (fp32[2], device):
- * {sc, mag} unscaled.  The *_bwd writes d(w[0]*sc + w[1]*mag)/dpred into dpred; w is a DEVICE
- * pointer to the two upstream gradients (loss weights x grad-scaler scale) so that no host
- * synchronisation is needed between forward and backward.
+ * {sc, mag}, multiplied by weights[0], weights[1] (device fp32[2], the loss factors of NeRAF_model.py:592-599) when weights != NULL.
+ * The *_bwd writes d(total)/dpred into dpred with d total/d sc = *g_sc * weights[0] * extra and d total/d mag = *g_mag * weights[1]
+ * * extra: g_sc / g_mag are DEVICE scalars (the upstream gradients, i.e. the grad-scaler scale; NULL = 0), weights as in the forward
+ * (NULL = 1), extra a host factor (the data-parallel world size, see neraf_amd/losses.py) -- no host synchronisation and no scalar
+ * torch ops between forward and backward.
  * ---------------------------------------------------------------------------------- */
 int neraf_stft_loss_fwd(neraf_ctx* ctx, const float* pred, const float* gt, size_t n, int loss_type,
                         float* sums, float* losses, neraf_stream_t stream);
@@ -164,10 +166,11 @@ int neraf_stft_loss_fwd(neraf_ctx* ctx, const float* pred, const float* gt, size
  * (RCCL), then finalize with the global element count n_total. */
 int neraf_stft_loss_sums(neraf_ctx* ctx, const float* pred, const float* gt, size_t n, int loss_type,
                          float* sums, neraf_stream_t stream);
-int neraf_stft_loss_finalize(neraf_ctx* ctx, const float* sums, size_t n_total, float* losses,
+int neraf_stft_loss_finalize(neraf_ctx* ctx, const float* sums, size_t n_total, const float* weights, float* losses,
                              neraf_stream_t stream);
 int neraf_stft_loss_bwd(neraf_ctx* ctx, const float* pred, const float* gt, size_t n, size_t n_total,
-                        int loss_type, const float* sums, const float* w, float* dpred, neraf_stream_t stream);
+                        int loss_type, const float* sums, const float* g_sc, const float* g_mag, const float* weights, float extra,
+                        float* dpred, neraf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Radiance half (forward).  Replaces what NeRAFVisionModel (NeRAF_model.py:54-79) inherits from
@@ -378,13 +381,37 @@ int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_real, int co
 /* ------------------------------------------------------------------------------------
  * Camera-pose refinement on a ray bundle (nerfstudio CameraOptimizer(mode="SO3xR3").apply_to_raybundle, NeRAF_config.py:97):
  * pose_adjustment fp32 [n_cameras, 6] = (translation | so(3) log); per ray origins_out = origins + t[cam], dirs_out = exp(w[cam]) dirs
- * (Rodrigues, squared angle clamped at 1e-4 as nerfstudio does).  The backward ACCUMULATES d pose [n_cameras, 6] (caller zeroes)
- * from d origins_out / d dirs_out [R,3] (e.g. the d_rays halves of neraf_field_backward_rays).
+ * (Rodrigues, squared angle clamped at 1e-4 as nerfstudio does).  With reg_out3 != NULL the forward also writes nerfstudio's
+ * CameraOptimizer.get_loss_dict / get_metrics_dict values [NS-recall] in the same launch: reg_out3 = {sum_c |t_c| * w_trans +
+ * sum_c |w_c| * w_rot, |t|_F, |w|_F} (w_trans = trans_l2_penalty / n_cameras, w_rot = rot_l2_penalty / n_cameras).
+ * The backward WRITES d pose [n_cameras, 6] = g_reg * d regulariser / d pose (g_reg: device scalar or NULL = 0) + the pull-back of
+ * d origins_out / d dirs_out (rows g_stride floats apart: 3 = two [R,3] arrays, 6 = the halves of neraf_field_backward_rays' [R,6]
+ * d_rays; both NULL = regulariser only).
  * ---------------------------------------------------------------------------------- */
 int neraf_camera_apply(neraf_ctx* ctx, const float* pose_adjustment, const int32_t* cam_idx, const float* origins, const float* dirs,
-                       int R, float* origins_out, float* dirs_out, neraf_stream_t stream);
+                       int R, float* origins_out, float* dirs_out, int n_cameras, float w_trans, float w_rot, float* reg_out3,
+                       neraf_stream_t stream);
 int neraf_camera_apply_bwd(neraf_ctx* ctx, const float* pose_adjustment, const int32_t* cam_idx, const float* dirs,
-                           const float* d_origins, const float* d_dirs, int R, float* d_pose, neraf_stream_t stream);
+                           const float* d_origins, const float* d_dirs, int g_stride, int R, int n_cameras, float w_trans, float w_rot,
+                           const float* g_reg, float* d_pose, neraf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Scalar plumbing of a training iteration as single launches (csrc/glue.hip): what NerfactoModel.get_loss_dict / get_metrics_dict and
+ * Trainer.train_iteration build from scalar torch ops [NS-recall] -- loss = reduce(add, loss_dict.values()),
+ * grad_scaler.scale(loss), psnr = -10 log10(mse).
+ *   neraf_loss_sum_scale:       out2 = {scale * sum_i *terms[i], sum_i *terms[i]}; terms = HOST array of n <= 12 device scalars,
+ *                               added left to right; scale = device scalar or NULL (1).
+ *   neraf_vision_loss_finalize: out4 = {sums[0] k3[0], sums[1] k3[1], sums[2] k3[2], -10 log10(out4[0])} from the raw sums of
+ *                               neraf_render_loss / neraf_interlevel_loss (rgb squared error, distortion, interlevel).
+ *   neraf_vision_bwd_prologue:  d_rgb [n,3] = u_rgb * *g_rgb;  d_dens [n] = u_dens * *g_rgb + u_dist * *g_dist (unit gradients as
+ *                               neraf_render_loss wrote them; g_* device scalars, NULL = 0); up3 = {*g_rgb, *g_inter, *g_dist} for
+ *                               neraf_interlevel_loss' backward; zero-fills d_rays (n_ray_floats, may be NULL) and sums4 (may be NULL).
+ * ---------------------------------------------------------------------------------- */
+int neraf_loss_sum_scale(neraf_ctx* ctx, const float* const* terms, int n, const float* scale, float* out2, neraf_stream_t stream);
+int neraf_vision_loss_finalize(neraf_ctx* ctx, const float* sums, const float* k3, float* out4, neraf_stream_t stream);
+int neraf_vision_bwd_prologue(neraf_ctx* ctx, const float* u_rgb, const float* u_dens, const float* u_dist, const float* g_rgb,
+                              const float* g_inter, const float* g_dist, size_t n_samples, float* d_rgb, float* d_dens, float* up3,
+                              float* d_rays, size_t n_ray_floats, float* sums4, neraf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * fp16 working copies of the radiance parameters (tiny-cuda-nn keeps fp32 masters + fp16 copies inside its optimizer; the

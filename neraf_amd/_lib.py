@@ -69,9 +69,9 @@ SIGNATURES = {
     "neraf_stft_loss_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "neraf_stft_loss_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
-    "neraf_stft_loss_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "neraf_stft_loss_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_stft_loss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "neraf_prof_event_overhead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "neraf_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "neraf_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -140,8 +140,14 @@ SIGNATURES = {
     "neraf_resnet3d_pack_weights_bwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), c_fpp, C.c_void_p, C.c_void_p]),
     "neraf_resnet3d_bwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, c_fpp, C.c_void_p, C.c_void_p,
                                      C.c_void_p, c_fpp, c_fpp, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "neraf_camera_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "neraf_camera_apply_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "neraf_camera_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "neraf_camera_apply_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_loss_sum_scale": (C.c_int, [C.c_void_p, c_fpp, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_vision_loss_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_vision_bwd_prologue": (C.c_int, [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_void_p]),
     "neraf_cvt_f16_segments": (C.c_int, [C.c_void_p, c_fpp, c_fpp, C.POINTER(C.c_longlong), C.c_int, C.c_void_p]),
     "neraf_gather_f16": (C.c_int, [C.c_void_p, c_fpp, C.POINTER(C.c_longlong), C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "neraf_resnet3d_debug_locate": (C.c_int, [C.POINTER(ResnetDesc), C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int),

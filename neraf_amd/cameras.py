@@ -160,37 +160,61 @@ def exp_map_SO3xR3(tangent: torch.Tensor) -> torch.Tensor:
     return torch.cat([R, tangent[:, :3, None]], dim=-1)
 
 
+def _update_epoch() -> int:
+    from . import optim
+    return optim.UPDATE_EPOCH
+
+
 class _CameraApplyFn(torch.autograd.Function):
     """``apply_to_raybundle`` on the device as ONE launch each way (csrc/camera.hip) instead of the ~35 small launches the PyTorch
     expression below costs per training step once autograd has replayed it.  Inputs: pose_adjustment [n,6], camera index [R] int32,
-    origins / directions [R,3] fp32 (constants: the data manager's rays)."""
+    origins / directions [R,3] fp32 (constants: the data manager's rays).  The same launch evaluates the pose regulariser and the
+    two pose-norm metrics (``CameraOptimizer.get_loss_dict`` / ``get_metrics_dict``): outputs 3 and 4, the first differentiable; the
+    backward writes d pose = regulariser gradient + ray pull-back in two launches (the ray gradients are read where they lie,
+    e.g. as the two halves of the field backward's [R,6] buffer)."""
 
     @staticmethod
-    def forward(ctx, pose: torch.Tensor, cam: torch.Tensor, o: torch.Tensor, d: torch.Tensor):
+    def forward(ctx, pose: torch.Tensor, cam: torch.Tensor, o: torch.Tensor, d: torch.Tensor, w_t: float, w_r: float):
         from . import _lib
         from .field import _dev_index, _stream_ptr
         lib = _lib.load()
         dev = _dev_index(o)
         R = o.shape[0]
         o_out, d_out = torch.empty_like(o), torch.empty_like(d)
+        reg = torch.empty(3, dtype=torch.float32, device=o.device)
         _lib.check(lib.neraf_camera_apply(_lib.ctx(dev), pose.data_ptr(), cam.data_ptr(), o.data_ptr(), d.data_ptr(), R, o_out.data_ptr(),
-                                          d_out.data_ptr(), _stream_ptr()), dev)
+                                          d_out.data_ptr(), pose.shape[0], w_t, w_r, reg.data_ptr(), _stream_ptr()), dev)
         ctx.save_for_backward(pose, cam, d)
-        ctx.dev = dev
-        return o_out, d_out
+        ctx.dev, ctx.w = dev, (w_t, w_r)
+        ctx.set_materialize_grads(False)
+        norms = reg[1:]
+        ctx.mark_non_differentiable(norms)
+        return o_out, d_out, reg[0], norms
 
     @staticmethod
-    def backward(ctx, g_o: torch.Tensor, g_d: torch.Tensor):
+    def backward(ctx, g_o, g_d, g_reg, _g_norms):
         from . import _lib
         from .field import _stream_ptr
         pose, cam, d = ctx.saved_tensors
         lib = _lib.load()
-        g_pose = torch.zeros_like(pose)
-        g_o = g_o.contiguous().float() if g_o is not None else torch.zeros_like(d)
-        g_d = g_d.contiguous().float() if g_d is not None else torch.zeros_like(d)
-        _lib.check(lib.neraf_camera_apply_bwd(_lib.ctx(ctx.dev), pose.data_ptr(), cam.data_ptr(), d.data_ptr(), g_o.data_ptr(), g_d.data_ptr(),
-                                              d.shape[0], g_pose.data_ptr(), _stream_ptr()), ctx.dev)
-        return g_pose, None, None, None
+        g_pose = torch.empty_like(pose)
+        stride = 3
+        if (g_o is None) != (g_d is None):
+            z = torch.zeros_like(d)
+            g_o, g_d = (g_o if g_o is not None else z), (g_d if g_d is not None else z)
+        if g_o is not None:
+            same = (g_o.dtype == torch.float32 and g_d.dtype == torch.float32 and g_o.stride(1) == 1 and g_d.stride(1) == 1
+                    and g_o.stride(0) == g_d.stride(0) and g_o.stride(0) >= 3)
+            if not same:
+                g_o, g_d = g_o.contiguous().float(), g_d.contiguous().float()
+            stride = g_o.stride(0)
+        if g_reg is not None:
+            g_reg = g_reg.float().reshape(())
+        _lib.check(lib.neraf_camera_apply_bwd(_lib.ctx(ctx.dev), pose.data_ptr(), cam.data_ptr(), d.data_ptr(),
+                                              g_o.data_ptr() if g_o is not None else None, g_d.data_ptr() if g_d is not None else None,
+                                              stride, d.shape[0], pose.shape[0], ctx.w[0], ctx.w[1],
+                                              g_reg.data_ptr() if g_reg is not None else None, g_pose.data_ptr(), _stream_ptr()), ctx.dev)
+        return g_pose, None, None, None, None, None
 
 
 class CameraOptimizer(nn.Module):
@@ -228,16 +252,30 @@ class CameraOptimizer(nn.Module):
             return ray_bundle
         if ray_bundle.origins.is_cuda and not ray_bundle.origins.requires_grad and not ray_bundle.directions.requires_grad:
             cam = ray_bundle.camera_indices.reshape(-1).to(torch.int32).contiguous()
-            o, d = _CameraApplyFn.apply(self.pose_adjustment, cam, ray_bundle.origins.float().contiguous(),
-                                        ray_bundle.directions.float().contiguous())
+            o, d, reg, norms = _CameraApplyFn.apply(self.pose_adjustment, cam, ray_bundle.origins.float().contiguous(),
+                                                    ray_bundle.directions.float().contiguous(),
+                                                    self.trans_l2_penalty / self.num_cameras, self.rot_l2_penalty / self.num_cameras)
+            # the regulariser and the pose norms of THIS parameter state came with the launch: get_loss_dict / get_metrics_dict of
+            # the same iteration pick them up (consumed once each; without them they fall back to the torch expressions)
+            self._fused = {"reg": reg, "norms": norms, "key": (self.pose_adjustment.data_ptr(), self.pose_adjustment._version, _update_epoch())}
             return RayBundle(o, d, ray_bundle.camera_indices, ray_bundle.nears, ray_bundle.fars)
         corr = self(ray_bundle.camera_indices)
         origins = ray_bundle.origins + corr[:, :3, 3]
         directions = torch.bmm(corr[:, :3, :3], ray_bundle.directions[..., None]).squeeze(-1)
         return RayBundle(origins, directions, ray_bundle.camera_indices, ray_bundle.nears, ray_bundle.fars)
 
+    def _take_fused(self, what: str):
+        f = getattr(self, "_fused", None)
+        if f is None or what not in f or f["key"] != (self.pose_adjustment.data_ptr(), self.pose_adjustment._version, _update_epoch()):
+            return None
+        return f.pop(what)
+
     def get_loss_dict(self, loss_dict: Dict[str, torch.Tensor]) -> None:
         if self.mode != "off":
+            reg = self._take_fused("reg")
+            if reg is not None:
+                loss_dict["camera_opt_regularizer"] = reg
+                return
             # mean |t| * trans_l2_penalty + mean |w| * rot_l2_penalty, as three launches: norms of the [n, 2, 3] view, weights, sum
             w = getattr(self, "_reg_w", None)
             if w is None or w.device != self.pose_adjustment.device:
@@ -249,6 +287,10 @@ class CameraOptimizer(nn.Module):
 
     def get_metrics_dict(self, metrics_dict: Dict[str, torch.Tensor]) -> None:
         if self.mode != "off":
+            norms = self._take_fused("norms")
+            if norms is not None:
+                metrics_dict["camera_opt_translation"], metrics_dict["camera_opt_rotation"] = norms[0], norms[1]
+                return
             metrics_dict["camera_opt_translation"] = self.pose_adjustment[:, :3].norm()
             metrics_dict["camera_opt_rotation"] = self.pose_adjustment[:, 3:].norm()
 

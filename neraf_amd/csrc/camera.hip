@@ -29,7 +29,28 @@ __device__ __forceinline__ void cross(float ax, float ay, float az, float bx, fl
 }
 
 __global__ __launch_bounds__(256) void camera_apply_kernel(const float* __restrict__ pose, const int* __restrict__ cam, const float* __restrict__ o,
-                                                          const float* __restrict__ d, int R, float* __restrict__ o_out, float* __restrict__ d_out) {
+                                                          const float* __restrict__ d, int R, float* __restrict__ o_out, float* __restrict__ d_out,
+                                                          int n_cams, float w_t, float w_r, float* __restrict__ reg_out3) {
+  // nerfstudio's CameraOptimizer.get_loss_dict / get_metrics_dict on the way (workgroup 0): reg_out3 = {mean|t| * trans_l2_penalty +
+  // mean|w| * rot_l2_penalty (w_t, w_r carry the 1/n), |t|_F, |w|_F}
+  if (reg_out3 && blockIdx.x == 0) {
+    __shared__ float red[4][4];
+    float a = 0.f, b = 0.f, a2 = 0.f, b2 = 0.f;
+    for (int c = threadIdx.x; c < n_cams; c += 256) {
+      const float* q = pose + (size_t)c * 6;
+      const float t2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2], r2 = q[3] * q[3] + q[4] * q[4] + q[5] * q[5];
+      a += sqrtf(t2); b += sqrtf(r2); a2 += t2; b2 += r2;
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) { a += __shfl_xor(a, o2); b += __shfl_xor(b, o2); a2 += __shfl_xor(a2, o2); b2 += __shfl_xor(b2, o2); }
+    if ((threadIdx.x & 63) == 0) { float* r4 = red[threadIdx.x >> 6]; r4[0] = a; r4[1] = b; r4[2] = a2; r4[3] = b2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < 4; ++w) for (int k = 0; k < 4; ++k) s[k] += red[w][k];
+      reg_out3[0] = s[0] * w_t + s[1] * w_r; reg_out3[1] = sqrtf(s[2]); reg_out3[2] = sqrtf(s[3]);
+    }
+  }
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
   const float* p = pose + (size_t)cam[i] * 6;
@@ -48,7 +69,7 @@ __global__ __launch_bounds__(256) void camera_apply_kernel(const float* __restri
 // d pose[cam] += (d_o | J_w^T d_d); runs of rays with the same camera inside a wave are summed first (the sampler draws rays image
 // by image or at random: either way one atomic per run instead of one per ray)
 __global__ __launch_bounds__(256) void camera_apply_bwd_kernel(const float* __restrict__ pose, const int* __restrict__ cam, const float* __restrict__ d,
-                                                              const float* __restrict__ g_o, const float* __restrict__ g_d, int R,
+                                                              const float* __restrict__ g_o, const float* __restrict__ g_d, int gs, int R,
                                                               float* __restrict__ g_pose) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -60,8 +81,8 @@ __global__ __launch_bounds__(256) void camera_apply_bwd_kernel(const float* __re
     const float wx = p[3], wy = p[4], wz = p[5];
     const Rod r = rodrigues(wx, wy, wz);
     const float dx = d[i * 3], dy = d[i * 3 + 1], dz = d[i * 3 + 2];
-    const float ux = g_d[i * 3], uy = g_d[i * 3 + 1], uz = g_d[i * 3 + 2];
-    g[0] = g_o[i * 3]; g[1] = g_o[i * 3 + 1]; g[2] = g_o[i * 3 + 2];
+    const float ux = g_d[(size_t)i * gs], uy = g_d[(size_t)i * gs + 1], uz = g_d[(size_t)i * gs + 2];
+    g[0] = g_o[(size_t)i * gs]; g[1] = g_o[(size_t)i * gs + 1]; g[2] = g_o[(size_t)i * gs + 2];
     float kx, ky, kz, k2x, k2y, k2z;
     cross(wx, wy, wz, dx, dy, dz, kx, ky, kz);
     cross(wx, wy, wz, kx, ky, kz, k2x, k2y, k2z);
@@ -102,24 +123,42 @@ __global__ __launch_bounds__(256) void camera_apply_bwd_kernel(const float* __re
   }
 }
 
+// d pose = g_reg * d regulariser / d pose (the zero vector has subgradient 0, as torch's norm backward), or zero: initialises the
+// buffer the ray-gradient kernel then adds into
+__global__ void camera_reg_bwd_init_kernel(const float* __restrict__ pose, int n_cams, float w_t, float w_r, const float* __restrict__ g_reg,
+                                           float* __restrict__ g_pose) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cams * 2) return;
+  const float g = g_reg ? *g_reg : 0.f;
+  const float* q = pose + (size_t)i * 3;
+  const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  const float k = (g != 0.f && n > 0.f) ? g * ((i & 1) ? w_r : w_t) / n : 0.f;
+  g_pose[(size_t)i * 3] = k * q[0]; g_pose[(size_t)i * 3 + 1] = k * q[1]; g_pose[(size_t)i * 3 + 2] = k * q[2];
+}
+
 }  // namespace
 
 extern "C" int neraf_camera_apply(neraf_ctx* ctx, const float* pose_adjustment, const int32_t* cam_idx, const float* origins,
-                                  const float* dirs, int R, float* origins_out, float* dirs_out, neraf_stream_t stream) {
-  if (!pose_adjustment || !cam_idx || !origins || !dirs || R <= 0 || !origins_out || !dirs_out)
+                                  const float* dirs, int R, float* origins_out, float* dirs_out, int n_cams, float w_trans, float w_rot,
+                                  float* reg_out3, neraf_stream_t stream) {
+  if (!pose_adjustment || !cam_idx || !origins || !dirs || R <= 0 || !origins_out || !dirs_out || (reg_out3 && n_cams <= 0))
     return neraf_fail(ctx, NERAF_EINVAL, "camera_apply: bad arguments");
   hipLaunchKernelGGL(camera_apply_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose_adjustment, cam_idx, origins, dirs, R,
-                     origins_out, dirs_out);
+                     origins_out, dirs_out, n_cams, w_trans, w_rot, reg_out3);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
 
 extern "C" int neraf_camera_apply_bwd(neraf_ctx* ctx, const float* pose_adjustment, const int32_t* cam_idx, const float* dirs,
-                                      const float* d_origins, const float* d_dirs, int R, float* d_pose, neraf_stream_t stream) {
-  if (!pose_adjustment || !cam_idx || !dirs || !d_origins || !d_dirs || R <= 0 || !d_pose)
+                                      const float* d_origins, const float* d_dirs, int g_stride, int R, int n_cams, float w_trans,
+                                      float w_rot, const float* g_reg, float* d_pose, neraf_stream_t stream) {
+  if (!pose_adjustment || !cam_idx || !dirs || R <= 0 || !d_pose || n_cams <= 0 || g_stride < 3 || (!d_origins) != (!d_dirs))
     return neraf_fail(ctx, NERAF_EINVAL, "camera_apply_bwd: bad arguments");
-  hipLaunchKernelGGL(camera_apply_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose_adjustment, cam_idx, dirs, d_origins,
-                     d_dirs, R, d_pose);
+  hipLaunchKernelGGL(camera_reg_bwd_init_kernel, dim3((n_cams * 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose_adjustment, n_cams,
+                     w_trans, w_rot, g_reg, d_pose);
+  if (d_origins)
+    hipLaunchKernelGGL(camera_apply_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose_adjustment, cam_idx, dirs, d_origins,
+                       d_dirs, g_stride, R, d_pose);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }

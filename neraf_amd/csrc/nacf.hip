@@ -395,18 +395,25 @@ __global__ __launch_bounds__(256) void stft_loss_sums_kernel(const float* __rest
   }
 }
 
-__global__ void stft_loss_final_kernel(const float* __restrict__ sums, float inv_n, float* __restrict__ losses) {
+__global__ void stft_loss_final_kernel(const float* __restrict__ sums, float inv_n, const float* __restrict__ weights,
+                                       float* __restrict__ losses) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    losses[0] = sqrtf(sums[0]) / sqrtf(sums[1]);   // NeRAF_evaluator.py:26
-    losses[1] = sums[2] * inv_n;                   // :51 / :53
+    const float sc = sqrtf(sums[0]) / sqrtf(sums[1]);   // NeRAF_evaluator.py:26
+    const float mag = sums[2] * inv_n;                  // :51 / :53
+    losses[0] = weights ? sc * weights[0] : sc;         // loss factors of NeRAF_model.py:592-599
+    losses[1] = weights ? mag * weights[1] : mag;
   }
 }
 
 __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, size_t n,
-                                                           size_t n_total, int l1, const float* __restrict__ sums, const float* __restrict__ w,
+                                                           size_t n_total, int l1, const float* __restrict__ sums, const float* g_sc,
+                                                           const float* g_mag, const float* __restrict__ weights, float extra,
                                                            float* __restrict__ dx) {
-  const float inv_den = w[0] / (sqrtf(sums[0]) * sqrtf(sums[1]));
-  const float wm = w[1] / (float)n_total;
+  // upstream scalars: d total / d sc, d total / d mag (device scalars, null = 0) x loss factors x `extra` (data-parallel world size)
+  const float w0 = (g_sc ? *g_sc : 0.f) * (weights ? weights[0] : 1.f) * extra;
+  const float w1 = (g_mag ? *g_mag : 0.f) * (weights ? weights[1] : 1.f) * extra;
+  const float inv_den = w0 / (sqrtf(sums[0]) * sqrtf(sums[1]));
+  const float wm = w1 / (float)n_total;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float xv = x[i], yv = y[i];
     const float ex = expf(xv);
@@ -758,10 +765,10 @@ extern "C" int neraf_stft_loss_sums(neraf_ctx* ctx, const float* pred, const flo
   return NERAF_OK;
 }
 
-extern "C" int neraf_stft_loss_finalize(neraf_ctx* ctx, const float* sums, size_t n_total, float* losses,
+extern "C" int neraf_stft_loss_finalize(neraf_ctx* ctx, const float* sums, size_t n_total, const float* weights, float* losses,
                                         neraf_stream_t stream) {
   if (!sums || !losses || n_total == 0) return neraf_fail(ctx, NERAF_EINVAL, "stft_loss_finalize: bad arguments");
-  hipLaunchKernelGGL(stft_loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, 1.0f / (float)n_total, losses);
+  hipLaunchKernelGGL(stft_loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, 1.0f / (float)n_total, weights, losses);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
@@ -769,18 +776,18 @@ extern "C" int neraf_stft_loss_finalize(neraf_ctx* ctx, const float* sums, size_
 extern "C" int neraf_stft_loss_fwd(neraf_ctx* ctx, const float* pred, const float* gt, size_t n, int loss_type,
                                    float* sums, float* losses, neraf_stream_t stream) {
   if (int e = neraf_stft_loss_sums(ctx, pred, gt, n, loss_type, sums, stream)) return e;
-  return neraf_stft_loss_finalize(ctx, sums, n, losses, stream);
+  return neraf_stft_loss_finalize(ctx, sums, n, nullptr, losses, stream);
 }
 
 extern "C" int neraf_stft_loss_bwd(neraf_ctx* ctx, const float* pred, const float* gt, size_t n, size_t n_total,
-                                   int loss_type, const float* sums, const float* w, float* dpred,
-                                   neraf_stream_t stream) {
-  if (!pred || !gt || !sums || !w || !dpred || n == 0 || n_total < n)
+                                   int loss_type, const float* sums, const float* g_sc, const float* g_mag, const float* weights,
+                                   float extra, float* dpred, neraf_stream_t stream) {
+  if (!pred || !gt || !sums || !dpred || n == 0 || n_total < n)
     return neraf_fail(ctx, NERAF_EINVAL, "stft_loss_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(stft_loss_bwd_kernel, dim3(blocks), dim3(256), 0, st, pred, gt, n, n_total, loss_type, sums, w, dpred);
+  hipLaunchKernelGGL(stft_loss_bwd_kernel, dim3(blocks), dim3(256), 0, st, pred, gt, n, n_total, loss_type, sums, g_sc, g_mag, weights, extra, dpred);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }

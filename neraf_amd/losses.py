@@ -40,10 +40,9 @@ class _StftLossFn(torch.autograd.Function):
             import torch.distributed as dist
             n_total = allreduce_loss_sums(sums, x.numel(), group=group if group is not True else None, uniform_shards=True)
             world = dist.get_world_size(group if group is not True else None)
-        _lib.check(lib.neraf_stft_loss_finalize(_lib.ctx(dev), sums.data_ptr(), n_total, losses.data_ptr(),
-                                                _stream_ptr()), dev)
-        if weights is not None:
-            losses = losses * weights
+        _lib.check(lib.neraf_stft_loss_finalize(_lib.ctx(dev), sums.data_ptr(), n_total,
+                                                weights.data_ptr() if weights is not None else None, losses.data_ptr(), _stream_ptr()), dev)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, y, sums)
         ctx.loss_type, ctx.dev, ctx.n_total, ctx.weights, ctx.world = loss_type, dev, n_total, weights, world
         return losses[0], losses[1]
@@ -53,21 +52,18 @@ class _StftLossFn(torch.autograd.Function):
         x, y, sums = ctx.saved_tensors
         lib = _lib.load()
         dx = torch.empty_like(x)
-        # upstream scalars (loss weights x GradScaler scale) stay on the device: no host sync
-        zero = torch.zeros((), dtype=torch.float32, device=x.device) if (g_sc is None or g_mag is None) else None
-        w = torch.stack([(g_sc if g_sc is not None else zero).float().reshape(()),
-                         (g_mag if g_mag is not None else zero).float().reshape(())]).contiguous()
-        if ctx.weights is not None:
-            w = w * ctx.weights
-        if ctx.world > 1:
-            # Data parallel: the loss value is already the GLOBAL one (sums all-reduced above), so this rank's dx is
-            # dL_global/dx_local, and the sum over ranks of the resulting parameter gradients is dL_global/dtheta.  The gradient
-            # reducer AVERAGES over ranks (right for the per-rank-mean radiance losses): pre-multiply by the world size so that the
-            # averaged gradient of the audio loss is the single-process global-batch gradient, not 1/world of it.
-            w = w * float(ctx.world)
-        _lib.check(lib.neraf_stft_loss_bwd(_lib.ctx(ctx.dev), x.data_ptr(), y.data_ptr(), x.numel(), ctx.n_total,
-                                           ctx.loss_type, sums.data_ptr(), w.data_ptr(), dx.data_ptr(), _stream_ptr()),
-                   ctx.dev)
+        # upstream scalars (GradScaler scale), the loss factors and the world size are combined inside the kernel: no host sync, no
+        # scalar launches.  Data parallel: the loss value is already the GLOBAL one (sums all-reduced in the forward), so this rank's dx is
+        # dL_global/dx_local, and the sum over ranks of the resulting parameter gradients is dL_global/dtheta.  The gradient reducer
+        # AVERAGES over ranks (right for the per-rank-mean radiance losses): the factor `world` makes the averaged gradient of the
+        # audio loss the single-process global-batch gradient, not 1/world of it.
+        g_sc = g_sc.float().reshape(()) if g_sc is not None else None
+        g_mag = g_mag.float().reshape(()) if g_mag is not None else None
+        _lib.check(lib.neraf_stft_loss_bwd(_lib.ctx(ctx.dev), x.data_ptr(), y.data_ptr(), x.numel(), ctx.n_total, ctx.loss_type,
+                                           sums.data_ptr(), g_sc.data_ptr() if g_sc is not None else None,
+                                           g_mag.data_ptr() if g_mag is not None else None,
+                                           ctx.weights.data_ptr() if ctx.weights is not None else None, float(ctx.world), dx.data_ptr(),
+                                           _stream_ptr()), ctx.dev)
         return dx, None, None, None, None
 
 

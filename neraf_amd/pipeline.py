@@ -26,22 +26,34 @@ class _ScaledLossSum(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, scaler, *losses):
-        stacked = torch.stack([l.reshape(()).float() for l in losses])
-        total = stacked.sum()
+        scale = None
         if scaler is not None and scaler.is_enabled():
             if scaler._scale is None:
-                scaler._lazy_init_scale_growth_tracker(total.device)
+                scaler._lazy_init_scale_growth_tracker(losses[0].device)
             scale = scaler._scale.reshape(())
-            scaled = total * scale
-        else:
-            scale, scaled = None, total.clone()
         ctx.scale = scale
         ctx.n = len(losses)
+        ctx.set_materialize_grads(False)
+        if losses[0].is_cuda and len(losses) <= 12:
+            # {scale * sum, sum} in one launch (csrc/glue.hip), terms added left to right as reduce(add, ...) does
+            from . import _lib
+            from .field import _dev_index, _stream_ptr
+            terms = [l.reshape(()).float() for l in losses]
+            out = torch.empty(2, dtype=torch.float32, device=losses[0].device)
+            dev = _dev_index(out)
+            _lib.check(_lib.load().neraf_loss_sum_scale(_lib.ctx(dev), _lib.ptr_array(terms), len(terms),
+                                                        scale.data_ptr() if scale is not None else None, out.data_ptr(), _stream_ptr()), dev)
+            scaled, total = out[0], out[1]
+        else:
+            total = torch.stack([l.reshape(()).float() for l in losses]).sum()
+            scaled = total * scale if scale is not None else total.clone()
         ctx.mark_non_differentiable(total)
         return scaled, total
 
     @staticmethod
     def backward(ctx, g, _g_total):
+        if g is None:
+            return (None,) * (ctx.n + 1)
         gi = g if ctx.scale is None else g * ctx.scale
         return (None,) + (gi,) * ctx.n
 

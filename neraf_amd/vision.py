@@ -403,35 +403,43 @@ class _VisionLossFn(torch.autograd.Function):
                                                  ps.e_bins.data_ptr(), st["prop_dens"][i].data_ptr(), Sp, R, model.interlevel_loss_mult,
                                                  None, None, sums.data_ptr(), stream), dev)
         ctx.model, ctx.st, ctx.gt, ctx.dev = model, st, gt, dev
+        ctx.set_materialize_grads(False)            # unused loss terms arrive as None, not as zero tensors (a fill launch each)
         ctx.n_params = len(params)
         ctx.need_rays = bool(ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
-        # {sum (rgb-gt)^2, sum distortion, sum outer} -> the three means in one launch
+        # {sum (rgb-gt)^2, sum distortion, sum outer} -> the three means and the batch psnr in one launch
         key = (R, S2, model.distortion_loss_mult, model.interlevel_loss_mult, str(gt.device))
         sc = getattr(model, "_loss_scale", None)
         if sc is None or sc[0] != key:
             sc = (key, torch.tensor([1.0 / (3.0 * R), model.distortion_loss_mult / R, model.interlevel_loss_mult / (R * S2)], **f32))
             model._loss_scale = sc
-        losses = sums[:3] * sc[1]
-        return losses[0], losses[2], losses[1]
+        out4 = torch.empty(4, **f32)
+        _lib.check(lib.neraf_vision_loss_finalize(h, sums.data_ptr(), sc[1].data_ptr(), out4.data_ptr(), stream), dev)
+        psnr_v = out4[3]
+        ctx.mark_non_differentiable(psnr_v)
+        return out4[0], out4[2], out4[1], psnr_v
 
     @staticmethod
-    def backward(ctx, g_rgb, g_inter, g_dist):
+    def backward(ctx, g_rgb, g_inter, g_dist, _g_psnr=None):
         lib = _lib.load()
         model, st, gt, dev = ctx.model, ctx.st, ctx.gt, ctx.dev
         h, stream = _lib.ctx(dev), _stream_ptr()
         device = gt.device
         f32 = dict(dtype=torch.float32, device=device)
-        zero = torch.zeros((), **f32)
-        up = torch.stack([(g if g is not None else zero).float().reshape(()) for g in (g_rgb, g_inter, g_dist)]).contiguous()
         fine = st["samples"][-1]
         R, S2 = st["dens"].shape
         field = model.field.module
-        sums = torch.zeros(4, **f32)
         u_rgb, u_dens, u_dens_dist = ctx.unit
-        d_rgb_s = u_rgb * up[0]
-        d_dens = torch.addcmul(u_dens * up[0], u_dens_dist, up[2])
+        # one launch: upstream scalars gathered, unit gradients scaled (d rgb = u_rgb g_rgb, d density = u_dens g_rgb + u_dist g_dist),
+        # the ray-gradient buffer and the interlevel sums zeroed
+        scal = [(g.float().reshape(()) if g is not None else None) for g in (g_rgb, g_inter, g_dist)]
+        up, sums = torch.empty(3, **f32), torch.empty(4, **f32)
+        d_rgb_s, d_dens = torch.empty_like(u_rgb), torch.empty_like(u_dens)
+        d_rays = torch.empty((R, 6), **f32) if ctx.need_rays else None
+        _lib.check(lib.neraf_vision_bwd_prologue(h, u_rgb.data_ptr(), u_dens.data_ptr(), u_dens_dist.data_ptr(),
+                                                 *[(g.data_ptr() if g is not None else None) for g in scal], R * S2, d_rgb_s.data_ptr(),
+                                                 d_dens.data_ptr(), up.data_ptr(), d_rays.data_ptr() if d_rays is not None else None,
+                                                 R * 6 if d_rays is not None else 0, sums.data_ptr(), stream), dev)
         # ---- main field (+ the camera-pose edge: d loss / d (origin, direction) per ray)
-        d_rays = torch.zeros((R, 6), **f32) if ctx.need_rays else None
         grads = field.backward_query(st["field_packed"], st["o"], st["d"], fine.e_bins, st["cam"], st["dens"], d_rgb_s, d_dens,
                                      d_rays=d_rays, saved=st.get("field_saved"))
         ray_grads = (d_rays[:, :3], d_rays[:, 3:]) if ctx.need_rays else (None, None)
@@ -659,8 +667,8 @@ class NeRAFVisionModel(nn.Module):
 
     def get_metrics_dict(self, outputs, batch):
         """NerfactoModel.get_metrics_dict [NS-recall]: psnr of the batch (+ camera-optimizer norms in training).  In training the
-        psnr is filled in by ``get_loss_dict`` from the rgb loss it computes anyway (psnr = -10 log10(mse): two launches instead of
-        a second pass over the batch); outside training it is computed here."""
+        psnr is filled in by ``get_loss_dict`` from the rgb loss it computes anyway (psnr = -10 log10(mse), written by the launch that
+        finalises the losses); outside training it is computed here."""
         m: Dict[str, torch.Tensor] = {}
         if self.training:
             self.camera_optimizer.get_metrics_dict(m)
@@ -676,11 +684,11 @@ class NeRAFVisionModel(nn.Module):
             raise RuntimeError("get_loss_dict needs the outputs of a training-mode get_outputs call")
         gt = (batch["image"] if "image" in batch else batch["rgb"]).to(outputs["rgb"].device).float().contiguous()
         st = outputs["_state"]
-        rgb_l, inter, dist = _VisionLossFn.apply(self, st, gt, st["ray_o"], st["ray_d"], *self.loss_params())
+        rgb_l, inter, dist, psnr_v = _VisionLossFn.apply(self, st, gt, st["ray_o"], st["ray_d"], *self.loss_params())
         d = {"rgb_loss": rgb_l, "interlevel_loss": inter, "distortion_loss": dist}
         self.camera_optimizer.get_loss_dict(d)
         if metrics_dict is not None and "psnr" not in metrics_dict:
-            metrics_dict["psnr"] = torch.log10(rgb_l.detach()) * -10.0
+            metrics_dict["psnr"] = psnr_v                      # -10 log10(mse), from the loss-finalising launch
         return d
 
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:

@@ -220,3 +220,57 @@ def test_fused_camera_apply_matches_the_pytorch_expression():
     g, g_ref = co.pose_adjustment.grad.cpu().double(), pr.grad
     assert float((g - g_ref).norm() / g_ref.norm()) <= 1e-4, float((g - g_ref).norm() / g_ref.norm())
     np.testing.assert_allclose(g[:6].numpy(), g_ref[:6].numpy(), rtol=2e-3, atol=1e-3)       # guarded rows
+
+
+def test_fused_camera_regulariser_and_norm_metrics():
+    """The launch that applies the pose corrections also evaluates nerfstudio's ``camera_opt_regularizer`` (mean |t| 1e-2 + mean |w| 1e-3)
+    and the two pose-norm metrics; the backward starts d pose from the regulariser's gradient (zero rows: subgradient 0) and adds the ray
+    pull-back -- value, metrics and the summed gradient against the PyTorch expressions in fp64."""
+    from neraf_amd.cameras import CameraOptimizer, exp_map_SO3xR3
+    from neraf_amd.vision import RayBundle
+    dev = torch.device("cuda:0")
+    n_cam, R = 37, 3000
+    pose = T(synth.normal("t.camreg.pose", (n_cam, 6), 0.2))
+    pose[5] = 0.0
+    pose[6, :3] = 0.0
+    cam = T(synth.integers("t.camreg.idx", (R,), 0, n_cam))
+    o = T(synth.uniform("t.camreg.o", (R, 3), -1, 1))
+    d = torch.nn.functional.normalize(T(synth.normal("t.camreg.d", (R, 3))), dim=-1)
+    wo, wd = T(synth.normal("t.camreg.wo", (R, 3))), T(synth.normal("t.camreg.wd", (R, 3)))
+    pr = pose.double().clone().requires_grad_(True)
+    corr = exp_map_SO3xR3(pr[cam])
+    o_ref = o.double() + corr[:, :3, 3]
+    d_ref = torch.bmm(corr[:, :3, :3], d.double()[..., None]).squeeze(-1)
+    reg_ref = pr[:, :3].norm(dim=-1).mean() * 1e-2 + pr[:, 3:].norm(dim=-1).mean() * 1e-3
+    ((o_ref * wo.double()).sum() + (d_ref * wd.double()).sum() + 250.0 * reg_ref).backward()
+    co = CameraOptimizer(n_cam, mode="SO3xR3").to(dev)
+    with torch.no_grad():
+        co.pose_adjustment.copy_(pose.to(dev))
+    out = co.apply_to_raybundle(RayBundle(o.to(dev), d.to(dev), cam.to(dev)[:, None]))
+    md, ld = {}, {}
+    co.get_metrics_dict(md)
+    co.get_loss_dict(ld)
+    assert co._fused.keys() == {"key"}                       # both came from the fused launch and were consumed
+    np.testing.assert_allclose(float(ld["camera_opt_regularizer"]), float(reg_ref), rtol=1e-5)
+    np.testing.assert_allclose(float(md["camera_opt_translation"]), float(pose[:, :3].double().norm()), rtol=1e-5)
+    np.testing.assert_allclose(float(md["camera_opt_rotation"]), float(pose[:, 3:].double().norm()), rtol=1e-5)
+    ((out.origins * wo.to(dev)).sum() + (out.directions * wd.to(dev)).sum() + 250.0 * ld["camera_opt_regularizer"]).backward()
+    g, g_ref = co.pose_adjustment.grad.cpu().double(), pr.grad
+    assert bool(torch.isfinite(g).all())
+    assert float((g - g_ref).norm() / g_ref.norm()) <= 1e-4, float((g - g_ref).norm() / g_ref.norm())
+    # regulariser only (no ray gradient reaches the node): d pose = the regulariser's gradient alone
+    co.pose_adjustment.grad = None
+    out = co.apply_to_raybundle(RayBundle(o.to(dev), d.to(dev), cam.to(dev)[:, None]))
+    ld = {}
+    co.get_loss_dict(ld)
+    ld["camera_opt_regularizer"].backward()
+    pr2 = pose.double().clone().requires_grad_(True)
+    (pr2[:, :3].norm(dim=-1).mean() * 1e-2 + pr2[:, 3:].norm(dim=-1).mean() * 1e-3).backward()
+    np.testing.assert_allclose(co.pose_adjustment.grad.cpu().numpy(), pr2.grad.numpy(), rtol=1e-4, atol=1e-9)
+    # a parameter edit between the launch and get_loss_dict invalidates the stashed value: the torch expression is used instead
+    out = co.apply_to_raybundle(RayBundle(o.to(dev), d.to(dev), cam.to(dev)[:, None]))
+    with torch.no_grad():
+        co.pose_adjustment.mul_(2.0)
+    ld = {}
+    co.get_loss_dict(ld)
+    np.testing.assert_allclose(float(ld["camera_opt_regularizer"]), 2.0 * float(reg_ref), rtol=1e-5)
