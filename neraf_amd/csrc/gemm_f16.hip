@@ -72,9 +72,9 @@ __device__ __forceinline__ void tclass_coords(const ConvGeom& g, int m, int& z, 
   const int x2 = r % h, y2 = (r / h) % h, z2 = r / (h * h);
   z = 2 * z2 + ((cls >> 2) & 1); y = 2 * y2 + ((cls >> 1) & 1); x = 2 * x2 + (cls & 1);
 }
-template <int BM>
+template <int BM, bool TC>
 __device__ __forceinline__ int out_row(const GemmParams& p, int m) {
-  if (!p.conv.tclass) return m;
+  if (!TC) return m;
   int z, y, x;
   tclass_coords<BM>(p.conv, m, z, y, x);
   return (z * p.conv.dout + y) * p.conv.dout + x;
@@ -82,7 +82,7 @@ __device__ __forceinline__ int out_row(const GemmParams& p, int m) {
 
 // ------------------------------------------------------------------------------------------------------
 // Epilogue of the GEMM kernel (the split-K reducer applies the same operations element-wise).
-template <int BM, int BN, bool BF, int WAVES_M = 2>
+template <int BM, int BN, bool BF, int WAVES_M = 2, bool TC = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[Tile<BM, BN, WAVES_M>::FM][Tile<BM, BN, WAVES_M>::FN],
                                               char* smem, int bm, int bn, int lane, int wave, int M, int N, float* C32, int ldc32) {
   using T = Tile<BM, BN, WAVES_M>;
@@ -115,7 +115,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         for (int r = 0; r < 4; ++r) v[r] *= ((float)mk[r] > 0.f) ? 1.f : p.mask_slope;
       }
       if (p.add16) {
-        const E4 ad = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.add16) + (size_t)out_row<BM>(p, m) * p.ldadd + n0);
+        const E4 ad = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.add16) + (size_t)out_row<BM, TC>(p, m) * p.ldadd + n0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)ad[r];
       }
@@ -183,7 +183,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     for (int it = 0; it < WM * CPR / 64; ++it) {
       const int idx = it * 64 + lane, row = idx / CPR, ch = idx - row * CPR;
       const uint4 d = *reinterpret_cast<const uint4*>(im + row * T::IMG16_LD + ch * 8);
-      *reinterpret_cast<uint4*>(p.C16 + (size_t)out_row<BM>(p, m_w0 + row) * p.ldc16 + n_w0 + ch * 8) = d;
+      *reinterpret_cast<uint4*>(p.C16 + (size_t)out_row<BM, TC>(p, m_w0 + row) * p.ldc16 + n_w0 + ch * 8) = d;
     }
     __syncthreads();
   }
@@ -258,7 +258,7 @@ struct PipeTile {
 };
 
 // LOADER: 0 plain GEMM, 1 conv tap-per-K-step (cin % 64 == 0), 2 conv tap-per-chunk (cin == 8).  KS = filter size.
-template <int BM, int BN, int NST, int LOADER, int KS, bool BF>
+template <int BM, int BN, int NST, int LOADER, int KS, bool BF, bool TC = false>
 __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int splits) {
   using T = Tile<BM, BN>;
   using E8 = typename ET<BF>::v8;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
   const int bn = in_group / gsz;
 
   // parity-class rows of a stride-2 transposed convolution: this tile's class walks taps t0 + 2i per axis only
-  const bool tclass = LOADER == 1 && p.conv.tclass;
+  constexpr bool tclass = LOADER == 1 && TC;     // compile-time: the tap decode below must not weigh on the ordinary conv loaders
   int t0z = 0, t0y = 0, t0x = 0, cy = KS, cx = KS;
   int nk_total = p.K / BK;
   if (tclass) {
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
       const int m = bm * BM + row;
       const int d = p.conv.dout;
       int x = m % d, y = (m / d) % d, z = m / (d * d);
-      if (LOADER == 1 && p.conv.tclass) tclass_coords<BM>(p.conv, m, z, y, x);
+      if (tclass) tclass_coords<BM>(p.conv, m, z, y, x);
       az[i] = z * p.conv.stride - p.conv.pad; ay[i] = y * p.conv.stride - p.conv.pad; ax[i] = x * p.conv.stride - p.conv.pad;
     }
   }
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
       }
     return;
   }
-  gemm_epilogue<BM, BN, BF>(p, acc, smem, bm, bn, lane, wave, Mg, Ng, C32g, ldc32g);
+  gemm_epilogue<BM, BN, BF, 2, tclass>(p, acc, smem, bm, bn, lane, wave, Mg, Ng, C32g, ldc32g);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -680,12 +680,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
   }
 }
 
-template <int BM, int BN, int NST, int LOADER, int KS, bool BF>
+template <int BM, int BN, int NST, int LOADER, int KS, bool BF, bool TC = false>
 int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t stream) {
   using PT = PipeTile<BM, BN, NST>;
   static bool attr_set = false;
   if (!attr_set) {
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF>),
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF, TC>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, PT::LDS_BYTES));
     attr_set = true;
   }
@@ -697,7 +697,7 @@ int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
                       : LOADER == 1 ? (BM * BN == 128 * 128 ? PROF_CONV128 : (BM == 128 ? PROF_CONV12864 : (BF ? PROF_CONV64_BF16 : PROF_CONV)))
                                     : (BM * BN == 128 * 128 ? PROF_GEMM128 : (BM == 128 ? PROF_GEMM12864 : (BF ? PROF_GEMM64_BF16 : PROF_GEMM64)));
   ProfScope prof(ctx, stream, kid, flops);
-  hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF>), dim3(ntiles * splits * ng), dim3(256), PT::LDS_BYTES,
+  hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF, TC>), dim3(ntiles * splits * ng), dim3(256), PT::LDS_BYTES,
                      stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   if (splits > 1) {
@@ -1147,7 +1147,7 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p_in, hipStream_t stream) {
       p.Mpad == p.conv.dout * p.conv.dout * p.conv.dout && (p.Mpad % 512) == 0 && (p.Npad % 64) == 0 && !p.lmask && !p.C16T && !p.C32 &&
       !p.colsum && !p.colsumsq) {
     p.conv.tclass = 1;
-    return launch_pipe<64, 64, 4, LOADER, KS, BF>(ctx, p, 1, stream);
+    return launch_pipe<64, 64, 4, LOADER, KS, BF, LOADER == 1>(ctx, p, 1, stream);
   }
   const int nk = p.K / BK;
   // tile choice: 128x128 when it fills the chip; 128x64 for 64-wide outputs; otherwise 64x64 (4x the workgroups)
