@@ -451,6 +451,11 @@ int neraf_fused_adam_chunk(void);
 /* GradScaler's non-finite check over the same tensor table: found_inf[0] = 1.0f if any gradient element is inf / nan, else 0. */
 int neraf_grads_nonfinite(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
                           int n_blocks, float* found_inf, neraf_stream_t stream);
+/* GradScaler.update for up to 8 optimizers in one launch: torch._amp_update_scale_(scale, growth_tracker, sum of found_infs, ...)
+ * -- any flag set: scale *= backoff_factor, tracker = 0; else tracker += 1 and, at growth_interval, scale *= growth_factor (kept
+ * finite), tracker = 0.  found_infs: HOST array of n device flags (as neraf_grads_nonfinite writes them). */
+int neraf_amp_update_scale(neraf_ctx* ctx, float* scale, int32_t* growth_tracker, const float* const* found_infs, int n,
+                           double growth_factor, double backoff_factor, int growth_interval, neraf_stream_t stream);
 int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
                      int n_blocks, const float* group_lr, int n_groups, unsigned group_mask, double beta1, double beta2, double eps,
                      float* step, const float* grad_scale, const float* found_inf, neraf_stream_t stream);

@@ -144,6 +144,7 @@ SIGNATURES = {
                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "neraf_camera_apply_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_amp_update_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_fpp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "neraf_loss_sum_scale": (C.c_int, [C.c_void_p, c_fpp, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_vision_loss_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_vision_bwd_prologue": (C.c_int, [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

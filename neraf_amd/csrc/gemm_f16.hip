@@ -342,6 +342,38 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
       az[i] = z * p.conv.stride - p.conv.pad; ay[i] = y * p.conv.stride - p.conv.pad; ax[i] = x * p.conv.stride - p.conv.pad;
     }
   }
+  // Loader 1, fast path (everything but a stride-2 transposed convolution in plain row order).  The K-loop of a 64..128-row tile
+  // runs ONE wave per SIMD, so every instruction between the barrier and the MFMAs is exposed: the generic form below decodes the
+  // tap with scalar divisions and builds each chunk's address with bounds tests, a branch and 64-bit multiplies (~150 dependent
+  // instructions per K-step, more than the MFMAs take).  Here a chunk keeps a 32-bit element offset of its base voxel and a packed
+  // per-axis validity mask (bit a of byte 0 / 1 / 2: tap offset a along z / y / x stays inside the source grid), and the K-step keeps
+  // scalar tap counters: a chunk's source is one AND, one compare, one add and two selects.
+  const bool fastc = LOADER == 1 && (tclass || p.conv.tstride != 2) && nk_total > 0;
+  int c_off[T::A_CH];
+  unsigned c_msk[T::A_CH];
+  int jz = 0, jy = 0, jx = 0, jcb = 0;                    // tap counters / channel block of the NEXT K-step to issue (uniform)
+  const int lim_y = tclass ? cy : KS, lim_x = tclass ? cx : KS;
+  const int tsgn = (LOADER == 1 && p.conv.tflip) ? -1 : 1;
+  if (fastc) {
+    const int cpb = p.conv.cin >> 6, din = p.conv.din;
+    int t = k_begin / cpb;
+    jcb = k_begin - t * cpb;
+    jx = t % lim_x; t /= lim_x; jy = t % lim_y; jz = t / lim_y;
+#pragma unroll
+    for (int i = 0; i < T::A_CH; ++i) {
+      int bz = az[i], by = ay[i], bx = ax[i];
+      if (tclass) { bz = (bz - t0z) >> 1; by = (by - t0y) >> 1; bx = (bx - t0x) >> 1; }   // tap t0 + 2j reaches source voxel b - j
+      unsigned m = 0;
+#pragma unroll
+      for (int a = 0; a < KS; ++a) {
+        m |= ((unsigned)(bz + tsgn * a) < (unsigned)din ? 1u : 0u) << a;
+        m |= ((unsigned)(by + tsgn * a) < (unsigned)din ? 1u : 0u) << (8 + a);
+        m |= ((unsigned)(bx + tsgn * a) < (unsigned)din ? 1u : 0u) << (16 + a);
+      }
+      c_msk[i] = m;
+      c_off[i] = ((bz * din + by) * din + bx) * p.conv.cin + alc[i] * 8;
+    }
+  }
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -353,6 +385,18 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
 #pragma unroll
       for (int i = 0; i < T::A_CH; ++i)
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + (size_t)kt * BK), (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
+    } else if (LOADER == 1 && fastc) {
+      const int cpb = p.conv.cin >> 6, din = p.conv.din;
+      const unsigned sel = (1u << jz) | (1u << (8 + jy)) | (1u << (16 + jx));
+      const int toff = tsgn * ((jz * din + jy) * din + jx) * p.conv.cin + jcb * 64;
+      const int rz = tclass ? t0z + 2 * jz : jz, ry = tclass ? t0y + 2 * jy : jy, rx = tclass ? t0x + 2 * jx : jx;
+      kb = ((rz * KS + ry) * KS + rx) * cpb + jcb;
+#pragma unroll
+      for (int i = 0; i < T::A_CH; ++i) {
+        const half_t* src = (c_msk[i] & sel) == sel ? p.A + (c_off[i] + toff) : p.conv.zero_page;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
+      }
+      if (++jcb == cpb) { jcb = 0; if (++jx == lim_x) { jx = 0; if (++jy == lim_y) { jy = 0; ++jz; } } }
     } else if (LOADER == 1) {
       const int cpb = p.conv.cin >> 6;
       int tap = kt / cpb;

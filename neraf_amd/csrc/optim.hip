@@ -96,6 +96,28 @@ __global__ __launch_bounds__(256) void grads_nonfinite_kernel(const AdamTensor* 
 
 __global__ void set_f32_kernel(float* p, float v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
 
+struct FoundPtrs { const float* p[8]; int n; };
+
+// torch._amp_update_scale_ over the OR of up to 8 per-optimizer found_inf flags (GradScaler.update sums them first: one more launch)
+__global__ void amp_update_scale_kernel(float* scale, int* growth_tracker, FoundPtrs f, float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float found = 0.f;
+  for (int i = 0; i < f.n; ++i) found += *f.p[i];
+  if (found != 0.f) {
+    *scale = *scale * backoff;
+    *growth_tracker = 0;
+  } else {
+    const int ok = *growth_tracker + 1;
+    if (ok == interval) {
+      const float ns = *scale * growth;
+      if (fabsf(ns) <= 3.4028234e38f) *scale = ns;
+      *growth_tracker = 0;
+    } else {
+      *growth_tracker = ok;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int neraf_grads_nonfinite(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
@@ -105,6 +127,18 @@ extern "C" int neraf_grads_nonfinite(neraf_ctx* ctx, const void* table, const vo
   hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(64), 0, st, found_inf, 0.f);
   hipLaunchKernelGGL(grads_nonfinite_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, (const AdamTensor*)table,
                      (const unsigned long long*)g_ptrs, blk_tensor, blk_chunk, found_inf);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
+extern "C" int neraf_amp_update_scale(neraf_ctx* ctx, float* scale, int32_t* growth_tracker, const float* const* found_infs, int n,
+                                      double growth_factor, double backoff_factor, int growth_interval, neraf_stream_t stream) {
+  if (!scale || !growth_tracker || !found_infs || n < 1 || n > 8) return neraf_fail(ctx, NERAF_EINVAL, "amp_update_scale: 1..8 found_inf flags");
+  FoundPtrs f{};
+  f.n = n;
+  for (int i = 0; i < n; ++i) { if (!found_infs[i]) return neraf_fail(ctx, NERAF_EINVAL, "amp_update_scale: null flag"); f.p[i] = found_infs[i]; }
+  hipLaunchKernelGGL(amp_update_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scale, (int*)growth_tracker, f, (float)growth_factor,
+                     (float)backoff_factor, growth_interval);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }

@@ -214,3 +214,50 @@ class GradScaler(torch.amp.GradScaler):
         state = self._per_optimizer_states[id(optimizer)]
         state["found_inf_per_device"] = {found.device: found}
         return state["found_inf_per_device"]
+
+    def step(self, optimizer, *args, **kwargs):
+        """``torch.amp.GradScaler.step`` for a ``FusedAdam``: the inherited path builds ``found_inf`` with ``sum([...])`` and the scale
+        with ``scaler * 1`` -- two scalar launches per optimizer; here the optimizer receives the check's flag and the scale tensor
+        themselves.  States, errors and every other optimizer follow the inherited code."""
+        from torch.amp.grad_scaler import OptState
+        if not self._enabled or not isinstance(optimizer, FusedAdam) or args or kwargs:
+            return super().step(optimizer, *args, **kwargs)
+        self._check_scale_growth_tracker("step")
+        state = self._per_optimizer_states[id(optimizer)]
+        if state["stage"] is OptState.STEPPED:
+            raise RuntimeError("step() has already been called since the last update().")
+        if state["stage"] is OptState.READY:
+            self._check_inf_per_device(optimizer)
+            optimizer.grad_scale = self._scale                     # gradients are still scaled: the kernel un-scales them
+        else:
+            optimizer.grad_scale = None                            # unscale_() already divided them
+        founds = list(state["found_inf_per_device"].values())
+        if len(founds) != 1:
+            raise RuntimeError("FusedAdam holds the parameters of one device")
+        optimizer.found_inf = founds[0]
+        try:
+            retval = optimizer.step()
+        finally:
+            del optimizer.grad_scale
+            del optimizer.found_inf
+        state["stage"] = OptState.STEPPED
+        return retval
+
+    def update(self, new_scale=None):
+        """``GradScaler.update`` in one launch when every recorded flag lives on the scale's device (the inherited code adds the
+        flags pairwise, then calls ``torch._amp_update_scale_``)."""
+        if not self._enabled:
+            return
+        if new_scale is None and self._scale is not None and self._scale.is_cuda:
+            founds = [f for st in self._per_optimizer_states.values() for f in st["found_inf_per_device"].values()]
+            if 1 <= len(founds) <= 8 and all(f.device == self._scale.device and f.dtype == torch.float32 for f in founds):
+                from collections import defaultdict
+                from torch.amp.grad_scaler import _refresh_per_optimizer_state
+                _scale, _growth_tracker = self._check_scale_growth_tracker("update")
+                dev = _dev_index(_scale)
+                _lib.check(_lib.load().neraf_amp_update_scale(_lib.ctx(dev), _scale.data_ptr(), _growth_tracker.data_ptr(),
+                                                              _lib.ptr_array(founds), len(founds), float(self._growth_factor),
+                                                              float(self._backoff_factor), int(self._growth_interval), _stream_ptr()), dev)
+                self._per_optimizer_states = defaultdict(_refresh_per_optimizer_state)
+                return
+        return super().update(new_scale)

@@ -60,3 +60,43 @@ def test_fused_adam_under_grad_scaler_skips_on_inf_and_unscales():
     for x, y in zip(pa, pb):
         np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
     assert float(oa.state[pa[0]]["step"]) == 4.0
+
+
+def test_grad_scaler_update_two_optimizers_growth_and_backoff():
+    """neraf_amd.optim.GradScaler.step / .update (flags handed over as they are, scale update in one launch over both optimizers'
+    flags) against torch.amp.GradScaler driving torch.optim.Adam: growth every 3 clean steps, back-off when EITHER optimizer saw a
+    non-finite gradient, explicit unscale_() before step, parameters equal at the end."""
+    from neraf_amd.optim import FusedAdam, GradScaler
+    dev = torch.device("cuda:0")
+    pa, pb = _params(dev, 5), _params(dev, 5)
+    oa = [FusedAdam(pa[:3], lr=1e-3, eps=1e-15), FusedAdam(pa[3:], lr=2e-3, eps=1e-8)]
+    ob = [torch.optim.Adam(pb[:3], lr=1e-3, eps=1e-15), torch.optim.Adam(pb[3:], lr=2e-3, eps=1e-8)]
+    kw = dict(init_scale=256.0, growth_interval=3, growth_factor=2.0, backoff_factor=0.5)
+    sa, sb = GradScaler("cuda", **kw), torch.amp.GradScaler("cuda", **kw)
+    g = torch.Generator().manual_seed(7)
+    scales = []
+    for it in range(11):
+        for o in oa + ob:
+            o.zero_grad(set_to_none=True)
+        w = [torch.randn(x.shape, generator=g).to(dev) for x in pa]
+        sa.scale(sum((x * wi).sum() for x, wi in zip(pa, w))).backward()
+        sb.scale(sum((y * wi).sum() for y, wi in zip(pb, w))).backward()
+        if it == 4:                                     # second optimizer only
+            pa[4].grad[7] = float("nan"); pb[4].grad[7] = float("nan")
+        if it == 8:                                     # first optimizer only
+            pa[0].grad[3, 3] = float("-inf"); pb[0].grad[3, 3] = float("-inf")
+        if it == 6:                                     # explicit unscale_ (e.g. before gradient clipping)
+            sa.unscale_(oa[0]); sb.unscale_(ob[0])
+            np.testing.assert_allclose(pa[0].grad.cpu().numpy(), pb[0].grad.cpu().numpy(), rtol=1e-6)
+        for x, y in zip(oa, ob):
+            sa.step(x); sb.step(y)
+        sa.update(); sb.update()
+        assert sa.get_scale() == sb.get_scale(), (it, sa.get_scale(), sb.get_scale())
+        assert int(sa._growth_tracker) == int(sb._growth_tracker)
+        scales.append(sa.get_scale())
+    assert max(scales) > 256.0 and min(scales) < max(scales)          # it both grew and backed off
+    with pytest.raises(RuntimeError):
+        sa.scale(pa[0].sum()).backward()
+        sa.step(oa[0]); sa.step(oa[0])
+    for x, y in zip(pa, pb):
+        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
