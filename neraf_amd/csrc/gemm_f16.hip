@@ -1002,17 +1002,31 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
   const int dl = D.dl, dmask = (1 << dl) - 1;
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(t.zero_page);
   // per B half: filter tap and channel block of its 64 columns (loader 1), validity
-  int h_dz[4], h_dy[4], h_dx[4], h_cb[4];
+  // Per B half (loader 1) or per (row, B half) chunk (loader 2: the tap is the lane's 16-byte chunk): the tap as a packed selector
+  // (bit dz | bit 8+dy | bit 16+dx) and as an element offset from the row's base voxel.  A K-step then computes, per staged row, the
+  // base voxel offset and a packed per-axis validity mask, and a chunk's source is one AND, one compare, one multiply-add and a select
+  // -- this loop runs one wave per SIMD, and the generic bounds tests + 64-bit address products cost more than its 32 MFMAs.
+  int h_cb[4];
   bool h_ok[4];
+  unsigned h_sel[2][4];
+  int h_toff[2][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int b64 = bnw * NH + j;
     h_ok[j] = j < NH && b64 < n64;
-    h_dz[j] = h_dy[j] = h_dx[j] = h_cb[j] = 0;
-    if (loader == 1 && h_ok[j]) {
-      const int n0 = b64 * 64;
-      const int tap = n0 / cin; h_cb[j] = n0 - tap * cin;
-      h_dz[j] = tap / (KS * KS); h_dy[j] = (tap / KS) % KS; h_dx[j] = tap % KS;
+    h_cb[j] = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { h_sel[i][j] = 0u; h_toff[i][j] = 0; }
+    if (loader != 0 && h_ok[j]) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int tap;
+        if (loader == 1) { const int n0 = b64 * 64; tap = n0 / cin; h_cb[j] = n0 - tap * cin; }
+        else tap = b64 * 8 + lcs[i];
+        const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
+        h_sel[i][j] = tap < KS * KS * KS ? (1u << dz) | (1u << (8 + dy)) | (1u << (16 + dx)) : 0x80000000u;   // bit 31 is never valid
+        h_toff[i][j] = (dz * din + dy) * din + dx;
+      }
     }
   }
 
@@ -1043,25 +1057,29 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
 #pragma unroll
         for (int h = 0; h < MHc; ++h)
           __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ab + (size_t)m * cout + h * 64 + lcs[i] * 8), (lds_ptr_t)(base + h * HALF + i * 4096), 16, 0, 0);
-        int vz = 0, vy = 0, vx = 0;
-        if (loader != 0) { const int x = m & dmask, y = (m >> dl) & dmask, z = m >> (2 * dl); vz = z * stride - pad; vy = y * stride - pad; vx = x * stride - pad; }
+        int vbase = 0;
+        unsigned vmask = 0u;
+        if (loader != 0) {
+          const int x = m & dmask, y = (m >> dl) & dmask, z = m >> (2 * dl);
+          const int vz = z * stride - pad, vy = y * stride - pad, vx = x * stride - pad;
+          vbase = (vz * din + vy) * din + vx;
+#pragma unroll
+          for (int a = 0; a < 5; ++a)
+            if (a < KS) {
+              vmask |= ((unsigned)(vz + a) < (unsigned)din ? 1u : 0u) << a;
+              vmask |= ((unsigned)(vy + a) < (unsigned)din ? 1u : 0u) << (8 + a);
+              vmask |= ((unsigned)(vx + a) < (unsigned)din ? 1u : 0u) << (16 + a);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NHc; ++j) {
           const bf16_t* src = zero;
           if (h_ok[j]) {
             if (loader == 0) {
               src = Bb + (size_t)m * cin + (bnw * NHc + j) * 64 + lcs[i] * 8;
-            } else {
-              int dz = h_dz[j], dy = h_dy[j], dx = h_dx[j];
-              if (loader == 2) {
-                const int tap = (bnw * NHc + j) * 8 + lcs[i];
-                dz = tap / (KS * KS); dy = (tap / KS) % KS; dx = tap % KS;
-                if (tap >= KS * KS * KS) dz = 1 << 20;
-              }
-              const int iz = vz + dz, iy = vy + dy, ix = vx + dx;
-              const bool ok = (unsigned)iz < (unsigned)din && (unsigned)iy < (unsigned)din && (unsigned)ix < (unsigned)din;
-              const size_t vox = ((size_t)(iz * din + iy) * din + ix);
-              if (ok) src = loader == 2 ? Bb + vox * 8 : Bb + vox * cin + h_cb[j] + lcs[i] * 8;
+            } else if ((vmask & h_sel[i][j]) == h_sel[i][j]) {
+              const int vox = vbase + h_toff[i][j];
+              src = loader == 2 ? Bb + vox * 8 : Bb + (vox * cin + h_cb[j] + lcs[i] * 8);
             }
           }
           __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(base + (MHc + j) * HALF + i * 4096), 16, 0, 0);
