@@ -238,23 +238,20 @@ __global__ __launch_bounds__(256, SAVE == 2 ? 2 : 3) void field_query_kernel(Fie
     // --- hash encode: this lane's 4 levels -> B fragment of the first layer (k = 8q + 2*li + f)
     half8 xin;
     if (SAVE == 2) {
-      // [li][feature][axis] = 24 halfs per lane, stored level by level (12 bytes each) so that no level's derivatives stay live
-      unsigned* dst = reinterpret_cast<unsigned*>(a.denc_out + ((size_t)n * 4 + q) * 24);
+      half8 dh[3];                                 // [li][feature][axis] = 24 halfs
+      half_t* dp = reinterpret_cast<half_t*>(dh);
 #pragma unroll
       for (int li = 0; li < 4; ++li) {
         const int l = 4 * q + li;
         float f0, f1, d0[3], d1_[3];
         encode_level_grad(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1, d0, d1_);
         xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
-        if (valid) {
-          half2v h01, h23, h45;
-          h01[0] = (half_t)(sel ? d0[0] : 0.f); h01[1] = (half_t)(sel ? d0[1] : 0.f);
-          h23[0] = (half_t)(sel ? d0[2] : 0.f); h23[1] = (half_t)(sel ? d1_[0] : 0.f);
-          h45[0] = (half_t)(sel ? d1_[1] : 0.f); h45[1] = (half_t)(sel ? d1_[2] : 0.f);
-          dst[li * 3 + 0] = *reinterpret_cast<const unsigned*>(&h01);
-          dst[li * 3 + 1] = *reinterpret_cast<const unsigned*>(&h23);
-          dst[li * 3 + 2] = *reinterpret_cast<const unsigned*>(&h45);
-        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dp[li * 6 + k] = (half_t)(sel ? d0[k] : 0.f); dp[li * 6 + 3 + k] = (half_t)(sel ? d1_[k] : 0.f); }
+      }
+      if (valid) {
+        half8* dst = reinterpret_cast<half8*>(a.denc_out + ((size_t)n * 4 + q) * 24);
+        dst[0] = dh[0]; dst[1] = dh[1]; dst[2] = dh[2];
       }
     } else {
 #pragma unroll
