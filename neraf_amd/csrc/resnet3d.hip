@@ -176,11 +176,12 @@ extern "C" int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_
     const int taps = c.k * c.k * c.k;
     if (brick_packable(c) && conv_kpad(c) == taps * c.cin && conv_npad(c) == c.cout) {
       const int j = bt.n++;
-      const int cib = brick_cib(c);
+      int cob, cib;
+      brick_shape(c, 0, &cob, &cib);
       bt.src[j] = conv_w[i]; bt.tile_begin[j] = tiles; bt.dst_off[j] = L.w[i];
-      bt.cout[j] = c.cout; bt.cin[j] = c.cin; bt.taps[j] = taps; bt.cib[j] = cib;
-      tiles += (c.cout / 32) * (c.cin / cib);
-      max_run = std::max(max_run, cib * taps);
+      bt.cout[j] = c.cout; bt.cin[j] = c.cin; bt.taps[j] = taps; bt.cib[j] = cib; bt.cob[j] = cob;
+      tiles += (c.cout / cob) * (c.cin / cib);
+      max_run = std::max(max_run, cob * (cib * taps + 2));
       continue;
     }
     const int j = t.n++;

@@ -483,11 +483,12 @@ extern "C" int neraf_resnet3d_pack_weights_bwd(neraf_ctx* ctx, const neraf_resne
     const int nrows = c.cin == 64 || c.cin == 8 ? 64 : round_up(c.cin, 128);
     if (brick_packable(c) && nrows == c.cin) {
       const int j = bt.n++;
-      const int cib = brick_cib(c);
+      int cob, cib;
+      brick_shape(c, 1, &cob, &cib);
       bt.src[j] = conv_w[i]; bt.tile_begin[j] = tiles; bt.dst_off[j] = B.wt[i];
-      bt.cout[j] = c.cout; bt.cin[j] = c.cin; bt.taps[j] = taps; bt.cib[j] = cib;
-      tiles += (c.cout / 32) * (c.cin / cib);
-      max_run = std::max(max_run, cib * taps);
+      bt.cout[j] = c.cout; bt.cin[j] = c.cin; bt.taps[j] = taps; bt.cib[j] = cib; bt.cob[j] = cob;
+      tiles += (c.cout / cob) * (c.cin / cib);
+      max_run = std::max(max_run, cob * (cib * taps + 2));
       continue;
     }
     const int j = t.n++;

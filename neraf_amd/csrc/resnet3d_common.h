@@ -208,80 +208,88 @@ __global__ __launch_bounds__(256) void pack_all_conv_weights_kernel(PackTable t,
   reinterpret_cast<half_t*>(packed + t.dst_off[i])[e] = (half_t)v;
 }
 
-// Brick packer for the un-padded convolutions (cin, cout multiples of 32): a workgroup moves a [32 co][CIB ci][taps] brick.
-// The fp32 source [cout][cin][taps] is read in contiguous runs of CIB*taps floats per co row, converted and parked in LDS in
-// source order; the destination is written in runs along its fastest index with no per-element divisions:
-//   MODE 0  forward layout   fp16  dst[co][tap*cin + ci]     (ld = taps*cin)
-//   MODE 1  dgrad layout     bf16  dst[ci][tap*cout + co]    (ld = taps*cout)
-// CIB is 32 for the 3x3x3 filters and up to 256 for the 1x1x1 ones (bricks of 27,648 / 8,192 elements).
+// Brick packer for the un-padded convolutions (cin, cout multiples of 64): a workgroup moves a [COB co][CIB ci][taps] brick through
+// LDS.  The fp32 source [cout][cin][taps] is read in contiguous runs of CIB*taps floats per co row (16-byte loads), converted and
+// parked in LDS in source order; the brick shape is chosen PER LAYOUT so that the destination is written in whole lines too:
+//   MODE 0  forward layout   fp16  dst[co][tap*cin + ci]     CIB = cin: a brick is COB complete destination rows (contiguous)
+//   MODE 1  dgrad layout     bf16  dst[ci][tap*cout + co]    COB = cout: every (ci, tap) run is a complete row segment of cout
+// (the first version used [32 co][32 ci] bricks for both: 64-byte destination runs, 2 TB/s).  COB / CIB come from brick_shape().
 struct BrickTable {
   int n;
   const float* src[48];
-  int tile_begin[49];                // prefix of (cout/32)*(cin/CIB) bricks
+  int tile_begin[49];                // prefix of (cout/COB)*(cin/CIB) bricks
   unsigned long long dst_off[48];
-  int cout[48], cin[48], taps[48], cib[48];
+  int cout[48], cin[48], taps[48], cib[48], cob[48];
 };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void pack_bricks_kernel(BrickTable t, char* __restrict__ packed) {
-  extern __shared__ unsigned short brick16[];          // [32 co][pitch]
+  extern __shared__ unsigned short brick16[];          // [COB co][pitch]
   int lo = 0, hi = t.n - 1;
   const int bid = blockIdx.x;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.tile_begin[mid] <= bid) lo = mid; else hi = mid - 1; }
   const int i = lo;
   const int tile = bid - t.tile_begin[i];
-  const int taps = t.taps[i], cin = t.cin[i], cout = t.cout[i], cib = t.cib[i];
+  const int taps = t.taps[i], cin = t.cin[i], cout = t.cout[i], cib = t.cib[i], cob = t.cob[i];
   const int ci_tiles = cin / cib;
-  const int co0 = (tile / ci_tiles) * 32, ci0 = (tile % ci_tiles) * cib;
-  const int run = cib * taps;                          // even
+  const int co0 = (tile / ci_tiles) * cob, ci0 = (tile % ci_tiles) * cib;
+  const int run = cib * taps;                          // multiple of 4
   const int pitch = ((run >> 1) & 1) ? run : run + 2;  // odd number of dwords per row: column reads (MODE 1) hit distinct banks
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* src = t.src[i] + ((size_t)co0 * cin + ci0) * taps;
-  for (int co_l = wave; co_l < 32; co_l += 4) {
-    const float* row = src + (size_t)co_l * cin * taps;
-    unsigned short* dst = brick16 + co_l * pitch;
-    auto put = [&](int idx, float v) {
-      if (MODE == 0) { const half_t h = (half_t)v; dst[idx] = *reinterpret_cast<const unsigned short*>(&h); }
-      else { const bf16_t h = (bf16_t)v; dst[idx] = *reinterpret_cast<const unsigned short*>(&h); }
+  {
+    // 16-byte loads over the flat list of (co row, chunk) pairs, two in flight per thread (run and every row offset are multiples
+    // of 4 floats); short runs (1x1x1 filters in MODE 1: 16 floats per co row) keep every lane busy this way
+    const int run4 = run >> 2, total4 = cob * run4;
+    const size_t row_stride = (size_t)cin * taps;
+    auto put4 = [&](int e, const f32x4& v) {
+      const int co_l = e / run4, i4 = e - co_l * run4;
+      unsigned short* dst = brick16 + co_l * pitch + 4 * i4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (MODE == 0) { const half_t h = (half_t)v[k]; dst[k] = *reinterpret_cast<const unsigned short*>(&h); }
+        else { const bf16_t h = (bf16_t)v[k]; dst[k] = *reinterpret_cast<const unsigned short*>(&h); }
+      }
     };
-    // 16-byte loads, two in flight per lane (run and every row offset are multiples of 4 floats): with 4-byte loads a wave kept
-    // 1 KiB in flight and the kernel ran at 1.6 TB/s
-    const f32x4* row4 = reinterpret_cast<const f32x4*>(row);
-    const int run4 = run >> 2;
-    int i4 = lane;
-    for (; i4 + 64 < run4; i4 += 128) {
-      const f32x4 v0 = row4[i4], v1 = row4[i4 + 64];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { put(4 * i4 + e, v0[e]); put(4 * (i4 + 64) + e, v1[e]); }
+    auto get4 = [&](int e) {
+      const int co_l = e / run4, i4 = e - co_l * run4;
+      return reinterpret_cast<const f32x4*>(src + (size_t)co_l * row_stride)[i4];
+    };
+    int e = threadIdx.x;
+    for (; e + 768 < total4; e += 1024) {      // four loads in flight per lane: the kernel is bound by bytes in flight per CU
+      const f32x4 v0 = get4(e), v1 = get4(e + 256), v2 = get4(e + 512), v3 = get4(e + 768);
+      put4(e, v0); put4(e + 256, v1); put4(e + 512, v2); put4(e + 768, v3);
     }
-    for (; i4 < run4; i4 += 64) {
-      const f32x4 v0 = row4[i4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) put(4 * i4 + e, v0[e]);
-    }
+    for (; e < total4; e += 256) put4(e, get4(e));
   }
   __syncthreads();
-  // destination runs are written two elements (4 bytes) per lane: cib, cin, cout, co0 and ci0 are all even
-  unsigned* out = reinterpret_cast<unsigned*>(packed + t.dst_off[i]);
+  // destination: 8 elements (16 bytes) per lane along the layout's fastest index
   if (MODE == 0) {
-    // runs of cib ci for every (co, tap)
-    const int lpr = (cib >> 1) < 256 ? (cib >> 1) : 256;      // lanes per run (cib is 32, 64, 128 or 256)
-    const int cp = threadIdx.x % lpr, rg = threadIdx.x / lpr, nrg = 256 / lpr;
-    const size_t ld = (size_t)taps * cin;
-    for (int co_l = rg; co_l < 32; co_l += nrg) {
-      const unsigned short* srow = brick16 + co_l * pitch + 2 * cp * taps;
-      unsigned* drow = out + (((size_t)(co0 + co_l) * ld + ci0) >> 1) + cp;
-      for (int tap = 0; tap < taps; ++tap) drow[((size_t)tap * cin) >> 1] = (unsigned)srow[tap] | ((unsigned)srow[taps + tap] << 16);
+    // the brick is cob complete rows [tap][ci] of the destination (cib == cin): lanes run over (tap, ci / 8)
+    uint4* out = reinterpret_cast<uint4*>(packed + t.dst_off[i]) + (((size_t)co0 * taps * cin) >> 3);
+    const int c8 = cin >> 3, per_row = taps * c8, total = cob * per_row;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int co_l = e / per_row, r = e - co_l * per_row, tap = r / c8, ci = (r - tap * c8) * 8;
+      const unsigned short* sp = brick16 + co_l * pitch + ci * taps + tap;
+      uint4 v;
+      v.x = (unsigned)sp[0] | ((unsigned)sp[taps] << 16);
+      v.y = (unsigned)sp[2 * taps] | ((unsigned)sp[3 * taps] << 16);
+      v.z = (unsigned)sp[4 * taps] | ((unsigned)sp[5 * taps] << 16);
+      v.w = (unsigned)sp[6 * taps] | ((unsigned)sp[7 * taps] << 16);
+      out[e] = v;
     }
   } else {
-    // runs of 32 co for every (ci, tap)
-    const int cp = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const size_t ld = (size_t)taps * cout;
-    for (int ci_l = rg; ci_l < cib; ci_l += 16) {
-      const unsigned short* s0 = brick16 + (2 * cp) * pitch + ci_l * taps;
-      const unsigned short* s1 = s0 + pitch;
-      unsigned* drow = out + (((size_t)(ci0 + ci_l) * ld + co0) >> 1) + cp;
-      for (int tap = 0; tap < taps; ++tap) drow[((size_t)tap * cout) >> 1] = (unsigned)s0[tap] | ((unsigned)s1[tap] << 16);
+    // runs of cout co (cob == cout) for every (ci, tap) of the brick: lanes run over (ci, tap, co / 8)
+    uint4* out = reinterpret_cast<uint4*>(packed + t.dst_off[i]);
+    const int c8 = cout >> 3, per_ci = taps * c8, total = cib * per_ci;
+    for (int e = threadIdx.x; e < total; e += 256) {
+      const int ci_l = e / per_ci, r = e - ci_l * per_ci, tap = r / c8, co = (r - tap * c8) * 8;
+      const unsigned short* sp = brick16 + co * pitch + ci_l * taps + tap;
+      uint4 v;
+      v.x = (unsigned)sp[0] | ((unsigned)sp[pitch] << 16);
+      v.y = (unsigned)sp[2 * pitch] | ((unsigned)sp[3 * pitch] << 16);
+      v.z = (unsigned)sp[4 * pitch] | ((unsigned)sp[5 * pitch] << 16);
+      v.w = (unsigned)sp[6 * pitch] | ((unsigned)sp[7 * pitch] << 16);
+      out[(((size_t)(ci0 + ci_l) * taps * cout) >> 3) + r] = v;
     }
   }
 }
@@ -290,8 +298,25 @@ __global__ __launch_bounds__(256) void pack_bricks_kernel(BrickTable t, char* __
 inline bool brick_packable(const ConvSpec& c) {
   return c.cin == c.cin_real && (c.cin % 64) == 0 && (c.cout % 64) == 0 && (c.k == 1 || c.k == 3);
 }
-inline int brick_cib(const ConvSpec& c) { return c.k == 1 ? (c.cin < 256 ? c.cin : 256) : 32; }
-inline size_t brick_lds_bytes(int max_run) { return (size_t)32 * (max_run + 2) * 2; }
+// brick [cob co][cib ci][taps] of at most ~28 KiB of 16-bit elements (four or five workgroups per CU: with two, 2.7 TB/s)
+inline void brick_shape(const ConvSpec& c, int mode, int* cob, int* cib) {
+  const int taps = c.k * c.k * c.k, budget = 14336;
+  if (mode == 0) {
+    *cib = c.cin;
+    int b = budget / (c.cin * taps);
+    b = b >= 32 ? 32 : (b >= 16 ? 16 : (b >= 8 ? 8 : (b >= 4 ? 4 : (b >= 2 ? 2 : 1))));
+    while (c.cout % b) b >>= 1;
+    *cob = b;
+  } else {
+    *cob = c.cout;
+    int b = budget / (c.cout * taps);
+    b = b >= 32 ? 32 : (b >= 16 ? 16 : (b >= 8 ? 8 : (b >= 4 ? 4 : (b >= 2 ? 2 : 1))));
+    while (c.cin % b) b >>= 1;
+    if (b < 4) b = 4;                 // source runs of whole 16-byte chunks (taps is odd for 3x3x3)
+    *cib = b;
+  }
+}
+inline size_t brick_lds_bytes(int max_elems) { return (size_t)max_elems * 2; }
 
 // out = [relu]( bn(x) [+ residual | + bn_r(xr)] ) ; 8 channels (16 B) per thread; rows >= M are written as zeros
 struct BnApplyArgs {
