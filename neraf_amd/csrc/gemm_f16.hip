@@ -249,6 +249,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+// s_waitcnt vmcnt(min(after, MAXT) * LOADS): the counter is an immediate, so the (uniform) tile count selects among MAXT + 1 forms
+template <int LOADS, int MAXT>
+__device__ __forceinline__ void wait_tiles(int after) {
+  static_assert(MAXT * LOADS <= 63, "vmcnt is a 6-bit counter");
+  if constexpr (MAXT <= 0) { wait_vmcnt<0>(); }
+  else {
+    if (after >= MAXT) wait_vmcnt<MAXT * LOADS>();
+    else wait_tiles<LOADS, MAXT - 1>(after);
+  }
+}
 
 template <int BM, int BN, int NST>
 struct PipeTile {
@@ -456,10 +466,9 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // iteration kt:  s_waitcnt vmcnt(loads of the tiles issued after kt) ; s_barrier ; issue tile kt+NST-1 ; MFMA
+    // tile kt must have landed; the tiles issued after it (at most NST - 2: tile kt + NST - 1 is issued below) may stay in flight
     const int after = nk - 1 - kt;
-    if (NST >= 4 && after >= 2) wait_vmcnt<2 * LOADS>();
-    else if (NST >= 3 && after >= 1) wait_vmcnt<LOADS>();
-    else wait_vmcnt<0>();
+    wait_tiles<LOADS, NST - 2>(after);
     __builtin_amdgcn_s_barrier();     // also frees stage (kt-1)%NST for the DMA issued below
     if (kt + NST - 1 < nk) {
       int st2 = stage + NST - 1; if (st2 >= NST) st2 -= NST;
