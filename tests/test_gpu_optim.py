@@ -95,8 +95,11 @@ def test_grad_scaler_update_two_optimizers_growth_and_backoff():
         assert int(sa._growth_tracker) == int(sb._growth_tracker)
         scales.append(sa.get_scale())
     assert max(scales) > 256.0 and min(scales) < max(scales)          # it both grew and backed off
-    with pytest.raises(RuntimeError):
-        sa.scale(pa[0].sum()).backward()
-        sa.step(oa[0]); sa.step(oa[0])
+    for o in oa + ob:
+        o.zero_grad(set_to_none=True)
+    sa.scale(pa[0].sum()).backward(); sb.scale(pb[0].sum()).backward()
+    sa.step(oa[0]); sb.step(ob[0])
+    with pytest.raises(RuntimeError):                   # a second step() before update(), as the inherited class
+        sa.step(oa[0])
     for x, y in zip(pa, pb):
         np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
