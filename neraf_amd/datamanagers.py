@@ -161,31 +161,15 @@ class _AudioDataset:
         return self.bank.get_data(int(i))
 
 
-class SyntheticAudioDataManager:
-    """Exponentially decaying noise RIRs in a RAF-like room, tokenised once into a DeviceRIRBank (neraf_amd/data.py)."""
+class _BankDataManager:
+    """Common surface of the audio managers (``NeRAFDataManager``, NeRAF_datamanager.py:43-143): ``next_train`` / ``next_eval`` serve
+    batches of time slices sampled on the device from a DeviceRIRBank, ``next_eval_image`` whole RIRs in turn."""
 
-    def __init__(self, n_train: int = 6, n_eval: int = 2, dataset: str = "RAF", batch_size: int = 2048, device="cpu", seed: int = 0,
-                 world_size: int = 1, local_rank: int = 0):
-        from .data import DeviceRIRBank
+    train_dataset: _AudioDataset
+    eval_dataset: _AudioDataset
+
+    def _finish(self, batch_size: int, device):
         self.batch_size = batch_size
-        fs, max_len, hop = (48000, 60, 256) if dataset == "RAF" else (16000, 60, 128)
-        n = hop * (max_len - 1)
-        aabb = torch.from_numpy(synth.audio_aabb())
-        box = SceneBox(aabb)
-
-        def make(nr, tag):
-            t = np.arange(n) / fs
-            tau = synth.uniform(tag + ".tau", (nr, 1), 0.03, 0.08).astype(np.float64)
-            w = synth.normal(tag + ".wave", (nr, n)).astype(np.float64) * np.exp(-t[None, :] / tau)
-            lo, hi = np.array([-3.0, -1.5, -4.0]), np.array([3.0, 1.5, 4.0])
-            mic = synth.uniform(tag + ".mic", (nr, 3), 0, 1, np.float64) * (hi - lo) + lo
-            src = synth.uniform(tag + ".src", (nr, 3), 0, 1, np.float64) * (hi - lo) + lo
-            ang = np.deg2rad(synth.integers(tag + ".rot", (nr,), 0, 360).astype(np.float64))
-            rot = (np.stack([np.cos(ang), np.zeros_like(ang), np.sin(ang)], -1) + 1.0) / 2.0
-            waves = torch.from_numpy(w.astype(np.float32))
-            bank = DeviceRIRBank.from_waveforms(waves, fs, max_len, torch.from_numpy(mic), torch.from_numpy(src), torch.from_numpy(rot))
-            return _AudioDataset(bank, waves[:, None, :], box)
-        self.train_dataset, self.eval_dataset = make(n_train, "adm.train"), make(n_eval, "adm.eval")
         self.generator = None
         self._eval_i = 0
         self.to(device)
@@ -212,3 +196,67 @@ class SyntheticAudioDataManager:
 
     def get_param_groups(self):
         return {}
+
+
+class SyntheticAudioDataManager(_BankDataManager):
+    """Exponentially decaying noise RIRs in a RAF-like room, tokenised once into a DeviceRIRBank (neraf_amd/data.py)."""
+
+    def __init__(self, n_train: int = 6, n_eval: int = 2, dataset: str = "RAF", batch_size: int = 2048, device="cpu", seed: int = 0,
+                 world_size: int = 1, local_rank: int = 0):
+        from .data import DeviceRIRBank
+        fs, max_len, hop = (48000, 60, 256) if dataset == "RAF" else (16000, 60, 128)
+        n = hop * (max_len - 1)
+        aabb = torch.from_numpy(synth.audio_aabb())
+        box = SceneBox(aabb)
+
+        def make(nr, tag):
+            t = np.arange(n) / fs
+            tau = synth.uniform(tag + ".tau", (nr, 1), 0.03, 0.08).astype(np.float64)
+            w = synth.normal(tag + ".wave", (nr, n)).astype(np.float64) * np.exp(-t[None, :] / tau)
+            lo, hi = np.array([-3.0, -1.5, -4.0]), np.array([3.0, 1.5, 4.0])
+            mic = synth.uniform(tag + ".mic", (nr, 3), 0, 1, np.float64) * (hi - lo) + lo
+            src = synth.uniform(tag + ".src", (nr, 3), 0, 1, np.float64) * (hi - lo) + lo
+            ang = np.deg2rad(synth.integers(tag + ".rot", (nr,), 0, 360).astype(np.float64))
+            rot = (np.stack([np.cos(ang), np.zeros_like(ang), np.sin(ang)], -1) + 1.0) / 2.0
+            waves = torch.from_numpy(w.astype(np.float32))
+            bank = DeviceRIRBank.from_waveforms(waves, fs, max_len, torch.from_numpy(mic), torch.from_numpy(src), torch.from_numpy(rot))
+            return _AudioDataset(bank, waves[:, None, :], box)
+        self.train_dataset, self.eval_dataset = make(n_train, "adm.train"), make(n_eval, "adm.eval")
+        self._finish(batch_size, device)
+
+
+class DiskAudioDataManager(_BankDataManager):
+    """``RAFDataManager`` / ``SoundSpacesDataManager`` (NeRAF_datamanager.py:169-251, :270-356) over the datasets' on-disk formats,
+    without the DataLoader: both splits are parsed and tokenised ONCE into device-resident banks (neraf_amd/dataparsers.py), and a
+    training batch is an index computation plus four gathers on the GPU.  ``max_len`` as in the reference's configs: seconds for RAF
+    (0.32 -> 60 frames of 256 samples at 48 kHz, NeRAF_datamanager.py:213-214), frames for SoundSpaces (NeRAF_config.py:43).
+    The train split's scene box is the audio model's AABB (NeRAF_pipeline.py:135-139).  Ground-truth waveforms for the eval metrics
+    are kept for RAF (the decoded, cropped signal, NeRAF_dataset.py:172-173); SoundSpaces' 44.1 -> 22.05 kHz resampling
+    (librosa, :335-342) is not restated and its ``waveform`` entries are empty."""
+
+    def __init__(self, data: str, dataset: str = "RAF", max_len: float = None, batch_size: int = 2048, device="cpu",
+                 eval_split: str = "test", world_size: int = 1, local_rank: int = 0):
+        from .dataparsers import bank_from_raf, bank_from_soundspaces, read_wav_mono
+        import os
+        if dataset == "RAF":
+            seconds = 0.32 if max_len is None else float(max_len)
+            frames, n_time = int(seconds * 48000 / 256), int(seconds * 48000)
+
+            def make(split):
+                bank, out = bank_from_raf(data, split, fs=48000, max_len=frames, max_len_time=n_time)
+                waves = torch.zeros((len(out.audios_filenames), 1, n_time))
+                for i, name in enumerate(out.audios_filenames):
+                    w = torch.from_numpy(read_wav_mono(os.path.join(data, "data", name, "rir.wav"))[:n_time])
+                    waves[i, 0, :w.shape[0]] = w
+                return _AudioDataset(bank, waves, out.scene_box), out
+        elif dataset == "SoundSpaces":
+            frames = 76 if max_len is None else int(max_len)
+
+            def make(split):
+                bank, out = bank_from_soundspaces(data, split, max_len=frames)
+                return _AudioDataset(bank, torch.zeros((len(out.audios_filenames), 2, 0)), out.scene_box), out
+        else:
+            raise ValueError("dataset must be 'RAF' or 'SoundSpaces'")
+        (self.train_dataset, self.train_dataparser_outputs), (self.eval_dataset, self.eval_dataparser_outputs) = make("train"), make(eval_split)
+        self.max_len = frames
+        self._finish(batch_size, device)

@@ -13,7 +13,7 @@ reference (source or bytecode) is written anywhere; fixtures are data only.
     PYTHONDONTWRITEBYTECODE=1 python tests/tools/gen_golden.py
 
 Fixtures: G1 resnet3d, G2 nacf, G3 stft_loss, G4 grid scatter,
-G5 helper metrics.
+G5 helper metrics, G6 dataparsers (poses / rotations / scene boxes of synthetic RAF and SoundSpaces trees).
 """
 import enum
 import importlib.abc
@@ -39,7 +39,13 @@ STUB_ROOTS = ("nerfstudio", "torchaudio", "pyroomacoustics", "librosa", "jaxtypi
 
 class _Dummy:
     def __init__(self, *a, **k):
-        pass
+        self._kw = k                 # e.g. SceneBox(aabb=...): the argument is what the fixture records
+
+    def __enter__(self):             # rich.progress.Progress(...) as a context manager
+        return self
+
+    def __exit__(self, *a):
+        return False
 
     def __call__(self, *a, **k):
         return _Dummy()
@@ -310,12 +316,46 @@ def g5_helper(nh):
     print("g5", {k: np.asarray(v).tolist() for k, v in out.items()})
 
 
+def g6_dataparsers():
+    """The reference's own dataparsers (NeRAF_dataparser.py: RAFDataParser / SoundSpacesDataParser._generate_dataparser_outputs) on
+    synthetic scene trees in the datasets' on-disk formats (neraf_amd.synth.raf_tree / soundspaces_tree): poses, direction cosines
+    and the audio scene box of every split."""
+    import tempfile
+    import types as _types
+    import NeRAF.NeRAF_dataparser as ndp
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        synth.write_tree(tmp, synth.raf_tree())
+        parser = object.__new__(ndp.RAFDataParser)
+        parser.config = _types.SimpleNamespace(data=tmp)
+        for split in ("train", "val", "test"):
+            o = parser._generate_dataparser_outputs(split)
+            out[f"raf_{split}_mic"] = o.microphone_poses.numpy()
+            out[f"raf_{split}_src"] = o.source_poses.numpy()
+            out[f"raf_{split}_rot"] = o.source_rotations.numpy()
+            out[f"raf_{split}_aabb"] = o.scene_box._kw["aabb"].numpy()
+            out[f"raf_{split}_names"] = np.array(list(o.audios_filenames))
+    with tempfile.TemporaryDirectory() as tmp:
+        synth.write_tree(tmp, synth.soundspaces_tree())
+        parser = object.__new__(ndp.SoundSpacesDataParser)
+        parser.config = _types.SimpleNamespace(data=tmp)
+        for split in ("train", "test"):
+            o = parser._generate_dataparser_outputs(split)
+            out[f"ss_{split}_mic"] = o.microphone_poses.numpy()
+            out[f"ss_{split}_src"] = o.source_poses.numpy()
+            out[f"ss_{split}_rot"] = o.microphone_rotations.numpy()
+            out[f"ss_{split}_aabb"] = o.scene_box._kw["aabb"].numpy()
+            out[f"ss_{split}_names"] = np.array(list(o.audios_filenames))
+    np.savez_compressed(os.path.join(OUT, "g6_dataparsers.npz"), **out)
+    print("g6", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "container-only tool: /root/reference is absent"
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     r3, nf, ne, nh, nm = import_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     if "g2" in which:
         g2_nacf(nf)
     if "g3" in which:
@@ -324,5 +364,7 @@ if __name__ == "__main__":
         g4_grid(nm)
     if "g5" in which:
         g5_helper(nh)
+    if "g6" in which:
+        g6_dataparsers()
     if "g1" in which:
         g1_resnet3d(r3)
