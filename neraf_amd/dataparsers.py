@@ -106,6 +106,40 @@ def parse_soundspaces(root: str, split: str = "train") -> AudioDataparserOutputs
                                   microphone_rotations=torch.from_numpy(_direction_cosine(deg)))
 
 
+def parse_raf_inference(poses_file: str) -> AudioDataparserOutputs:
+    """Split 'inference' of the RAF parser (NeRAF_dataparser.py:130-138, :248-260): a pickled dict {'mic_poses' [N,3], 'source_poses' [3],
+    'rots' [3]} (the file `AVN_RENDER_POSES` points to); the one source pose and rotation are repeated for every microphone pose."""
+    data = np.load(poses_file, allow_pickle=True).item()
+    mic = np.asarray(data["mic_poses"], dtype=np.float64)
+    n = mic.shape[0]
+    src = np.repeat(np.expand_dims(np.asarray(data["source_poses"], dtype=np.float64), 0), n, axis=0)
+    rot = np.repeat(np.expand_dims(np.asarray(data["rots"], dtype=np.float64), 0), n, axis=0)
+    return AudioDataparserOutputs(list(range(n)), torch.from_numpy(mic), torch.from_numpy(src), _scene_box(mic),
+                                  source_rotations=torch.from_numpy(rot))
+
+
+def parse_soundspaces_inference(poses_file: str) -> AudioDataparserOutputs:
+    """Split 'inference' of the SoundSpaces parser (NeRAF_dataparser.py:311-322, :396-447): a pickle {'scene_obs': [{'pose', 'quat',
+    'source'}, ...]} from the Habitat renderer.  Listener yaw = first angle of the intrinsic y-z-x Euler decomposition of the xyzw
+    quaternion, wrapped to [0, 360); the microphone is put at the source's height (training used a fixed height)."""
+    import pickle
+    from scipy.spatial.transform import Rotation
+    with open(poses_file, "rb") as f:
+        obs = pickle.load(f)["scene_obs"]
+    n = len(obs)
+    mic, src, deg = np.empty((n, 3)), np.empty((n, 3)), np.empty((n,))
+    for i, v in enumerate(obs):
+        yaw = Rotation.from_quat(v["quat"]).as_euler("yzx", degrees=True)[0]
+        if yaw < 0:
+            yaw = 360 + yaw
+        deg[i] = yaw % 360
+        src[i] = np.asarray(v["source"], dtype=np.float64)[:3]
+        mic[i] = np.asarray(v["pose"], dtype=np.float64)[:3]
+        mic[i, 1] = src[i, 1]
+    return AudioDataparserOutputs(list(obs), torch.from_numpy(mic), torch.from_numpy(src), _scene_box(mic),
+                                  microphone_rotations=torch.from_numpy(_direction_cosine(deg)))
+
+
 def read_wav_mono(path: str, expect_sr: Optional[int] = 48000) -> np.ndarray:
     """float32 mono samples of a PCM / float wav, as `librosa.load(path, sr=None)` returns them."""
     from scipy.io import wavfile

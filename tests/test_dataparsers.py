@@ -147,3 +147,25 @@ def test_disk_datamanager_serves_reference_shaped_batches(tmp_path):
     assert tuple(e["data"].shape) == (1, 513, 60) and tuple(e["waveform"].shape) == (1, 15360)
     first_test = parse_raf(root, "test").audios_filenames[0]
     np.testing.assert_array_equal(e["waveform"][0].numpy(), sig[first_test][:15360])
+
+
+def test_inference_pose_files_match_the_reference_parsers(tmp_path):
+    """The 'inference' splits (pose files named by AVN_RENDER_POSES, NeRAF_dataparser.py:130-138, :311-322, :248-260, :396-447)."""
+    import pickle
+    from neraf_amd.dataparsers import parse_raf_inference, parse_soundspaces_inference
+    g = np.load(GOLD)
+    raf, ss = synth.inference_pose_files()
+    p1, p2 = str(tmp_path / "raf.npy"), str(tmp_path / "ss.pkl")
+    np.save(p1, raf, allow_pickle=True)
+    with open(p2, "wb") as f:
+        pickle.dump(ss, f)
+    o = parse_raf_inference(p1)
+    np.testing.assert_array_equal(o.microphone_poses.numpy(), g["raf_inf_mic"])
+    np.testing.assert_array_equal(o.source_poses.numpy(), g["raf_inf_src"])
+    np.testing.assert_array_equal(o.source_rotations.numpy(), g["raf_inf_rot"])
+    np.testing.assert_array_equal(o.scene_box.aabb.numpy(), g["raf_inf_aabb"])
+    o = parse_soundspaces_inference(p2)
+    np.testing.assert_array_equal(o.microphone_poses.numpy(), g["ss_inf_mic"])
+    np.testing.assert_array_equal(o.source_poses.numpy(), g["ss_inf_src"])
+    np.testing.assert_allclose(o.microphone_rotations.numpy(), g["ss_inf_rot"], rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(o.scene_box.aabb.numpy(), g["ss_inf_aabb"])

@@ -346,6 +346,30 @@ def g6_dataparsers():
             out[f"ss_{split}_rot"] = o.microphone_rotations.numpy()
             out[f"ss_{split}_aabb"] = o.scene_box._kw["aabb"].numpy()
             out[f"ss_{split}_names"] = np.array(list(o.audios_filenames))
+    # the 'inference' splits: pose files named by AVN_RENDER_POSES (NeRAF_dataparser.py:130-138, :311-322)
+    import pickle
+    with tempfile.TemporaryDirectory() as tmp:
+        raf_inf, ss_inf = synth.inference_pose_files()
+        p1 = os.path.join(tmp, "raf_poses.npy")
+        np.save(p1, raf_inf, allow_pickle=True)
+        os.environ["AVN_RENDER_POSES"] = p1
+        parser = object.__new__(ndp.RAFDataParser)
+        parser.config = _types.SimpleNamespace(data=tmp)
+        o = parser._generate_dataparser_outputs("inference")
+        out["raf_inf_mic"], out["raf_inf_src"], out["raf_inf_rot"] = (np.asarray(o.microphone_poses), np.asarray(o.source_poses),
+                                                                      np.asarray(o.source_rotations))
+        out["raf_inf_aabb"] = o.scene_box._kw["aabb"].numpy()
+        synth.write_tree(tmp, synth.soundspaces_tree())
+        p2 = os.path.join(tmp, "ss_poses.pkl")
+        with open(p2, "wb") as f:
+            pickle.dump(ss_inf, f)
+        os.environ["AVN_RENDER_POSES"] = p2
+        parser = object.__new__(ndp.SoundSpacesDataParser)
+        parser.config = _types.SimpleNamespace(data=tmp)
+        o = parser._generate_dataparser_outputs("inference")
+        out["ss_inf_mic"], out["ss_inf_src"], out["ss_inf_rot"] = (np.asarray(o.microphone_poses), np.asarray(o.source_poses),
+                                                                   np.asarray(o.microphone_rotations))
+        out["ss_inf_aabb"] = o.scene_box._kw["aabb"].numpy()
     np.savez_compressed(os.path.join(OUT, "g6_dataparsers.npz"), **out)
     print("g6", {k: v.shape for k, v in out.items()})
 
