@@ -21,8 +21,9 @@ from .datamanagers import FixedBatchDataManager, RIRBankDataManager  # noqa: F40
 
 
 class _ScaledLossSum(torch.autograd.Function):
-    """(scale * sum_i loss_i, sum_i loss_i) of 0-d device losses in three small launches (stack, sum, multiply) with a one-launch
-    backward, instead of the chain of scalar adds and multiplies the Trainer's two lines build."""
+    """(scale * sum_i loss_i, sum_i loss_i) of 0-d device losses -- Trainer.train_iteration's ``functools.reduce(add, loss_dict.values())``
+    and ``grad_scaler.scale(loss)`` [NS-recall] -- as ONE launch (csrc/glue.hip: terms added left to right, as ``reduce`` does) with a
+    one-multiply backward, instead of the chain of scalar adds and multiplies those two lines build."""
 
     @staticmethod
     def forward(ctx, scaler, *losses):
