@@ -296,6 +296,8 @@ def _family_regex(pattern: str):
             continue
         rx = re.escape(part).replace(r"\*", r"[^,>]+").replace(r"\|", "|")
         rx = re.sub(r"(\d+)\|(\d+)", r"(?:\1|\2)", rx)
+        if rx.endswith(">"):                      # kernels may carry further trailing template arguments (e.g. the parity-class flag)
+            rx = rx[:-1] + r"(?:, [^,>]+)*>"
         alts.append(rx)
     return re.compile("(?:" + "|".join(alts) + ")")
 

@@ -19,7 +19,7 @@ def fam(n):
     """rocprofv3 kernel name -> the bench.py profiling scope (neraf_prof_kernel_name) it is timed under"""
     if "gemm_f16_nt_wide_kernel" in n: return "gemm_f16_nt_wide_kernel<*, 160|128, 3, *>"
     if "wgrad_grouped_tn_kernel" in n or "wgrad_wide_tn_kernel" in n: return "wgrad_wide_tn_kernel | wgrad_grouped_tn_kernel"
-    m = re.search(r"gemm_f16_nt_pipe_kernel<(\d+), (\d+), \d, (\d), (\d), (true|false)>", n)
+    m = re.search(r"gemm_f16_nt_pipe_kernel<(\d+), (\d+), \d, (\d), (\d), (true|false)(?:, (?:true|false))*>", n)
     if m:
         bm, bn, ld, bf = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(5) == "true"
         if ld == 2: return "gemm_f16_nt_pipe_kernel<128, 64, 3, 2, 5, false>"
