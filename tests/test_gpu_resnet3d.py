@@ -80,6 +80,10 @@ def test_resnet3d_running_stats_update():
     (128, 128, 128, 3, 2, 1, 16),    # 3x3x3 stride 2: parity-filtered transposed-conv loader
     (256, 256, 512, 1, 2, 0, 16),    # strided 1x1x1 downsample
     (8, 7, 64, 5, 2, 2, 32),         # the 7->64 stem (wgrad only; its input gradient is covered by the grid test)
+    (128, 128, 128, 3, 2, 1, 8),     # parity-class dgrad at the smallest edge (512 result voxels = 8 tiles, one per class)
+    (64, 64, 128, 3, 2, 1, 32),      # ... and at 32768 result voxels (512 tiles)
+    (256, 256, 512, 1, 2, 0, 8),     # strided 1x1x1 at edge 8: seven of eight classes have no tap
+    (256, 256, 256, 3, 1, 1, 8),     # layer-3 shape: 108 K-steps, split-K + reducer, fast loader with cin = 256 (4 channel blocks)
 ])
 def test_conv_bn_relu_stage_backward(cin, cin_real, cout, k, stride, pad, din):
     """One conv -> BatchNorm(train) -> ReLU stage on random data against torch autograd (fp32 CPU).  This is the tight check
