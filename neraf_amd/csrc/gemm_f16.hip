@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
   }
   const int frow = lane & 15, fq = lane >> 4;
   const int N = D.taps * cin, Npad = tiles_n * BN;
-  if (splits == 1) {
+  if (splits == 1 && D.taps == 1) {      // 1x1x1: [cout][cin] rows are contiguous; filters with taps go through the row reducer
     const float alpha = t.alpha_dev ? *t.alpha_dev : 1.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
   const int frow = lane & 15, fq = lane >> 4;
   const int N = D.taps * cin, Npad = n64 * 64;
   const int m_base = (bm * MH + ha) * 64, n_base = b64 * 64;
-  if (splits == 1) {
+  if (splits == 1 && D.taps == 1) {      // 1x1x1: [cout][cin] rows are contiguous; filters with taps go through the row reducer
     const float alpha = t.alpha_dev ? *t.alpha_dev : 1.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1169,35 +1169,49 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
 // one workgroup per 32x32 output tile of every split item: sums the slabs, scales, writes the PyTorch layout
 struct WgRedTable { int n; const float* alpha_dev; const float* slab; int tile_begin[kMaxWg + 1]; unsigned char item[kMaxWg]; };
 
+// rows of the result in the PyTorch layout [cout][cin_real][taps] are CONTIGUOUS over (ci, tap): a workgroup takes one filter row m
+// and a block of CB input channels, sums the K-split slabs for all taps (coalesced runs of CB floats per tap), turns the
+// [tap][ci] block through LDS and writes CB * taps consecutive floats.  (The first reducer, and the direct epilogue of un-split
+// items, wrote element by element at a stride of `taps` floats: 4-byte stores to one line each -- 13.8 M of them per step for the
+// 512-voxel layers alone; with every load, LDS read and MFMA of the weight-gradient kernel removed it still took 154 of its 300 us.)
+__device__ __forceinline__ int wg_red_cb(const WgDesc& D) { return D.taps == 1 ? (D.cin < 256 ? D.cin : 256) : (D.taps > 32 ? D.cin : (D.cin < 128 ? D.cin : 128)); }
+
 __global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(WgTable t, WgRedTable r) {
+  __shared__ float blk[3584];                       // [CB][taps + 1] (128 x 28, 8 x 126) or [256] for taps == 1
   int lo = 0, hi = r.n - 1;
   const int bid = blockIdx.x;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (r.tile_begin[mid] <= bid) lo = mid; else hi = mid - 1; }
   const WgDesc& D = t.d[r.item[lo]];
   const int tile = bid - r.tile_begin[lo];
-  const int Npad = D.tiles_n * 64, tn = Npad / 32;
-  const int m0 = (tile / tn) * 32, n0 = (tile % tn) * 32;
-  const int tt = threadIdx.x, row = tt >> 3, c4 = (tt & 7) * 4;
-  const int m = m0 + row, n = n0 + c4;
+  const int taps = D.taps, cin = D.cin, CB = wg_red_cb(D), cbs = cin / CB;
+  const int m = tile / cbs, ci0 = (tile - m * cbs) * CB;
+  const int Npad = D.tiles_n * 64;
   const size_t slab = (size_t)D.cout * Npad;
-  const float* src = r.slab + D.slab_off + (size_t)m * Npad + n;
-  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-  int s = 0;
-  const int splits = D.splits;
-  for (; s + 8 <= splits; s += 8) {
-    f32x4 a[8];
+  const float* src = r.slab + D.slab_off + (size_t)m * Npad + ci0;
+  const int splits = D.splits, pitch = taps + 1, q4 = CB >> 2, total4 = q4 * taps;      // 16-byte loads: four channels per thread
+  for (int e = threadIdx.x; e < total4; e += 256) {
+    const int tap = e / q4, c = (e - tap * q4) * 4;
+    const float* p = src + tap * cin + c;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    int s2 = 0;
+    for (; s2 + 8 <= splits; s2 += 8) {
+      f32x4 a[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + u) * slab);
+      for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(s2 + u) * slab);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v += a[u];
+      for (int u = 0; u < 8; ++u) v += a[u];
+    }
+    for (; s2 < splits; ++s2) v += *reinterpret_cast<const f32x4*>(p + (size_t)s2 * slab);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) blk[taps == 1 ? c + k : (c + k) * pitch + tap] = v[k];
   }
-  for (; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * slab);
+  __syncthreads();
   const float alpha = r.alpha_dev ? *r.alpha_dev : 1.f;
-  const int N = D.taps * D.cin;
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int nn = n + rr;
-    if (nn < N && (nn % D.cin) < D.cin_real) D.out[wg_out_index(D, m, nn)] = v[rr] * alpha;
+  const int creal = (D.cin_real - ci0) < CB ? (D.cin_real - ci0) : CB;          // the stem: 7 real channels of 8
+  float* dst = D.out + ((size_t)m * D.cin_real + ci0) * taps;
+  for (int j = threadIdx.x; j < creal * taps; j += 256) {
+    const int c = j / taps, tap = j - c * taps;
+    dst[j] = blk[taps == 1 ? c : c * pitch + tap] * alpha;
   }
 }
 
@@ -1315,10 +1329,11 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
     if (wide) blocks += (it.cout / (64 * d.mh)) * ((tiles_n + (d.mh == 2 ? 2 : 4) - 1) / (d.mh == 2 ? 2 : 4)) * splits;
     else blocks += tiles_m * tiles_n * splits;
     d.slab_off = slab_off;
-    if (splits > 1) {
+    if (splits > 1 || taps > 1) {
       slab_off += (size_t)splits * it.cout * tiles_n * 64;
       r.item[nred] = (unsigned char)i; r.tile_begin[nred] = red_tiles; ++nred;
-      red_tiles += (it.cout / 32) * (tiles_n * 2);
+      const int cb = taps == 1 ? (it.cin < 256 ? it.cin : 256) : (taps > 32 ? it.cin : (it.cin < 128 ? it.cin : 128));      // wg_red_cb
+      red_tiles += it.cout * (it.cin / cb);
     }
     flops += 2.0 * it.cout * taps * it.cin_real * (double)it.K;
   }

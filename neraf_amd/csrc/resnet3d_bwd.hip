@@ -383,7 +383,7 @@ void make_bwd_layout(const Arch& A, BwdLayout* L) {
   L->gm = take(max_act); L->da = take(max_act);
   L->dpost = take(cube(A.conv[0].dout) * 64 * 4);
   L->wtmp = take(max_wtmp);
-  L->splitk_bytes = (size_t)64 << 20;
+  L->splitk_bytes = (size_t)192 << 20;      // K-split slabs of the weight-gradient launch + one slab per un-split filter with taps
   L->splitk = take(L->splitk_bytes);
   L->total = off;
 }
