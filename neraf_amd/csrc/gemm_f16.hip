@@ -1155,15 +1155,25 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
       }
     return;
   }
+  // the 64x64 fp32 product leaves through LDS so that a store instruction writes four whole 256-byte row segments (straight from the
+  // MFMA layout it wrote sixteen 64-byte pieces of sixteen rows: half-lines, 120 MB of them per step)
   float* slab = t.slab + D.slab_off + (size_t)split * cout * Npad;
+  constexpr int IM_LD = 68;
+  __syncthreads();                                   // every wave is done with the staging ring
+  float* im = reinterpret_cast<float*>(smem) + wave * (64 * IM_LD);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m_base + i * 16 + frow;
-      const int n0 = n_base + j * 16 + fq * 4;
-      *reinterpret_cast<f32x4*>(slab + (size_t)m * Npad + n0) = acc[i][j];
-    }
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(im + (i * 16 + frow) * IM_LD + j * 16 + fq * 4) = acc[i][j];
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 4 + (lane >> 4), col = (lane & 15) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(im + row * IM_LD + col);
+    *reinterpret_cast<f32x4*>(slab + (size_t)(m_base + row) * Npad + n_base + col) = v;
+  }
 }
 
 // one workgroup per 32x32 output tile of every split item: sums the slabs, scales, writes the PyTorch layout
