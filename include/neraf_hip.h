@@ -351,8 +351,12 @@ size_t neraf_resnet3d_packed_bytes(const neraf_resnet3d_desc* d);
 size_t neraf_resnet3d_workspace_bytes(const neraf_resnet3d_desc* d);
 int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const float* const* conv_w, void* packed,
                                 neraf_stream_t stream);
+/* win_cells > 0: only the grid cells [win_start, win_start + win_cells) (flat index, the refresh window of NeRAF_model.py:395-404)
+ * are converted into the workspace's fp16 channels-last input image; the CALLER vouches that every other cell of `grid` is unchanged
+ * since the previous forward on this (grid, workspace, use_batch_stats).  win_cells == 0 converts the whole grid. */
 int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed, const float* const* bn,
-                       const float* grid, void* workspace, float* feat, int use_batch_stats, neraf_stream_t stream);
+                       const float* grid, void* workspace, float* feat, int use_batch_stats, size_t win_start, int win_cells,
+                       neraf_stream_t stream);
 /* After a train-mode forward: running_mean/var <- (1-m) running + m batch (unbiased var), as nn.BatchNorm3d. */
 int neraf_resnet3d_update_running_stats(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* workspace,
                                         float* const* bn, float momentum, neraf_stream_t stream);

@@ -132,7 +132,7 @@ SIGNATURES = {
     "neraf_resnet3d_workspace_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),
     "neraf_resnet3d_pack_weights": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), c_fpp, C.c_void_p, C.c_void_p]),
     "neraf_resnet3d_fwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_int, C.c_void_p]),
+                                     C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p]),
     "neraf_resnet3d_update_running_stats": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, C.c_float,
                                                       C.c_void_p]),
     "neraf_resnet3d_bwd_packed_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),

@@ -66,6 +66,8 @@ def load_pipeline(loaded_state: Dict[str, Any], vision_model: Optional[torch.nn.
         with torch.no_grad():
             audio_model.grid.copy_(grid.to(audio_model.grid.device, audio_model.grid.dtype))        # :456
         audio_model._feat_key = None
+        if hasattr(audio_model, "mark_grid_written"):
+            audio_model.mark_grid_written()                                                          # a write of unknown extent
     if vision_model is not None and hasattr(vision_model, "field"):
         audio_model.spatial_distortion = vision_model.field.module.spatial_distortion               # :459
         # :465 -- kept a plain attribute: registering the audio model as a sub-module of the vision model would duplicate its

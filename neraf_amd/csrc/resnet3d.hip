@@ -23,6 +23,24 @@ __global__ __launch_bounds__(256) void grid_to_ndhwc8_kernel(const float* __rest
   if (out_bf) reinterpret_cast<bf16x8*>(out_bf)[v] = b;
 }
 
+// the same for the cells [*start, *start + n) only: the grid refresh rewrites one window of 4096 cells per step (NeRAF_model.py:395-404)
+// and the converted image in the workspace is persistent; the window's first cell travels through device memory (graph replay)
+__global__ __launch_bounds__(256) void grid_window_to_ndhwc8_kernel(const float* __restrict__ grid, size_t nvox, const unsigned long long* start,
+                                                                   int n, half_t* __restrict__ out, bf16_t* __restrict__ out_bf) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const size_t v = (size_t)*start + t;
+  if (v >= nvox) return;
+  half8 h; bf16x8 b;
+#pragma unroll
+  for (int c = 0; c < 7; ++c) { h[c] = (half_t)grid[c * nvox + v]; b[c] = (bf16_t)(float)h[c]; }
+  h[7] = (half_t)0.f; b[7] = (bf16_t)0.f;
+  reinterpret_cast<half8*>(out)[v] = h;
+  if (out_bf) reinterpret_cast<bf16x8*>(out_bf)[v] = b;
+}
+
+__global__ void set_u64_fwd_kernel(unsigned long long* p, unsigned long long v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
+
 struct RunTable {
   int n;
   int begin[49];                     // prefix of channel counts
@@ -148,6 +166,7 @@ extern "C" int neraf_resnet3d_debug_locate(const neraf_resnet3d_desc* d, int kin
     *rows = (int)cube(c.dout); *cols = c.cout;
     return NERAF_OK;
   }
+  if (kind == 7) { *offset = L.x0; *rows = (int)cube(A.S); *cols = 8; return NERAF_OK; }       // the converted input image [S^3][8] fp16
   if (kind == 3) { *offset = L.act_pool; *rows = (int)cube(A.pooled); *cols = 64; return NERAF_OK; }
   if (kind == 4) { *offset = L.pool_arg; *rows = (int)cube(A.pooled); *cols = 64; return NERAF_OK; }
   if (kind == 5 || kind == 6) {
@@ -208,12 +227,17 @@ extern "C" int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_
 }
 
 static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, const char* packed, const float* const* bn, const float* grid,
-                             char* ws, float* feat, int use_batch_stats, hipStream_t st) {
+                             char* ws, float* feat, int use_batch_stats, int win_cells, hipStream_t st) {
   neraf_zero3_async(st, ws + L.zero_page, 256, ws + L.stats_begin, L.stats_bytes, feat, 1024 * sizeof(float));
   const size_t nvox = cube(A.S);
   const bool shadow = use_batch_stats != 0;      // training forward: keep bfloat16 copies for the weight-gradient GEMMs
-  hipLaunchKernelGGL(grid_to_ndhwc8_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, grid, nvox, (half_t*)(ws + L.x0),
-                     shadow ? (bf16_t*)(ws + L.x0_bf) : nullptr);
+  if (win_cells > 0)      // the rest of the image is the previous call's (the caller vouches for it)
+    hipLaunchKernelGGL(grid_window_to_ndhwc8_kernel, dim3((unsigned)((win_cells + 255) / 256)), dim3(256), 0, st, grid, nvox,
+                       reinterpret_cast<const unsigned long long*>(ws + L.win), win_cells, (half_t*)(ws + L.x0),
+                       shadow ? (bf16_t*)(ws + L.x0_bf) : nullptr);
+  else
+    hipLaunchKernelGGL(grid_to_ndhwc8_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, grid, nvox, (half_t*)(ws + L.x0),
+                       shadow ? (bf16_t*)(ws + L.x0_bf) : nullptr);
   // stem: conv1 -> bn1 -> relu -> maxpool (NeRAF_resnet3d.py:185-188)
   if (int e = run_conv(ctx, st, A, L, 0, packed, ws, (const half_t*)(ws + L.x0))) return e;
   {
@@ -267,18 +291,22 @@ static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
 }
 
 extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed_, const float* const* bn,
-                                  const float* grid, void* workspace, float* feat, int use_batch_stats,
+                                  const float* grid, void* workspace, float* feat, int use_batch_stats, size_t win_start, int win_cells,
                                   neraf_stream_t stream) {
   Arch A; Layout L;
-  if (make_arch(d, &A) || !packed_ || !bn || !grid || !workspace || !feat)
-    return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_fwd: bad arguments (grid_size 64|128, in_channels 7, n_features 1024)");
+  if (make_arch(d, &A) || !packed_ || !bn || !grid || !workspace || !feat || win_cells < 0 ||
+      (win_cells > 0 && win_start + (size_t)win_cells > cube(d->grid_size)))
+    return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_fwd: bad arguments (grid_size 64|128, in_channels 7, n_features 1024, window inside the grid)");
   make_layout(A, &L);
+  if (win_cells > 0)      // the window moves every step: its first cell travels through device memory, outside the captured sequence
+    hipLaunchKernelGGL(set_u64_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       reinterpret_cast<unsigned long long*>((char*)workspace + L.win), (unsigned long long)win_start);
   // ~107 launches of mostly 3-10 us kernels with arguments fixed by these values: replayed as one hipGraph
   ArgHash k;
   k.add(0x66776431u); k.add(d->grid_size); k.add(packed_); k.ptrs((const void* const*)bn, 4 * A.nconv); k.add(grid); k.add(workspace);
-  k.add(feat); k.add(use_batch_stats);
+  k.add(feat); k.add(use_batch_stats); k.add(win_cells);
   return neraf_run_graphed(ctx, (hipStream_t)stream, k.h, [&](hipStream_t st) {
-    return resnet3d_fwd_body(ctx, A, L, (const char*)packed_, bn, grid, (char*)workspace, feat, use_batch_stats, st);
+    return resnet3d_fwd_body(ctx, A, L, (const char*)packed_, bn, grid, (char*)workspace, feat, use_batch_stats, win_cells, st);
   });
 }
 

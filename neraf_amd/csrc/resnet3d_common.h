@@ -65,7 +65,7 @@ struct Layout {
   size_t w[64];                 // packed fp16 weights [npad][kpad]
   size_t packed_total;
   // workspace
-  size_t zero_page, x0;         // zero page, NDHWC8 input
+  size_t zero_page, x0, win;    // zero page, NDHWC8 input, device scalar: first cell of the window to re-convert
   size_t pre[64], stat[64];     // per conv: pre-BN output fp16 [rows_pad][cout], stats fp32 [rep][2][cpad] (replica stride kStatStride)
   size_t fin[64];               // per conv: finalised batch statistics fp32 [2][cpad] = mean, biased variance (written by the BN pass)
   size_t act_pool;              // stem: pooled activation
@@ -86,6 +86,7 @@ void make_layout(const Arch& A, Layout* L) {
   L->packed_total = off;
   off = 0;
   L->zero_page = take(256);
+  L->win = take(256);
   L->x0 = take(cube(A.S) * 8 * 2);
   L->stats_begin = off;
   for (int i = 0; i < A.nconv; ++i) {

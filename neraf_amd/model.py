@@ -164,6 +164,7 @@ class NeRAFAudioModel(nn.Module):
         self._feat_cache = None
         self._feat_key = None
         self._window = None
+        self._grid_gen, self._grid_dirty = 0, None          # write generation of the grid; (gen, gen before, first cell, n cells) of the last write
         self.eval_source_pose = self.eval_mic_pose = self.eval_rot = self.eval_gt = None
 
     # ---- A2: grid --------------------------------------------------------------------------------
@@ -178,6 +179,24 @@ class NeRAFAudioModel(nn.Module):
         ax = torch.arange(0 + self.grid_step / 2, 1, self.grid_step)
         self.grid.copy_(self._fresh_grid(S, ax).to(self.grid.device))
         self._feat_key = None
+        self.mark_grid_written()
+
+    def mark_grid_written(self, cell_start: int = None, n_cells: int = None, version_before: int = None):
+        """Every write to ``self.grid`` goes through here: the ResNet3D host layer keeps the grid's fp16 channels-last image between
+        steps and re-converts only the window a refresh wrote -- which it may do only while it has seen every generation.  A write
+        of unknown extent (reset, checkpoint load, anything from outside) passes no window and forces the next full conversion.
+        ``version_before`` / the tensor's current version bracket the write, so that a torch in-place operation on the grid by anybody
+        else (which bumps the version counter) is noticed too; writes through a raw pointer are the caller's to report."""
+        before = self._grid_gen
+        self._grid_gen = before + 1
+        self._grid_dirty = ((self._grid_gen, before, int(cell_start), int(n_cells), int(version_before), int(self.grid._version))
+                            if cell_start is not None and version_before is not None else None)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        if getattr(self, "use_grid", False):
+            self.mark_grid_written()
+            self._feat_key = None
 
     def _generate_fixed_viewing_directions(self) -> torch.Tensor:                       # :279-292, reproduced literally
         phis = [math.pi / 3, 0, -math.pi]
@@ -229,8 +248,10 @@ class NeRAFAudioModel(nn.Module):
                     local = _RefreshFn.apply(module, coords[lo:hi], aabb, dirs, nd, self._delta, self._refresh_consts(dirs, hi - lo),
                                              *module.grad_params()) if hi > lo else torch.zeros((4, 0), device=coords.device)
                     vals = gather_shards(local, lo, hi, batch_size, group)
+                vb = self.grid._version
                 with torch.no_grad():
                     self.grid.view(7, nvox)[0:4, i:i + batch_size] = vals
+                self.mark_grid_written(i, batch_size, vb)
                 self._window = (i, batch_size, vals)
             else:
                 with torch.no_grad():
@@ -250,8 +271,10 @@ class NeRAFAudioModel(nn.Module):
                     if renderer_rgb is None:
                         rgb = torch.sigmoid(rgb)
                     dev = _dev_index(rgb)
+                    vb = self.grid._version
                     _lib.check(lib.neraf_grid_refresh_write(_lib.ctx(dev), rgb.data_ptr(), den.data_ptr(), batch_size, nd, self._delta,
                                                             self.grid.data_ptr(), nvox, i, _stream_ptr()), dev)
+                    self.mark_grid_written(i, batch_size, vb)
             self.grid_batch_i += batch_size                                             # :402-404
             if self.grid_batch_i >= n_cells:
                 self.grid_batch_i = 0
@@ -289,11 +312,13 @@ class NeRAFAudioModel(nn.Module):
         if not self.training and self._feat_key is not None and self._feat_cache is not None:
             return self._feat_cache
         win = getattr(self, "_window", None)
+        d = self._grid_dirty
+        gs = d if (d is not None and d[0] == self._grid_gen) else (self._grid_gen, -1, 0, 0, -1, -1)
         if self.training and win is not None:
-            feat = self.resnet3d(self.grid.unsqueeze(0), window=(win[0], win[1], 4), window_vals=win[2]).flatten()
+            feat = self.resnet3d(self.grid.unsqueeze(0), window=(win[0], win[1], 4), window_vals=win[2], grid_state=gs).flatten()
             self._window = None
         else:
-            feat = self.resnet3d(self.grid.unsqueeze(0)).flatten()                      # :554-557
+            feat = self.resnet3d(self.grid.unsqueeze(0), grid_state=gs).flatten()       # :554-557
         if not self.training:
             self._feat_cache, self._feat_key = feat, True
         return feat

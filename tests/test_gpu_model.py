@@ -255,3 +255,79 @@ def test_device_rir_bank_equals_cpu_tokenisation_and_reference_item_semantics():
     assert item["audio_idx"] == 3 and item["time_query"] == 7 and torch.equal(item["data"], gpu.log_mag[3, 7])
     ev = gpu.get_data_eval(2)
     assert tuple(ev["data"].shape) == (1, 513, 60) and torch.equal(ev["data"][:, :, 11], gpu.log_mag[2, 11])
+
+
+def test_window_only_grid_conversion_keeps_the_input_image_exact():
+    """The ResNet3D host layer re-converts only the refreshed window of the grid into its persistent fp16 channels-last input image
+    (neraf_resnet3d_fwd win_cells > 0) when the audio model vouches for everything else: after every step the image in the workspace
+    must equal a full conversion of the current grid bit for bit -- across the cursor's wrap-around, after an in-place edit of the
+    grid by somebody else (version counter), after a reset and after load_state_dict (all of which must fall back to the full pass)."""
+    import ctypes as C
+    from neraf_amd import _lib
+    from neraf_amd import resnet3d as R3
+    from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
+    from neraf_amd.vision import NeRAFVisionModel
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    vm = NeRAFVisionModel(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), 8).to(dev).train()
+    am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 64), T(synth.audio_aabb())).to(dev).train()
+    bb = am.resnet3d.backbone_net
+    lib = _lib.load()
+    off, rows, cols = C.c_size_t(0), C.c_int(0), C.c_int(0)
+    _lib.check(lib.neraf_resnet3d_debug_locate(C.byref(bb._desc), 7, 0, C.byref(off), C.byref(rows), C.byref(cols)), 0)
+    assert (rows.value, cols.value) == (64 ** 3, 8)
+
+    def image():
+        return bb._ws[off.value:off.value + rows.value * 16].view(torch.float16).reshape(rows.value, 8).clone()
+
+    def expect():
+        g = am.grid.reshape(7, -1).t().half()
+        return torch.cat([g, torch.zeros((g.shape[0], 1), dtype=torch.float16, device=dev)], dim=1)
+
+    calls = []
+    real = lib.neraf_resnet3d_fwd
+
+    def spy(*a):
+        calls.append(int(a[9]))                      # win_cells
+        return real(*a)
+    lib.neraf_resnet3d_fwd = spy
+    try:
+        n_cells = 64 ** 3
+        bs = 100_000                                 # 3 windows per sweep: the third is partial (62,144 cells) and wraps the cursor
+        for step in range(7):
+            am.query_grid_one_batch(step, vm.field, renderer_rgb=vm.renderer_rgb, batch_size=bs)
+            am.scene_feature()
+            assert torch.equal(image(), expect()), step
+        assert calls[0] == 0 and calls[1] == bs and calls[2] == n_cells - 2 * bs and calls[3] == bs, calls
+        # somebody else edits the grid in place: noticed through the version counter -> full conversion
+        with torch.no_grad():
+            am.grid[0, 3, 3, 3] += 0.25
+        am.query_grid_one_batch(7, vm.field, renderer_rgb=vm.renderer_rgb, batch_size=bs)
+        am.scene_feature()
+        assert calls[-1] == 0 and torch.equal(image(), expect())
+        am.query_grid_one_batch(8, vm.field, renderer_rgb=vm.renderer_rgb, batch_size=bs)
+        am.scene_feature()
+        assert calls[-1] > 0 and torch.equal(image(), expect())
+        # two refreshes between two features: a generation was missed -> full
+        am.query_grid_one_batch(9, vm.field, renderer_rgb=vm.renderer_rgb, batch_size=bs)
+        am.query_grid_one_batch(10, vm.field, renderer_rgb=vm.renderer_rgb, batch_size=bs)
+        am.scene_feature()
+        assert calls[-1] == 0 and torch.equal(image(), expect())
+        # reset and load_state_dict are writes of unknown extent
+        am.reset_grid()
+        am.query_grid_one_batch(11, vm.field, renderer_rgb=vm.renderer_rgb, batch_size=bs)
+        am.scene_feature()
+        assert calls[-1] == 0 and torch.equal(image(), expect())
+        sd = {k: v.clone() for k, v in am.state_dict().items()}
+        sd["grid"] = sd["grid"] * 0.5
+        am.load_state_dict(sd)
+        am.query_grid_one_batch(12, vm.field, renderer_rgb=vm.renderer_rgb, batch_size=bs)
+        am.scene_feature()
+        assert calls[-1] == 0 and torch.equal(image(), expect())
+        # the non-differentiable refresh (raw-pointer write, reported by the model) takes the window path too
+        with torch.no_grad():
+            am.query_grid_one_batch(13, vm.field, renderer_rgb=vm.renderer_rgb, batch_size=bs)
+        am.scene_feature()
+        assert calls[-1] > 0 and torch.equal(image(), expect())
+    finally:
+        lib.neraf_resnet3d_fwd = real
