@@ -440,14 +440,17 @@ int neraf_resnet3d_debug_locate(const neraf_resnet3d_desc* d, int kind, int inde
 /* ------------------------------------------------------------------------------------
  * Optimizer step (SURVEY 8f "optimizer fusion"): torch.optim.Adam as nerfstudio's Optimizers apply it to the
  * `fields` and `audio_fields` groups (NeRAF_config.py:116-127), one launch per optimizer.  `table` is a device
- * array of 48-byte records {float* p; const float* g; float* m; float* v; int64 numel; int32 group; int32 pad}
+ * array of 48-byte records {float* p; const float* g; float* m; float* v; int64 numel; int32 group; int32 slot}
  * and group_lr a HOST array of the n_groups (<= 8) learning rates (passed by value: schedulers change them every step);
  * g_ptrs (device uint64[n], may be NULL) overrides the records' gradient pointers -- autograd hands out new gradient
  * tensors every step, and this column can be refreshed with an asynchronous copy while the rest of the table stays;
  * workgroup b updates elements [blk_chunk[b]*chunk, +chunk) of tensor blk_tensor[b] (chunk =
- * neraf_fused_adam_chunk()).  step: device float[8][4], one record {t, 1/(1-b1^t), 1/sqrt(1-b2^t), -} per parameter group; the call
- * increments t of the groups whose bit is set in group_mask (the groups that hold gradients this step: torch.optim.Adam skips
- * parameters without a gradient, so e.g. the proposal networks' bias correction only advances on their update steps);
+ * neraf_fused_adam_chunk()).  step: device float[n_slots][4], one record {t, 1/(1-b1^t), 1/sqrt(1-b2^t), -} per counter slot; a
+ * tensor's record names its slot (the host layer gives every parameter tensor its own, as torch.optim.Adam keeps a `step` per
+ * parameter).  The call increments t of the slots of the n_tensors records of `table` (the tensors that hold gradients this step:
+ * torch.optim.Adam skips parameters without a gradient, so the proposal networks' bias correction only advances on their update
+ * steps, and the NAcF / ResNet3D members of "audio_fields" start at t = 1 when the audio branch starts although the radiance-field
+ * members of the same group have been stepped since iteration 0, NeRAF_pipeline.py:186, :487);
  * grad_scale / found_inf: the GradScaler's device scalars (NULL = no scaling); when *found_inf != 0 nothing is modified.
  * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), exactly torch's formula (no weight decay, no amsgrad).
  * ---------------------------------------------------------------------------------- */
@@ -461,7 +464,7 @@ int neraf_grads_nonfinite(neraf_ctx* ctx, const void* table, const void* g_ptrs,
 int neraf_amp_update_scale(neraf_ctx* ctx, float* scale, int32_t* growth_tracker, const float* const* found_infs, int n,
                            double growth_factor, double backoff_factor, int growth_interval, neraf_stream_t stream);
 int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
-                     int n_blocks, const float* group_lr, int n_groups, unsigned group_mask, double beta1, double beta2, double eps,
+                     int n_blocks, const float* group_lr, int n_groups, int n_tensors, double beta1, double beta2, double eps,
                      float* step, const float* grad_scale, const float* found_inf, neraf_stream_t stream);
 
 #ifdef __cplusplus

@@ -29,8 +29,10 @@ def pipeline_state_dict(vision_model: torch.nn.Module, audio_model: torch.nn.Mod
 
 
 def load_pipeline(loaded_state: Dict[str, Any], vision_model: Optional[torch.nn.Module], audio_model: torch.nn.Module,
-                  step: Optional[int] = None) -> Dict[str, List[str]]:
-    """Mirror of NeRAFPipeline.load_pipeline.  Returns {'loaded', 'skipped_tcnn', 'ignored', 'missing'} key lists."""
+                  step: Optional[int] = None, convert_tcnn: bool = False) -> Dict[str, List[str]]:
+    """Mirror of NeRAFPipeline.load_pipeline.  Returns {'loaded', 'skipped_tcnn', 'ignored', 'missing'} key lists.
+    ``convert_tcnn`` (opt-in): also load tiny-cuda-nn flat parameter blobs through ``tcnn_blobs_to_native``; its layout hypothesis is
+    UNVERIFIED in this image (module docstring), so blobs are left in ``skipped_tcnn`` by default and a conversion warns."""
     state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in loaded_state.items()}
     report = {"loaded": [], "skipped_tcnn": [], "ignored": [], "missing": []}
     if step is not None and vision_model is not None and hasattr(vision_model, "update_to_step"):
@@ -57,10 +59,14 @@ def load_pipeline(loaded_state: Dict[str, Any], vision_model: Optional[torch.nn.
     load_into(audio_model, "audio_model.")
     if vision_model is not None:
         load_into(vision_model, "_model.")
-        if report["skipped_tcnn"] and hasattr(vision_model, "proposal_networks"):
+        if convert_tcnn and report["skipped_tcnn"] and hasattr(vision_model, "proposal_networks"):
             conv = tcnn_blobs_to_native(state, vision_model, "_model.")          # blobs whose element counts match the documented layout
             report["converted_tcnn"] = conv["converted"]
             report["skipped_tcnn"] = [k for k in report["skipped_tcnn"] if k not in conv["converted"]]
+            if conv["converted"]:
+                import warnings
+                warnings.warn("loaded %d tiny-cuda-nn parameter blobs under an UNVERIFIED layout hypothesis (element counts matched); "
+                              "compare one forward against the reference before trusting the radiance field" % len(conv["converted"]))
     report["ignored"] += [k for k in state if not k.startswith(("audio_model.", "_model."))]       # datamanager.*, camera optimizer
     if grid is not None and getattr(audio_model, "use_grid", False):
         with torch.no_grad():

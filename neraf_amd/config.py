@@ -90,8 +90,8 @@ class Optimizers:
     ``optimizer_scaler_step_all``, ``scheduler_step_all``).
 
     MI355X-side difference: groups whose optimizer settings allow it are stepped by ONE ``FusedAdam`` launch -- ``proposal_networks``
-    and ``fields`` share betas / eps, so they become two groups (each with its own learning rate and its own bias-correction
-    counter, csrc/optim.hip) of one fused optimizer; ``audio_fields`` (which also contains the field parameters,
+    and ``fields`` share betas / eps, so they become two groups (each with its own learning rate; the bias-correction counter is
+    per parameter tensor, csrc/optim.hip, as torch.optim.Adam's) of one fused optimizer; ``audio_fields`` (which also contains the field parameters,
     NeRAF_pipeline.py:487) is a second one, stepped after it exactly as the reference's dict order does.  Parameters that are not
     contiguous fp32 device tensors (``camera_opt``'s 6-vectors live wherever the caller put them) use torch.optim.Adam."""
 
@@ -121,7 +121,7 @@ class Optimizers:
                     if not (ids & seen):
                         chosen.append(m)
                         seen |= ids
-                opt = FusedAdam([{"params": param_groups[m], "lr": config[m]["optimizer"].lr} for m in chosen], eps=oc.eps)
+                opt = FusedAdam([{"params": param_groups[m], "lr": config[m]["optimizer"].lr, "name": m} for m in chosen], eps=oc.eps)
                 for gi, m in enumerate(chosen):
                     self._group_of[m] = (opt, gi)
                     done.add(m)

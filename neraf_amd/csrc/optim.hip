@@ -7,21 +7,23 @@
 
 namespace {
 
-struct AdamTensor { float* p; const float* g; float* m; float* v; long long numel; int group; int pad; };
+struct AdamTensor { float* p; const float* g; float* m; float* v; long long numel; int group; int slot; };
 struct AdamLrs { float lr[8]; };
 static_assert(sizeof(AdamTensor) == 48, "table layout is shared with neraf_amd/optim.py");
 
 constexpr int kAdamChunk = 4096;       // elements per workgroup
 
-// One counter record {t, 1 / (1 - b1^t), 1 / sqrt(1 - b2^t), -} per parameter group (torch keeps a step per parameter and skips
-// parameters without a gradient; the groups here receive their gradients together -- the proposal networks only every few steps --
-// so a counter per group reproduces torch's bias correction).  Lane g advances group g if bit g of `mask` is set (unless a gradient
-// was non-finite); the corrections in double as torch computes them on the host (1 - 0.999^t cancels catastrophically in fp32).
+// One counter record {t, 1 / (1 - b1^t), 1 / sqrt(1 - b2^t), -} per parameter TENSOR (slot = AdamTensor::slot), as torch.optim.Adam
+// keeps a `step` per parameter and skips parameters without a gradient: tensors of one group need not receive their first gradient
+// together (the reference's "audio_fields" group holds the radiance field, trained from step 0, and the NAcF / ResNet3D, whose
+// gradients are None until start_step_audio -- NeRAF_pipeline.py:186, :487 -- and must start their bias correction at t = 1 then).
+// Thread i advances the slot of the i-th tensor of the launch (unless a gradient was non-finite); the corrections in double as torch
+// computes them on the host (1 - 0.999^t cancels catastrophically in fp32).
 __global__ void adam_advance_step_kernel(float* __restrict__ step, const float* __restrict__ found_inf, double beta1, double beta2,
-                                         unsigned mask) {
-  const int g = threadIdx.x;
-  if (blockIdx.x != 0 || g >= 8 || !((mask >> g) & 1u)) return;
-  float* s = step + 4 * g;
+                                         const AdamTensor* __restrict__ table, int n_tensors) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tensors) return;
+  float* s = step + 4 * table[i].slot;
   if (!(found_inf && found_inf[0] != 0.f)) s[0] += 1.f;
   const double t = (double)s[0];
   s[1] = (float)(1.0 / (1.0 - pow(beta1, t)));
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256) void fused_adam_kernel(const AdamTensor* __res
   if (g_ptrs) t.g = reinterpret_cast<const float*>(g_ptrs[blk_tensor[blockIdx.x]]);
   const long long base = (long long)blk_chunk[blockIdx.x] * kAdamChunk;
   const float inv_scale = grad_scale ? 1.f / grad_scale[0] : 1.f;
-  const float step_size = lrs.lr[t.group & 7] * step[4 * (t.group & 7) + 1], inv_sqrt_bc2 = step[4 * (t.group & 7) + 2];
+  const float step_size = lrs.lr[t.group & 7] * step[4 * t.slot + 1], inv_sqrt_bc2 = step[4 * t.slot + 2];
   const bool vec = ((reinterpret_cast<size_t>(t.p) | reinterpret_cast<size_t>(t.g) | reinterpret_cast<size_t>(t.m) |
                      reinterpret_cast<size_t>(t.v)) & 15) == 0;
 #pragma unroll
@@ -146,14 +148,15 @@ extern "C" int neraf_amp_update_scale(neraf_ctx* ctx, float* scale, int32_t* gro
 extern "C" int neraf_fused_adam_chunk(void) { return kAdamChunk; }
 
 extern "C" int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
-                                int n_blocks, const float* group_lr, int n_groups, unsigned group_mask, double beta1, double beta2, double eps,
+                                int n_blocks, const float* group_lr, int n_groups, int n_tensors, double beta1, double beta2, double eps,
                                 float* step, const float* grad_scale, const float* found_inf, neraf_stream_t stream) {
-  if (!table || !blk_tensor || !blk_chunk || n_blocks <= 0 || !step || !group_lr || n_groups < 1 || n_groups > 8)
+  if (!table || !blk_tensor || !blk_chunk || n_blocks <= 0 || !step || !group_lr || n_groups < 1 || n_groups > 8 || n_tensors < 1)
     return neraf_fail(ctx, NERAF_EINVAL, "fused_adam: bad arguments (1..8 parameter groups)");
   AdamLrs lrs{};
   for (int i = 0; i < n_groups; ++i) lrs.lr[i] = group_lr[i];
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_advance_step_kernel, dim3(1), dim3(64), 0, st, step, found_inf, beta1, beta2, group_mask);
+  hipLaunchKernelGGL(adam_advance_step_kernel, dim3((unsigned)((n_tensors + 63) / 64)), dim3(64), 0, st, step, found_inf, beta1, beta2,
+                     (const AdamTensor*)table, n_tensors);
   hipLaunchKernelGGL(fused_adam_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, (const AdamTensor*)table, (const unsigned long long*)g_ptrs,
                      blk_tensor, blk_chunk, lrs, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, step,
                      grad_scale, found_inf);

@@ -168,17 +168,38 @@ class _BankDataManager:
     train_dataset: _AudioDataset
     eval_dataset: _AudioDataset
 
-    def _finish(self, batch_size: int, device):
+    def _finish(self, batch_size: int, device, seed: int = 0, world_size: int = 1, local_rank: int = 0):
         self.batch_size = batch_size
+        self.world_size, self.local_rank, self.seed = world_size, local_rank, seed
         self.generator = None
         self._eval_i = 0
         self.to(device)
+
+    def _rank_generator(self, device):
+        """Data parallel: every rank draws its OWN slices (a per-rank device generator, seed + 7919 * global rank) -- ranks that seeded
+        torch identically for identical initial weights would otherwise all train on the same audio batch while the STFT loss is
+        summed over the ranks as if the batches were distinct.  Single process: torch's default generator, as before."""
+        if self.world_size <= 1:
+            return None
+        rank = self.local_rank
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank()
+        except Exception:
+            pass
+        dev = torch.device(device)
+        g = torch.Generator(device=dev if dev.type == "cuda" else "cpu")
+        g.manual_seed(int(self.seed) + 7919 * int(rank))
+        return g
 
     def to(self, device):
         for ds in (self.train_dataset, self.eval_dataset):
             b = ds.bank
             b.log_mag, b.mic_pose, b.source_pose, b.rot = b.log_mag.to(device), b.mic_pose.to(device), b.source_pose.to(device), b.rot.to(device)
             ds.waveforms = ds.waveforms.to(device)
+        if getattr(self, "world_size", 1) > 1 and (self.generator is None or self.generator.device != torch.device(device)):
+            self.generator = self._rank_generator(device)
         return self
 
     def next_train(self, step: int):
@@ -222,7 +243,7 @@ class SyntheticAudioDataManager(_BankDataManager):
             bank = DeviceRIRBank.from_waveforms(waves, fs, max_len, torch.from_numpy(mic), torch.from_numpy(src), torch.from_numpy(rot))
             return _AudioDataset(bank, waves[:, None, :], box)
         self.train_dataset, self.eval_dataset = make(n_train, "adm.train"), make(n_eval, "adm.eval")
-        self._finish(batch_size, device)
+        self._finish(batch_size, device, seed=seed, world_size=world_size, local_rank=local_rank)
 
 
 class DiskAudioDataManager(_BankDataManager):
@@ -231,32 +252,42 @@ class DiskAudioDataManager(_BankDataManager):
     training batch is an index computation plus four gathers on the GPU.  ``max_len`` as in the reference's configs: seconds for RAF
     (0.32 -> 60 frames of 256 samples at 48 kHz, NeRAF_datamanager.py:213-214), frames for SoundSpaces (NeRAF_config.py:43).
     The train split's scene box is the audio model's AABB (NeRAF_pipeline.py:135-139).  Ground-truth waveforms for the eval metrics
-    are kept for RAF (the decoded, cropped signal, NeRAF_dataset.py:172-173); SoundSpaces' 44.1 -> 22.05 kHz resampling
-    (librosa, :335-342) is not restated and its ``waveform`` entries are empty."""
+    are kept for RAF (the decoded, cropped signal, NeRAF_dataset.py:172-173) and for SoundSpaces (``binaural_rirs/<name>.wav``,
+    44.1 -> 22.05 kHz, :326-349); the sample-rate conversions use scipy's polyphase resampler in librosa's place
+    (``dataparsers.resample``: tolerance-level parity).  ``fs``: RAF 48000 (default) or 16000; SoundSpaces 22050."""
 
     def __init__(self, data: str, dataset: str = "RAF", max_len: float = None, batch_size: int = 2048, device="cpu",
-                 eval_split: str = "test", world_size: int = 1, local_rank: int = 0):
-        from .dataparsers import bank_from_raf, bank_from_soundspaces, read_wav_mono
+                 eval_split: str = "test", world_size: int = 1, local_rank: int = 0, fs: int = None, seed: int = 0):
+        from .dataparsers import bank_from_raf, bank_from_soundspaces, load_raf_rir, load_soundspaces_waveform
         import os
         if dataset == "RAF":
+            fs = 48000 if fs is None else int(fs)
+            hop = 256 if fs == 48000 else 128
             seconds = 0.32 if max_len is None else float(max_len)
-            frames, n_time = int(seconds * 48000 / 256), int(seconds * 48000)
+            frames, n_time = int(seconds * fs) // hop, int(seconds * fs)                 # NeRAF_datamanager.py:213-214
 
             def make(split):
-                bank, out = bank_from_raf(data, split, fs=48000, max_len=frames, max_len_time=n_time)
+                bank, out = bank_from_raf(data, split, fs=fs, max_len=frames, max_len_samples=n_time)
                 waves = torch.zeros((len(out.audios_filenames), 1, n_time))
                 for i, name in enumerate(out.audios_filenames):
-                    w = torch.from_numpy(read_wav_mono(os.path.join(data, "data", name, "rir.wav"))[:n_time])
+                    w = torch.from_numpy(load_raf_rir(os.path.join(data, "data", name, "rir.wav"), fs)[:n_time])
                     waves[i, 0, :w.shape[0]] = w
                 return _AudioDataset(bank, waves, out.scene_box), out
         elif dataset == "SoundSpaces":
+            fs = 22050 if fs is None else int(fs)
             frames = 76 if max_len is None else int(max_len)
+            n_time = frames * 128                                                         # NeRAF_datamanager.py:311 (hop 128)
 
             def make(split):
                 bank, out = bank_from_soundspaces(data, split, max_len=frames)
-                return _AudioDataset(bank, torch.zeros((len(out.audios_filenames), 2, 0)), out.scene_box), out
+                waves = torch.zeros((len(out.audios_filenames), 2, n_time))
+                for i, name in enumerate(out.audios_filenames):
+                    path = os.path.join(data, "binaural_rirs", name + ".wav")
+                    if os.path.exists(path):                                              # training splits may ship without the wavs
+                        waves[i] = torch.from_numpy(load_soundspaces_waveform(path, fs, n_time))
+                return _AudioDataset(bank, waves, out.scene_box), out
         else:
             raise ValueError("dataset must be 'RAF' or 'SoundSpaces'")
         (self.train_dataset, self.train_dataparser_outputs), (self.eval_dataset, self.eval_dataparser_outputs) = make("train"), make(eval_split)
-        self.max_len = frames
-        self._finish(batch_size, device)
+        self.max_len, self.fs = frames, fs
+        self._finish(batch_size, device, seed=seed, world_size=world_size, local_rank=local_rank)

@@ -155,25 +155,85 @@ def read_wav_mono(path: str, expect_sr: Optional[int] = 48000) -> np.ndarray:
     return data.mean(axis=1).astype(np.float32) if data.ndim == 2 else data
 
 
-def bank_from_raf(root: str, split: str = "train", fs: int = 48000, max_len: int = 60, max_len_time: float = 0.32,
-                  device=None, chunk: int = 256):
-    """One pass over a RAF split -> (DeviceRIRBank [N, max_len, 1, 513], AudioDataparserOutputs).  `max_len_time` in seconds
-    (NeRAF_datamanager.py: the dataset receives it in samples); RIRs are decoded, cropped, transformed `chunk` at a time on `device`."""
+def resample(x: np.ndarray, orig_sr: int, target_sr: int) -> np.ndarray:
+    """Sample-rate conversion along the last axis: the role of ``librosa.resample`` in NeRAF_dataset.py:98-105, :145-155, :335-342.
+    librosa 0.10 defaults to the soxr_hq resampler; neither librosa nor soxr is in this image, so this is scipy's polyphase FIR
+    (``scipy.signal.resample_poly``, Kaiser window beta 5.0) -- the same band-limited interpolation up to the anti-aliasing filter's
+    shape: TOLERANCE-level parity (pass band within ~1e-2 relative on broadband RIRs), not sample-exact, and documented as such in
+    DESIGN.md.  Output length ceil(n * target / orig), as librosa's."""
+    from math import gcd
+    from scipy.signal import resample_poly
+    if orig_sr == target_sr:
+        return np.asarray(x, dtype=np.float32)
+    g = gcd(int(orig_sr), int(target_sr))
+    y = resample_poly(np.asarray(x, dtype=np.float64), int(target_sr) // g, int(orig_sr) // g, axis=-1)
+    n_out = int(np.ceil(x.shape[-1] * target_sr / orig_sr))
+    return np.ascontiguousarray(y[..., :n_out], dtype=np.float32)
+
+
+def _fix_length(x: np.ndarray, size: int) -> np.ndarray:
+    """librosa.util.fix_length along the last axis: crop or zero-pad to ``size``."""
+    n = x.shape[-1]
+    if n >= size:
+        return x[..., :size]
+    pad = [(0, 0)] * (x.ndim - 1) + [(0, size - n)]
+    return np.pad(x, pad, "constant")
+
+
+def load_raf_rir(path: str, fs: int = 48000) -> np.ndarray:
+    """One RAF recording as the dataset hands it to the STFT (NeRAF_dataset.py:93-105): decoded at 48 kHz; for ``fs`` = 16000
+    zero-extended to at least 0.1 s and resampled (the reference's own branch tests ``data.shape[1]`` on a mono signal and cannot run;
+    its intent is what is implemented)."""
+    data = read_wav_mono(path)
     if fs != 48000:
-        raise NotImplementedError("RAF at 16 kHz needs librosa's resampler (NeRAF_dataset.py:98-105): not restated")
+        if data.shape[-1] < int(48000 * 0.1):
+            data = _fix_length(data, int(48000 * 0.1))
+        data = resample(data, 48000, fs)
+    return data
+
+
+def bank_from_raf(root: str, split: str = "train", fs: int = 48000, max_len: int = 60, max_len_seconds: float = None,
+                  max_len_samples: int = None, device=None, chunk: int = 256):
+    """One pass over a RAF split -> (DeviceRIRBank [N, max_len, 1, F], AudioDataparserOutputs).  The crop length is given EITHER as
+    ``max_len_seconds`` (the config's ``max_len``, 0.32) OR as ``max_len_samples`` (what the dataset receives,
+    NeRAF_datamanager.py:214: int(max_len * fs)); default 0.32 s.  RIRs are decoded, (for fs = 16000: resampled, see ``resample``),
+    cropped, transformed ``chunk`` at a time on ``device``."""
+    if fs not in (48000, 16000):
+        raise ValueError("Sample rate not supported")                                              # NeRAF_dataset.py:56-66
+    if max_len_seconds is not None and max_len_samples is not None:
+        raise ValueError("give max_len_seconds or max_len_samples, not both")
     out = parse_raf(root, split)
-    n_time = int(round(max_len_time * fs)) if max_len_time < 1000 else int(max_len_time)
+    n_time = int(max_len_samples) if max_len_samples is not None else int((0.32 if max_len_seconds is None else max_len_seconds) * fs)
     banks = []
     for c0 in range(0, len(out.audios_filenames), chunk):
         names = out.audios_filenames[c0:c0 + chunk]
         waves = np.zeros((len(names), n_time), np.float32)
         for i, name in enumerate(names):
-            w = read_wav_mono(os.path.join(root, "data", name, "rir.wav"))[:n_time]
+            w = load_raf_rir(os.path.join(root, "data", name, "rir.wav"), fs)[:n_time]
             waves[i, :w.shape[0]] = w          # a shorter file is zero-extended (its STFT frames past the end are silence)
         sl = slice(c0, c0 + len(names))
         banks.append(DeviceRIRBank.from_waveforms(torch.from_numpy(waves), fs, max_len, out.microphone_poses[sl], out.source_poses[sl],
                                                   out.rotations[sl], device=device))
     return _concat(banks), out
+
+
+def load_soundspaces_waveform(path: str, fs: int = 22050, max_len_time: int = 76 * 128) -> np.ndarray:
+    """Ground-truth binaural waveform of a SoundSpaces eval item (NeRAF_dataset.py:326-349): ``binaural_rirs/<name>.wav`` (44.1 kHz,
+    [n, 2]) clipped to [-1, 1], an empty file replaced by 0.5 s of silence, resampled to ``fs`` (zero-extended to 0.1 s first when
+    shorter), cropped or zero-padded to ``max_len_time`` samples -> float32 [2, max_len_time]."""
+    from scipy.io import wavfile
+    _, data = wavfile.read(path)
+    if np.issubdtype(data.dtype, np.integer):          # the simulator writes float wavs; integer PCM is scaled like librosa would
+        data = data.astype(np.float32) / float(2 ** (8 * data.dtype.itemsize - 1))
+    w = np.clip(np.asarray(data, dtype=np.float32), -1.0, 1.0)
+    w = w.T if w.ndim == 2 else np.stack([w, w])
+    if w.shape[1] == 0:
+        w = np.zeros((2, int(fs * 0.5)), np.float32)
+    if fs != 44100:
+        if w.shape[1] < int(44100 * 0.1):
+            w = _fix_length(w, int(44100 * 0.1))
+        w = resample(w, 44100, fs)
+    return np.ascontiguousarray(_fix_length(w, int(max_len_time)), dtype=np.float32)
 
 
 def bank_from_soundspaces(root: str, split: str = "train", max_len: int = 76, device=None):

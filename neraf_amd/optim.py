@@ -20,7 +20,7 @@ from .field import _dev_index, _stream_ptr
 # derived data (packed fp16 weights used in eval mode) key on this as well.
 UPDATE_EPOCH = 0
 
-_REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("numel", "<i8"), ("group", "<i4"), ("pad", "<i4")])
+_REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("numel", "<i8"), ("group", "<i4"), ("slot", "<i4")])
 assert _REC.itemsize == 48
 
 
@@ -36,58 +36,77 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("FusedAdam: betas and eps must be the same in every group (the learning rate may differ)")
         self._plans = {}                       # ids of the parameters holding a gradient -> device tables (the proposal networks
                                                # only receive gradients every few steps: two plans alternate)
-        self._step_t = None                    # device float [8][4]: per-group step counter + bias corrections
+        self._step_t = None                    # device float [n_slots][4]: per-TENSOR step counter + bias corrections (slot = position
+                                               # of the tensor in param-group order), torch.optim.Adam's per-parameter `step`
         self._found = None
         self._fresh_plan = None
+        self._reindex()
+
+    def _reindex(self):
         self._flat = [(p, gi) for gi, group in enumerate(self.param_groups) for p in group["params"]]
         self._all_sig = tuple(id(e[0]) for e in self._flat)
+        self._slot = {id(p): i for i, (p, _) in enumerate(self._flat)}
+
+    def group_steps(self, gi: int) -> torch.Tensor:
+        """Step counters (device float [n]) of the tensors of parameter group ``gi``, in group order."""
+        idx = [self._slot[id(p)] for p in self.param_groups[gi]["params"]]
+        return self._steps(self.param_groups[gi]["params"][0].device)[idx, 0]
 
     def _steps(self, device) -> torch.Tensor:
-        if self._step_t is None or self._step_t.device != device:
+        n = len(self._flat)
+        if self._step_t is None or self._step_t.device != device or self._step_t.shape[0] < n:
             old = self._step_t
-            self._step_t = torch.zeros((8, 4), dtype=torch.float32, device=device)    # per group {t, 1/(1-b1^t), 1/sqrt(1-b2^t), -}
+            self._step_t = torch.zeros((max(n, 8), 4), dtype=torch.float32, device=device)   # per tensor {t, 1/(1-b1^t), 1/sqrt(1-b2^t), -}
             if old is not None:
-                self._step_t.copy_(old)
+                self._step_t[:old.shape[0]].copy_(old)
+                for q, _ in self._flat:                     # `step` entries are views of the table: re-point them
+                    stq = self.state.get(q)
+                    if stq and "step" in stq:
+                        stq["step"] = self._step_t[self._slot[id(q)], 0]
+                self._plans, self._fresh_plan = {}, None
         return self._step_t
 
     def _state_for(self, p: torch.Tensor, gi: int):
         st = self.state[p]
         if not st:
-            st["step"] = self._steps(p.device)[gi, 0]     # one device counter per parameter group (see csrc/optim.hip)
+            st["step"] = self._steps(p.device)[self._slot[id(p)], 0]     # one device counter per tensor (see csrc/optim.hip)
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
     def _adopt_loaded_state(self):
-        """After ``load_state_dict`` / unpickling: the loaded ``step`` values become the per-group device counters again (the
-        kernel advances those, and every parameter's ``state['step']`` is a view of its group's), moments move to the
-        parameter's device, and every cached launch plan -- which holds raw moment pointers -- is dropped."""
+        """After ``load_state_dict`` / unpickling: the loaded per-parameter ``step`` values become the device counters again (the
+        kernel advances those, and every parameter's ``state['step']`` is a view of its slot), moments move to the parameter's
+        device, and every cached launch plan -- which holds raw moment pointers -- is dropped."""
         self._plans, self._fresh_plan = {}, None
         self._step_t = None
-        self._flat = [(p, gi) for gi, group in enumerate(self.param_groups) for p in group["params"]]
-        self._all_sig = tuple(id(e[0]) for e in self._flat)
+        self._reindex()
         loaded = {}
         for p, gi in self._flat:
             st = self.state.get(p)
-            if not st:
-                continue
-            t = float(st["step"]) if "step" in st else 0.0
-            loaded[gi] = max(loaded.get(gi, 0.0), t)
+            if st:
+                loaded[id(p)] = float(st["step"]) if "step" in st else 0.0
         if not loaded:
             return
         dev = next(p for p, _ in self._flat).device
         steps = self._steps(dev)
         b1, b2 = self.param_groups[0]["betas"]
-        for gi, t in loaded.items():
-            steps[gi, 0] = t
+        host = np.zeros((steps.shape[0], 4), np.float32)
+        for p, gi in self._flat:
+            t = loaded.get(id(p))
+            if t is None:
+                continue
+            i = self._slot[id(p)]
+            host[i, 0] = t
             if t > 0:
-                steps[gi, 1] = 1.0 / (1.0 - b1 ** t)
-                steps[gi, 2] = 1.0 / (1.0 - b2 ** t) ** 0.5
+                host[i, 1] = 1.0 / (1.0 - b1 ** t)
+                host[i, 2] = 1.0 / (1.0 - b2 ** t) ** 0.5
+        steps.copy_(torch.from_numpy(host))
         for p, gi in self._flat:
             st = self.state.get(p)
             if not st:
                 continue
-            st["step"] = steps[gi, 0]
+            st["step"] = steps[self._slot[id(p)], 0]
             for k in ("exp_avg", "exp_avg_sq"):
                 st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
 
@@ -111,14 +130,11 @@ class FusedAdam(torch.optim.Optimizer):
             if p.device != device:
                 raise ValueError("FusedAdam: all parameters on one device")
             st = self._state_for(p, gi)
-            rec[i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi, 0)
+            rec[i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi, self._slot[id(p)])
             n = (p.numel() + chunk - 1) // chunk
             bt.append(np.full(n, i, np.int32)); bc.append(np.arange(n, dtype=np.int32))
         n = len(entries)
-        mask = 0
-        for _, gi in entries:
-            mask |= 1 << gi
-        return dict(group_mask=mask, table=torch.from_numpy(rec.view(np.uint8).copy()).to(device),
+        return dict(n_tensors=n, table=torch.from_numpy(rec.view(np.uint8).copy()).to(device),
                     blk_tensor=torch.from_numpy(np.concatenate(bt)).to(device),
                     blk_chunk=torch.from_numpy(np.concatenate(bc)).to(device),
                     # gradient-pointer column, refreshed asynchronously every step: (pinned, device, event, used) x 4
@@ -129,7 +145,7 @@ class FusedAdam(torch.optim.Optimizer):
         """Device tables for the parameters that currently hold a gradient, with the gradient-pointer column refreshed (through
         pinned memory, without synchronising).  Cached while the gradient tensors are the same objects' storages."""
         if len(self._flat) != sum(len(g["params"]) for g in self.param_groups):       # add_param_group since construction
-            self._flat = [(p, gi) for gi, group in enumerate(self.param_groups) for p in group["params"]]
+            self._reindex()
         entries, gp = [], []
         for e in self._flat:
             g = e[0].grad
@@ -196,7 +212,7 @@ class FusedAdam(torch.optim.Optimizer):
         fi = getattr(self, "found_inf", None)
         _lib.check(lib.neraf_fused_adam(_lib.ctx(dev), plan["table"].data_ptr(), plan["gdev"].data_ptr(), plan["blk_tensor"].data_ptr(),
                                         plan["blk_chunk"].data_ptr(), int(plan["blk_tensor"].numel()), lrs, len(self.param_groups),
-                                        plan["group_mask"], float(b1), float(b2), float(self.param_groups[0]["eps"]), self._step_t.data_ptr(),
+                                        plan["n_tensors"], float(b1), float(b2), float(self.param_groups[0]["eps"]), self._step_t.data_ptr(),
                                         gs.data_ptr() if gs is not None else None, fi.data_ptr() if fi is not None else None,
                                         _stream_ptr()), dev)
         return loss

@@ -59,6 +59,22 @@ class _ScaledLossSum(torch.autograd.Function):
         return (None,) + (gi,) * ctx.n
 
 
+def _write_png(path: str, rgb_u8) -> None:
+    """8-bit RGB [H,W,3] -> PNG (stdlib zlib; cv2 / PIL are not in the image): what the reference's cv2.imwrite leaves on disk."""
+    import struct
+    import zlib
+    import numpy as np
+    a = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
+    h, w = a.shape[:2]
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), a.reshape(h, w * 3)], axis=1).tobytes()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 class NeRAFPipeline(nn.Module):
     """Joint radiance + acoustic pipeline (NeRAF_pipeline.py:64-222)."""
 
@@ -73,7 +89,9 @@ class NeRAFPipeline(nn.Module):
         self.world_size, self.local_rank = world_size, local_rank
         self.save_eval_audio_path = getattr(config, "save_eval_audio_path", None)
         self.audio_model.spatial_distortion = self.model.field.module.spatial_distortion        # :143
-        self.model.audio_model = self.audio_model                                                # :152 (viewer hand-off)
+        # :152 (viewer hand-off) -- a plain attribute, as in checkpoint.load_pipeline: registering the audio model as a sub-module of the
+        # vision model would duplicate every audio tensor (incl. the 128^3 grid) in the vision state dict and tie their train/eval modes
+        object.__setattr__(self.model, "audio_model", self.audio_model)
         self._reducer = None
 
     @classmethod
@@ -198,6 +216,10 @@ class NeRAFPipeline(nn.Module):
         self.eval()
         try:
             rank, world = (self.local_rank, self.world_size) if self.world_size > 1 else (0, 1)
+            if world > 1:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():                       # the GLOBAL rank deals the items
+                    rank, world = dist.get_rank(), dist.get_world_size()
             rows_v: List[Dict[str, float]] = []
             for i, (camera, batch) in enumerate(self.datamanager.fixed_indices_eval_dataloader):           # :323
                 if i % world != rank:
@@ -207,8 +229,9 @@ class NeRAFPipeline(nn.Module):
                 num_rays = camera.height * camera.width
                 metrics_dict, im = self.model.get_image_metrics_and_images(outputs, batch)                  # :328
                 if output_path is not None:                                                                # :329-338 (cv2.imwrite)
+                    # the reference writes eval_XXXXX.png here and eval_XXXXX.npy for the audio below (:374-380): distinct names
                     arr = (im["img"].detach().cpu().numpy() * 255).astype(np.uint8)
-                    np.save(os.path.join(output_path, f"eval_{str(i).zfill(5)}.npy"), arr)
+                    _write_png(os.path.join(output_path, f"eval_{str(i).zfill(5)}.png"), arr)
                 torch.cuda.synchronize() if torch.cuda.is_available() else None
                 metrics_dict["num_rays_per_sec"] = num_rays / (time() - t0)                                 # :341
                 metrics_dict["fps"] = metrics_dict["num_rays_per_sec"] / num_rays                           # :343-344
@@ -334,5 +357,5 @@ class NeRAFPipeline(nn.Module):
     def state_dict(self, *args, **kwargs) -> Dict[str, Any]:                                    # :492-497
         return pipeline_state_dict(self.model, self.audio_model)
 
-    def load_pipeline(self, loaded_state: Dict[str, Any], step: int):                           # :438-464
-        return _load_pipeline(loaded_state, self.model, self.audio_model, step=step)
+    def load_pipeline(self, loaded_state: Dict[str, Any], step: int, convert_tcnn: bool = False):    # :438-464
+        return _load_pipeline(loaded_state, self.model, self.audio_model, step=step, convert_tcnn=convert_tcnn)

@@ -2,6 +2,7 @@
 DDP "module." prefixes, the grid under "audio_model.grid", tcnn blobs and foreign buffers for the rest) loads into the models;
 a checkpoint written by this package round-trips completely.  CPU test (modules are only containers)."""
 import numpy as np
+import pytest
 import torch
 
 from neraf_amd import synth
@@ -81,7 +82,11 @@ def test_tcnn_blob_converter_round_trips_under_the_documented_layout():
              "_model.proposal_networks.0.mlp_base_mlp.tcnn_encoding.params": join_tcnn_mlp([vm.proposal_networks[0].w0.detach(), vm.proposal_networks[0].w1.detach()]),
              "_model.proposal_networks.1.mlp_base.params": torch.zeros(12345)}            # wrong size: must be skipped
     vm2, am2 = _models()
-    rep = load_pipeline(dict(state), vm2, am2)
+    before = vm2.field.module.table.detach().clone()
+    rep0 = load_pipeline(dict(state), vm2, am2)                       # default: blobs are NOT loaded under the unverified layout
+    assert "converted_tcnn" not in rep0 and len(rep0["skipped_tcnn"]) == 5 and torch.equal(vm2.field.module.table.detach(), before)
+    with pytest.warns(UserWarning, match="UNVERIFIED"):
+        rep = load_pipeline(dict(state), vm2, am2, convert_tcnn=True)  # opt-in, and it says so
     assert "_model.proposal_networks.1.mlp_base.params" in rep["skipped_tcnn"]
     assert len(rep["converted_tcnn"]) == 5
     f2 = vm2.field.module
@@ -93,3 +98,28 @@ def test_tcnn_blob_converter_round_trips_under_the_documented_layout():
         assert torch.equal(a.detach(), b.detach())
     rep2 = tcnn_blobs_to_native({"_model.field.mlp_head.tcnn_encoding.params": state["_model.field.module.mlp_head.params"]}, vm2)
     assert rep2["converted"] == ["_model.field.mlp_head.tcnn_encoding.params"]
+
+
+def test_write_png_round_trips_through_a_minimal_decoder(tmp_path):
+    """pipeline._write_png (the reference's cv2.imwrite of eval frames, NeRAF_pipeline.py:329-338): valid signature, IHDR fields and
+    IDAT payload (filter byte 0 per row) that inflates back to the pixels."""
+    import struct
+    import zlib
+    import numpy as np
+    from neraf_amd.pipeline import _write_png
+    rgb = (np.arange(5 * 7 * 3).reshape(5, 7, 3) * 3 % 256).astype(np.uint8)
+    path = str(tmp_path / "eval_00000.png")
+    _write_png(path, rgb)
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    off, chunks = 8, {}
+    while off < len(b):
+        n, tag = struct.unpack(">I4s", b[off:off + 8])
+        data = b[off + 8:off + 8 + n]
+        assert struct.unpack(">I", b[off + 8 + n:off + 12 + n])[0] == zlib.crc32(tag + data) & 0xFFFFFFFF
+        chunks[tag] = data
+        off += 12 + n
+    assert struct.unpack(">IIBBBBB", chunks[b"IHDR"]) == (7, 5, 8, 2, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(chunks[b"IDAT"]), np.uint8).reshape(5, 1 + 7 * 3)
+    assert (raw[:, 0] == 0).all()
+    np.testing.assert_array_equal(raw[:, 1:].reshape(5, 7, 3), rgb)

@@ -54,3 +54,23 @@ def test_batches_are_collated_items():
     # uniform over (rir, slice): every RIR shows up in a large batch
     big = bank.next_train(4096, generator=g)
     assert len(torch.unique(big["audio_idx"])) == 5 and len(torch.unique(big["time_query"])) == 60
+
+
+def test_bank_datamanagers_draw_distinct_batches_per_rank():
+    """Advisor finding (round 2): with world_size > 1 every rank must draw its own slices even when all ranks seeded torch
+    identically (identical initial weights): per-rank generator = seed + 7919 * rank."""
+    import torch
+    from neraf_amd.datamanagers import SyntheticAudioDataManager
+    idx = []
+    for rank in (0, 1):
+        torch.manual_seed(0)
+        dm = SyntheticAudioDataManager(3, 1, batch_size=64, world_size=2, local_rank=rank)
+        assert dm.generator is not None
+        _, b = dm.next_train(0)
+        idx.append((b["audio_idx"] * 1000 + b["time_query"]).clone())
+    assert not torch.equal(idx[0], idx[1])
+    torch.manual_seed(0)
+    dm = SyntheticAudioDataManager(3, 1, batch_size=64, world_size=2, local_rank=1)       # reproducible per rank
+    _, b = dm.next_train(0)
+    assert torch.equal(b["audio_idx"] * 1000 + b["time_query"], idx[1])
+    assert SyntheticAudioDataManager(3, 1, batch_size=8).generator is None               # single process: default generator

@@ -69,7 +69,7 @@ def test_raf_bank_is_the_tokenised_split(tmp_path, dtype):
     synth.write_tree(root, synth.raf_tree())
     out = parse_raf(root, "train")
     sig = _write_raf_wavs(root, out.audios_filenames, dtype=dtype)
-    bank, out2 = bank_from_raf(root, "train", fs=48000, max_len=60, max_len_time=0.32, chunk=2)       # several chunks
+    bank, out2 = bank_from_raf(root, "train", fs=48000, max_len=60, max_len_seconds=0.32, chunk=2)       # several chunks
     assert out2.audios_filenames == out.audios_filenames
     assert tuple(bank.log_mag.shape) == (5, 60, 1, 513) and len(bank) == 5 * 60
     # the reference item (NeRAF_dataset.py:107-115): decode, crop to max_len_time samples, STFT, log(|.| + 1e-3) of slice t
@@ -92,8 +92,8 @@ def test_raf_rejects_other_sample_rates(tmp_path):
         wavfile.write(os.path.join(root, "data", name, "rir.wav"), 44100, np.zeros(20000, np.float32))
     with pytest.raises(ValueError, match="48kHz"):                      # NeRAF_dataset.py:95-96
         bank_from_raf(root, "val")
-    with pytest.raises(NotImplementedError):                            # 16 kHz needs librosa's resampler
-        bank_from_raf(root, "val", fs=16000)
+    with pytest.raises(ValueError, match="not supported"):              # NeRAF_dataset.py:56-66
+        bank_from_raf(root, "val", fs=22050)
 
 
 def test_soundspaces_bank_crops_long_and_pads_short_files(tmp_path):
@@ -169,3 +169,81 @@ def test_inference_pose_files_match_the_reference_parsers(tmp_path):
     np.testing.assert_array_equal(o.source_poses.numpy(), g["ss_inf_src"])
     np.testing.assert_allclose(o.microphone_rotations.numpy(), g["ss_inf_rot"], rtol=0, atol=1e-15)
     np.testing.assert_array_equal(o.scene_box.aabb.numpy(), g["ss_inf_aabb"])
+
+
+def test_resample_is_band_limited_interpolation():
+    """dataparsers.resample stands in for librosa.resample (soxr_hq; neither is in the image): a tone well inside the new pass band
+    must come out as the same tone at the new rate (amplitude / phase within 1e-2 away from the edges), a tone above the new Nyquist
+    must be suppressed, and the length follows librosa's ceil(n * target / orig)."""
+    from neraf_amd.dataparsers import resample
+    n = 44100
+    t = np.arange(n) / 44100.0
+    x = np.sin(2 * np.pi * 1000.0 * t).astype(np.float32)
+    y = resample(x, 44100, 22050)
+    assert y.shape == (22050,) and y.dtype == np.float32
+    want = np.sin(2 * np.pi * 1000.0 * np.arange(22050) / 22050.0)
+    assert np.abs(y[200:-200] - want[200:-200]).max() < 1e-2
+    hi = np.sin(2 * np.pi * 15000.0 * t).astype(np.float32)          # above 11.025 kHz: aliased unless filtered
+    assert np.abs(resample(hi, 44100, 22050)[200:-200]).max() < 2e-2
+    assert resample(np.zeros((2, 4801), np.float32), 48000, 16000).shape == (2, 1601)     # ceil(4801 / 3)
+    np.testing.assert_array_equal(resample(x, 22050, 22050), x)
+
+
+def test_raf_bank_at_16k_resamples_and_uses_the_16k_stft(tmp_path):
+    """RAF at fs = 16000 (NeRAF_dataset.py:56-66, :98-105): decode at 48 kHz, resample, crop to int(0.32 * 16000) samples,
+    STFT (512, 256, 128) -> [N, 40, 1, 257]; items equal the same pipeline applied by hand."""
+    from neraf_amd.dataparsers import load_raf_rir, resample
+    root = str(tmp_path)
+    synth.write_tree(root, synth.raf_tree())
+    out = parse_raf(root, "train")
+    sig = _write_raf_wavs(root, out.audios_filenames)
+    bank, _ = bank_from_raf(root, "train", fs=16000, max_len=40, max_len_seconds=0.32)
+    assert tuple(bank.log_mag.shape) == (5, 40, 1, 257)
+    n_time = int(0.32 * 16000)
+    waves = torch.from_numpy(np.stack([resample(sig[n], 48000, 16000)[:n_time] for n in out.audios_filenames]))
+    ref = DeviceRIRBank.from_waveforms(waves, 16000, 40, out.microphone_poses, out.source_poses, out.source_rotations)
+    torch.testing.assert_close(bank.log_mag, ref.log_mag, rtol=0, atol=0)
+    w = load_raf_rir(os.path.join(root, "data", out.audios_filenames[0], "rir.wav"), 16000)
+    assert w.shape[0] == int(np.ceil(sig[out.audios_filenames[0]].shape[0] / 3))
+    with pytest.raises(ValueError, match="not both"):
+        bank_from_raf(root, "train", max_len_seconds=0.32, max_len_samples=15360)
+    # explicit units (advisor finding): a very short crop given in SAMPLES is not reinterpreted as seconds
+    b2, _ = bank_from_raf(root, "train", fs=48000, max_len=2, max_len_samples=600)
+    b3, _ = bank_from_raf(root, "train", fs=48000, max_len=2, max_len_seconds=600 / 48000)
+    torch.testing.assert_close(b2.log_mag, b3.log_mag, rtol=0, atol=0)
+
+
+def test_soundspaces_disk_manager_serves_ground_truth_waveforms(tmp_path):
+    """SoundSpaces eval items carry the ground-truth binaural waveform (NeRAF_dataset.py:326-349): binaural_rirs/<name>.wav at
+    44.1 kHz -> clip -> 22.05 kHz -> crop / zero-pad to max_len * 128 samples; an empty file becomes silence."""
+    from scipy.io import wavfile
+    from neraf_amd.datamanagers import DiskAudioDataManager
+    from neraf_amd.dataparsers import resample
+    root = str(tmp_path)
+    synth.write_tree(root, synth.soundspaces_tree())
+    names = {n for split in ("train", "test") for n in parse_soundspaces(root, split).audios_filenames}
+    test_names = parse_soundspaces(root, "test").audios_filenames
+    sig = {}
+    for k, name in enumerate(sorted(names)):
+        m = np.abs(synth.normal(f"ssw.mag.{name}", (2, 257, 80), 0.2, np.float64)).astype(np.float32) + 1e-4
+        pm = os.path.join(root, "binaural_magnitudes_sr22050", name + ".npy")
+        os.makedirs(os.path.dirname(pm), exist_ok=True)
+        np.save(pm, m)
+        n = 0 if name == test_names[1] else 9000 + 3000 * k             # one empty file; short and long ones around 76*128*2
+        w = (synth.normal(f"ssw.wav.{name}", (n, 2), 0.7, np.float64) * np.exp(-np.arange(n) / 4000.0)[:, None]).astype(np.float32)
+        pw = os.path.join(root, "binaural_rirs", name + ".wav")
+        os.makedirs(os.path.dirname(pw), exist_ok=True)
+        wavfile.write(pw, 44100, w)
+        sig[name] = w
+    dm = DiskAudioDataManager(root, dataset="SoundSpaces", batch_size=16)
+    dm.eval_dataset.mode = "eval_image"
+    n_time = 76 * 128
+    for i, name in enumerate(test_names):
+        item = dm.eval_dataset[i]
+        assert tuple(item["data"].shape) == (2, 257, 76) and tuple(item["waveform"].shape) == (2, n_time)
+        if sig[name].shape[0] == 0:
+            assert float(item["waveform"].abs().max()) == 0.0
+            continue
+        want = resample(np.clip(sig[name], -1, 1).T, 44100, 22050)
+        want = want[:, :n_time] if want.shape[1] >= n_time else np.pad(want, ((0, 0), (0, n_time - want.shape[1])))
+        np.testing.assert_array_equal(item["waveform"].numpy(), want)

@@ -76,9 +76,31 @@ def test_average_eval_image_metrics_matches_manual_loop(pipe, tmp_path):
     audio_keys = [k for k in res if k not in ("psnr", "ssim", "num_rays_per_sec", "fps") and not k.endswith("_std")]
     assert len(audio_keys) >= 4, audio_keys                 # audio metrics (T60 / EDT / C50 / ...) + the two throughput keys
     # saving predictions (the reference writes eval_XXXXX.npy for every RIR, :374-380)
+    # and eval_XXXXX.png for every frame, :329-338 -- two file sets that must not overwrite each other (advisor finding, round 2)
     p.get_average_eval_image_metrics(step=None, output_path=str(tmp_path))
     import os
-    assert len([f for f in os.listdir(tmp_path) if f.endswith(".npy")]) >= 3
+    files = sorted(os.listdir(tmp_path))
+    n_rir = p.audio_datamanager.eval_dataset.bank.n_rir
+    assert [f for f in files if f.endswith(".npy")] == [f"eval_{i:05d}.npy" for i in range(n_rir)]
+    assert [f for f in files if f.endswith(".png")] == [f"eval_{i:05d}.png" for i in range(3)]
+    a = np.load(os.path.join(tmp_path, "eval_00000.npy"))
+    assert a.shape == (1, 513, 60)                                  # an STFT [C, F, T], not an image
+    assert open(os.path.join(tmp_path, "eval_00000.png"), "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+
+
+def test_pipeline_state_dict_holds_every_audio_tensor_once(pipe):
+    """The audio model is a plain attribute of the vision model (viewer hand-off, NeRAF_pipeline.py:152), not a registered
+    sub-module: no `_model.audio_model.*` duplicates in the checkpoint, and vision.eval() does not flip the audio model's mode."""
+    p, _ = pipe
+    keys = list(p.state_dict().keys())
+    assert not [k for k in keys if k.startswith("_model.audio_model.")]
+    assert len(keys) == len(set(keys)) and "audio_model.grid" in keys
+    assert sum(1 for k in keys if k.endswith("resnet3d.backbone_net.conv1.weight")) == 1
+    assert p.model.audio_model is p.audio_model
+    p.audio_model.train()
+    p.model.eval()
+    assert p.audio_model.training
+    p.model.train()
 
 
 def test_fused_adam_state_dict_save_load_continue_matches_torch_adam():

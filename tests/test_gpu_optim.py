@@ -103,3 +103,41 @@ def test_grad_scaler_update_two_optimizers_growth_and_backoff():
         sa.step(oa[0])
     for x, y in zip(pa, pb):
         np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_fused_adam_late_first_gradient_starts_bias_correction_at_one():
+    """Advisor finding (round 2): the reference's "audio_fields" group holds the radiance field (gradients from iteration 0) AND the
+    NAcF / ResNet3D (gradient None until start_step_audio, NeRAF_pipeline.py:186, :487).  torch.optim.Adam keeps `step` per
+    parameter, so the late tensors start at t = 1; a per-group counter would start them at t = N + 1 (bc2 ~ 0.87 instead of 0.001 for
+    N = 2000: first updates 3-6x too large).  Part of ONE group receives its first gradient 7 steps late; also across a
+    state_dict round trip."""
+    from neraf_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    pa, pb = _params(dev, 4), _params(dev, 4)
+    oa = FusedAdam([{"params": pa, "lr": 1e-3}], eps=1e-15)
+    ob = torch.optim.Adam([{"params": pb, "lr": 1e-3}], eps=1e-15)
+    g = torch.Generator().manual_seed(5)
+    late = {2, 3, 5}
+
+    def run(oa, pa, n0, n1):
+        for it in range(n0, n1):
+            for i, (x, y) in enumerate(zip(pa, pb)):
+                if i in late and it < 7:
+                    x.grad = y.grad = None
+                    continue
+                gr = torch.randn(x.shape, generator=g).to(dev)
+                x.grad, y.grad = gr.clone(), gr.clone()
+            oa.step(); ob.step()
+    run(oa, pa, 0, 9)
+    for i, (x, y) in enumerate(zip(pa, pb)):
+        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=str(i))
+        assert float(oa.state[x]["step"]) == float(ob.state[y]["step"]) == (2.0 if i in late else 9.0)
+    # save / load / continue: per-parameter steps survive
+    sd = oa.state_dict()
+    pc = [x.detach().clone().requires_grad_(True) for x in pa]
+    oc = FusedAdam([{"params": pc, "lr": 1e-3}], eps=1e-15)
+    oc.load_state_dict(sd)
+    run(oc, pc, 9, 12)
+    for i, (x, y) in enumerate(zip(pc, pb)):
+        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=str(i))
+        assert float(oc.state[x]["step"]) == float(ob.state[y]["step"])
