@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--slices", type=int, default=2048, help="RIR STFT slices per step: per GPU (weak) or global (strong) (NeRAF_config.py:57)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="extra timed windows of --steps steps after the headline window (median / min / max reported; the headline "
+                         "value is the FIRST window, exactly --steps steps as the contract says)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the short trajectory-parity run (tests/golden/g7_trajectory.npz)")
     ap.add_argument("--plain", action="store_true",
                     help="priming + warm-up + timed steps only (no second regime, no instrumented replay, no CPU baseline): the form that "
                          "runs under rocprofv3, so that its per-kernel totals divide by exactly PRIME_STEPS + warmup + steps")
@@ -126,6 +130,10 @@ class JointStep:
         self.pipe = NeRAFPipeline(self.vm, self.am, datamanager=FixedBatchDataManager(self.bundle, self.gt, R),
                                   audio_datamanager=FixedBatchDataManager(None, self.batch), start_step_audio=2000, world_size=world,
                                   local_rank=rank)
+        if os.environ.get("NERAF_OVERLAP") is not None:          # experiment knob (tools/gpu_overlap_ab.sh); the default is the pipeline's
+            self.pipe.overlap_radiance = os.environ["NERAF_OVERLAP"] in ("1", "2")
+            self.pipe.overlap_loss_late = os.environ["NERAF_OVERLAP"] == "2"
+            self.pipe.side_cu_mask = int(os.environ.get("NERAF_SIDE_CUS", "0"))
         self.opt_wrapper, self.scaler = self.pipe.make_optimizers(init_scale=65536.0, with_schedulers=True)
         self.optimizers = self.opt_wrapper.steppers
         if world > 1:
@@ -272,6 +280,39 @@ def cpu_baseline(R, B):
                       % (nv[0], nv[1], nr[0], nr[1], na[0], na[1], R, B, step_train, step_fwd, ncores)}
 
 
+def trajectory_parity(dev):
+    """BASELINE.json's metric, second half ("PSNR & T60 err vs ref"): a short in-process training run of the HIP pipeline on the
+    trajectory scenario (tests/tools/trajectory_common.py: 100 iterations of 512 rays + 128 RIR slices, 64^3 grid) compared with
+    the CPU oracle's run from the same weights on the same batches, whose outputs are the committed fixture
+    tests/golden/g7_trajectory.npz (tests/tools/gen_trajectory.py).  The same comparison is asserted by tests/test_gpu_trajectory.py."""
+    import numpy as np
+    fx = os.path.join(ROOT, "tests", "golden", "g7_trajectory.npz")
+    if not os.path.exists(fx):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import trajectory_common as TC
+    g = np.load(fx)
+    curves, img, stft, pipe, evb = TC.run_hip_trajectory(dev)
+    r = TC.parity_summary(g, curves, img, stft, pipe.audio_model, evb)
+    out = {"steps": r["steps"], "psnr_db": r["psnr_hip_vs_gt_db"], "psnr_db_oracle": r["psnr_oracle_vs_gt_db"],
+           "psnr_hip_vs_oracle_db": r["psnr_hip_vs_oracle_db"],
+           "t60_err_pct": r.get("audio_T60_hip"), "t60_err_pct_oracle": r.get("audio_T60_oracle"),
+           "edt_err_s": r.get("audio_EDT_hip"), "edt_err_s_oracle": r.get("audio_EDT_oracle"),
+           "c50_err_db": r.get("audio_C50_hip"), "c50_err_db_oracle": r.get("audio_C50_oracle"),
+           "stft_rel_l2_hip_vs_oracle": r["stft_rel_l2_hip_vs_oracle"], "stft_rel_l2_vs_gt": r["stft_rel_l2_hip_vs_gt"],
+           "stft_rel_l2_vs_gt_oracle": r["stft_rel_l2_oracle_vs_gt"],
+           "stft_batch_stats_rel_l2_hip_vs_oracle": r["stft_bs_rel_l2_hip_vs_oracle"],
+           "fixture": "tests/golden/g7_trajectory.npz",
+           "note": "held-out camera (32x48) and 2 held-out RIRs after 100 joint training iterations from identical weights on identical "
+                   "batches: HIP pipeline (this run) vs CPU fp32 oracle (fixture); *_oracle = the oracle's own error against ground truth"}
+    if "psnr_fp16param_oracle_vs_oracle_db" in r:
+        out["fp16_rounding_band"] = {"psnr_db": r["psnr_fp16param_oracle_vs_oracle_db"], "stft_rel_l2": r["stft_rel_l2_fp16param_oracle_vs_oracle"],
+                                     "stft_batch_stats_rel_l2": r["stft_bs_rel_l2_fp16param_oracle_vs_oracle"],
+                                     "note": "the same oracle trained with fp16-rounded parameters vs its fp32 run: what 16-bit rounding alone "
+                                             "does to this trajectory"}
+    return out
+
+
 def _rocprof_reference():
     """Average kernel durations from the newest committed rocprofv3 --kernel-trace --stats summary of this command (profiles/), so
     that the HIP-event durations in ``roofline`` can be cross-checked without re-running the profiler."""
@@ -379,6 +420,8 @@ def main():
         return el
 
     elapsed = timed_steps(a.steps)
+    # the same window again, `--repeats` times: 20 steps are 87 ms -- one sample; the spread says how much to trust it
+    repeat_ms = [elapsed / a.steps * 1e3] + ([timed_steps(a.steps) / a.steps * 1e3 for _ in range(max(a.repeats - 1, 0))] if not a.plain else [])
 
     if a.plain:
         if rank == 0:
@@ -430,8 +473,8 @@ def main():
     fams = []
     kid = 0
     while lib.neraf_prof_kernel_name(kid):
-        ms, n, w = C.c_double(), C.c_int(), C.c_double()
-        _lib.check(lib.neraf_prof_summary(h, kid, C.byref(ms), C.byref(n), C.byref(w)), local)
+        ms, n, w, ex = C.c_double(), C.c_int(), C.c_double(), C.c_double()
+        _lib.check(lib.neraf_prof_summary_ex(h, kid, C.byref(ms), C.byref(n), C.byref(w), C.byref(ex)), local)
         if n.value:
             name = lib.neraf_prof_kernel_name(kid).decode()
             is_bytes = kid in (2, 3, 5, 6, 7)     # gather / scatter kernels are priced in bytes against HBM (ids: csrc/common.h PROF_*)
@@ -439,7 +482,11 @@ def main():
             rate = w.value / (ms.value * 1e-3) / (1e9 if is_bytes else 1e12) if ms.value > 0 else 0.0
             fam = {"kernel": name, "bound": "hbm" if is_bytes else "mfma", "launches_per_step": n.value / nprof,
                    "avg_us": ms.value * 1e3 / n.value, "ms_per_step": ms.value / nprof, "achieved": rate,
-                   "unit": "GB/s" if is_bytes else "TFLOP/s", "peak": peak, "frac": rate / peak, "work_per_launch": w.value / n.value}
+                   "unit": "GB/s" if is_bytes else "TFLOP/s", "peak": peak, "frac": rate / peak, "work_per_launch": w.value / n.value,
+                   # `work` / `frac` are ALGORITHMIC (a conv, its dgrad and its wgrad = 2 dout^3 taps cin cout each, real
+                   # channels and taps); `executed` is what the grid multiplied (padded K / channels / voxel rows, zero-page taps)
+                   "executed_per_launch": ex.value / n.value, "executed_frac": (ex.value / (ms.value * 1e-3) / (1e9 if is_bytes else 1e12) / peak) if ms.value > 0 else 0.0,
+                   "work_per_step": w.value / nprof}
             if ref_rows:
                 rx = _family_regex(name)
                 calls = sum(c for k, (c, _) in ref_rows.items() if rx.search(k))
@@ -475,6 +522,9 @@ def main():
             "warmup": a.warmup,
             "priming_steps": PRIME_STEPS,
             "ms_per_step": ms_step,
+            "repeat_windows": {"n": len(repeat_ms), "steps_each": a.steps, "ms_per_step": [round(v, 4) for v in repeat_ms],
+                               "median": _median(repeat_ms), "min": min(repeat_ms), "max": max(repeat_ms),
+                               "note": "window 0 is the headline (value, ms_per_step); the others repeat it back to back"},
             "higher_is_better": True,
             "scaling": a.scaling,
             "vs_baseline": None,
@@ -518,12 +568,24 @@ def main():
                                "rocprof_reference": ref_name,
                                "dense_equiv_gflop_per_step": {"nacf_fwd_bwd": 3 * NACF_DENSE_FLOP_PER_SLICE_FWD * B_local / 1e9,
                                                               "resnet3d_fwd_bwd": 3 * RESNET_FWD_GFLOP},
+                               "instrumented_gflop_per_step": {
+                                   "algorithmic": sum(k["work_per_step"] for k in fams if k["bound"] == "mfma") / 1e9,
+                                   "executed": sum(k["executed_per_launch"] * k["launches_per_step"] for k in fams if k["bound"] == "mfma") / 1e9,
+                                   "note": "sum over the MFMA-priced families; algorithmic = ResNet3D 3 x 94.72 - 29.36 (the stem's input "
+                                           "gradient is a per-cell kernel, not a GEMM) + the NAcF GEMMs as executed (layer-0 split: the "
+                                           "1024 shared inputs are a GEMV, so less than the dense-equivalent 3 x 40.84 MFLOP/slice) + the "
+                                           "radiance field's weight-gradient GEMMs"},
                                "whole_step_mfma_frac": ((3 * NACF_DENSE_FLOP_PER_SLICE_FWD * B_local / 1e9 + 3 * RESNET_FWD_GFLOP) / 1e3)
                                                        / (ms_step * 1e-3) / MFMA_PEAK_TFLOPS,
                                "all_kernel_families": fams}
         g_cap, g_launch = C.c_int(), C.c_int()
         out["hip_graphs"] = {"enabled": bool(lib.neraf_graph_stats(h, C.byref(g_cap), C.byref(g_launch))), "captures": g_cap.value,
                              "launches": g_launch.value}
+        if not a.no_parity and world == 1:
+            try:
+                out["parity"] = trajectory_parity(dev)
+            except Exception as e:                      # a measurement aid must not take the bench line down
+                out["parity"] = {"error": repr(e)}
         if not a.no_cpu_baseline and world == 1:      # the host baseline is reported by the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(a.rays, a.slices)
         print(json.dumps(out))

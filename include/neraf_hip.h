@@ -50,7 +50,7 @@ const char* neraf_last_error(neraf_ctx* ctx);
  * neraf_prof_summary synchronises those events and returns totals since the last enable.
  * kernel ids: 0 = gemm_f16 128x128 tile (work = FLOPs), 1 = gemm_f16 64x64 tile (FLOPs),
  * 2 = proposal_density (work = gathered hash-table bytes), 3 = field_query (gathered bytes),
- * 4 = implicit-GEMM convolution instances of gemm_f16 (FLOPs, zero-padded taps/channels included),
+ * 4 = implicit-GEMM convolution instances of gemm_f16 (algorithmic FLOPs; neraf_prof_summary_ex adds the executed count),
  * 5 = proposal_backward (gathered + atomically added table bytes), 6 = field_backward (MLP chain; work =
  * gathered table bytes), 7 = field_scatter (work = 8 bytes per (sample, level, corner) 64-bit atomic);
  * neraf_prof_kernel_name(id) returns NULL past the end.
@@ -61,6 +61,11 @@ const char* neraf_last_error(neraf_ctx* ctx);
 int neraf_graph_stats(neraf_ctx* ctx, int* captures, int* launches);
 int neraf_prof_enable(neraf_ctx* ctx, int on);
 int neraf_prof_summary(neraf_ctx* ctx, int kernel_id, double* total_ms, int* launches, double* work);
+/* As neraf_prof_summary, plus the EXECUTED work of the same launches (SURVEY 8d asks for both): `work` is the algorithmic count
+ * (a convolution, its transposed form and its weight gradient are each 2 dout^3 taps cin cout FLOPs with the real channel / tap
+ * counts), `exec_work` what the grid multiplied (K padded to the tile, channels padded to 8, zero-page taps at the volume's faces,
+ * padded voxel rows).  Equal for plain GEMMs and for the byte-priced gather kernels. */
+int neraf_prof_summary_ex(neraf_ctx* ctx, int kernel_id, double* total_ms, int* launches, double* work, double* exec_work);
 /* Median elapsed time (ms) of an empty HIP event pair on `stream` behind a 4-byte fill of `scratch_word` (device): the part of
  * every profiled interval that is not the kernel; callers subtract it per launch. */
 int neraf_prof_event_overhead(neraf_ctx* ctx, void* scratch_word, neraf_stream_t stream, double* ms);
@@ -349,6 +354,9 @@ typedef struct neraf_resnet3d_desc {
 int neraf_resnet3d_num_convs(const neraf_resnet3d_desc* d); /* 43 */
 size_t neraf_resnet3d_packed_bytes(const neraf_resnet3d_desc* d);
 size_t neraf_resnet3d_workspace_bytes(const neraf_resnet3d_desc* d);
+/* Algorithmic forward FLOPs of the encoder: sum over its 43 convolutions of 2 dout^3 taps cin cout with the real channel
+ * and tap counts -- 94.72e9 for the 7 x 128^3 grid.  Host arithmetic only; < 0 for an unsupported descriptor. */
+double neraf_resnet3d_forward_flops(const neraf_resnet3d_desc* d);
 int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const float* const* conv_w, void* packed,
                                 neraf_stream_t stream);
 /* win_cells > 0: only the grid cells [win_start, win_start + win_cells) (flat index, the refresh window of NeRAF_model.py:395-404)
@@ -466,6 +474,19 @@ int neraf_amp_update_scale(neraf_ctx* ctx, float* scale, int32_t* growth_tracker
 int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
                      int n_blocks, const float* group_lr, int n_groups, int n_tensors, double beta1, double beta2, double eps,
                      float* step, const float* grad_scale, const float* found_inf, neraf_stream_t stream);
+
+/* neraf_fused_adam with the update of doubly-stepped tensors fused: the reference steps the radiance-field parameters with the
+ * "fields" optimizer and then again with "audio_fields" (NeRAF_pipeline.py:487) -- two passes over p and g.  Here the first optimizer's
+ * call leaves those tensors out of its workgroup map (their counters still advance: every record of `table` does) and the second
+ * optimizer's call passes `dual`, a device array parallel to its table of 24-byte records {float* m; float* v; int32 group; int32 slot}
+ * (m == NULL: none) naming the FIRST optimizer's moments, parameter group (index into group_lr0, its HOST learning rates) and counter slot in `step0` (the first optimizer's step
+ * table, already advanced by its own call) and its non-finite flag `found_inf0` (may be NULL).  For such a tensor the kernel applies
+ * update 0 (unless *found_inf0) and then update 1 (unless *found_inf) in registers: the same fp32 operations in the same order as
+ * the two launches, bit for bit.  n_blocks may be 0 (nothing but deferred tensors).  dual == NULL: plain neraf_fused_adam. */
+int neraf_fused_adam_dual(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
+                          int n_blocks, const float* group_lr, int n_groups, int n_tensors, double beta1, double beta2, double eps,
+                          float* step, const float* grad_scale, const float* found_inf, const void* dual, const float* step0,
+                          const float* found_inf0, const float* group_lr0, int n_groups0, neraf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,9 @@ SIGNATURES = {
     "neraf_grads_nonfinite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "neraf_fused_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                    C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_fused_adam_dual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "neraf_nacf_packed_bytes": (C.c_size_t, [C.POINTER(NacfDesc)]),
     "neraf_nacf_workspace_bytes": (C.c_size_t, [C.POINTER(NacfDesc), C.c_int, C.c_int]),
     "neraf_nacf_pack_weights": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), c_fpp, C.c_void_p, C.c_void_p]),
@@ -76,6 +79,8 @@ SIGNATURES = {
     "neraf_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "neraf_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "neraf_prof_summary": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "neraf_prof_summary_ex": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double)]),
     "neraf_prof_kernel_name": (C.c_char_p, [C.c_int]),
     "neraf_grid_layout": (C.c_int, [C.POINTER(GridDesc), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32)]),
@@ -130,6 +135,7 @@ SIGNATURES = {
     "neraf_resnet3d_num_convs": (C.c_int, [C.POINTER(ResnetDesc)]),
     "neraf_resnet3d_packed_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),
     "neraf_resnet3d_workspace_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),
+    "neraf_resnet3d_forward_flops": (C.c_double, [C.POINTER(ResnetDesc)]),
     "neraf_resnet3d_pack_weights": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), c_fpp, C.c_void_p, C.c_void_p]),
     "neraf_resnet3d_fwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p]),

@@ -134,6 +134,11 @@ class Optimizers:
             opt, gi = self._group_of[n]
             self.optimizers[n] = opt
             self.parameters[n] = param_groups[n]
+        # tensors held by two consecutive fused optimizers (the radiance field: "fields", then "audio_fields") get both updates in
+        # the later optimizer's launch (one pass over p and g instead of two; bit-identical, neraf_amd/optim.py)
+        for a, b in zip(self._steppers[:-1], self._steppers[1:]):
+            if isinstance(a, FusedAdam) and isinstance(b, FusedAdam):
+                a.fuse_shared_updates_into(b)
         # one LambdaLR per optimizer object, one lambda per param group (LambdaLR accepts a list)
         for opt in self._steppers:
             lambdas = []

@@ -100,6 +100,14 @@ extern "C" int neraf_prof_summary(neraf_ctx* ctx, int kernel_id, double* total_m
   return NERAF_OK;
 }
 
+extern "C" int neraf_prof_summary_ex(neraf_ctx* ctx, int kernel_id, double* total_ms, int* launches, double* work, double* exec_work) {
+  if (!ctx || kernel_id < 0 || kernel_id >= PROF_NUM_KERNELS) return NERAF_EINVAL;
+  double e = 0.0;
+  for (auto& r : ctx->recs) if (r.kid == kernel_id) e += r.exec;
+  if (exec_work) *exec_work = e;
+  return neraf_prof_summary(ctx, kernel_id, total_ms, launches, work);
+}
+
 extern "C" const char* neraf_prof_kernel_name(int kernel_id) {
   // the rocprofv3 kernel-name prefix each scope covers (template arguments that vary inside a scope are written as *)
   static const char* names[PROF_NUM_KERNELS] = {"gemm_f16_nt_pipe_kernel<128, 128, *, 0, 1, *>", "gemm_f16_nt_pipe_kernel<64, 64, 4, 0, 1, false>",

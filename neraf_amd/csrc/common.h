@@ -23,7 +23,7 @@ enum { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_PROP_DENSITY = 2, PROF_FIELD_QUER
        PROF_FIELD_SCATTER = 7, PROF_GEMM_WIDE = 8, PROF_WGRAD = 9, PROF_GEMM64_BF16 = 10, PROF_GEMM12864 = 11,
        PROF_CONV64_BF16 = 12, PROF_CONV12864 = 13, PROF_CONV128 = 14, PROF_CONV_STEM = 15, PROF_NUM_KERNELS = 16 };
 
-struct ProfRec { hipEvent_t a, b; int kid; double work; };
+struct ProfRec { hipEvent_t a, b; int kid; double work; double exec; };   // work: ALGORITHMIC FLOPs / bytes; exec: as executed (padding, zero taps)
 
 struct GraphEntry { uint64_t key; hipGraphExec_t exec; uint64_t last_use; };
 
@@ -53,11 +53,11 @@ struct ArgHash {
 // RAII bracket: records an event pair around a launch when profiling is on.
 struct ProfScope {
   neraf_ctx* ctx; hipStream_t st; ProfRec r; bool on;
-  ProfScope(neraf_ctx* c, hipStream_t s, int kid, double work) : ctx(c), st(s), on(c && c->prof) {
+  ProfScope(neraf_ctx* c, hipStream_t s, int kid, double work, double exec = -1.0) : ctx(c), st(s), on(c && c->prof) {
     if (!on) return;
     auto get = [&]() { hipEvent_t e; if (!c->free_events.empty()) { e = c->free_events.back(); c->free_events.pop_back(); }
                        else (void)hipEventCreate(&e); return e; };
-    r.a = get(); r.b = get(); r.kid = kid; r.work = work;
+    r.a = get(); r.b = get(); r.kid = kid; r.work = work; r.exec = exec >= 0.0 ? exec : work;
     (void)hipEventRecord(r.a, st);
   }
   ~ProfScope() { if (on) { (void)hipEventRecord(r.b, st); ctx->recs.push_back(r); } }
@@ -203,6 +203,8 @@ struct GemmParams {
   ConvGeom conv;                     // conv.loader == 0 for a plain GEMM
   float* splitk_ws; size_t splitk_ws_bytes;   // optional fp32 scratch enabling split-K for under-filled grids
   int tile_n;                        // 0 = auto; 64 forces the 128x64 tile (Cout = 64 layers)
+  double alg_flops;                  // ALGORITHMIC FLOPs of the operation this GEMM implements (a convolution's
+                                     // 2 dout^3 taps cin cout, also for its transposed form); 0 = 2 M N K.  Profiling only.
   int bf16;                          // 1: every 16-bit operand/result (A, B, lmask, add16, C16, C16T) is bfloat16 (gradient chains)
   // grouped launch (plain loader, fp32 results only): ngroups > 1 runs ngroups GEMMs of identical padded shape (Mpad, Npad, K,
   // lda, ldb) in one grid; group g takes A/B/C32/M/N/ldc32 from grp[g].  Used for the small-output weight gradients.

@@ -744,12 +744,15 @@ int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
   }
   const int ntiles = (p.Mpad / BM) * (p.Npad / BN);
   const int ng = p.ngroups > 1 ? p.ngroups : 1;
+  // executed: what the grid multiplies (padded K, zero-page taps of a convolution's faces); algorithmic: the operation's own count
   double flops = 2.0 * p.M * p.N * p.K;
   if (ng > 1) { flops = 0.0; for (int g = 0; g < ng; ++g) flops += 2.0 * p.grp[g].M * p.grp[g].N * p.K; }
+  const double exec_flops = (LOADER != 0 && p.conv.tstride > 1) ? (p.alg_flops > 0.0 ? p.alg_flops : flops) : flops;   // parity-class dgrad walks only reaching taps
+  if (p.alg_flops > 0.0) flops = p.alg_flops;
   constexpr int kid = LOADER == 2 ? PROF_CONV_STEM
                       : LOADER == 1 ? (BM * BN == 128 * 128 ? PROF_CONV128 : (BM == 128 ? PROF_CONV12864 : (BF ? PROF_CONV64_BF16 : PROF_CONV)))
                                     : (BM * BN == 128 * 128 ? PROF_GEMM128 : (BM == 128 ? PROF_GEMM12864 : (BF ? PROF_GEMM64_BF16 : PROF_GEMM64)));
-  ProfScope prof(ctx, stream, kid, flops);
+  ProfScope prof(ctx, stream, kid, flops, exec_flops);
   hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF, TC>), dim3(ntiles * splits * ng), dim3(256), PT::LDS_BYTES,
                      stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
@@ -773,7 +776,7 @@ int launch_wide(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
     attr_set = true;
   }
   const int ntiles = (p.Mpad / BM) * (p.Npad / BN);
-  ProfScope prof(ctx, stream, PROF_GEMM_WIDE, 2.0 * p.M * p.N * p.K);
+  ProfScope prof(ctx, stream, PROF_GEMM_WIDE, p.alg_flops > 0.0 ? p.alg_flops : 2.0 * p.M * p.N * p.K, 2.0 * p.M * p.N * p.K);
   hipLaunchKernelGGL((gemm_f16_nt_wide_kernel<BM, BN, NST, BF>), dim3(ntiles * splits), dim3(512), LDS_BYTES, stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   if (splits > 1) {
@@ -1315,7 +1318,7 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
   int target = (int)(total_steps / (cus * (double)(wide ? wide_rounds : rounds))) + 1;       // K-steps per workgroup: ~8 (4 wide) rounds of the chip
   if (target < 16) target = 16;
   size_t slab_off = 0; int blocks = 0, red_tiles = 0, nred = 0;
-  double flops = 0.0;
+  double flops = 0.0, exec_flops = 0.0;
   for (int i = 0; i < n; ++i) {
     const WgradItem& it = items[i];
     const int taps = it.ksize * it.ksize * it.ksize;
@@ -1345,13 +1348,14 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
       const int cb = taps == 1 ? (it.cin < 256 ? it.cin : 256) : (taps > 32 ? it.cin : (it.cin < 128 ? it.cin : 128));      // wg_red_cb
       red_tiles += it.cout * (it.cin / cb);
     }
-    flops += 2.0 * it.cout * taps * it.cin_real * (double)it.K;
+    flops += 2.0 * it.cout * taps * it.cin_real * (double)it.dout * it.dout * it.dout;       // algorithmic
+    exec_flops += 2.0 * it.cout * (double)tiles_n * 64 * (double)it.K;                       // padded columns and voxel rows
   }
   if (slab_off * 4 > slab_bytes) return neraf_fail(ctx, NERAF_EINVAL, "wgrad_grouped: split-K scratch too small");
   t.total_blocks = blocks;
   r.n = nred; r.tile_begin[nred] = red_tiles;
   {
-    ProfScope prof(ctx, stream, PROF_WGRAD, flops);
+    ProfScope prof(ctx, stream, PROF_WGRAD, flops, exec_flops);
     if (wide && wide_nst == 2) hipLaunchKernelGGL(wgrad_wide_tn_kernel<2>, dim3(blocks), dim3(256), 2 * 5 * 8192, stream, t);
     else if (wide) hipLaunchKernelGGL(wgrad_wide_tn_kernel<3>, dim3(blocks), dim3(256), 3 * 5 * 8192, stream, t);
     else if (nst == 2) hipLaunchKernelGGL(wgrad_grouped_tn_kernel<2>, dim3(blocks), dim3(256), LDS_BYTES, stream, t);

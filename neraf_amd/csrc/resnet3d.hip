@@ -153,6 +153,19 @@ extern "C" size_t neraf_resnet3d_workspace_bytes(const neraf_resnet3d_desc* d) {
   return L.total;
 }
 
+// algorithmic forward FLOPs of the encoder = sum over its convolutions of 2 dout^3 taps cin cout (real channels / taps;
+// 94.72 GFLOP for the 7 x 128^3 grid).  Pure host arithmetic over the architecture table the launches are generated from.
+extern "C" double neraf_resnet3d_forward_flops(const neraf_resnet3d_desc* d) {
+  Arch A;
+  if (make_arch(d, &A)) return -1.0;
+  double f = 0.0;
+  for (int i = 0; i < A.nconv; ++i) {
+    const ConvSpec& c = A.conv[i];
+    f += 2.0 * (double)cube(c.dout) * (c.k * c.k * c.k) * c.cin_real * c.cout;
+  }
+  return f;
+}
+
 // Test aid: byte offset / extent of a forward tensor inside the workspace (the gate-matched backward parity test reads the ReLU
 // gates and the max-pool routing the forward actually used).
 extern "C" int neraf_resnet3d_debug_locate(const neraf_resnet3d_desc* d, int kind, int index, size_t* offset, int* rows, int* cols) {

@@ -438,6 +438,7 @@ int conv_dgrad(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* add16, bf16
   g.B = (const half_t*)(c.packed_t + c.B->wt[ci]); g.ldb = taps * cs.cout;
   g.M = (int)cube(cs.din); g.N = cs.cin; g.K = taps * cs.cout; g.Mpad = (int)rows_pad(cs.din);
   g.Npad = cs.cin == 64 ? 64 : round_up(cs.cin, 128); g.tile_n = cs.cin == 64 ? 64 : 0; g.alpha = 1.f;
+  g.alg_flops = 2.0 * (double)cube(cs.dout) * taps * cs.cin_real * cs.cout;      // the transposed conv has the forward's MAC count
   g.add16 = (const half_t*)add16; g.ldadd = cs.cin;
   g.C16 = (half_t*)dx; g.ldc16 = cs.cin;
   g.splitk_ws = (float*)(c.bws + c.B->splitk); g.splitk_ws_bytes = c.B->splitk_bytes;

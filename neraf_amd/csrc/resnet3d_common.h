@@ -386,6 +386,7 @@ inline int run_conv(neraf_ctx* ctx, hipStream_t st, const Arch& A, const Layout&
   g.B = (const half_t*)(packed + L.w[ci]); g.ldb = conv_kpad(c);
   g.M = M; g.N = c.cout; g.K = conv_kpad(c); g.Mpad = (int)rows_pad(c.dout); g.Npad = conv_npad(c); g.alpha = 1.f;
   g.tile_n = c.cout == 64 ? 64 : 0;
+  g.alg_flops = 2.0 * (double)cube(c.dout) * (c.k * c.k * c.k) * c.cin_real * c.cout;       // un-padded taps x cin
   g.C16 = (half_t*)(ws + L.pre[ci]); g.ldc16 = c.cout;
   float* stats = (float*)(ws + L.stat[ci]);
   g.colsum = stats; g.colsumsq = stats + round_up(c.cout, 128);

@@ -22,6 +22,8 @@ UPDATE_EPOCH = 0
 
 _REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("numel", "<i8"), ("group", "<i4"), ("slot", "<i4")])
 assert _REC.itemsize == 48
+_DUAL = np.dtype([("m", "<u8"), ("v", "<u8"), ("group", "<i4"), ("slot", "<i4")])      # AdamDual, csrc/optim.hip
+assert _DUAL.itemsize == 24
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -40,7 +42,29 @@ class FusedAdam(torch.optim.Optimizer):
                                                # of the tensor in param-group order), torch.optim.Adam's per-parameter `step`
         self._found = None
         self._fresh_plan = None
+        self._defer_to = None                  # see fuse_shared_updates_into
+        self._dual_from = None
+        self._pending = None
         self._reindex()
+
+    def fuse_shared_updates_into(self, later: "FusedAdam") -> None:
+        """The reference steps the radiance-field parameters with "fields" and then again with "audio_fields" (NeRAF_pipeline.py:487):
+        two full passes over p and g.  After ``first.fuse_shared_updates_into(second)`` the FIRST optimizer's ``step`` only advances
+        the counters of the tensors both optimizers hold, and the SECOND optimizer's ``step`` applies both updates to them in one
+        pass (``neraf_fused_adam_dual``: same fp32 operations in the same order, bit-identical parameters and moments).  Contract:
+        the two are stepped alternately, first then second, every iteration -- what ``Optimizers.optimizer_scaler_step_all`` does; a
+        second ``first.step()`` before ``second.step()`` raises (the deferred update's gradient would be gone)."""
+        if later is self or not isinstance(later, FusedAdam):
+            raise ValueError("fuse_shared_updates_into needs another FusedAdam")
+        if self.param_groups[0]["betas"] != later.param_groups[0]["betas"] or self.param_groups[0]["eps"] != later.param_groups[0]["eps"]:
+            raise ValueError("fused double updates need equal betas / eps in both optimizers")
+        mine = {id(p) for p, _ in self._flat}
+        self._shared = {id(p) for p, _ in later._flat if id(p) in mine}
+        if not self._shared:
+            return
+        self._defer_to, later._dual_from = later, self
+        self._plans, later._plans = {}, {}
+        self._fresh_plan = later._fresh_plan = None
 
     def _reindex(self):
         self._flat = [(p, gi) for gi, group in enumerate(self.param_groups) for p in group["params"]]
@@ -79,6 +103,10 @@ class FusedAdam(torch.optim.Optimizer):
         kernel advances those, and every parameter's ``state['step']`` is a view of its slot), moments move to the parameter's
         device, and every cached launch plan -- which holds raw moment pointers -- is dropped."""
         self._plans, self._fresh_plan = {}, None
+        for other in (getattr(self, "_defer_to", None), getattr(self, "_dual_from", None)):
+            if other is not None:               # the partner's plans hold raw pointers to this optimizer's moments / expect them
+                other._plans, other._fresh_plan = {}, None
+        self._pending = None
         self._step_t = None
         self._reindex()
         loaded = {}
@@ -134,9 +162,26 @@ class FusedAdam(torch.optim.Optimizer):
             n = (p.numel() + chunk - 1) // chunk
             bt.append(np.full(n, i, np.int32)); bc.append(np.arange(n, dtype=np.int32))
         n = len(entries)
+        extra = {}
+        if self._defer_to is not None:         # update map without the tensors the later optimizer updates for this one
+            keep = [i for i, (p, _) in enumerate(entries) if id(p) not in self._shared]
+            ubt = [bt[i] for i in keep] or [np.zeros(0, np.int32)]
+            ubc = [bc[i] for i in keep] or [np.zeros(0, np.int32)]
+            extra.update(upd_blk_tensor=torch.from_numpy(np.concatenate(ubt)).to(device),
+                         upd_blk_chunk=torch.from_numpy(np.concatenate(ubc)).to(device),
+                         deferred=any(id(p) in self._shared for p, _ in entries))
+        if self._dual_from is not None:        # the earlier optimizer's moments / group / counter slot of the shared tensors
+            first = self._dual_from
+            dual = np.zeros(n, dtype=_DUAL)
+            gi0 = {id(p): g for p, g in first._flat}
+            for i, (p, _) in enumerate(entries):
+                if id(p) in first._shared:
+                    st0 = first._state_for(p, gi0[id(p)])
+                    dual[i] = (st0["exp_avg"].data_ptr(), st0["exp_avg_sq"].data_ptr(), gi0[id(p)], first._slot[id(p)])
+            extra["dual"] = torch.from_numpy(dual.view(np.uint8).copy()).to(device)
         return dict(n_tensors=n, table=torch.from_numpy(rec.view(np.uint8).copy()).to(device),
                     blk_tensor=torch.from_numpy(np.concatenate(bt)).to(device),
-                    blk_chunk=torch.from_numpy(np.concatenate(bc)).to(device),
+                    blk_chunk=torch.from_numpy(np.concatenate(bc)).to(device), **extra,
                     # gradient-pointer column, refreshed asynchronously every step: (pinned, device, event, used) x 4
                     ring=[[torch.empty(n, dtype=torch.int64).pin_memory(), torch.empty(n, dtype=torch.int64, device=device),
                            torch.cuda.Event(), False] for _ in range(4)], ring_i=0, gp=None, gdev=None)
@@ -210,11 +255,28 @@ class FusedAdam(torch.optim.Optimizer):
         b1, b2 = self.param_groups[0]["betas"]
         gs = getattr(self, "grad_scale", None)
         fi = getattr(self, "found_inf", None)
-        _lib.check(lib.neraf_fused_adam(_lib.ctx(dev), plan["table"].data_ptr(), plan["gdev"].data_ptr(), plan["blk_tensor"].data_ptr(),
-                                        plan["blk_chunk"].data_ptr(), int(plan["blk_tensor"].numel()), lrs, len(self.param_groups),
-                                        plan["n_tensors"], float(b1), float(b2), float(self.param_groups[0]["eps"]), self._step_t.data_ptr(),
-                                        gs.data_ptr() if gs is not None else None, fi.data_ptr() if fi is not None else None,
-                                        _stream_ptr()), dev)
+        bt, bc = plan["blk_tensor"], plan["blk_chunk"]
+        if self._defer_to is not None and plan.get("deferred"):
+            if self._pending is not None:
+                raise RuntimeError("FusedAdam: this optimizer's shared tensors are updated by the optimizer it was fused into "
+                                   "(fuse_shared_updates_into): step that one before stepping this one again")
+            bt, bc = plan["upd_blk_tensor"], plan["upd_blk_chunk"]
+            # what the later optimizer needs to apply this update: the learning rates as of NOW and this step's non-finite flag
+            self._pending = (lrs, fi)
+        dual = step0 = fi0 = lrs0 = None
+        n0 = 0
+        first = self._dual_from
+        if first is not None and first._pending is not None and "dual" in plan:
+            lrs0, fi0 = first._pending
+            first._pending = None
+            dual, step0, n0 = plan["dual"], first._step_t, len(first.param_groups)
+        _lib.check(lib.neraf_fused_adam_dual(_lib.ctx(dev), plan["table"].data_ptr(), plan["gdev"].data_ptr(), bt.data_ptr(), bc.data_ptr(),
+                                             int(bt.numel()), lrs, len(self.param_groups), plan["n_tensors"], float(b1), float(b2),
+                                             float(self.param_groups[0]["eps"]), self._step_t.data_ptr(),
+                                             gs.data_ptr() if gs is not None else None, fi.data_ptr() if fi is not None else None,
+                                             dual.data_ptr() if dual is not None else None,
+                                             step0.data_ptr() if step0 is not None else None,
+                                             fi0.data_ptr() if fi0 is not None else None, lrs0, n0, _stream_ptr()), dev)
         return loss
 
 

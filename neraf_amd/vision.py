@@ -281,9 +281,14 @@ class NerfactoField(nn.Module):
         return self._dumps[key]
 
     def splitk_buffer(self, device) -> torch.Tensor:
-        if getattr(self, "_splitk", None) is None or self._splitk.device != device:
-            self._splitk = torch.empty(4 << 20, dtype=torch.float32, device=device)
-        return self._splitk
+        """Split-K scratch of the weight-gradient GEMMs: one per (device, stream) -- the render batch's backward and the grid
+        refresh's backward may run on different streams (two-stream step, neraf_amd/pipeline.py)."""
+        key = (str(device), torch.cuda.current_stream().cuda_stream)
+        if not isinstance(getattr(self, "_splitk", None), dict):
+            self._splitk = {}
+        if key not in self._splitk:
+            self._splitk[key] = torch.empty(4 << 20, dtype=torch.float32, device=device)
+        return self._splitk[key]
 
     def backward_query(self, packed, origins, directions, e_bins, camera_indices, density, d_rgb, d_density, pos_run: int = 1,
                        d_rays: Optional[torch.Tensor] = None, saved=None):
@@ -517,6 +522,9 @@ class NeRAFVisionModel(nn.Module):
         self.audio_model = None
         self.step = 0
         self._steps_since_update = 0
+        # optional ``jitter_fn(step, num_rays, device) -> 3 tensors [R]``: replaces torch.rand as the source of the sampler's single
+        # jitter per ray and stage in training (reproducible runs; the trajectory parity test feeds the oracle's values)
+        self.jitter_fn = None
 
     @property
     def device(self):
@@ -598,7 +606,8 @@ class NeRAFVisionModel(nn.Module):
         R = o.shape[0]
         near, far = self.near_plane, self.far_plane
         if self.training and jitters is None:
-            jitters = [torch.rand(R, device=o.device) for _ in range(3)]
+            jitters = (self.jitter_fn(self.step, R, o.device) if self.jitter_fn is not None
+                       else [torch.rand(R, device=o.device) for _ in range(3)])
         jit = [j.reshape(-1).float().contiguous() if j is not None else None for j in (jitters or [None] * 3)]
         jp = [j.data_ptr() if j is not None else None for j in jit]
         S0, S1 = self.num_proposal_samples_per_ray

@@ -141,3 +141,72 @@ def test_fused_adam_late_first_gradient_starts_bias_correction_at_one():
     for i, (x, y) in enumerate(zip(pc, pb)):
         np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-6, atol=1e-7, err_msg=str(i))
         assert float(oc.state[x]["step"]) == float(ob.state[y]["step"])
+
+
+def test_fused_double_update_of_shared_tensors_is_bit_identical_to_two_steps():
+    """The radiance-field parameters belong to "fields" AND "audio_fields" (NeRAF_pipeline.py:487): the reference steps them twice per
+    iteration.  ``first.fuse_shared_updates_into(second)`` applies both updates in the second optimizer's launch; parameters and all
+    four moment tensors must equal the two-launch form BIT FOR BIT over several iterations, including an iteration where only the
+    first optimizer's gradients are non-finite (its update is skipped, the second's is applied) and one where only the second's are;
+    and both must agree with two torch.optim.Adam instances to fp32 rounding."""
+    from neraf_amd.optim import FusedAdam, GradScaler
+    dev = torch.device("cuda:0")
+
+    def build(linked):
+        ps = _params(dev, 7)
+        shared, only0, only1 = ps[:3], ps[3:4], ps[4:]
+        o0 = FusedAdam([{"params": only0, "lr": 1e-2}, {"params": shared, "lr": 5e-3}], eps=1e-15)
+        o1 = FusedAdam([{"params": only1 + shared, "lr": 1e-4}], eps=1e-15)
+        if linked:
+            o0.fuse_shared_updates_into(o1)
+        sc = GradScaler("cuda", init_scale=256.0)
+        sc.scale(torch.zeros(1, device=dev))                 # initialises the device-side scale (the gradients below are pre-scaled)
+        return ps, o0, o1, sc
+    (pa, a0, a1, sa), (pb, b0, b1, sb) = build(True), build(False)
+    pt = _params(dev, 7)
+    t0 = torch.optim.Adam([{"params": pt[3:4], "lr": 1e-2}, {"params": pt[:3], "lr": 5e-3}], eps=1e-15)
+    t1 = torch.optim.Adam([{"params": pt[4:] + pt[:3], "lr": 1e-4}], eps=1e-15)
+    g = torch.Generator().manual_seed(11)
+    for it in range(7):
+        grads = [torch.randn(x.shape, generator=g).to(dev) * 256.0 for x in pa]
+        if it == 2:
+            grads[3][0] = float("inf")          # only the FIRST optimizer sees a non-finite gradient
+        if it == 4:
+            grads[5].view(-1)[3] = float("nan")  # only the SECOND
+        for ps in (pa, pb):
+            for x, gr in zip(ps, grads):
+                x.grad = gr.clone()
+        if it == 5:                              # learning rates move (schedulers)
+            for o in (a0, b0):
+                o.param_groups[1]["lr"] = 2e-3
+            t0.param_groups[1]["lr"] = 2e-3
+        for sc, o0, o1 in ((sa, a0, a1), (sb, b0, b1)):
+            sc.step(o0); sc.step(o1); sc.update()
+        if it not in (2, 4):
+            for x, gr in zip(pt, grads):
+                x.grad = gr / float(256.0 if it < 2 else (128.0 if it < 4 else 64.0))
+            t0.step(); t1.step()
+        elif it == 2:                            # first skipped, second applied
+            for x, gr in zip(pt, grads):
+                x.grad = gr / 256.0
+            t1.step()
+        else:
+            for x, gr in zip(pt, grads):
+                x.grad = gr / 128.0
+            t0.step()
+    assert sa.get_scale() == sb.get_scale() == 64.0
+    for i, (x, y) in enumerate(zip(pa, pb)):
+        assert torch.equal(x.detach(), y.detach()), i
+    for oa, ob, ps_a, ps_b in ((a0, b0, pa, pb), (a1, b1, pa, pb)):
+        for x, y in zip(ps_a, ps_b):
+            if x in oa.state:
+                assert torch.equal(oa.state[x]["exp_avg"], ob.state[y]["exp_avg"]) and torch.equal(oa.state[x]["exp_avg_sq"], ob.state[y]["exp_avg_sq"])
+                assert float(oa.state[x]["step"]) == float(ob.state[y]["step"])
+    for i, (x, y) in enumerate(zip(pa, pt)):
+        np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=3e-6, atol=2e-7, err_msg=str(i))
+    # protocol: stepping the first optimizer twice without the second is an error, not a silently lost update
+    for x in pa:
+        x.grad = torch.ones_like(x)
+    a0.step()
+    with pytest.raises(RuntimeError, match="fused into"):
+        a0.step()

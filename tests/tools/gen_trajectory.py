@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/g7_trajectory.npz: the CPU oracle (oracle/trainer.py, fp32) trained for CFG['steps'] iterations on the
+trajectory scenario (tests/tools/trajectory_common.py), then evaluated on a held-out camera and two held-out RIRs.
+
+    python tests/tools/gen_trajectory.py [--threads 8] [--probe]
+
+Stored: per-iteration loss-dict curves, the rendered held-out image + its analytic ground truth, the predicted log-magnitude STFTs
+[T, C, F] of the held-out RIRs + their ground truth, scalar summaries.  ``--probe`` additionally trains the SAME oracle with its
+radiance and NAcF parameters rounded to fp16 in every forward (straight-through) and stores that run's outputs next to the fp32
+ones: the distance between the two oracle runs is the sensitivity of this training trajectory to 16-bit parameter rounding alone --
+the band inside which an fp16 engine (the HIP path here, tiny-cuda-nn + AMP in the reference) can be expected to land.
+Runs only in the build container (minutes of CPU); the GPU test reads the committed fixture."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(__file__))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import trajectory_common as TC  # noqa: E402
+from oracle.trainer import OracleTrainer  # noqa: E402
+
+
+def run(fp16_params: bool, log):
+    cfg = TC.CFG
+    P, sdn, sdr = TC.initial_weights()
+    tr = OracleTrainer(P, sdn, sdr, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), TC.T(TC.synth.audio_aabb()), cfg["grid_step"], cfg["T"],
+                       cfg["start_step_audio"], cfg["R"], fp16_params=fp16_params)
+    bank = TC.rir_bank(cfg["n_rir"], cfg["tag"] + ".train")
+    keys = ["rgb_loss", "interlevel_loss", "distortion_loss", "audio_sc_loss", "audio_mag_loss", "loss", "proposal_updated"]
+    curves = np.full((cfg["steps"], len(keys)), np.nan, np.float64)
+    t0 = time.time()
+    for s in range(cfg["steps"]):
+        r = tr.train_iteration(s, TC.ray_batch(s), TC.audio_batch(s, bank))
+        curves[s] = [r.get(k, np.nan) for k in keys]
+        if s % 10 == 0 or s == cfg["steps"] - 1:
+            log(f"[{'fp16-param probe' if fp16_params else 'fp32'}] step {s} {time.time() - t0:.0f}s " +
+                " ".join(f"{k}={r[k]:.5f}" for k in keys[:5] if k in r))
+    ev = TC.synth.trajectory_eval_camera(*cfg["eval_hw"], tag=cfg["tag"])
+    img = tr.render(TC.T(ev["origins"]), TC.T(ev["directions"])).reshape(*cfg["eval_hw"], 3).numpy()
+    evb = TC.rir_bank(cfg["n_rir_eval"], cfg["tag"] + ".eval")
+    stft = np.stack([tr.predict_rir(evb["mic_pose"][i], evb["source_pose"][i], evb["rot"][i]).numpy() for i in range(cfg["n_rir_eval"])])
+    # the same queries with the encoder's BatchNorms on the grid's own statistics (as in training): separates what the running
+    # statistics add -- 43 exponential averages with a ~10-iteration memory over weights that move every iteration -- from the rest
+    stft_bs = np.stack([tr.predict_rir(evb["mic_pose"][i], evb["source_pose"][i], evb["rot"][i], batch_stats=True).numpy()
+                        for i in range(cfg["n_rir_eval"])])
+    log(f"  held-out PSNR vs ground truth {TC.psnr(img, ev['image']):.2f} dB; STFT rel-L2 vs ground truth "
+        f"{float(np.linalg.norm(stft - evb['log_mag'].numpy()) / np.linalg.norm(evb['log_mag'].numpy())):.4f}")
+    return {"curves": curves, "image": img.astype(np.float32), "stft": stft.astype(np.float32), "stft_batch_stats": stft_bs.astype(np.float32),
+            "keys": np.array(keys),
+            "gt_image": ev["image"], "gt_stft": evb["log_mag"].numpy()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--probe", action="store_true")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "g7_trajectory.npz"))
+    a = ap.parse_args()
+    torch.set_num_threads(a.threads)
+    log = lambda m: print(m, flush=True)      # noqa: E731
+    cfg = TC.CFG
+    main_run = run(False, log)
+    out = {"steps": cfg["steps"], "R": cfg["R"], "B": cfg["B"], "start_step_audio": cfg["start_step_audio"], "keys": main_run["keys"],
+           "curves": main_run["curves"], "image": main_run["image"], "stft": main_run["stft"],
+           "stft_batch_stats": main_run["stft_batch_stats"], "gt_image": main_run["gt_image"],
+           "gt_stft": main_run["gt_stft"].astype(np.float32)}
+    if a.probe:
+        p = run(True, log)
+        out.update({"probe_curves": p["curves"], "probe_image": p["image"], "probe_stft": p["stft"],
+                    "probe_stft_batch_stats": p["stft_batch_stats"]})
+        log(f"probe vs fp32 oracle: image PSNR {TC.psnr(p['image'], main_run['image']):.2f} dB, STFT rel-L2 "
+            f"{float(np.linalg.norm(p['stft'] - main_run['stft']) / np.linalg.norm(main_run['stft'])):.4f}")
+    np.savez_compressed(a.out, **out)
+    log(f"wrote {a.out} ({os.path.getsize(a.out) / 1e3:.0f} kB)")
+
+
+if __name__ == "__main__":
+    main()

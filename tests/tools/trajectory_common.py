@@ -1,0 +1,194 @@
+"""The scenario of the trajectory-level parity test (tests/test_gpu_trajectory.py, fixture g7): a small LEARNABLE joint scene --
+a textured box room seen by 12 cameras + position-dependent decaying RIRs in a RAF-like room -- whose batches are pure functions
+of the iteration number (neraf_amd/synth.py), so the HIP pipeline on the GPU and the CPU oracle (oracle/trainer.py) train on
+identical data from identical initial weights.  Imported by the fixture generator (gen_trajectory.py) and by the GPU test.
+
+Horizon: 100 iterations, the audio branch from iteration 6.  Joint training of a 43-layer train-mode-BatchNorm encoder with Adam is
+chaotic in the strict sense: two fp32 oracle runs that differ only by fp16 rounding of their parameters track each other to 1e-2
+(predicted log-magnitudes) for ~100 audio iterations and then separate within ~15 iterations (audio loss 0.0033 vs 0.0066 at
+iteration 120; measured with this scenario, DESIGN.md "Trajectory-level parity").  A parity statement about an fp16 engine is
+therefore only meaningful inside that horizon, and only relative to that band, which the fixture carries (``probe_*`` arrays)."""
+import numpy as np
+import torch
+
+from neraf_amd import synth
+
+CFG = dict(R=512, B=128, steps=100, start_step_audio=5, grid_step=1 / 64, n_cam=12, n_rir=16, n_rir_eval=2, T=60, F=513, C=1, fs=48000,
+           eval_hw=(32, 48), tag="traj")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rir_bank(n: int, tag: str, cfg=CFG):
+    """(log-magnitude [n, T, C, F] as the dataset tokenises RIRs -- NeRAF_dataset.py:107-117: STFT(1024, 512, 256), log(|.| + 1e-3) --
+    waveforms [n, 1, samples], poses)."""
+    from neraf_amd.evaluator import spectrogram
+    r = synth.trajectory_rirs(n, tag, fs=cfg["fs"], n_samples=256 * cfg["T"])
+    w = T(r["waveforms"])
+    mag = spectrogram(w[:, None, :], 1024, 512, 256).abs()[..., :cfg["T"]]              # [n, 1, F, T]
+    log_mag = torch.log(mag + 1e-3).permute(0, 3, 1, 2).contiguous()                   # [n, T, C, F]
+    return {"log_mag": log_mag, "waveforms": w[:, None, :], "mic_pose": T(r["mic_pose"]), "source_pose": T(r["source_pose"]),
+            "rot": T(r["rot"]), "tau": r["tau"]}
+
+
+def ray_batch(step: int, cfg=CFG):
+    rb = synth.trajectory_ray_batch(step, cfg["R"], cfg["n_cam"], cfg["tag"])
+    return {"origins": T(rb["origins"]), "directions": T(rb["directions"]), "camera_indices": T(rb["camera_indices"]),
+            "rgb": T(rb["rgb"]), "jitters": [T(j) for j in rb["jitters"]]}
+
+
+def audio_batch(step: int, bank, cfg=CFG):
+    idx = T(synth.trajectory_audio_indices(step, cfg["B"], cfg["n_rir"], cfg["T"], cfg["tag"]))
+    r, t = idx // cfg["T"], idx % cfg["T"]
+    return {"time_query": t, "mic_pose": bank["mic_pose"][r], "source_pose": bank["source_pose"][r], "rot": bank["rot"][r],
+            "data": bank["log_mag"][r, t]}
+
+
+def initial_weights(grid_totals=None, cfg=CFG):
+    """``grid_totals`` = hash-table rows (proposal 0, proposal 1, main field); None: from the oracle's grid specs (the generator's
+    side; the HIP side passes its models' table sizes, so that a disagreement about the tcnn level layout fails loudly)."""
+    if grid_totals is None:
+        from oracle import vision as V
+        spec = V.NerfactoSpec()
+        grid_totals = (spec.prop_grids[0].total, spec.prop_grids[1].total, spec.main_grid.total)
+    tot = tuple(int(v) for v in grid_totals)
+    P = {k: T(v) for k, v in synth.vision_params(tot, num_train_data=cfg["n_cam"], table_scale=1e-4, prefix="traj.").items()}
+    sdn = {k: T(v) for k, v in synth.nacf_state_dict(1187, 512, cfg["C"], cfg["F"]).items()}
+    sdr = {k: T(v) for k, v in synth.resnet3d_state_dict(7).items()}
+    return P, sdn, sdr
+
+
+def psnr(a, b) -> float:
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float(10.0 * torch.log10(1.0 / torch.mean((a - b) ** 2)))
+
+
+# ---- the HIP side: train neraf_amd's pipeline on the scenario, evaluate, compare with the fixture -------------------------------------
+class _StepRays:
+    """Vision data manager of the scenario: iteration ``step`` -> its ray bundle and target colours."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.train_num_rays_per_batch = CFG["R"]
+        self.jit = {}
+
+    def next_train(self, step):
+        from neraf_amd.vision import RayBundle
+        b = ray_batch(step)
+        self.jit[step] = [j.reshape(-1).to(self.dev) for j in b["jitters"]]
+        return (RayBundle(b["origins"].to(self.dev), b["directions"].to(self.dev), b["camera_indices"].to(self.dev)),
+                {"image": b["rgb"].to(self.dev)})
+
+
+class _StepSlices:
+    def __init__(self, bank, dev):
+        self.bank, self.dev = bank, dev
+
+    def next_train(self, step):
+        return None, {k: v.to(self.dev) for k, v in audio_batch(step, self.bank).items()}
+
+
+def run_hip_trajectory(dev, steps=None):
+    """Train the HIP pipeline on the scenario; returns (loss curves [steps, 5], held-out image [H,W,3], held-out STFTs [n,T,C,F],
+    pipeline, eval bank)."""
+    from neraf_amd import config as Cfg
+    from neraf_amd import synth
+    from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
+    from neraf_amd.pipeline import NeRAFPipeline
+    from neraf_amd.vision import NeRAFVisionModel, RayBundle
+    cfg = CFG
+    steps = cfg["steps"] if steps is None else steps
+    vm = NeRAFVisionModel(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), cfg["n_cam"])
+    P, sdn, sdr = initial_weights((vm.proposal_networks[0].table.shape[0], vm.proposal_networks[1].table.shape[0],
+                                   vm.field.module.table.shape[0]))
+    with torch.no_grad():
+        for i in range(2):
+            vm.proposal_networks[i].table.copy_(P[f"prop{i}.table"])
+            vm.proposal_networks[i].w0.copy_(P[f"prop{i}.w0"])
+            vm.proposal_networks[i].w1.copy_(P[f"prop{i}.w1"])
+        f = vm.field.module
+        f.table.copy_(P["field.table"])
+        for k in ("base_w0", "base_w1", "head_w0", "head_w1", "head_w2", "embedding"):
+            getattr(f, k).copy_(P["field." + k])
+    am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=cfg["grid_step"]), T(synth.audio_aabb()))
+    am.field.load_state_dict(sdn)
+    am.resnet3d.backbone_net.load_state_dict(sdr)
+    vm.to(dev).train(); am.to(dev).train()
+    bank = rir_bank(cfg["n_rir"], cfg["tag"] + ".train")
+    rays = _StepRays(dev)
+    vm.jitter_fn = lambda step, R, device: rays.jit[step]
+    pipe = NeRAFPipeline(vm, am, datamanager=rays, audio_datamanager=_StepSlices(bank, dev), start_step_audio=cfg["start_step_audio"])
+    opts, scaler = pipe.make_optimizers(init_scale=65536.0, optimizers_config=Cfg.default_optimizers(cfg["start_step_audio"]),
+                                        with_schedulers=True)
+    keys = ["rgb_loss", "interlevel_loss", "distortion_loss", "audio_sc_loss", "audio_mag_loss"]
+    rows = []
+    for s in range(steps):
+        _, ld = pipe.train_iteration(s, opts, scaler)
+        rows.append(torch.stack([ld[k].detach().float().reshape(()) if k in ld else torch.full((), float("nan"), device=dev) for k in keys]))
+    curves = torch.stack(rows).cpu().numpy().astype(np.float64)
+    assert scaler.get_scale() == 65536.0, "a GradScaler skip would shift the trajectory by one iteration"
+    ev = synth.trajectory_eval_camera(*cfg["eval_hw"], tag=cfg["tag"])
+    img = vm.get_outputs_for_camera_ray_bundle(RayBundle(T(ev["origins"]).to(dev), T(ev["directions"]).to(dev), None))["rgb"]
+    img = img.reshape(*cfg["eval_hw"], 3).cpu().numpy()
+    evb = rir_bank(cfg["n_rir_eval"], cfg["tag"] + ".eval")
+    am.eval()
+    stft = []
+    for i in range(cfg["n_rir_eval"]):
+        out = am.get_outputs_for_camera(None, None, batch_audio={"mic_pose": evb["mic_pose"][i], "source_pose": evb["source_pose"][i],
+                                                                 "rot": evb["rot"][i], "data": evb["log_mag"][i].permute(1, 2, 0)})
+        stft.append(out["raw_output"].float().cpu().numpy())
+    am.train()
+    # the same queries with the encoder's BatchNorms on the grid's own statistics (training-mode forward, as the fixture's
+    # ``stft_batch_stats``); after the eval-mode pass, since a training-mode forward also updates the running statistics
+    stft_bs = []
+    with torch.no_grad():
+        feat = am.scene_feature()
+        tq = torch.arange(cfg["T"], device=dev)
+        for i in range(cfg["n_rir_eval"]):
+            e = lambda k: evb[k][i].to(dev).reshape(1, 3).expand(cfg["T"], -1)       # noqa: E731
+            stft_bs.append(am.field.forward_queries(feat, tq, e("mic_pose"), e("source_pose"), e("rot"), am.aabb, cfg["T"]).float().cpu().numpy())
+    return curves, img, {"eval": np.stack(stft), "batch_stats": np.stack(stft_bs)}, pipe, evb
+
+
+def audio_metrics(am, stft_tcf: np.ndarray, evb, i: int, seed: int = 0):
+    """T60 / EDT / C50 (+ the evaluator's other keys) of a predicted log-magnitude STFT [T,C,F] against held-out RIR i."""
+    dev = am.aabb.device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    out = {"raw_output": torch.from_numpy(stft_tcf)}
+    batch = {"data": evb["log_mag"][i].permute(1, 2, 0), "waveform": evb["waveforms"][i]}
+    return am.get_audio_metrics(out, batch, generator=g)
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(np.asarray(b, np.float64)))
+
+
+def parity_summary(g, curves, img, stft, am, evb):
+    """All the numbers of the comparison: HIP (this run) vs oracle (fixture ``g``), each against ground truth, the fixture's
+    fp16-rounding band, audio metrics of the eval-branch predictions, loss-curve tails."""
+    res = {"steps": int(g["steps"]),
+           "psnr_hip_vs_oracle_db": psnr(img, g["image"]),
+           "psnr_hip_vs_gt_db": psnr(img, g["gt_image"]), "psnr_oracle_vs_gt_db": psnr(g["image"], g["gt_image"]),
+           "stft_rel_l2_hip_vs_oracle": rel_l2(stft["eval"], g["stft"]),
+           "stft_rel_l2_hip_vs_gt": rel_l2(stft["eval"], g["gt_stft"]), "stft_rel_l2_oracle_vs_gt": rel_l2(g["stft"], g["gt_stft"]),
+           "stft_bs_rel_l2_hip_vs_oracle": rel_l2(stft["batch_stats"], g["stft_batch_stats"]),
+           "stft_bs_rel_l2_hip_vs_gt": rel_l2(stft["batch_stats"], g["gt_stft"]),
+           "stft_bs_rel_l2_oracle_vs_gt": rel_l2(g["stft_batch_stats"], g["gt_stft"])}
+    if "probe_image" in g:
+        res["psnr_fp16param_oracle_vs_oracle_db"] = psnr(g["probe_image"], g["image"])
+        res["stft_rel_l2_fp16param_oracle_vs_oracle"] = rel_l2(g["probe_stft"], g["stft"])
+        res["stft_bs_rel_l2_fp16param_oracle_vs_oracle"] = rel_l2(g["probe_stft_batch_stats"], g["stft_batch_stats"])
+    n = stft["eval"].shape[0]
+    mh = [audio_metrics(am, stft["eval"][i], evb, i) for i in range(n)]
+    mo = [audio_metrics(am, np.asarray(g["stft"][i]), evb, i) for i in range(n)]
+    for k in mh[0]:
+        res[f"{k}_hip"] = float(np.mean([m[k] for m in mh]))
+        res[f"{k}_oracle"] = float(np.mean([m[k] for m in mo]))
+    keys = [str(k) for k in g["keys"]][:5]
+    tail = slice(int(g["steps"]) - 20, int(g["steps"]))
+    for j, k in enumerate(keys):
+        res[f"{k}_tail_hip"] = float(np.nanmean(curves[tail, j]))
+        res[f"{k}_tail_oracle"] = float(np.nanmean(np.asarray(g["curves"])[tail, j]))
+    return res
