@@ -258,10 +258,10 @@ def cpu_baseline(R, B):
         return out, (n1, n2)
 
     t = {}
-    v, nv = extrapolated(vision, R, 2)
-    rf, nr = extrapolated(refresh, R, 2)
-    t["resnet3d_fwd"], t["resnet3d_train"] = timed(resnet(False), 2), timed(resnet(True), 2)
-    au, na = extrapolated(audio, B, 3)
+    v, nv = extrapolated(vision, R, 3)
+    rf, nr = extrapolated(refresh, R, 3)
+    t["resnet3d_fwd"], t["resnet3d_train"] = timed(resnet(False), 3), timed(resnet(True), 3)
+    au, na = extrapolated(audio, B, 5)
     t.update({"vision_fwd": v["fwd"], "vision_train": v["train"], "refresh_fwd": rf["fwd"], "refresh_train": rf["train"],
               "audio_fwd": au["fwd"], "audio_train": au["train"]})
     step_train = t["vision_train"] + t["refresh_train"] + t["resnet3d_train"] + t["audio_train"]
@@ -272,7 +272,7 @@ def cpu_baseline(R, B):
             "bins_per_s_train": bins / (t["resnet3d_train"] + t["audio_train"]), "bins_per_s_fwd": bins / (t["resnet3d_fwd"] + t["audio_fwd"]),
             "field_samples_per_s_fwd": (R + bins) / step_fwd,
             "stage_seconds_full_step": {k: round(v_, 3) for k, v_ in t.items()},
-            "sample": ("per stage 1 warm-up (at the smaller sample) + 2-3 timed runs per sample size, median; radiance step at %d and %d rays, grid refresh at %d and %d cells x 18 "
+            "sample": ("per stage 1 warm-up (at the smaller sample) + 3 timed runs per sample size (5 for the NAcF stage), median; radiance step at %d and %d rays, grid refresh at %d and %d cells x 18 "
                        "directions, NAcF + STFT loss at %d and %d slices, each extrapolated linearly to the full batch (%d rays / cells, %d "
                        "slices); ResNet3D forward + backward on the full 7x128^3 grid; train = forward + backward + torch Adam (radiance "
                        "parameters lr 1e-2; NAcF + ResNet3D lr 1e-4); the refresh backward uses a unit upstream gradient; extrapolated full "
@@ -284,15 +284,16 @@ def trajectory_parity(dev):
     """BASELINE.json's metric, second half ("PSNR & T60 err vs ref"): a short in-process training run of the HIP pipeline on the
     trajectory scenario (tests/tools/trajectory_common.py: 100 iterations of 512 rays + 128 RIR slices, 64^3 grid) compared with
     the CPU oracle's run from the same weights on the same batches, whose outputs are the committed fixture
-    tests/golden/g7_trajectory.npz (tests/tools/gen_trajectory.py).  The same comparison is asserted by tests/test_gpu_trajectory.py."""
+    tests/golden/g8_trajectory_pose.npz (tests/tools/gen_trajectory.py).  The same comparison is asserted by tests/test_gpu_trajectory.py."""
     import numpy as np
-    fx = os.path.join(ROOT, "tests", "golden", "g7_trajectory.npz")
+    scenario = "g8_trajectory_pose"          # the reference's configuration: camera optimizer on, as in the timed step
+    fx = os.path.join(ROOT, "tests", "golden", scenario + ".npz")
     if not os.path.exists(fx):
         return None
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import trajectory_common as TC
     g = np.load(fx)
-    curves, img, stft, pipe, evb = TC.run_hip_trajectory(dev)
+    curves, img, stft, pipe, evb = TC.run_hip_trajectory(dev, cfg=TC.SCENARIOS[scenario])
     r = TC.parity_summary(g, curves, img, stft, pipe.audio_model, evb)
     out = {"steps": r["steps"], "psnr_db": r["psnr_hip_vs_gt_db"], "psnr_db_oracle": r["psnr_oracle_vs_gt_db"],
            "psnr_hip_vs_oracle_db": r["psnr_hip_vs_oracle_db"],
@@ -306,7 +307,8 @@ def trajectory_parity(dev):
                                    "this early in training in the reference's own arithmetic, see fp16_rounding_band.stft_rel_l2"},
            "stft_rel_l2_hip_vs_oracle": r["stft_bs_rel_l2_hip_vs_oracle"], "stft_rel_l2_vs_gt": r["stft_bs_rel_l2_hip_vs_gt"],
            "stft_rel_l2_vs_gt_oracle": r["stft_bs_rel_l2_oracle_vs_gt"],
-           "fixture": "tests/golden/g7_trajectory.npz",
+           "fixture": "tests/golden/" + scenario + ".npz",
+           "scenario": "camera optimizer SO3xR3 on (NeRAF_config.py:97); tests/test_gpu_trajectory.py also runs the scenario without it (G7)",
            "note": "held-out camera (32x48) and 2 held-out RIRs after 100 joint training iterations from identical weights on identical "
                    "batches: HIP pipeline (this run) vs CPU fp32 oracle (fixture); *_oracle = the oracle's own error against ground truth; the "
                    "RIR numbers are for predictions with the encoder's BatchNorms on batch statistics (as in training), eval_branch "

@@ -2,7 +2,7 @@
 """Generate tests/golden/g7_trajectory.npz: the CPU oracle (oracle/trainer.py, fp32) trained for CFG['steps'] iterations on the
 trajectory scenario (tests/tools/trajectory_common.py), then evaluated on a held-out camera and two held-out RIRs.
 
-    python tests/tools/gen_trajectory.py [--threads 8] [--probe]
+    python tests/tools/gen_trajectory.py [--scenario g7_trajectory|g8_trajectory_pose] [--threads 8] [--probe]
 
 Stored: per-iteration loss-dict curves, the rendered held-out image + its analytic ground truth, the predicted log-magnitude STFTs
 [T, C, F] of the held-out RIRs + their ground truth, scalar summaries.  ``--probe`` additionally trains the SAME oracle with its
@@ -26,11 +26,11 @@ import trajectory_common as TC  # noqa: E402
 from oracle.trainer import OracleTrainer  # noqa: E402
 
 
-def run(fp16_params: bool, log):
-    cfg = TC.CFG
+def run(fp16_params: bool, log, cfg):
     P, sdn, sdr = TC.initial_weights()
     tr = OracleTrainer(P, sdn, sdr, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), TC.T(TC.synth.audio_aabb()), cfg["grid_step"], cfg["T"],
-                       cfg["start_step_audio"], cfg["R"], fp16_params=fp16_params)
+                       cfg["start_step_audio"], cfg["R"], fp16_params=fp16_params,
+                       num_cameras=cfg["n_cam"] if cfg.get("camera_opt") else 0)
     bank = TC.rir_bank(cfg["n_rir"], cfg["tag"] + ".train")
     keys = ["rgb_loss", "interlevel_loss", "distortion_loss", "audio_sc_loss", "audio_mag_loss", "loss", "proposal_updated"]
     curves = np.full((cfg["steps"], len(keys)), np.nan, np.float64)
@@ -51,7 +51,8 @@ def run(fp16_params: bool, log):
                         for i in range(cfg["n_rir_eval"])])
     log(f"  held-out PSNR vs ground truth {TC.psnr(img, ev['image']):.2f} dB; STFT rel-L2 vs ground truth "
         f"{float(np.linalg.norm(stft - evb['log_mag'].numpy()) / np.linalg.norm(evb['log_mag'].numpy())):.4f}")
-    return {"curves": curves, "image": img.astype(np.float32), "stft": stft.astype(np.float32), "stft_batch_stats": stft_bs.astype(np.float32),
+    extra = {"pose": tr.pose.detach().numpy().copy()} if cfg.get("camera_opt") else {}
+    return {**extra, "curves": curves, "image": img.astype(np.float32), "stft": stft.astype(np.float32), "stft_batch_stats": stft_bs.astype(np.float32),
             "keys": np.array(keys),
             "gt_image": ev["image"], "gt_stft": evb["log_mag"].numpy()}
 
@@ -60,18 +61,26 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--probe", action="store_true")
-    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "g7_trajectory.npz"))
+    ap.add_argument("--scenario", default="g7_trajectory", choices=sorted(TC.SCENARIOS))
+    ap.add_argument("--out", default=None)
     a = ap.parse_args()
+    if a.out is None:
+        a.out = os.path.join(ROOT, "tests", "golden", a.scenario + ".npz")
     torch.set_num_threads(a.threads)
     log = lambda m: print(m, flush=True)      # noqa: E731
-    cfg = TC.CFG
-    main_run = run(False, log)
-    out = {"steps": cfg["steps"], "R": cfg["R"], "B": cfg["B"], "start_step_audio": cfg["start_step_audio"], "keys": main_run["keys"],
+    cfg = TC.SCENARIOS[a.scenario]
+    main_run = run(False, log, cfg)
+    out = {"steps": cfg["steps"], "R": cfg["R"], "B": cfg["B"], "start_step_audio": cfg["start_step_audio"],
+           "camera_opt": int(bool(cfg.get("camera_opt"))), "keys": main_run["keys"],
            "curves": main_run["curves"], "image": main_run["image"], "stft": main_run["stft"],
            "stft_batch_stats": main_run["stft_batch_stats"], "gt_image": main_run["gt_image"],
            "gt_stft": main_run["gt_stft"].astype(np.float32)}
+    if "pose" in main_run:
+        out["pose"] = main_run["pose"]
     if a.probe:
-        p = run(True, log)
+        p = run(True, log, cfg)
+        if "pose" in p:
+            out["probe_pose"] = p["pose"]
         out.update({"probe_curves": p["curves"], "probe_image": p["image"], "probe_stft": p["stft"],
                     "probe_stft_batch_stats": p["stft_batch_stats"]})
         log(f"probe vs fp32 oracle: image PSNR {TC.psnr(p['image'], main_run['image']):.2f} dB, STFT rel-L2 "

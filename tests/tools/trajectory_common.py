@@ -14,7 +14,14 @@ import torch
 from neraf_amd import synth
 
 CFG = dict(R=512, B=128, steps=100, start_step_audio=5, grid_step=1 / 64, n_cam=12, n_rir=16, n_rir_eval=2, T=60, F=513, C=1, fs=48000,
-           eval_hw=(32, 48), tag="traj")
+           eval_hw=(32, 48), tag="traj", camera_opt=False)
+
+# Two scenarios over the same scene, batches and initial weights:
+#   "g7_trajectory"      -- camera optimizer off: the clean diagnostic (nothing but the radiance and acoustic fields trains);
+#   "g8_trajectory_pose" -- camera optimizer SO3xR3 ON, the reference's configuration (NeRAF_config.py:97; what bench.py times): the
+#                           per-camera pose deltas start at zero on exact poses, so Adam (eps 1e-15) random-walks them on the sign of
+#                           tiny photometric gradients -- a second noise source, visible in the band of this scenario.
+SCENARIOS = {"g7_trajectory": dict(CFG), "g8_trajectory_pose": dict(CFG, camera_opt=True)}
 
 
 def T(a):
@@ -90,7 +97,7 @@ class _StepSlices:
         return None, {k: v.to(self.dev) for k, v in audio_batch(step, self.bank).items()}
 
 
-def run_hip_trajectory(dev, steps=None):
+def run_hip_trajectory(dev, steps=None, cfg=CFG):
     """Train the HIP pipeline on the scenario; returns (loss curves [steps, 5], held-out image [H,W,3], held-out STFTs [n,T,C,F],
     pipeline, eval bank)."""
     from neraf_amd import config as Cfg
@@ -98,9 +105,13 @@ def run_hip_trajectory(dev, steps=None):
     from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
     from neraf_amd.pipeline import NeRAFPipeline
     from neraf_amd.vision import NeRAFVisionModel, RayBundle
-    cfg = CFG
     steps = cfg["steps"] if steps is None else steps
-    vm = NeRAFVisionModel(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), cfg["n_cam"])
+    if cfg.get("camera_opt"):
+        vcfg = Cfg.NeRAFVisionModelConfig(camera_optimizer=Cfg.CameraOptimizerConfig(mode="SO3xR3"))
+        vm = vcfg.setup(scene_box=Cfg.SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), num_train_data=cfg["n_cam"], metadata={},
+                        device=dev, grad_scaler=None, seed_points=None)
+    else:
+        vm = NeRAFVisionModel(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), cfg["n_cam"])
     P, sdn, sdr = initial_weights((vm.proposal_networks[0].table.shape[0], vm.proposal_networks[1].table.shape[0],
                                    vm.field.module.table.shape[0]))
     with torch.no_grad():
