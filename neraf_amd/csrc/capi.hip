@@ -110,12 +110,12 @@ extern "C" int neraf_prof_summary_ex(neraf_ctx* ctx, int kernel_id, double* tota
 
 extern "C" const char* neraf_prof_kernel_name(int kernel_id) {
   // the rocprofv3 kernel-name prefix each scope covers (template arguments that vary inside a scope are written as *)
-  static const char* names[PROF_NUM_KERNELS] = {"gemm_f16_nt_pipe_kernel<128, 128, *, 0, 1, *>", "gemm_f16_nt_pipe_kernel<64, 64, 4, 0, 1, false>",
+  static const char* names[PROF_NUM_KERNELS] = {"gemm_f16_nt_pipe_kernel<128, 128, *, 0, 1, *>", "gemm_f16_nt_pipe_kernel<64|32, 64|32, 4, 0, 1, false>",
                                                       "proposal_density_kernel", "field_query_kernel",
                                                       "gemm_f16_nt_pipe_kernel<64, 64, 4, 1, *, false>", "proposal_backward_kernel",
                                                       "field_backward_kernel", "field_scatter_kernel | field_slice_ids_kernel + field_scatter_owner_kernel",
                                                       "gemm_f16_nt_wide_kernel<*, 160|128, 3, *>", "wgrad_wide_tn_kernel | wgrad_grouped_tn_kernel",
-                                                      "gemm_f16_nt_pipe_kernel<64, 64, 4, 0, 1, true>", "gemm_f16_nt_pipe_kernel<128, 64, 3, 0, 1, *>",
+                                                      "gemm_f16_nt_pipe_kernel<64|32, 64|32, 4, 0, 1, true>", "gemm_f16_nt_pipe_kernel<128, 64, 3, 0, 1, *>",
                                                       "gemm_f16_nt_pipe_kernel<64, 64, 4, 1, *, true>", "gemm_f16_nt_pipe_kernel<128, 64, 3, 1, *, *>",
                                                       "gemm_f16_nt_pipe_kernel<128, 128, 2, 1, *, *>", "gemm_f16_nt_pipe_kernel<128, 64, 3, 2, 5, false>"};
   return (kernel_id >= 0 && kernel_id < PROF_NUM_KERNELS) ? names[kernel_id] : nullptr;

@@ -178,10 +178,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
       }
     __syncthreads();
     constexpr int CPR = WN / 8;          // 16-B chunks per row
-    static_assert((WM * CPR) % 64 == 0, "whole wave-instructions");
+    static_assert((WM * CPR) % 64 == 0 || WM * CPR < 64, "whole wave-instructions (or one partial one)");
 #pragma unroll
-    for (int it = 0; it < WM * CPR / 64; ++it) {
+    for (int it = 0; it < (WM * CPR + 63) / 64; ++it) {
       const int idx = it * 64 + lane, row = idx / CPR, ch = idx - row * CPR;
+      if (WM * CPR < 64 && idx >= WM * CPR) break;
       const uint4 d = *reinterpret_cast<const uint4*>(im + row * T::IMG16_LD + ch * 8);
       *reinterpret_cast<uint4*>(p.C16 + (size_t)out_row<BM, TC>(p, m_w0 + row) * p.ldc16 + n_w0 + ch * 8) = d;
     }
@@ -199,10 +200,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
           im[(j * 16 + n_l + r) * T::IMG16T_LD + i * 16 + m_l] = (E)acc[i][j][r];
     __syncthreads();
     constexpr int CPR = WM / 8;
-    static_assert((WN * CPR) % 64 == 0, "whole wave-instructions");
+    static_assert((WN * CPR) % 64 == 0 || WN * CPR < 64, "whole wave-instructions (or one partial one)");
 #pragma unroll
-    for (int it = 0; it < WN * CPR / 64; ++it) {
+    for (int it = 0; it < (WN * CPR + 63) / 64; ++it) {
       const int idx = it * 64 + lane, row = idx / CPR, ch = idx - row * CPR;   // row = n, chunk along m
+      if (WN * CPR < 64 && idx >= WN * CPR) break;
       const uint4 d = *reinterpret_cast<const uint4*>(im + row * T::IMG16T_LD + ch * 8);
       *reinterpret_cast<uint4*>(p.C16T + (size_t)(n_w0 + row) * p.ldc16t + m_w0 + ch * 8) = d;
     }
@@ -1278,6 +1280,16 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p_in, hipStream_t stream) {
   if (LOADER == 0 && ng == 1 && kWide && bm == 128 && bn == 128 && splits == 1 && ntiles < 2 * cus)
     return launch_wide<128, 128, 3, BF>(ctx, p, 1, stream);
   // staging depth: the 128-wide tiles run faster with two workgroups per CU (2 / 3 stages) than with one and a deep ring
+  // plain GEMMs whose 64x64 tiling leaves half the chip or more idle (<= 128 tiles: the 512- and 4096-voxel 1x1x1 convolutions of
+  // layers 2-3 and their dgrads).  A CU takes in operand tiles at ~50-64 GB/s whatever the body and however deep the ring (0.247 us
+  // per 16 KiB K-step, cold or L2-warm operands alike), so the K loop is bound by how many CUs pull: 32x32 tiles on 4x the
+  // workgroups run it at 0.164 us per K-step -- 512 x 256 x 1024: 7.9 -> 5.8 us, 4096 x 128 x 512: 5.9 -> 4.9 us
+  // (tools/small_gemm_bench.py), step -0.05 ms.  NERAF_TILE32 = largest 64x64-tile count that still takes the 32x32 form (0: off).
+  static const int kTile32 = [] { const char* e = getenv("NERAF_TILE32"); return e ? atoi(e) : 128; }();
+  if constexpr (LOADER == 0) {
+    if (kTile32 && ng == 1 && splits == 1 && bm == 64 && bn == 64 && ntiles <= kTile32 && !p.C16T)
+      return launch_pipe<32, 32, 4, LOADER, KS, BF>(ctx, p, 1, stream);
+  }
   if (bm == 128 && bn == 128) return launch_pipe<128, 128, 2, LOADER, KS, BF>(ctx, p, splits, stream);
   if (bm == 128 && bn == 64) return launch_pipe<128, 64, 3, LOADER, KS, BF>(ctx, p, splits, stream);
   return launch_pipe<64, 64, 4, LOADER, KS, BF>(ctx, p, splits, stream);
