@@ -9,7 +9,8 @@ lib = _lib.load(); h = _lib.ctx(0)
 dev = torch.device("cuda:0")
 shapes = [(512, 256, 1024), (512, 1024, 256), (512, 256, 6912), (4096, 128, 512), (4096, 512, 128), (4096, 128, 3456),
           (32768, 64, 256), (32768, 256, 64), (32768, 64, 1728)]
-NB = 24
+NB = int(os.environ.get("NB_BUFFERS", "24"))      # distinct weight buffers in the chain (1: the same B every launch, L2-warm)
+NL = 24
 side = torch.cuda.Stream()
 for M, N, K in shapes:
     A = (torch.rand(M, K, device=dev) - 0.5).half()
@@ -17,8 +18,8 @@ for M, N, K in shapes:
     bias = torch.zeros(N, device=dev)
     Cs = [torch.empty(M, N, dtype=torch.float16, device=dev) for _ in range(2)]
     def chain(st):
-        for i in range(NB):
-            _lib.check(lib.neraf_gemm_f16(h, A.data_ptr(), K, Bs[i].data_ptr(), K, M, N, K, M, N, 1.0, bias.data_ptr(), 0,
+        for i in range(NL):
+            _lib.check(lib.neraf_gemm_f16(h, A.data_ptr(), K, Bs[i % NB].data_ptr(), K, M, N, K, M, N, 1.0, bias.data_ptr(), 0,
                                           Cs[i & 1].data_ptr(), N, None, 0, None, 0, C.c_void_p(st)))
     with torch.cuda.stream(side):
         chain(side.cuda_stream)
@@ -32,5 +33,5 @@ for M, N, K in shapes:
     R = 20
     for _ in range(R): g.replay()
     e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (R * NB)
+    us = e0.elapsed_time(e1) * 1e3 / (R * NL)
     print(f"M{M:6d} N{N:5d} K{K:5d}: {us:7.2f} us per launch   {2.0*M*N*K/us/1e6:7.1f} TF/s   weights {N*K*2/1e6:.2f} MB", flush=True)
