@@ -36,7 +36,8 @@ for e in leaf[-per:]:
     if e.name.startswith("aten::"):
         n_aten += len(e.kernels)
         tot += sum(x.duration for x in e.kernels)
-        print(f"  ATEN {e.name:26s} {str(e.input_shapes)[:90]:90s} thread {e.thread} {sum(x.duration for x in e.kernels):6.1f} us")
+        site = next((fr for fr in (e.stack or []) if "neraf_amd" in fr or "bench.py" in fr), "")
+        print(f"  ATEN {e.name:22s} {str(e.input_shapes)[:56]:56s} {sum(x.duration for x in e.kernels):5.1f} us  {site[-70:]}")
     else:
         print(f"{e.name[:60]:60s} -> {k.name[:70]}")
 print("aten launches in the step:", n_aten, "sum", tot, "us")
