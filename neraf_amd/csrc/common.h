@@ -200,6 +200,13 @@ struct GemmParams {
   float* colsumsq;                   // optional [Npad] fp32: atomically += column sums of squares (BatchNorm statistics)
   int stat_rep, stat_stride;         // colsum/colsumsq are replicated stat_rep (power of two, 0 = 1) times, stat_stride floats apart; a
                                      // workgroup adds into replica (m-tile % stat_rep) -- same-line atomics serialise in the memory system
+  // fused BatchNorm-backward reduction (dgrad GEMMs of the small ResNet3D layers): the result g is the gradient w.r.t. a
+  // post-activation tensor whose producer is BatchNorm + ReLU; with bnb_x set, g *= (bnb_mask > 0) AFTER add16, and colsum / colsumsq
+  // receive sum g and sum g * xhat (xhat = (bnb_x - mean) * rsqrt(var + 1e-5), mean / var = bnb_fin[c] / bnb_fin[bnb_cpad + c])
+  // instead of sum / sum of squares -- what bn_bwd_reduce_kernel computes in a launch of its own
+  const half_t* bnb_x; int ldbnb;    // pre-BN conv output fp16 [Mpad][N]
+  const half_t* bnb_mask;            // post-activation tensor in the GEMM's element type [Mpad][N] (ld = ldbnb), or null
+  const float* bnb_fin; int bnb_cpad;
   ConvGeom conv;                     // conv.loader == 0 for a plain GEMM
   float* splitk_ws; size_t splitk_ws_bytes;   // optional fp32 scratch enabling split-K for under-filled grids
   int tile_n;                        // 0 = auto; 64 forces the 128x64 tile (Cout = 64 layers)

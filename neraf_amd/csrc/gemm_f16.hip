@@ -119,6 +119,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)ad[r];
       }
+      if (p.bnb_mask) {
+        const E4 mk = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.bnb_mask) + (size_t)m * p.ldbnb + n0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (!((float)mk[r] > 0.f)) v[r] = 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (m >= M || (n0 + r) >= N) v[r] = 0.f;
@@ -137,8 +142,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bnb_x) {
+        // BatchNorm-backward sums: sum g and sum g * xhat over the tile's rows (rows >= M hold g = 0)
+        const int n0 = n_tile0 + wn * WN + j * 16 + n_l;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bnb_fin + n0);
+        f32x4 rs = *reinterpret_cast<const f32x4*>(p.bnb_fin + p.bnb_cpad + n0);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) { s += acc[i][j]; s2 += acc[i][j] * acc[i][j]; }
+        for (int r = 0; r < 4; ++r) rs[r] = rsqrtf(rs[r] + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int m = m_tile0 + wm * WM + i * 16 + m_l;
+          const half4 xv = *reinterpret_cast<const half4*>(p.bnb_x + (size_t)out_row<BM, TC>(p, m) * p.ldbnb + n0);
+          s += acc[i][j];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s2[r] += acc[i][j][r] * (((float)xv[r] - mu[r]) * rs[r]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) { s += acc[i][j]; s2 += acc[i][j] * acc[i][j]; }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = s[r], y = s2[r];
@@ -697,10 +719,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] += (float)ad[r];
   }
+  if (p.bnb_mask) {
+    const E4 mk = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.bnb_mask) + (size_t)m * p.ldbnb + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (!((float)mk[r] > 0.f)) v[r] = 0.f;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (m >= M || (n + r) >= N) v[r] = 0.f;
     tile[row][c4 + r] = v[r];
+  }
+  __shared__ float tile2[32][33];                 // g * xhat (fused BatchNorm-backward sums): one coalesced 8-byte load per thread
+  if (p.bnb_x) {
+    const half4 xv = *reinterpret_cast<const half4*>(p.bnb_x + (size_t)m * p.ldbnb + n);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bnb_fin + n);
+    const f32x4 var = *reinterpret_cast<const f32x4*>(p.bnb_fin + p.bnb_cpad + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile2[row][c4 + r] = v[r] * (((float)xv[r] - mu[r]) * rsqrtf(var[r] + 1e-5f));
   }
   if (p.C16) {
     E4 h;
@@ -725,13 +760,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
       reinterpret_cast<E*>(p.C16T)[(size_t)nn * p.ldc16t + mm] = (E)tile[tx][ty + i * 8];
     }
   }
-  if ((p.colsum || p.colsumsq) && ty == 0) {
-    float cs = 0.f, cs2 = 0.f;
+  if ((p.colsum || p.colsumsq) && ty < 2) {
+    // wave 0, lanes 0-31: column sums; lanes 32-63: the second statistic (squares, or g * xhat for the fused BatchNorm backward)
+    float cs = 0.f;
+    if (ty == 0) {
 #pragma unroll 8
-    for (int i = 0; i < 32; ++i) { const float x = tile[i][tx]; cs += x; cs2 += x * x; }
+      for (int i = 0; i < 32; ++i) cs += tile[i][tx];
+    } else if (p.bnb_x) {
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) cs += tile2[i][tx];
+    } else {
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) { const float x = tile[i][tx]; cs += x * x; }
+    }
     const int rep = p.stat_rep > 1 ? (blockIdx.y & (p.stat_rep - 1)) * p.stat_stride : 0;
-    if (p.colsum) atomicAdd(p.colsum + rep + n0 + tx, cs);
-    if (p.colsumsq) atomicAdd(p.colsumsq + rep + n0 + tx, cs2);
+    float* dst = ty == 0 ? p.colsum : p.colsumsq;
+    if (dst) atomicAdd(dst + rep + n0 + tx, cs);
   }
 }
 

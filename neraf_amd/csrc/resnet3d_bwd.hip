@@ -395,7 +395,8 @@ struct Ctx {
 };
 
 // BN backward of conv ci: gradient w.r.t. the conv output, into `dx`
-int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const half_t* act, bf16_t* dx, bf16_t* dy_masked) {
+int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const half_t* act, bf16_t* dx, bf16_t* dy_masked,
+                bool sums_done = false) {
   const ConvSpec& cs = c.A->conv[ci];
   BnBwdArgs p{};
   p.s = bn_src_bwd(*c.A, *c.L, c.ws, c.bn, ci);
@@ -406,7 +407,8 @@ int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const
   p.dx = dx; p.dy_masked = dy_masked;
   p.dgamma = c.bn_grads[2 * ci]; p.dbeta = c.bn_grads[2 * ci + 1]; p.inv_scale = c.inv_scale;
   const int nrb = (p.M + p.rows_per_block - 1) / p.rows_per_block;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nrb, p.C / 64), dim3(256), 0, c.st, p);
+  // sums_done: the dgrad GEMM that produced g16 already reduced sum g and sum g * xhat in its epilogue (fuse_bn_sums below)
+  if (!sums_done) hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nrb, p.C / 64), dim3(256), 0, c.st, p);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(p.Mpad / 64, p.C / 64), dim3(256), 0, c.st, p);
   NERAF_HIP_CHECK(c.ctx, hipGetLastError());
   return NERAF_OK;
@@ -428,8 +430,18 @@ int conv_wgrad(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* x_in) {
                               c.inv_scale, c.st);
 }
 
-// dX [din^3][cin] = conv_transpose(dY [dout^3][cout], W) (+ add16)
-int conv_dgrad(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* add16, bf16_t* dx) {
+// The BatchNorm-backward reduction of the layer that CONSUMES a dgrad's result, folded into that dgrad's epilogue (or split-K
+// reducer): for the <= 4096-voxel layers bn_bwd_reduce_kernel is a 3-4 us launch around a few hundred KB, 26 of them per backward.
+// NERAF_BN_FUSE_SUMS=0 restores the separate launches.
+inline bool fuse_bn_sums(const ConvSpec& bn_conv) {
+  static const int on = [] { const char* e = getenv("NERAF_BN_FUSE_SUMS"); return e ? atoi(e) : 1; }();
+  return on && cube(bn_conv.dout) <= 4096 && (bn_conv.cout % 64) == 0;
+}
+
+// dX [din^3][cin] = conv_transpose(dY [dout^3][cout], W) (+ add16).  bn_ci >= 0: the result is the gradient w.r.t. relu(bn_{bn_ci}(.))
+// (+ residual), `bn_act` that post-activation tensor (bf16 shadow): the epilogue masks the result with it and reduces the two
+// BatchNorm-backward sums of conv bn_ci into its accumulators.
+int conv_dgrad(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* add16, bf16_t* dx, int bn_ci = -1, const bf16_t* bn_act = nullptr) {
   const ConvSpec& cs = c.A->conv[ci];
   GemmParams g{};
   const int taps = cs.k * cs.k * cs.k;
@@ -442,6 +454,14 @@ int conv_dgrad(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* add16, bf16
   g.add16 = (const half_t*)add16; g.ldadd = cs.cin;
   g.C16 = (half_t*)dx; g.ldc16 = cs.cin;
   g.splitk_ws = (float*)(c.bws + c.B->splitk); g.splitk_ws_bytes = c.B->splitk_bytes;
+  if (bn_ci >= 0) {
+    const ConvSpec& bs = c.A->conv[bn_ci];        // bs.cout == cs.cin, cube(bs.dout) == cube(cs.din)
+    float* sums = (float*)(c.bws + c.B->sums[bn_ci]);
+    g.colsum = sums; g.colsumsq = sums + round_up(bs.cout, 128);
+    g.stat_rep = bwd_stat_rep(bs); g.stat_stride = kStatStride;
+    g.bnb_x = (const half_t*)(c.ws + c.L->pre[bn_ci]); g.ldbnb = bs.cout; g.bnb_mask = (const half_t*)bn_act;
+    g.bnb_fin = (const float*)(c.ws + c.L->fin[bn_ci]); g.bnb_cpad = round_up(bs.cout, 128);
+  }
   if (cs.k == 1 && cs.stride == 1) {
     g.conv.loader = 0;
   } else {
@@ -535,6 +555,7 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
   }
   bf16_t* gm = (bf16_t*)(bws + B.gm); bf16_t* da = (bf16_t*)(bws + B.da);
   WgradItem items[64]; int n_items = 0;     // every weight gradient is computed by ONE grouped launch at the end
+  bool g_sums_done = false;                 // the BatchNorm-backward sums of the NEXT block's bn3 were reduced by the dgrad that produced g
   for (int b = A.nblock - 1; b >= 0; --b) {
     const BlockSpec& Bk = A.block[b];
     const int i0 = Bk.conv[0], i1 = Bk.conv[1], i2 = Bk.conv[2];
@@ -547,13 +568,17 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     bf16_t* dy0 = (bf16_t*)(bws + B.dy[i0]); bf16_t* dy1 = (bf16_t*)(bws + B.dy[i1]); bf16_t* dy2 = (bf16_t*)(bws + B.dy[i2]);
     bf16_t* dyds = Bk.ds >= 0 ? (bf16_t*)(bws + B.dy[Bk.ds]) : nullptr;
     // out = relu(bn3(c3) + residual): dy = g * (out > 0) feeds bn3 and the residual branch
-    if (int e = bn_backward(c, i2, g, nullptr, out, dy2, Bk.ds < 0 ? gm : nullptr)) return e;
+    if (int e = bn_backward(c, i2, g, nullptr, out, dy2, Bk.ds < 0 ? gm : nullptr, g_sums_done)) return e;
+    g_sums_done = false;
     items[n_items++] = wgrad_item(c, i2, dy2, a2_bf);
-    if (int e = conv_dgrad(c, i2, dy2, nullptr, da)) return e;                 // d a2
-    if (int e = bn_backward(c, i1, da, nullptr, a2, dy1, nullptr)) return e;
+    const bool f1 = fuse_bn_sums(A.conv[i1]);                                  // d a2 feeds bn2 (mask a2)
+    if (int e = conv_dgrad(c, i2, dy2, nullptr, da, f1 ? i1 : -1, f1 ? a2_bf : nullptr)) return e;                 // d a2
+    if (int e = bn_backward(c, i1, da, nullptr, a2, dy1, nullptr, f1)) return e;
     items[n_items++] = wgrad_item(c, i1, dy1, a1_bf);
-    if (int e = conv_dgrad(c, i1, dy1, nullptr, da)) return e;                 // d a1
-    if (int e = bn_backward(c, i0, da, nullptr, a1, dy0, nullptr)) return e;
+    // d a1 feeds bn1 (mask a1); the stride-2 conv2 of a layer's first block runs the parity-class dgrad, which has no statistics epilogue
+    const bool f0 = fuse_bn_sums(A.conv[i0]) && A.conv[i1].stride == 1;
+    if (int e = conv_dgrad(c, i1, dy1, nullptr, da, f0 ? i0 : -1, f0 ? a1_bf : nullptr)) return e;                 // d a1
+    if (int e = bn_backward(c, i0, da, nullptr, a1, dy0, nullptr, f0)) return e;
     items[n_items++] = wgrad_item(c, i0, dy0, x_in_bf);
     if (Bk.ds >= 0) {
       if (int e = bn_backward(c, Bk.ds, g, nullptr, out, dyds, nullptr)) return e;
@@ -563,7 +588,12 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
       if (int e = conv_dgrad(c, i0, dy0, nullptr, g_next)) return e;
       if (int e = conv_dgrad(c, Bk.ds, dyds, g_next, g_next)) return e;
     } else {
-      if (int e = conv_dgrad(c, i0, dy0, gm, g_next)) return e;                // identity residual
+      // identity residual: g_next = dgrad + gm is the gradient w.r.t. the previous block's output out_{b-1} = relu(bn3 + residual):
+      // its mask and the sums of that block's bn3 ride on this epilogue -- unless that block has a downsample branch (its second
+      // BatchNorm needs its own pair of sums from the same gradient: both keep their launches)
+      const bool fg = b > 0 && A.block[b - 1].ds < 0 && fuse_bn_sums(A.conv[A.block[b - 1].conv[2]]);
+      if (int e = conv_dgrad(c, i0, dy0, gm, g_next, fg ? A.block[b - 1].conv[2] : -1, fg ? (const bf16_t*)(ws + L.out_bf[b - 1]) : nullptr)) return e;
+      g_sums_done = fg;
     }
     bf16_t* t = g; g = g_next; g_next = t;
   }
