@@ -33,6 +33,8 @@ if ROOT not in sys.path:
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 HBM_PEAK_GBS = 8000.0       # HBM3E spec, same guide
 PRIME_STEPS = 8             # untimed set-up steps before the --warmup steps (see main)
+CLOCK_STEPS = 120           # further untimed steps (~0.5 s) in the full run only: five consecutive 30-step windows of a fresh process read
+                            # 4.40 / 4.48 / 4.40 / 4.32 / 4.29 ms -- the first ~100 steps run before clocks and caches settle
 NACF_DENSE_FLOP_PER_SLICE_FWD = 40_836_464  # SURVEY.md 8(d), RAF head (C*F = 513)
 RESNET_FWD_GFLOP = 94.72
 C_, F_, T_ = 1, 513, 60
@@ -398,7 +400,7 @@ def main():
     # tools/step_trace.py shows them as 10-400 ms steps -- and a full Python garbage collection over the module graph costs
     # 50-80 ms wherever it falls (with W = 5 it fell inside the timed region of some runs and not of others: 6.3 vs 8 ms/step
     # for the same kernels).  PRIME_STEPS untimed steps run first, then the survivors are moved out of the collector's reach.
-    for _ in range(PRIME_STEPS):
+    for _ in range(PRIME_STEPS + (0 if a.plain else CLOCK_STEPS)):
         st.step()
     torch.cuda.synchronize()
     gc.collect()
@@ -528,7 +530,7 @@ def main():
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "priming_steps": PRIME_STEPS,
+            "priming_steps": PRIME_STEPS + CLOCK_STEPS,
             "ms_per_step": ms_step,
             "repeat_windows": {"n": len(repeat_ms), "steps_each": a.steps, "ms_per_step": [round(v, 4) for v in repeat_ms],
                                "median": _median(repeat_ms), "min": min(repeat_ms), "max": max(repeat_ms),
