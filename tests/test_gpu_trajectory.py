@@ -87,3 +87,55 @@ def test_training_trajectory_matches_the_oracle(golden, scenario):
                 pp = torch.from_numpy(np.asarray(g["probe_pose"])).double()
                 line += f"; band: |fp16-rounded oracle| {float(pp.norm()):.4f} cosine {float((pp * po).sum() / (pp.norm() * po.norm())):.3f}"
             print(line)
+
+
+def test_data_parallel_trajectory_matches_the_oracle(golden, tmp_path):
+    """SURVEY 8e at trajectory level: TWO ranks (sharing the one GPU of the test box, gloo) train scenario G7 data-parallel -- every
+    iteration's 512 rays and 128 RIR slices split in two contiguous shards, the 512-cell refresh window sharded by the model, the
+    STFT loss on global sums, every gradient averaged by the overlapped reducer -- and must land where the single-process run
+    lands: against the SAME oracle fixture, with the SAME tolerances.  The replicas must also agree with each other (identical
+    held-out predictions), and the mean of the two ranks' local radiance losses is the global batch's loss."""
+    import socket
+    import subprocess
+    import trajectory_common as TC
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs, outs = [], []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = str(tmp_path / f"rank{r}.npz")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "tools", "dp2_trajectory_worker.py"), "g7_trajectory", out],
+                                      env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-4000:]
+    a, b = (np.load(o) for o in outs)
+    # replicas: bit-identical parameters (tests/test_gpu_dp2.py) -> identical deterministic eval renders
+    np.testing.assert_array_equal(a["image"], b["image"])
+    g = golden("g7_trajectory")
+    curves = 0.5 * (a["curves"] + b["curves"])          # radiance terms: mean of the two shards' means; audio terms: global on both
+    np.testing.assert_allclose(a["curves"][:, 3:], b["curves"][:, 3:], rtol=1e-5, atol=1e-9, equal_nan=True)
+    dev = torch.device("cuda:0")
+    from neraf_amd import synth
+    from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
+    am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 64), TC.T(synth.audio_aabb())).to(dev)   # evaluator / Griffin-Lim host
+    evb = TC.rir_bank(TC.CFG["n_rir_eval"], TC.CFG["tag"] + ".eval")
+    r = TC.parity_summary(g, curves, a["image"], {"eval": a["stft_eval"], "batch_stats": a["stft_batch_stats"]}, am, evb)
+    print("trajectory parity [g7_trajectory, 2 ranks]:", {k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()})
+    assert r["psnr_hip_vs_oracle_db"] >= TOL["g7_trajectory"][0]
+    assert abs(r["psnr_hip_vs_gt_db"] - r["psnr_oracle_vs_gt_db"]) <= TOL["g7_trajectory"][1]
+    assert r["stft_bs_rel_l2_hip_vs_oracle"] <= 5e-2
+    assert abs(r["audio_T60_bs_hip"] - r["audio_T60_bs_oracle"]) <= 0.10 * r["audio_T60_bs_oracle"]
+    for k in ("rgb_loss", "interlevel_loss", "distortion_loss", "audio_sc_loss", "audio_mag_loss"):
+        x, y = r[f"{k}_tail_hip"], r[f"{k}_tail_oracle"]
+        assert abs(x - y) <= 0.15 * abs(y) + 1e-6, (k, x, y)

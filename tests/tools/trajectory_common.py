@@ -73,33 +73,44 @@ def psnr(a, b) -> float:
 
 
 # ---- the HIP side: train neraf_amd's pipeline on the scenario, evaluate, compare with the fixture -------------------------------------
-class _StepRays:
-    """Vision data manager of the scenario: iteration ``step`` -> its ray bundle and target colours."""
+def _shard(n: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of n items for ``rank`` (the global batch of an iteration is split, SURVEY 8e "Partitioning")."""
+    lo = (n * rank) // world
+    return lo, (n * (rank + 1)) // world
 
-    def __init__(self, dev):
-        self.dev = dev
-        self.train_num_rays_per_batch = CFG["R"]
+
+class _StepRays:
+    """Vision data manager of the scenario: iteration ``step`` -> (this rank's shard of) its ray bundle and target colours."""
+
+    def __init__(self, dev, rank: int = 0, world: int = 1):
+        self.dev, self.rank, self.world = dev, rank, world
+        self.train_num_rays_per_batch = CFG["R"]      # the GLOBAL batch: it sizes the grid-refresh window, which the model shards itself
         self.jit = {}
 
     def next_train(self, step):
         from neraf_amd.vision import RayBundle
         b = ray_batch(step)
-        self.jit[step] = [j.reshape(-1).to(self.dev) for j in b["jitters"]]
-        return (RayBundle(b["origins"].to(self.dev), b["directions"].to(self.dev), b["camera_indices"].to(self.dev)),
-                {"image": b["rgb"].to(self.dev)})
+        lo, hi = _shard(CFG["R"], self.rank, self.world)
+        self.jit[step] = [j.reshape(-1)[lo:hi].contiguous().to(self.dev) for j in b["jitters"]]
+        return (RayBundle(b["origins"][lo:hi].to(self.dev), b["directions"][lo:hi].to(self.dev), b["camera_indices"][lo:hi].to(self.dev)),
+                {"image": b["rgb"][lo:hi].to(self.dev)})
 
 
 class _StepSlices:
-    def __init__(self, bank, dev):
-        self.bank, self.dev = bank, dev
+    def __init__(self, bank, dev, rank: int = 0, world: int = 1):
+        self.bank, self.dev, self.rank, self.world = bank, dev, rank, world
 
     def next_train(self, step):
-        return None, {k: v.to(self.dev) for k, v in audio_batch(step, self.bank).items()}
+        lo, hi = _shard(CFG["B"], self.rank, self.world)
+        return None, {k: v[lo:hi].contiguous().to(self.dev) for k, v in audio_batch(step, self.bank).items()}
 
 
-def run_hip_trajectory(dev, steps=None, cfg=CFG):
+def run_hip_trajectory(dev, steps=None, cfg=CFG, rank: int = 0, world: int = 1):
     """Train the HIP pipeline on the scenario; returns (loss curves [steps, 5], held-out image [H,W,3], held-out STFTs [n,T,C,F],
-    pipeline, eval bank)."""
+    pipeline, eval bank).  ``world`` > 1 (torch.distributed initialised by the caller): this process is rank ``rank`` of a
+    data-parallel job -- it trains on its contiguous shard of every iteration's rays and RIR slices; rays / slices / refresh cells
+    are sharded, loss sums and gradients reduced by neraf_amd.parallel; the per-rank loss curves are local for the radiance terms
+    (mean over the rank's rays) and global for the audio terms."""
     from neraf_amd import config as Cfg
     from neraf_amd import synth
     from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
@@ -123,14 +134,18 @@ def run_hip_trajectory(dev, steps=None, cfg=CFG):
         f.table.copy_(P["field.table"])
         for k in ("base_w0", "base_w1", "head_w0", "head_w1", "head_w2", "embedding"):
             getattr(f, k).copy_(P["field." + k])
-    am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=cfg["grid_step"]), T(synth.audio_aabb()))
+    am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=cfg["grid_step"]), T(synth.audio_aabb()),
+                         process_group=True if world > 1 else None)
     am.field.load_state_dict(sdn)
     am.resnet3d.backbone_net.load_state_dict(sdr)
     vm.to(dev).train(); am.to(dev).train()
     bank = rir_bank(cfg["n_rir"], cfg["tag"] + ".train")
-    rays = _StepRays(dev)
+    rays = _StepRays(dev, rank, world)
     vm.jitter_fn = lambda step, R, device: rays.jit[step]
-    pipe = NeRAFPipeline(vm, am, datamanager=rays, audio_datamanager=_StepSlices(bank, dev), start_step_audio=cfg["start_step_audio"])
+    pipe = NeRAFPipeline(vm, am, datamanager=rays, audio_datamanager=_StepSlices(bank, dev, rank, world),
+                         start_step_audio=cfg["start_step_audio"], world_size=world, local_rank=rank)
+    if world > 1:
+        pipe.attach_gradient_reducer()
     opts, scaler = pipe.make_optimizers(init_scale=65536.0, optimizers_config=Cfg.default_optimizers(cfg["start_step_audio"]),
                                         with_schedulers=True)
     keys = ["rgb_loss", "interlevel_loss", "distortion_loss", "audio_sc_loss", "audio_mag_loss"]
