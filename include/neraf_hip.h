@@ -259,7 +259,12 @@ int neraf_interlevel_loss(neraf_ctx* ctx, const float* c_bins, const float* w_fi
                           float* d_density, float* sums, neraf_stream_t stream);
 /* Proposal network backward: d_density [R,S] -> table_grad fp32 [rows,2] and w_grad fp32 [16*16+16]
  * (layer 0 then layer-1 row), both ACCUMULATED (caller zeroes).  scratch (optional, >= 2048*272*4 bytes): per-workgroup
- * weight-gradient partials, folded by a second launch instead of 272 same-line atomics per workgroup. */
+ * weight-gradient partials, folded by a second launch instead of 272 same-line atomics per workgroup.  With a scratch of
+ * neraf_proposal_backward_scratch_bytes(R, S, n_levels) bytes the table gradient takes the packed two-pass path of the main field:
+ * the MLP-backward kernel stores the per-sample encoding gradients and each level's gradient mass, the scatter adds both features of
+ * an entry with one 64-bit fixed-point atomic (per-level power-of-two scale, overflow-proof, bit-reproducible), an in-place pass
+ * converts to fp32 -- table_grad must then be ZERO on entry (it doubles as the integer accumulator). */
+size_t neraf_proposal_backward_scratch_bytes(int R, int S, int n_levels);
 int neraf_proposal_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                             const float* origins, const float* dirs, const float* e_bins, const float* d_density, int R,
                             int S, float avg_density, float* table_grad, float* w_grad, void* scratch, size_t scratch_bytes,

@@ -101,6 +101,7 @@ SIGNATURES = {
                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_interlevel_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "neraf_proposal_backward_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "neraf_proposal_backward": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -242,6 +242,12 @@ struct PropBwdArgs {
   float* w_part;          // optional fp32 [blocks][272]: per-workgroup partials (folded by prop_wgrad_fold_kernel) instead of
                           // 272 atomics per workgroup on nine cache lines (~220 us of same-line serialisation at 2048 workgroups)
   float* d_ray;           // optional fp32 [R][6], ACCUMULATED: d loss / d (ray origin, ray direction)
+  // packed two-pass table gradient (all four non-null): this kernel only STORES the per-sample encoding gradient, fp32 pairs
+  // [level][npad], and each level's gradient mass sum_samples max(|g0|, |g1|) per workgroup; field_finalize_kernel turns the masses
+  // into the power-of-two fixed-point scales, field_scatter_kernel adds both features of a table entry with ONE 64-bit integer
+  // atomic (half the atomics of the fp32 pair path, and integer adds commute: the gradient becomes bit-reproducible),
+  // field_unpack_grad_kernel converts in place
+  float2* d32; long npad; float* t_part; float* one2;
 };
 
 __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
@@ -255,6 +261,8 @@ __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long N = (long)a.R * a.S;
   const long nchunks = (N + 255) / 256;
+  float tmass[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (a.d32 && blockIdx.x == 0 && threadIdx.x < 2) a.one2[threadIdx.x] = 1.f;
   for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const long idx = chunk * 256 + threadIdx.x;
     const bool valid = idx < N;
@@ -303,7 +311,11 @@ __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
         for (int j = 0; j < 16; ++j) { g0 = fmaf(dh[j], w0[j][2 * l], g0); g1 = fmaf(dh[j], w0[j][2 * l + 1], g1); }
         if (a.d_ray && valid && sel_pt)
           encode_level_dpos(a.table, x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.offset[l], a.g.hashed[l], g0, g1, rgx, rgy, rgz);
-        scatter_level_seg<64>(a.table_grad, x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.offset[l], a.g.hashed[l], g0, g1, lane);
+        if (a.d32) {
+          if (valid) { a.d32[(long)l * a.npad + idx] = make_float2(g0, g1); tmass[l] += fmaxf(fabsf(g0), fabsf(g1)); }
+        } else {
+          scatter_level_seg<64>(a.table_grad, x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.offset[l], a.g.hashed[l], g0, g1, lane);
+        }
       }
     if (a.d_ray) {
       // camera-pose edge: the position gradient of this sample -> d (origin, direction) of its ray; the 64 samples of a wave lie
@@ -350,6 +362,21 @@ __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
   for (int i = threadIdx.x; i < 272; i += 256) {
     if (a.w_part) a.w_part[(size_t)blockIdx.x * 272 + i] = acc[i];
     else atomicAdd(a.w_grad + i, acc[i]);
+  }
+  if (a.d32) {
+    // this workgroup's gradient mass per level -> t_part[block][16] (levels >= n_levels: 0), summed by field_finalize_kernel
+    __syncthreads();
+    float* red = &s_dh[0][0][0];                   // 4 x 64 x 17 floats, free now
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      float v = tmass[l];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) red[wv * 8 + l] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16)
+      a.t_part[(size_t)blockIdx.x * 16 + threadIdx.x] = threadIdx.x < 8 ? (red[threadIdx.x] + red[8 + threadIdx.x]) + (red[16 + threadIdx.x] + red[24 + threadIdx.x]) : 0.f;
   }
 }
 
@@ -783,6 +810,7 @@ struct FieldScatterArgs {
   int l_end;                           // levels [0, l_end) are scattered here (the rest by the owner kernels below)
   const float2* d_red; int run;        // run > 1: rays [k*run, (k+1)*run) share their (single) sample position and d_red [16][npad_r]
   long npad_r;                         // holds the gradients already summed over each run (the grid refresh: 18 directions per cell)
+  const float2* d32;                   // instead of d_enc: fp32 pairs [level][npad] (the proposal networks' two-pass table gradient)
 };
 
 // sums the encoding gradient over runs of rays that share a position: d_red[l][k] = sum_j d_enc[l][k*run + j]
@@ -837,6 +865,9 @@ __global__ __launch_bounds__(256) void field_scatter_kernel(FieldScatterArgs a) 
       float g0, g1;
       if (a.run > 1) {
         const float2 gr = valid ? a.d_red[(long)l * a.npad_r + n] : make_float2(0.f, 0.f);
+        g0 = gr.x * F; g1 = gr.y * F;
+      } else if (a.d32) {
+        const float2 gr = valid ? a.d32[(long)l * a.npad + n] : make_float2(0.f, 0.f);
         g0 = gr.x * F; g1 = gr.y * F;
       } else {
         const unsigned raw = valid ? a.d_enc[(long)l * a.npad + n] : 0u;
@@ -1130,6 +1161,11 @@ static int proposal_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, cons
                                   int R, int S, float avg_density, float* table_grad, float* w_grad, void* scratch,
                                   size_t scratch_bytes, float* d_rays, neraf_stream_t stream);
 
+extern "C" size_t neraf_proposal_backward_scratch_bytes(int R, int S, int n_levels) {
+  const size_t npad = ((size_t)R * S + 63) / 64 * 64;
+  return (size_t)2048 * 272 * sizeof(float) + (size_t)2048 * 16 * sizeof(float) + 64 * sizeof(float) + (size_t)n_levels * npad * sizeof(float2);
+}
+
 extern "C" int neraf_proposal_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                                        const float* origins, const float* dirs, const float* e_bins, const float* d_density,
                                        int R, int S, float avg_density, float* table_grad, float* w_grad, void* scratch,
@@ -1161,11 +1197,38 @@ static int proposal_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, cons
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   a.w_part = (scratch && scratch_bytes >= (size_t)blocks * 272 * sizeof(float)) ? (float*)scratch : nullptr;
-  {
-    ProfScope prof(ctx, (hipStream_t)stream, PROF_PROP_BWD, (double)n * a.g.n_levels * 8 * 8);   // fp32x2 atomically added bytes
-    hipLaunchKernelGGL(proposal_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  // packed two-pass table gradient when the scratch holds it (neraf_proposal_backward_scratch_bytes) -- NERAF_PROP_PACKED=0: fp32 atomics
+  static const int packed_on = [] { const char* e = getenv("NERAF_PROP_PACKED"); return e ? atoi(e) : 1; }();
+  const long npad = (n + 63) / 64 * 64;
+  float* lvl = nullptr;
+  if (packed_on && a.w_part && scratch_bytes >= neraf_proposal_backward_scratch_bytes(R, S, a.g.n_levels)) {
+    char* sp = (char*)scratch + (size_t)2048 * 272 * sizeof(float);
+    a.t_part = (float*)sp; sp += (size_t)2048 * 16 * sizeof(float);
+    lvl = (float*)sp; sp += 32 * sizeof(float);
+    a.one2 = (float*)sp; sp += 32 * sizeof(float);
+    a.d32 = (float2*)sp; a.npad = npad;
   }
-  if (a.w_part) hipLaunchKernelGGL(prop_wgrad_fold_kernel, dim3(34), dim3(256), 0, (hipStream_t)stream, a.w_part, (int)blocks, w_grad);
+  hipStream_t st = (hipStream_t)stream;
+  {
+    ProfScope prof(ctx, st, PROF_PROP_BWD, (double)n * a.g.n_levels * 8 * 8);   // 8 bytes added per (sample, level, corner)
+    hipLaunchKernelGGL(proposal_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (a.d32) {
+      hipLaunchKernelGGL(field_finalize_kernel, dim3(16), dim3(256), 0, st, a.t_part, (int)blocks, lvl, nullptr, nullptr, nullptr);
+      FieldScatterArgs sa{};
+      sa.g = a.g; sa.origins = origins; sa.dirs = dirs; sa.e_bins = e_bins; sa.R = R; sa.S = S; sa.mode = 0;
+      sa.npad = npad; sa.lvl = lvl; sa.acc = reinterpret_cast<unsigned long long*>(table_grad); sa.l_end = a.g.n_levels; sa.run = 1;
+      sa.d32 = a.d32;
+      long sblocks = ((n + 63) / 64 + 3) / 4;
+      const long cap = (long)(ctx ? ctx->num_cus : 256) * 8;
+      if (sblocks > cap) sblocks = cap;
+      hipLaunchKernelGGL(field_scatter_kernel, dim3((unsigned)sblocks, 1), dim3(256), 0, st, sa);
+      unsigned maxsize = 0;
+      for (int l = 0; l < a.g.n_levels; ++l) maxsize = a.g.size[l] > maxsize ? a.g.size[l] : maxsize;
+      hipLaunchKernelGGL(field_unpack_grad_kernel, dim3((maxsize + 1023) / 1024, a.g.n_levels), dim3(256), 0, st, a.g, lvl, a.one2,
+                         reinterpret_cast<unsigned long long*>(table_grad));
+    }
+  }
+  if (a.w_part) hipLaunchKernelGGL(prop_wgrad_fold_kernel, dim3(34), dim3(256), 0, st, a.w_part, (int)blocks, w_grad);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }

@@ -368,7 +368,8 @@ class NeRAFPipeline(nn.Module):
                   list(self.model.field.parameters()), [p for pn in self.model.proposal_networks for p in pn.parameters()],
                   list(self.model.camera_optimizer.parameters()) if hasattr(self.model, "camera_optimizer") else []]
         groups = [g for g in groups if g]
-        self._reducer = GradientReducer(groups, group=group)
+        import os
+        self._reducer = GradientReducer(groups, group=group, overlap=os.environ.get("NERAF_DP_OVERLAP", "1") != "0")
         if self.audio_model.use_grid:
             # the ResNet3D backward assigns its parameters' gradients itself (no per-parameter autograd hooks fire): it tells the
             # reducer when they are final

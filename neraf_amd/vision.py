@@ -461,7 +461,8 @@ class _VisionLossFn(torch.autograd.Function):
             ptab, pw = st["prop_packed"][i]
             g_pt = torch.zeros_like(pn.table)
             g_pw = torch.zeros(16 * 16 + 16, **f32)
-            scratch = torch.empty(2048 * 272, **f32)           # per-workgroup weight-gradient partials
+            # per-workgroup weight-gradient partials + the two-pass table gradient's per-sample encoding gradients and level masses
+            scratch = torch.empty((int(lib.neraf_proposal_backward_scratch_bytes(R, Sp, pn.desc.n_levels)) + 3) // 4, **f32)
             pargs = (h, C.byref(pn.desc), ptab.data_ptr(), pw.data_ptr(), st["o"].data_ptr(), st["d"].data_ptr(), ps.e_bins.data_ptr(),
                      d_pd.data_ptr(), R, Sp, pn.average_init_density, g_pt.data_ptr(), g_pw.data_ptr(), scratch.data_ptr(),
                      scratch.numel() * 4)

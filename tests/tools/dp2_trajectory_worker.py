@@ -21,8 +21,9 @@ def main():
     scenario, out_path = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
+    di = int(os.environ.get("NERAF_WORKER_DEVICE", "0"))        # one GPU per rank where the box has two; else the ranks share GPU 0
+    torch.cuda.set_device(di)
+    dev = torch.device("cuda", di)
     import trajectory_common as TC
     torch.manual_seed(0)
     curves, img, stft, pipe, evb = TC.run_hip_trajectory(dev, cfg=TC.SCENARIOS[scenario], rank=rank, world=world)
