@@ -11,7 +11,8 @@ import os
 from typing import Dict, Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libneraf_hip.so")
+# NERAF_HIP_LIB: load a differently built library (diagnostic builds of neraf_amd/csrc, see tools/README.md); same ABI check applies
+LIB_PATH = os.environ.get("NERAF_HIP_LIB") or os.path.join(_HERE, "libneraf_hip.so")
 
 _lib: Optional[C.CDLL] = None
 _ctxs: Dict[int, C.c_void_p] = {}

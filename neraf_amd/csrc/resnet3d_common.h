@@ -127,7 +127,22 @@ struct BnSrc {
   float* fin_w;             // forward BN pass: block 0 writes the finalised statistics here -- or null
   const float* gamma; const float* beta; const float* rmean; const float* rvar;
   int cpad, rep;
+  int read_mode;            // how the accumulators are read (NERAF_BN_STAT_READ): 0 plain loads, 1 atomic fetch-add of 0, 2 system-scope loads
 };
+
+// Reading one statistic accumulator.  Modes 1 and 2 go to the point of coherence the producing atomics used; mode 0 (the default)
+// is a plain load, valid because the producer is an earlier kernel of the same stream.
+// DO NOT REMOVE the mode-selected re-read in bn_mean_var below, although mode 0 never takes it: with it compiled in, the BatchNorm
+// kernels are the build that survives a second process on the same GPU -- 0 damaged forwards in 30,000 next to every neighbour
+// tried, against 12-25 % without it (same executed instructions, tools/share_gpu_ab_libs.sh, DESIGN.md section 6 "Two processes on
+// one GPU": the cause is not understood; padding the code, raising the SGPR allocation, dividing on the host, fences and scoped
+// loads on their own do not have the effect).  tools/share_gpu_regression.sh re-checks it.
+
+__device__ __forceinline__ float stat_ld(const float* p, int mode) {
+  if (mode == 1) return atomicAdd(const_cast<float*>(p), 0.f);
+  if (mode == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return *p;
+}
 
 __device__ __forceinline__ void bn_mean_var(const BnSrc& s, int c, float inv_m, float& mean, float& var) {
   if (s.fin_r) {
@@ -143,6 +158,10 @@ __device__ __forceinline__ void bn_mean_var(const BnSrc& s, int c, float inv_m, 
       a3 += s.stats[(r + 3) * kStatStride + c]; b3 += s.stats[(r + 3) * kStatStride + s.cpad + c];
     }
     for (; r < s.rep; ++r) { a += s.stats[r * kStatStride + c]; b += s.stats[r * kStatStride + s.cpad + c]; }
+    if (s.read_mode) {
+      a = b = a1 = b1 = a2 = b2 = a3 = b3 = 0.f;
+      for (r = 0; r < s.rep; ++r) { a += stat_ld(s.stats + r * kStatStride + c, s.read_mode); b += stat_ld(s.stats + r * kStatStride + s.cpad + c, s.read_mode); }
+    }
     a = (a + a1) + (a2 + a3); b = (b + b1) + (b2 + b3);
     mean = a * inv_m;
     var = fmaxf(b * inv_m - mean * mean, 0.f);    // biased variance, as nn.BatchNorm3d normalises with
@@ -165,6 +184,8 @@ __device__ __forceinline__ void bn_scale_shift(const BnSrc& s, int c, float inv_
 inline BnSrc bn_src_fwd(const Arch& A, const Layout& L, char* ws, const float* const* bn, int ci, int use_batch) {
   const ConvSpec& c = A.conv[ci];
   BnSrc s{};
+  static const int stat_read = [] { const char* e = getenv("NERAF_BN_STAT_READ"); return e ? atoi(e) : 0; }();
+  s.read_mode = stat_read;
   s.x = (const half_t*)(ws + L.pre[ci]);
   s.stats = use_batch ? (const float*)(ws + L.stat[ci]) : nullptr;
   s.fin_w = use_batch ? (float*)(ws + L.fin[ci]) : nullptr;

@@ -25,12 +25,19 @@ def _free_port():
 
 
 def test_two_ranks_one_gpu_replicas_stay_bit_identical(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import shared_gpu
+    shared_gpu.attempts_for_shared_gpu(lambda i: _run_two_ranks(tmp_path, i))
+
+
+def _run_two_ranks(tmp_path, attempt):
+    import shared_gpu
     port = _free_port()
     procs, outs = [], []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
-        out = str(tmp_path / f"rank{r}.json")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", NERAF_WORKER_DEVICE=str(shared_gpu.rank_device(r)))
+        out = str(tmp_path / f"attempt{attempt}_rank{r}.json")
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "dp2_worker.py"), out], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))

@@ -28,8 +28,9 @@ def main():
     out_path = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
+    di = int(os.environ.get("NERAF_WORKER_DEVICE", "0"))        # one GPU per rank where the box has two; else the ranks share GPU 0
+    torch.cuda.set_device(di)
+    dev = torch.device("cuda", di)
     import bench
     from neraf_amd import synth
     from neraf_amd.losses import STFTLoss
@@ -69,12 +70,19 @@ def main():
         return [p.grad.detach().clone() for p in field.parameters()], float(l["audio_sc_loss"]), float(l["audio_mag_loss"])
     lo, hi = rank * B // world, (rank + 1) * B // world
     g_dp, sc_dp, mag_dp = grads({k: v[lo:hi] for k, v in full.items()}, True)
+    local0 = g_dp[0].clone()
     for g in g_dp:                                        # what GradientReducer does on gloo: sum, then divide
         dist.all_reduce(g)
         g /= world
     g_ref, sc_ref, mag_ref = grads(full, None)
     rel = [float((a - b).norm() / (b.norm() + 1e-30)) for a, b in zip(g_dp, g_ref)]
     res["audio_grad_rel"] = rel
+    nf = 1024      # layer-0 weight gradient: columns < 1024 = bias gradient (x) grid feature, the rest a GEMM (for a failure report)
+    res["audio_grad_layer0"] = {"local_norm": float(local0.norm()), "reduced_norm": float(g_dp[0].norm()), "ref_norm": float(g_ref[0].norm()),
+                                "rel_outer": float((g_dp[0][:, :nf] - g_ref[0][:, :nf]).norm() / g_ref[0][:, :nf].norm()),
+                                "rel_gemm": float((g_dp[0][:, nf:] - g_ref[0][:, nf:]).norm() / g_ref[0][:, nf:].norm()),
+                                "local_outer_norm": float(local0[:, :nf].norm()), "ref_outer_norm": float(g_ref[0][:, :nf].norm()),
+                                "bias_rel": rel[1], "local_bias_norm_x2": 2 * float(g_dp[1].norm()), "ref_bias_norm": float(g_ref[1].norm())}
     res["audio_loss"] = [sc_dp, sc_ref, mag_dp, mag_ref]
     json.dump(res, open(out_path, "w"))
     dist.barrier()
