@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void pdf_resample_kernel(PdfArgs a) {
     loc += dd[k];
   }
   const float incl = wave_incl_scan(loc, lane);
-  float run = incl - loc;                         // exclusive prefix of this lane's chunk
+  float run = wave_excl_from_incl(incl, lane);    // exclusive prefix of this lane's chunk
   float wts[4], wl = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
   const float e0 = on ? eb[lane] : 0.f, e1 = on ? eb[lane + 1] : 0.f;
   const float dd = on ? (e1 - e0) * a.density[(size_t)ray * S + lane] : 0.f;
   const float incl = wave_incl_scan(dd, lane);
-  float w = (1.f - __expf(-dd)) * __expf(-(incl - dd));
+  float w = (1.f - __expf(-dd)) * __expf(-wave_excl_from_incl(incl, lane));
   if (!(w == w)) w = 0.f;
   if (!on) w = 0.f;
   if (on && a.weights) a.weights[(size_t)ray * S + lane] = w;

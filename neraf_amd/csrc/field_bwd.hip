@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void render_loss_kernel(RenderLossArgs a) {
   const float de = e1 - e0;
   const float dd = on ? de * a.density[(size_t)ray * S + lane] : 0.f;
   const float incl = wave_incl_scan(dd, lane);
-  const float Ti = __expf(-(incl - dd)), ex = __expf(-dd);
+  const float Ti = __expf(-wave_excl_from_incl(incl, lane)), ex = __expf(-dd);
   float w = (1.f - ex) * Ti;
   const bool bad = !(w == w);
   if (bad || !on) w = 0.f;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void interlevel_kernel(InterlevelArgs a) {
     loc += dd[k];
   }
   const float incl = wave_incl_scan(loc, lane);
-  float run = incl - loc, wp[4], Tk[4], exk[4], wl = 0.f;
+  float run = wave_excl_from_incl(incl, lane), wp[4], Tk[4], exk[4], wl = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     Tk[k] = __expf(-run); exk[k] = __expf(-dd[k]);

@@ -203,6 +203,17 @@ __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
   return v;
 }
 
+// EXCLUSIVE prefix from an inclusive one: the previous lane's inclusive value, not `incl - v`.  The optical depths of a trained
+// field reach 1e15 and beyond at surfaces (densities of 1e14-1e18 after a few thousand iterations of the trajectory scene):
+// `incl - v` then cancels catastrophically -- the sample BEHIND a surface sample got transmittance exp(-0) = 1 instead of 0, its
+// weight came out 1 next to the surface sample's 1, and the colour / the gradient of those rays were garbage (found by
+// tools/long_trajectory_curve.py against the CPU oracle on the same state; nerfstudio's get_weights takes the cumulative sum of
+// the PREVIOUS samples directly, RaySamples.get_weights [NS-recall]).
+__device__ __forceinline__ float wave_excl_from_incl(float incl, int lane) {
+  const float prev = __shfl_up(incl, 1);
+  return lane == 0 ? 0.f : prev;
+}
+
 
 // gradient scatter of one level: table_grad[(offset+idx)*2 + f] += w_corner * g_f  (fp32 atomics, 8 corners)
 __device__ __forceinline__ void scatter_level(float* __restrict__ tgrad, float x, float y, float z, float scale, int res,

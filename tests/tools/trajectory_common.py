@@ -105,7 +105,7 @@ class _StepSlices:
         return None, {k: v[lo:hi].contiguous().to(self.dev) for k, v in audio_batch(step, self.bank).items()}
 
 
-def run_hip_trajectory(dev, steps=None, cfg=CFG, rank: int = 0, world: int = 1):
+def run_hip_trajectory(dev, steps=None, cfg=CFG, rank: int = 0, world: int = 1, fixed_scale: bool = True):
     """Train the HIP pipeline on the scenario; returns (loss curves [steps, 5], held-out image [H,W,3], held-out STFTs [n,T,C,F],
     pipeline, eval bank).  ``world`` > 1 (torch.distributed initialised by the caller): this process is rank ``rank`` of a
     data-parallel job -- it trains on its contiguous shard of every iteration's rays and RIR slices; rays / slices / refresh cells
@@ -154,7 +154,8 @@ def run_hip_trajectory(dev, steps=None, cfg=CFG, rank: int = 0, world: int = 1):
         _, ld = pipe.train_iteration(s, opts, scaler)
         rows.append(torch.stack([ld[k].detach().float().reshape(()) if k in ld else torch.full((), float("nan"), device=dev) for k in keys]))
     curves = torch.stack(rows).cpu().numpy().astype(np.float64)
-    assert scaler.get_scale() == 65536.0, "a GradScaler skip would shift the trajectory by one iteration"
+    if fixed_scale:      # the parity fixtures: 100 iterations, far below the scaler's growth interval (long runs pass fixed_scale=False)
+        assert scaler.get_scale() == 65536.0, "a GradScaler skip would shift the trajectory by one iteration"
     ev = synth.trajectory_eval_camera(*cfg["eval_hw"], tag=cfg["tag"])
     img = vm.get_outputs_for_camera_ray_bundle(RayBundle(T(ev["origins"]).to(dev), T(ev["directions"]).to(dev), None))["rgb"]
     img = img.reshape(*cfg["eval_hw"], 3).cpu().numpy()
