@@ -128,6 +128,50 @@ def test_pdf_resample(dev, setup, S, n_new, anneal, jit):
     assert float(de.median()) <= 1e-4
 
 
+def test_weights_at_surface_densities(dev, setup):
+    """Round-3 regression: optical depths of 1e9-1e17 (surface densities of a trained field).  get_weights needs the exclusive
+    prefix sum of the PREVIOUS samples (RaySamples.get_weights [NS-recall]); inclusive-minus-self cancelled there and gave the sample
+    behind a surface transmittance 1.  Both kernels that compute weights -- the PDF resampler and the compositor -- against the
+    oracle on identical densities: rows with two adjacent huge samples, huge after moderate, moderate only, and an inf."""
+    from neraf_amd import _lib
+    _, _, spec, V = setup
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for S in (48, 96, 256):
+        R = 67
+        rb = synth.ray_batch(R, tag=f"t.surf{S}")
+        o, d = T(rb["origins"]), T(rb["directions"])
+        near, far = torch.full((R, 1), 0.05), torch.full((R, 1), 1000.0)
+        ray = V.sample_uniform(o, d, near, far, S, T(rb["jitters"][0]))
+        dens = T(synth.uniform(f"t.surf.dens{S}", (R, S), 0.0, 1.0)) ** 4 * 0.5
+        k = S // 3
+        dens[0::4, k] = 3.0e15; dens[0::4, k + 1] = 2.9e15; dens[0::4, k + 2] = 1.0e17      # noqa: E702 -- a surface: three huge neighbours
+        dens[1::4, k] = 5.0e5; dens[1::4, k + 1] = 1.0e15                                     # noqa: E702 -- opaque, then 2e9 x denser: the second must get weight 0
+        dens[2::4, k + 5] = float("inf")
+        w_ref = V.get_weights(dens, ray.deltas)
+        assert float(w_ref.sum(1).max()) <= 1.0 + 1e-5
+        dens_d, sb_d, eb_d = dens.to(dev), ray.s_bins.to(dev).contiguous(), ray.e_bins.to(dev).contiguous()
+        if S != 48:
+            n_new = 96 if S == 256 else 48
+            w = torch.empty((R, S), device=dev)
+            s_n, e_n = torch.empty((R, n_new + 1), device=dev), torch.empty((R, n_new + 1), device=dev)
+            j = T(rb["jitters"][1]).reshape(-1).to(dev)
+            _lib.check(lib.neraf_pdf_resample(_lib.ctx(0), dens_d.data_ptr(), sb_d.data_ptr(), eb_d.data_ptr(), R, S, 1.0, j.data_ptr(), n_new,
+                                              0.05, 1000.0, w.data_ptr(), s_n.data_ptr(), e_n.data_ptr(), st))
+            np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=2e-4, atol=1e-7)
+            assert bool(torch.isfinite(s_n).all()) and bool((s_n[:, 1:] >= s_n[:, :-1]).all())
+        else:
+            rgb_s = T(synth.uniform("t.surf.rgb", (R, S, 3), 0.0, 1.0)).to(dev)
+            w = torch.empty((R, S), device=dev)
+            rgb, depth = torch.empty((R, 3), device=dev), torch.empty((R, 1), device=dev)
+            expd, acc = torch.empty((R, 1), device=dev), torch.empty((R, 1), device=dev)
+            scratch = torch.empty(2, dtype=torch.int32, device=dev)
+            _lib.check(lib.neraf_composite(_lib.ctx(0), dens_d.data_ptr(), rgb_s.data_ptr(), eb_d.data_ptr(), R, S, 1, w.data_ptr(), rgb.data_ptr(),
+                                           depth.data_ptr(), expd.data_ptr(), acc.data_ptr(), scratch.data_ptr(), st))
+            np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=2e-4, atol=1e-7)
+            assert float(acc.max()) <= 1.0 + 1e-5 and bool(torch.isfinite(rgb).all())
+
+
 @pytest.mark.parametrize("mode,training", [("contract", True), ("contract", False), ("aabb", True)])
 def test_field_query(dev, setup, mode, training):
     m, P16, spec, V = setup
