@@ -105,12 +105,7 @@ __global__ __launch_bounds__(256) void render_loss_kernel(RenderLossArgs a) {
   }
   // get_weights backward (linear in gw): d dd_i = gw_i T_i exp(-dd_i) - sum_{k>i} gw_k w_k ; d sigma_i = delta_i d dd_i
   auto weights_bwd = [&](float gw) {
-    const float gww = gw * w;
-    const float incl2 = wave_incl_scan(gww, lane);
-    float tot = gww;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-    return de * (gw * Ti * ex - (tot - incl2));
+    return de * (gw * Ti * ex - wave_suffix_excl_scan(gw * w, lane));
   };
   if (unit) {
     const float dr = weights_bwd(gw_r), dd2 = weights_bwd(gw_d);
@@ -217,16 +212,12 @@ __global__ __launch_bounds__(256) void interlevel_kernel(InterlevelArgs a) {
   float rund = incd - dl, gw[4], gwl = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) { rund += dv[k]; gw[k] = rund * scale; gwl += gw[k] * wp[k]; }
-  const float incg = wave_incl_scan(gwl, lane);
-  float tot = gwl;
+  float later = wave_suffix_excl_scan(gwl, lane);       // sum over the samples AFTER this one: later lanes, then later k of this lane
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-  float rung = incg - gwl;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 3; k >= 0; --k) {
     const int i = lane * per + k;
-    rung += gw[k] * wp[k];
-    const float ddd = gw[k] * Tk[k] * exk[k] - (tot - rung);
+    const float ddd = gw[k] * Tk[k] * exk[k] - later;
+    later += gw[k] * wp[k];
     if (k < per && i < Sp && active) a.d_density[(size_t)ray * Sp + i] = (pe[i + 1] - pe[i]) * ddd;
   }
 }

@@ -214,6 +214,19 @@ __device__ __forceinline__ float wave_excl_from_incl(float incl, int lane) {
   return lane == 0 ? 0.f : prev;
 }
 
+// Sum over the LATER lanes (exclusive suffix), summed directly -- not `total - inclusive prefix`: behind an opaque sample every
+// later term is exactly zero and so must this sum be (torch's cumsum backward is a reversed cumsum); the difference of two
+// differently ordered fp32 sums leaves ~1e-7 of the total there, which the density's backward multiplies by up to e^15.
+__device__ __forceinline__ float wave_suffix_excl_scan(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float n = __shfl_down(v, o);
+    if (lane + o < 64) v += n;
+  }
+  const float next = __shfl_down(v, 1);
+  return lane == 63 ? 0.f : next;
+}
+
 
 // gradient scatter of one level: table_grad[(offset+idx)*2 + f] += w_corner * g_f  (fp32 atomics, 8 corners)
 __device__ __forceinline__ void scatter_level(float* __restrict__ tgrad, float x, float y, float z, float scale, int res,

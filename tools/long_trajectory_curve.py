@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "tools"
 ap = argparse.ArgumentParser()
 ap.add_argument("steps", type=int, nargs="?", default=3000); ap.add_argument("--no-growth", action="store_true")
 ap.add_argument("--every", type=int, default=250); ap.add_argument("--no-audio", action="store_true")
+ap.add_argument("--camera-opt", action="store_true", help="scenario G8: camera optimizer SO3xR3 on")
 ap.add_argument("--debug-from", type=int, default=-1, help="from this iteration on: report the first iterations whose GradScaler scale drops, with the non-finite gradients")
 a = ap.parse_args()
 import numpy as np, torch
@@ -16,7 +17,11 @@ from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
 from neraf_amd.pipeline import NeRAFPipeline
 from neraf_amd.vision import NeRAFVisionModel, RayBundle
 dev = torch.device("cuda:0"); cfg = TC.CFG; T = TC.T
-vm = NeRAFVisionModel(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), cfg["n_cam"])
+if a.camera_opt:
+    vm = Cfg.NeRAFVisionModelConfig(camera_optimizer=Cfg.CameraOptimizerConfig(mode="SO3xR3")).setup(
+        scene_box=Cfg.SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), num_train_data=cfg["n_cam"], metadata={}, device=dev, grad_scaler=None, seed_points=None)
+else:
+    vm = NeRAFVisionModel(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), cfg["n_cam"])
 P, sdn, sdr = TC.initial_weights((vm.proposal_networks[0].table.shape[0], vm.proposal_networks[1].table.shape[0], vm.field.module.table.shape[0]))
 with torch.no_grad():
     for i in range(2):
@@ -127,4 +132,5 @@ for s in range(a.steps):
         img = vm.get_outputs_for_camera_ray_bundle(RayBundle(T(ev["origins"]).to(dev), T(ev["directions"]).to(dev), None))["rgb"].reshape(*cfg["eval_hw"], 3).cpu().numpy()
         vm.train()
         print(f"iteration {s + 1:6d}: rgb {m[0]:.5f} interlevel {m[1]:.5f} distortion {m[2]:.5f} audio_mag {m[3]:.5f}  scale {scaler.get_scale():.0f}  "
-              f"held-out PSNR {TC.psnr(img, np.asarray(ev['image'])):.2f} dB  |field table| max {float(vm.field.module.table.abs().max()):.3f}", flush=True)
+              f"held-out PSNR {TC.psnr(img, np.asarray(ev['image'])):.2f} dB  |field table| max {float(vm.field.module.table.abs().max()):.3f}"
+              + (f"  |pose deltas| {float(vm.camera_optimizer.pose_adjustment.detach().norm()):.4f}" if a.camera_opt else ""), flush=True)
