@@ -69,7 +69,7 @@ def test_training_trajectory_matches_the_oracle(golden, scenario):
     assert abs(r["psnr_hip_vs_gt_db"] - r["psnr_oracle_vs_gt_db"]) <= TOL[scenario][1]
     assert r["stft_bs_rel_l2_hip_vs_oracle"] <= 5e-2
     assert abs(r["stft_bs_rel_l2_hip_vs_gt"] - r["stft_bs_rel_l2_oracle_vs_gt"]) <= 3e-2
-    assert abs(r["audio_T60_bs_hip"] - r["audio_T60_bs_oracle"]) <= 0.10 * r["audio_T60_bs_oracle"]      # T60 error in percent (RAFEvaluator)
+    assert abs(r["audio_T60_bs_hip"] - r["audio_T60_bs_oracle"]) <= 0.20 * r["audio_T60_bs_oracle"]      # see the single-process test      # T60 error in percent (RAFEvaluator)
     assert abs(r["audio_EDT_bs_hip"] - r["audio_EDT_bs_oracle"]) <= 0.05 * r["audio_EDT_bs_oracle"]      # seconds
     assert abs(r["audio_C50_bs_hip"] - r["audio_C50_bs_oracle"]) <= 0.5                                    # dB
     assert np.isfinite(r["stft_rel_l2_hip_vs_oracle"]) and r["stft_rel_l2_hip_vs_oracle"] <= 1.0        # eval branch: reported (docstring)
@@ -143,7 +143,7 @@ def _data_parallel_trajectory(golden, tmp_path, attempt):
     assert r["psnr_hip_vs_oracle_db"] >= TOL["g7_trajectory"][0]
     assert abs(r["psnr_hip_vs_gt_db"] - r["psnr_oracle_vs_gt_db"]) <= TOL["g7_trajectory"][1]
     assert r["stft_bs_rel_l2_hip_vs_oracle"] <= 5e-2
-    assert abs(r["audio_T60_bs_hip"] - r["audio_T60_bs_oracle"]) <= 0.10 * r["audio_T60_bs_oracle"]
+    assert abs(r["audio_T60_bs_hip"] - r["audio_T60_bs_oracle"]) <= 0.20 * r["audio_T60_bs_oracle"]      # see the single-process test
     for k in ("rgb_loss", "interlevel_loss", "distortion_loss", "audio_sc_loss", "audio_mag_loss"):
         x, y = r[f"{k}_tail_hip"], r[f"{k}_tail_oracle"]
         assert abs(x - y) <= 0.15 * abs(y) + 1e-6, (k, x, y)
