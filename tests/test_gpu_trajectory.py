@@ -69,7 +69,10 @@ def test_training_trajectory_matches_the_oracle(golden, scenario):
     assert abs(r["psnr_hip_vs_gt_db"] - r["psnr_oracle_vs_gt_db"]) <= TOL[scenario][1]
     assert r["stft_bs_rel_l2_hip_vs_oracle"] <= 5e-2
     assert abs(r["stft_bs_rel_l2_hip_vs_gt"] - r["stft_bs_rel_l2_oracle_vs_gt"]) <= 3e-2
-    assert abs(r["audio_T60_bs_hip"] - r["audio_T60_bs_oracle"]) <= 0.20 * r["audio_T60_bs_oracle"]      # see the single-process test      # T60 error in percent (RAFEvaluator)
+    # T60 error in percent (RAFEvaluator), ~640 % on both sides after 100 iterations: a Schroeder fit on a decay that is barely there
+    # yet, the most sensitive number of the comparison.  Seven runs of the final build: 1.0 / 1.3 / 1.7 / 2.0 / 5.9 % of the oracle's
+    # value and one at 13 % (whose STFT rel-L2 against the oracle was 1.2e-2 -- still well inside the 5e-2 gate above): 20 %
+    assert abs(r["audio_T60_bs_hip"] - r["audio_T60_bs_oracle"]) <= 0.20 * r["audio_T60_bs_oracle"]
     assert abs(r["audio_EDT_bs_hip"] - r["audio_EDT_bs_oracle"]) <= 0.05 * r["audio_EDT_bs_oracle"]      # seconds
     assert abs(r["audio_C50_bs_hip"] - r["audio_C50_bs_oracle"]) <= 0.5                                    # dB
     assert np.isfinite(r["stft_rel_l2_hip_vs_oracle"]) and r["stft_rel_l2_hip_vs_oracle"] <= 1.0        # eval branch: reported (docstring)
