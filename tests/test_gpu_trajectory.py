@@ -48,7 +48,9 @@ pytestmark = pytest.mark.gpu
 # per scenario: (min PSNR(HIP, oracle) dB, max |PSNR(HIP, GT) - PSNR(oracle, GT)| dB).  With the camera optimizer on, Adam random-walks
 # twelve pose deltas on the sign of near-zero photometric gradients: the fp16-rounded oracle itself lands 0.23 dB from the fp32 one on
 # the held-out view (35.0 dB between their images), the HIP run 0.6 dB -- the bound is 1 dB there.
-TOL = {"g7_trajectory": (33.0, 0.3), "g8_trajectory_pose": (32.0, 1.0)}
+# Measured on the final build of round 3 (a dozen runs): G7 33.7-34.5 dB between the images, G8 35.9-36.7 dB; the trajectory is chaotic
+# beyond ~100 audio iterations (order of the BatchNorm-statistic atomics), hence a dB of margin under the lowest run.
+TOL = {"g7_trajectory": (32.5, 0.3), "g8_trajectory_pose": (32.0, 1.0)}
 
 
 @pytest.mark.parametrize("scenario", ["g7_trajectory", "g8_trajectory_pose"])
