@@ -8,6 +8,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("steps", type=int, nargs="?", default=3000); ap.add_argument("--no-growth", action="store_true")
 ap.add_argument("--every", type=int, default=250); ap.add_argument("--no-audio", action="store_true")
 ap.add_argument("--camera-opt", action="store_true", help="scenario G8: camera optimizer SO3xR3 on")
+ap.add_argument("--rays", type=int, default=0); ap.add_argument("--start-audio", type=int, default=-1)
+ap.add_argument("--full-size", action="store_true", help="the bench's shapes on this scene: 4096 rays + 2048 RIR slices per iteration, 128^3 grid, audio branch from iteration 2000 (the reference's start_step_audio)")
 ap.add_argument("--debug-from", type=int, default=-1, help="from this iteration on: report the first iterations whose GradScaler scale drops, with the non-finite gradients")
 a = ap.parse_args()
 import numpy as np, torch
@@ -17,6 +19,12 @@ from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
 from neraf_amd.pipeline import NeRAFPipeline
 from neraf_amd.vision import NeRAFVisionModel, RayBundle
 dev = torch.device("cuda:0"); cfg = TC.CFG; T = TC.T
+if a.full_size:
+    cfg.update(R=4096, B=2048, grid_step=1 / 128, start_step_audio=2000)      # in place: trajectory_common's helpers read this dict
+if a.rays:
+    cfg.update(R=a.rays)
+if a.start_audio >= 0:
+    cfg.update(start_step_audio=a.start_audio)
 if a.camera_opt:
     vm = Cfg.NeRAFVisionModelConfig(camera_optimizer=Cfg.CameraOptimizerConfig(mode="SO3xR3")).setup(
         scene_box=Cfg.SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), num_train_data=cfg["n_cam"], metadata={}, device=dev, grad_scaler=None, seed_points=None)
