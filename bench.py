@@ -2,6 +2,7 @@
 """NeRAF hot-path benchmark on MI355X (contract: see the task brief / DESIGN.md "Measurement").
 
     python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--dataset raf|soundspaces] [--rays R --slices B]
+    python bench.py --mode eval [--steps K --warmup W --rirs M]         (BASELINE configs[4]: full eval render, see EvalRender)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 A *step* is one pass of NeRAFPipeline.get_train_loss_dict (NeRAF_pipeline.py:166-222) + backward + optimizer steps over one
@@ -56,6 +57,13 @@ def parse():
     ap.add_argument("--plain", action="store_true",
                     help="priming + warm-up + timed steps only (no second regime, no instrumented replay, no CPU baseline): the form that "
                          "runs under rocprofv3, so that its per-kernel totals divide by exactly PRIME_STEPS + warmup + steps")
+    ap.add_argument("--mode", choices=("train", "eval"), default="train",
+                    help="train (default): the joint training step, BASELINE's metric; eval: the no-grad eval render of configs[4] -- a step is "
+                         "one 684x1024 frame through get_outputs_for_camera (22 chunks of 32768 rays) + --rirs RIRs through the audio eval branch")
+    ap.add_argument("--rirs", type=int, default=32, help="eval mode: RIRs evaluated per step (one get_outputs_for_camera call each)")
+    ap.add_argument("--rotate", type=int, default=16,
+                    help="train mode: number of DISTINCT resident ray / slice batches the steps cycle through (1 = the same batch every step)")
+    ap.add_argument("--no-eval-line", action="store_true", help="train mode: skip the short eval-render measurement (key eval_render)")
     ap.add_argument("--dataset", choices=("raf", "soundspaces"), default="raf",
                     help="audio head shape: raf = 1 x 513 bins, T = 60 (BASELINE configs[1..2], the default and the metric's config); "
                          "soundspaces = 2 x 257 bins, T = 101 (configs[3]: globally 32768 rays + 6464 slices, i.e. per GPU 4096 + 808)")
@@ -97,7 +105,7 @@ class JointStep:
 
     ``R`` / ``B`` are THIS rank's rays / slices; ``tag_rank`` selects which synthetic shard it holds."""
 
-    def __init__(self, dev, R, B, world, dataset="raf", start_step=20000, camera_opt=True):
+    def __init__(self, dev, R, B, world, dataset="raf", start_step=20000, camera_opt=True, rotate=16):
         import torch
         from neraf_amd import synth
         from neraf_amd.config import NeRAFVisionModelConfig, CameraOptimizerConfig, SceneBox
@@ -121,21 +129,26 @@ class JointStep:
         self.am.resnet3d.backbone_net.load_state_dict({k: T(v) for k, v in synth.resnet3d_state_dict(7).items()})
         self.am.to(dev)
         self.vm.train(); self.am.train()
-        rb = synth.ray_batch(R, tag=f"bench.rays.r{rank}")
-        self.bundle = RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev))
-        self.batch = {k: T(v).to(dev) for k, v in synth.audio_batch(B, C_, F_, T_, tag=f"bench.r{rank}").items()}
-        self.gt = {"image": T(rb["rgb"]).to(dev)}
+        # `rotate` DISTINCT resident batches, cycled step by step: the reference draws a fresh ray batch and fresh slices every step
+        # (NeRAF_pipeline.py:175, :187), so consecutive steps gather other hash-table rows and scatter into other gradient rows.
+        # Batch k of rank r is a pure function of (k, r): tags "bench.rays.r{r}[.k]" / "bench.r{r}[.k]" (k = 0 keeps the round-3 tags).
+        bundles, gts, batches = [], [], []
+        for k in range(max(int(rotate), 1)):
+            sfx = "" if k == 0 else f".{k}"
+            rb = synth.ray_batch(R, tag=f"bench.rays.r{rank}{sfx}")
+            bundles.append(RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev)))
+            gts.append({"image": T(rb["rgb"]).to(dev)})
+            batches.append({kk: T(v).to(dev) for kk, v in synth.audio_batch(B, C_, F_, T_, tag=f"bench.r{rank}{sfx}").items()})
+        self.bundle, self.gt, self.batch = bundles[0], gts[0], batches[0]
         # the reference's pipeline object: get_train_loss_dict (NeRAF_pipeline.py:166-222) inside Trainer.train_iteration, with its
         # parameter groups / optimizers / schedulers (NeRAF_config.py:115-132; the field parameters are in "fields" AND
         # "audio_fields", :487)
-        from neraf_amd.pipeline import FixedBatchDataManager, NeRAFPipeline
-        self.pipe = NeRAFPipeline(self.vm, self.am, datamanager=FixedBatchDataManager(self.bundle, self.gt, R),
-                                  audio_datamanager=FixedBatchDataManager(None, self.batch), start_step_audio=2000, world_size=world,
-                                  local_rank=rank)
-        if os.environ.get("NERAF_OVERLAP") is not None:          # experiment knob (tools/gpu_overlap_ab.sh); the default is the pipeline's
-            self.pipe.overlap_radiance = os.environ["NERAF_OVERLAP"] in ("1", "2")
-            self.pipe.overlap_loss_late = os.environ["NERAF_OVERLAP"] == "2"
-            self.pipe.side_cu_mask = int(os.environ.get("NERAF_SIDE_CUS", "0"))
+        from neraf_amd.datamanagers import RotatingBatchDataManager
+        from neraf_amd.pipeline import NeRAFPipeline
+        self.dm = RotatingBatchDataManager(bundles, gts, R)
+        self.adm = RotatingBatchDataManager([None] * len(batches), batches)
+        self.pipe = NeRAFPipeline(self.vm, self.am, datamanager=self.dm, audio_datamanager=self.adm, start_step_audio=2000,
+                                  world_size=world, local_rank=rank)
         self.opt_wrapper, self.scaler = self.pipe.make_optimizers(init_scale=65536.0, with_schedulers=True)
         self.optimizers = self.opt_wrapper.steppers
         if world > 1:
@@ -147,10 +160,227 @@ class JointStep:
     def samples_per_step(self):
         return self.R + self.B * C_ * F_
 
+    def pin_batch(self, i):
+        """None: rotate through the resident batches (default); i: serve batch i every step (the round-3 fixed-batch form)."""
+        self.dm.pin(i)
+        self.adm.pin(i)
+
     def step(self):
         self.i += 1
         loss, _ = self.pipe.train_iteration(self.i, self.opt_wrapper, self.scaler)
         return loss
+
+
+class EvalRender:
+    """BASELINE configs[4] ("full eval render") on one GPU: what NeRAFPipeline.get_average_eval_image_metrics (NeRAF_pipeline.py:291-436)
+    runs per eval item, without the metric code around it.  One STEP =
+      * one 684 x 1024 RAF frame (data/RAF/*/transforms.json: 700,416 rays) through NeRAFVisionModel.get_outputs_for_camera(camera, None,
+        eval=True) (NeRAF_model.py:70-79): camera -> rays -> 22 chunks of 32,768 rays (NeRAF_config.py:95), each chunk sampler -> proposal
+        density x2 -> PDF resampling x2 -> fused field query -> composite, no grad, mean appearance embedding, rgb clipped;
+      * `rirs` RIRs through NeRAFAudioModel.get_outputs_for_camera(None, None, batch_audio) (NeRAF_model.py:648-728), one call each as the
+        reference's loop does (:355-362): T time queries -> prologue -> NAcF MLP -> [T,C,F] log-magnitudes + the per-channel panels,
+        with the ResNet3D scene feature computed ONCE and cached (the grid is static in eval; the reference recomputes it per RIR).
+    ``batched_rirs`` evaluates N RIRs as ONE N*T-row field call (NeRAFAudioModel.get_outputs_for_rirs) -- the engine-native form."""
+
+    def __init__(self, dev, dataset="raf", n_cams=4, n_items=64):
+        import torch
+        from neraf_amd import synth
+        from neraf_amd.config import NeRAFVisionModelConfig, CameraOptimizerConfig, SceneBox
+        from neraf_amd.datamanagers import synthetic_cameras
+        from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
+        self.dev = dev
+        rank = int(os.environ.get("RANK", "0"))
+        vcfg = NeRAFVisionModelConfig(camera_optimizer=CameraOptimizerConfig(mode="SO3xR3"))
+        self.vm = vcfg.setup(scene_box=SceneBox(torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])), num_train_data=210, metadata={},
+                             device=dev, grad_scaler=None, seed_points=None).to(dev)
+        with torch.no_grad():      # trained-like table magnitudes (synthetic, the training bench's)
+            g = torch.Generator(device="cpu").manual_seed(0)
+            for p in [self.vm.field.module.table] + [pn.table for pn in self.vm.proposal_networks]:
+                p.copy_((torch.rand(p.shape, generator=g) - 0.5).to(dev))
+        cfg = (NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 128) if dataset == "raf" else
+               NeRAFAudioModelConfig(dataset="SoundSpaces", grid_step=1 / 128, max_len=T_, N_freq_stft=F_))
+        self.am = NeRAFAudioModel(cfg, T(synth.audio_aabb()))
+        self.am.field.load_state_dict({k: T(v) for k, v in synth.nacf_state_dict(1187, 512, C_, F_).items()})
+        self.am.resnet3d.backbone_net.load_state_dict({k: T(v) for k, v in synth.resnet3d_state_dict(7).items()})
+        self.am.to(dev)
+        self.vm.eval(); self.am.eval()
+        self.cams = synthetic_cameras(n_cams, tag=f"bench.eval.cams.r{rank}").to(dev)       # RAF intrinsics incl. OPENCV distortion
+        self.H, self.W = self.cams.height, self.cams.width
+        ab = synth.audio_batch(n_items, C_, F_, T_, tag=f"bench.eval.r{rank}", outside_frac=0.0)
+        gt = T(synth.uniform(f"bench.eval.gt.r{rank}", (C_, F_, T_), -6.0, 1.0)).to(dev)       # eval item layout [C,F,T] (NeRAF_dataset.py:180-181)
+        self.items = [{"mic_pose": T(ab["mic_pose"][i]).to(dev), "source_pose": T(ab["source_pose"][i]).to(dev),
+                       "rot": T(ab["rot"][i]).to(dev), "data": gt} for i in range(n_items)]
+        self.mic = T(ab["mic_pose"]).to(dev)
+        self.src = T(ab["source_pose"]).to(dev)
+        self.rot = T(ab["rot"]).to(dev)
+        self.i = 0
+
+    rays_per_frame = property(lambda self: self.H * self.W)
+    bins_per_rir = property(lambda self: T_ * C_ * F_)
+
+    def frame(self, k=None):
+        k = self.i if k is None else k
+        return self.vm.get_outputs_for_camera(self.cams[k % self.cams.size], None, eval=True)
+
+    def rir(self, k):
+        return self.am.get_outputs_for_camera(None, None, batch_audio=self.items[k % len(self.items)])
+
+    def step(self, rirs):
+        out = self.frame()
+        for j in range(rirs):
+            self.rir(self.i * rirs + j)
+        self.i += 1
+        return out
+
+    def batched_rirs(self, n):
+        idx = [(k % len(self.items)) for k in range(n)]
+        return self.am.get_outputs_for_rirs(self.mic[idx], self.src[idx], self.rot[idx])
+
+
+def eval_cpu_baseline(n_rays=4096):
+    """The CPU oracle's eval forward on this host, bounded: `n_rays` rays strided over one 684x1024 frame through the eval-mode
+    nerfacto forward (no jitter, mean embedding), ONE RIR (T rows) through the prologue + NAcF with the feature given, and the
+    ResNet3D eval forward (BatchNorm on running statistics) once -- the reference recomputes that per RIR (NeRAF_model.py:680-684)."""
+    import torch
+    from neraf_amd import synth
+    from neraf_amd.datamanagers import synthetic_cameras
+    from oracle import audio as O
+    from oracle import vision as V
+    ncores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(ncores)
+    spec = V.NerfactoSpec()
+    tot = (spec.prop_grids[0].total, spec.prop_grids[1].total, spec.main_grid.total)
+    P = {k: T(v) for k, v in synth.vision_params(tot, num_train_data=210, table_scale=0.5).items()}
+    sdn = {k: T(v) for k, v in synth.nacf_state_dict(1187, 512, C_, F_).items()}
+    sdr = {k: T(v) for k, v in synth.resnet3d_state_dict(7).items()}
+    aabb = T(synth.audio_aabb())
+    cam = synthetic_cameras(1, tag="bench.eval.cams.r0")
+    rb = cam.generate_rays(0)
+    n = len(rb)
+    idx = torch.arange(0, n, max(n // n_rays, 1))[:n_rays]
+
+    def once(fn):
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
+
+    def render(ix):
+        with torch.no_grad():
+            V.nerfacto_forward(rb.origins[ix], rb.directions[ix], rb.camera_indices[ix, 0], P, spec, training=False)
+    render(idx[:64])
+    t_rays = once(lambda: render(idx))
+    grid = O.reset_grid(1 / 128)
+    box = {}
+
+    def resnet():
+        with torch.no_grad():
+            box["feat"] = O.resnet3d_forward(grid.unsqueeze(0), sdr, train=False).flatten()
+    t_resnet = once(resnet)
+    ab = synth.audio_batch(1, C_, F_, T_, tag="bench.eval.r0", outside_frac=0.0)
+    one = {"time_query": torch.arange(T_), "mic_pose": T(ab["mic_pose"]).expand(T_, 3), "source_pose": T(ab["source_pose"]).expand(T_, 3),
+           "rot": T(ab["rot"]).expand(T_, 3)}
+
+    def rir():
+        with torch.no_grad():
+            O.audio_get_outputs(one, box["feat"], sdn, aabb, T_)
+    rir()
+    t_rir = once(rir)
+    bins = T_ * C_ * F_
+    frame_s = t_rays * n / len(idx)
+    return {"value": (n + bins) / (frame_s + t_rir), "unit": "field-samples/s", "cores": ncores, "kind": "port",
+            "rays_per_s": len(idx) / t_rays, "bins_per_s_cached_feature": bins / t_rir, "bins_per_s_resnet_per_rir": bins / (t_rir + t_resnet),
+            "seconds": {"rays_sample": round(t_rays, 3), "resnet3d_eval_fwd": round(t_resnet, 3), "one_rir": round(t_rir, 4)},
+            "sample": ("%d rays strided over one 684x1024 frame through the oracle's eval-mode nerfacto forward (1 warm-up at 64 rays + 1 timed), "
+                       "one RIR = %d time queries through prologue + NAcF (1 warm-up + 1 timed) with the scene feature given, the ResNet3D eval "
+                       "forward on 7x128^3 once; value = (frame rays + one RIR's bins) / (rays time scaled to the %d-ray frame + one RIR, cached "
+                       "feature); torch-CPU fp32 oracle, %d threads") % (len(idx), T_, n, ncores)}
+
+
+def _prof_families(lib, h, local, nprof, ref_rows):
+    """Per-kernel-family records of the library's event profiler (neraf_prof_enable) after `nprof` instrumented steps."""
+    from neraf_amd import _lib
+    fams = []
+    kid = 0
+    while lib.neraf_prof_kernel_name(kid):
+        ms, n, w, ex = C.c_double(), C.c_int(), C.c_double(), C.c_double()
+        _lib.check(lib.neraf_prof_summary_ex(h, kid, C.byref(ms), C.byref(n), C.byref(w), C.byref(ex)), local)
+        if n.value:
+            name = lib.neraf_prof_kernel_name(kid).decode()
+            is_bytes = kid in (2, 3, 5, 6, 7)     # gather / scatter kernels are priced in bytes against HBM (ids: csrc/common.h PROF_*)
+            peak = HBM_PEAK_GBS if is_bytes else MFMA_PEAK_TFLOPS
+            rate = w.value / (ms.value * 1e-3) / (1e9 if is_bytes else 1e12) if ms.value > 0 else 0.0
+            fam = {"kernel": name, "bound": "hbm" if is_bytes else "mfma", "launches_per_step": n.value / nprof,
+                   "avg_us": ms.value * 1e3 / n.value, "ms_per_step": ms.value / nprof, "achieved": rate,
+                   "unit": "GB/s" if is_bytes else "TFLOP/s", "peak": peak, "frac": rate / peak, "work_per_launch": w.value / n.value,
+                   # SURVEY 8(d): `work` / `frac` are ALGORITHMIC (a conv, its dgrad and its wgrad = 2 dout^3 taps cin cout each, real
+                   # channels and taps); `executed` is what the grid multiplied (padded K / channels / voxel rows, zero-page taps)
+                   "executed_per_launch": ex.value / n.value, "executed_frac": (ex.value / (ms.value * 1e-3) / (1e9 if is_bytes else 1e12) / peak) if ms.value > 0 else 0.0,
+                   "work_per_step": w.value / nprof}
+            if ref_rows:
+                rx = _family_regex(name)
+                calls = sum(c for k, (c, _) in ref_rows.items() if rx.search(k))
+                tot = sum(t for k, (_, t) in ref_rows.items() if rx.search(k))
+                if calls:
+                    fam["rocprof_avg_us"] = tot / calls / 1e3
+                    fam["rocprof_frac"] = (w.value / n.value) / (tot / calls * 1e-9) / (1e9 if is_bytes else 1e12) / peak
+            fams.append(fam)
+        kid += 1
+    return fams
+
+
+GATHER_CEILING_GBS = 8600.0   # MI355X_MICROARCH.md "Indexed rows": 38 MB table, uniformly random rows served from the Infinity Cache
+
+
+def measure_eval(er, steps, warmup, rirs, lib, h, local, sync, full=True):
+    """Time `steps` eval steps (see EvalRender) after `warmup`; returns the measurement dict shared by `--mode eval` and the
+    `eval_render` key of the training line."""
+    import torch
+    for _ in range(max(warmup, 1)):
+        er.step(rirs)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        er.step(rirs)
+    sync()
+    el = time.perf_counter() - t0
+    # the two halves on their own (the reference reports them separately: num_rays_per_sec / fps, num_rays_per_sec_audio / fps_audio)
+    sync(); t1 = time.perf_counter()
+    for _ in range(steps):
+        er.frame()
+        er.i += 1
+    sync(); t_frames = time.perf_counter() - t1
+    n_r = max(steps * rirs, 8)
+    sync(); t2 = time.perf_counter()
+    for k in range(n_r):
+        er.rir(k)
+    sync(); t_rirs = time.perf_counter() - t2
+    nb = 32
+    er.batched_rirs(nb)
+    reps = max(steps, 4)
+    sync(); t3 = time.perf_counter()
+    for _ in range(reps):
+        er.batched_rirs(nb)
+    sync(); t_batched = time.perf_counter() - t3
+    rays, bins = er.rays_per_frame, er.bins_per_rir
+    out = {"ms_per_step": el / steps * 1e3, "value": (rays + rirs * bins) * steps / el,
+           "rays_per_s": rays * steps / t_frames, "fps": steps / t_frames, "ms_per_frame": t_frames / steps * 1e3,
+           "bins_per_s": bins * n_r / t_rirs, "fps_audio": n_r / t_rirs, "us_per_rir": t_rirs / n_r * 1e6,
+           "batched_rirs": {"rirs_per_call": nb, "rows_per_call": nb * T_, "bins_per_s": bins * nb * reps / t_batched,
+                            "rirs_per_s": nb * reps / t_batched, "us_per_rir": t_batched / (nb * reps) * 1e6,
+                            "note": "NeRAFAudioModel.get_outputs_for_rirs: N RIRs as one N*T-row field call (device tensor out, no per-RIR panels)"},
+           "rays_per_frame": rays, "chunks_per_frame": (rays + er.vm.eval_num_rays_per_chunk - 1) // er.vm.eval_num_rays_per_chunk,
+           "bins_per_rir": bins, "rirs_per_step": rirs}
+    if not full:
+        return out, None
+    # instrumented replay: per-kernel-family HIP-event durations over whole frames (and the RIRs of a step)
+    lib.neraf_prof_enable(h, 1)
+    nprof = min(steps, 4)
+    for _ in range(nprof):
+        er.step(rirs)
+    torch.cuda.synchronize()
+    fams = _prof_families(lib, h, local, nprof, {})
+    lib.neraf_prof_enable(h, 0)
+    return out, fams
 
 
 def _median(xs):
@@ -159,13 +389,13 @@ def _median(xs):
 
 
 def cpu_baseline(R, B):
-    """The CPU oracle (torch fp32; audio half pinned to the reference on G1-G5, radiance half unpinned) timed on this host, stage by
-    stage, for the stages the GPU step contains.  A complete CPU step is minutes, so each ray / cell / slice-proportional stage is
-    timed at TWO sample sizes (1/32 and 1/16 of the batch: 1 warm-up + 2-3 timed runs each, median) and extrapolated linearly to the
-    full batch -- t(N) = t(n2) + (t(n2) - t(n1)) / (n2 - n1) * (N - n2) -- which keeps the per-step fixed costs (dense hash-table
-    gradients, Adam over 13 M radiance parameters) counted once instead of multiplied by the sampling ratio; the per-step-constant
-    ResNet3D forward + backward runs on the full 7 x 128^3 grid.  Forward-only and forward+backward are reported separately, rays/s and
-    bins/s separately (the promised 3 + 10 repetitions do not fit the ~20 s budget of a default run)."""
+    """The CPU oracle (torch fp32; audio half pinned to the reference on G1-G5, radiance half unpinned) timed on this host: ONE
+    complete step at the FULL batch -- every stage the GPU step contains, at its full size, forward + backward + torch Adam -- timed
+    stage by stage, once each, after a warm-up of the same code path at 1/64 of the batch (thread-pool start-up, first-touch
+    allocations; the per-step-constant ResNet3D forward + backward has no smaller size and is run twice, second run timed).  No
+    extrapolation.  A full step is ~17 s on 64 threads, so SURVEY 8(d)'s 3 warm-up + >= 10 timed steps (~4 minutes) do not fit the
+    ~20 s of host time a default run may spend here; `sample` says exactly what was timed.  Forward-only figures come from a
+    second, no-grad pass of the same stages."""
     import torch
     from neraf_amd import synth
     from oracle import audio as O
@@ -184,15 +414,10 @@ def cpu_baseline(R, B):
     opt_v = torch.optim.Adam([v for v in P.values()], lr=1e-2, eps=1e-15)
     opt_a = torch.optim.Adam(list(sdn.values()) + [v for v in sdr.values() if v.requires_grad], lr=1e-4, eps=1e-15)
 
-    def timed(fn, reps, warm=True):
-        if warm:
-            fn()
-        ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            fn()
-            ts.append(time.perf_counter() - t0)
-        return _median(ts)
+    def once(fn):
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
 
     def vision(n, train):
         rb = synth.ray_batch(n, tag="bench.rays.r0")
@@ -250,22 +475,15 @@ def cpu_baseline(R, B):
                     opt_a.step()
         return run
 
-    def extrapolated(make, n_full, reps):
-        n1, n2 = max(n_full // 32, 8), max(n_full // 16, 16)
-        out = {}
-        for train in (False, True):
-            t1, t2 = timed(make(n1, train), reps), timed(make(n2, train), reps, warm=False)
-            slope = max((t2 - t1) / (n2 - n1), 0.0)
-            out["train" if train else "fwd"] = t2 + slope * (n_full - n2)
-        return out, (n1, n2)
-
     t = {}
-    v, nv = extrapolated(vision, R, 3)
-    rf, nr = extrapolated(refresh, R, 3)
-    t["resnet3d_fwd"], t["resnet3d_train"] = timed(resnet(False), 3), timed(resnet(True), 3)
-    au, na = extrapolated(audio, B, 5)
-    t.update({"vision_fwd": v["fwd"], "vision_train": v["train"], "refresh_fwd": rf["fwd"], "refresh_train": rf["train"],
-              "audio_fwd": au["fwd"], "audio_train": au["train"]})
+    for name, make, n_full in (("vision", vision, R), ("refresh", refresh, R), ("audio", audio, B)):
+        if name == "audio":      # the NAcF stage consumes the feature: the ResNet3D comes first, as in the step
+            resnet(True)()                                           # warm-up (first-touch of 87 M activation elements + autograd graph)
+            t["resnet3d_train"] = once(resnet(True))
+            t["resnet3d_fwd"] = once(resnet(False))
+        make(max(n_full // 64, 8), True)()                           # warm-up of this stage's code path
+        t[name + "_train"] = once(make(n_full, True))
+        t[name + "_fwd"] = once(make(n_full, False))
     step_train = t["vision_train"] + t["refresh_train"] + t["resnet3d_train"] + t["audio_train"]
     step_fwd = t["vision_fwd"] + t["refresh_fwd"] + t["resnet3d_fwd"] + t["audio_fwd"]
     bins = B * C_ * F_
@@ -274,12 +492,14 @@ def cpu_baseline(R, B):
             "bins_per_s_train": bins / (t["resnet3d_train"] + t["audio_train"]), "bins_per_s_fwd": bins / (t["resnet3d_fwd"] + t["audio_fwd"]),
             "field_samples_per_s_fwd": (R + bins) / step_fwd,
             "stage_seconds_full_step": {k: round(v_, 3) for k, v_ in t.items()},
-            "sample": ("per stage 1 warm-up (at the smaller sample) + 3 timed runs per sample size (5 for the NAcF stage), median; radiance step at %d and %d rays, grid refresh at %d and %d cells x 18 "
-                       "directions, NAcF + STFT loss at %d and %d slices, each extrapolated linearly to the full batch (%d rays / cells, %d "
-                       "slices); ResNet3D forward + backward on the full 7x128^3 grid; train = forward + backward + torch Adam (radiance "
-                       "parameters lr 1e-2; NAcF + ResNet3D lr 1e-4); the refresh backward uses a unit upstream gradient; extrapolated full "
-                       "step %.1f s train / %.1f s forward; torch-CPU fp32 oracle, %d threads")
-                      % (nv[0], nv[1], nr[0], nr[1], na[0], na[1], R, B, step_train, step_fwd, ncores)}
+            "extrapolated": False,
+            "sample": ("ONE full-batch step, every stage timed once at its full size after a warm-up of the same code path at 1/64 of the "
+                       "batch (ResNet3D: run twice, second timed): radiance step at %d rays (sampler, 2 proposal nets, field, composite, "
+                       "3 losses, backward, torch Adam lr 1e-2), grid refresh at %d cells x 18 directions (forward + backward with a unit "
+                       "upstream gradient), ResNet3D forward + backward on the full 7x128^3 grid, NAcF + STFT loss at %d slices (forward + "
+                       "backward + torch Adam lr 1e-4 over NAcF + ResNet3D); forward-only figures from a second no-grad pass; measured "
+                       "full step %.1f s train / %.1f s forward; torch-CPU fp32 oracle, %d threads; SURVEY 8(d)'s 3 + 10 repetitions "
+                       "would take ~4 minutes") % (R, R, B, step_train, step_fwd, ncores)}
 
 
 def trajectory_parity(dev):
@@ -353,6 +573,111 @@ def _family_regex(pattern: str):
     return re.compile("(?:" + "|".join(alts) + ")")
 
 
+def run_eval_mode(a, dev, rank, local, world):
+    """`bench.py --mode eval`: BASELINE configs[4] (full eval render) as a throughput line -- see EvalRender for what a step is.
+    N > 1: frames and RIRs are independent, every rank renders its own (the pipeline deals eval items round-robin, SURVEY 8e "Eval"):
+    no collective in the loop, weak scaling."""
+    import torch
+    from neraf_amd import _lib
+    lib = _lib.load()
+    h = _lib.ctx(local)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+    er = EvalRender(dev, dataset=a.dataset)
+    for _ in range(2):                       # plans, allocator pools, the cached ResNet3D feature
+        er.step(a.rirs)
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.freeze()
+    if a.plain:
+        for _ in range(a.warmup):
+            er.step(a.rirs)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            er.step(a.rirs)
+        sync()
+        el = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({"metric": "field-samples/sec (rays + RIR STFT bins), eval render", "mode": "eval", "plain": True,
+                              "value": (er.rays_per_frame + a.rirs * er.bins_per_rir) * a.steps * world / el, "unit": "field-samples/s",
+                              "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+                              "steps_executed_in_process": 2 + a.warmup + a.steps, "rirs_per_step": a.rirs}))
+        return
+    m, fams = measure_eval(er, a.steps, a.warmup, a.rirs, lib, h, local, sync)
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([m["ms_per_step"]], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        m["ms_per_step"] = float(tt.item())
+        m["value"] = (er.rays_per_frame + a.rirs * er.bins_per_rir) * world / (m["ms_per_step"] * 1e-3)
+    if rank != 0:
+        return
+    import glob
+    pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_eval_pmc_traffic.json")))
+    pmc = json.load(open(pmc_files[-1]))["families"] if pmc_files and a.dataset == "raf" and world == 1 else {}
+    ref = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_eval_kernel_stats.csv")))
+    ref_rows = {}
+    if ref:
+        import csv
+        with open(ref[-1]) as f:
+            for r in csv.DictReader(f):
+                ref_rows[r["Name"]] = (int(r["Calls"]), float(r["TotalDurationNs"]))
+    for k in fams:
+        t = pmc.get(k["kernel"])
+        k["traffic"] = t["hbm_bytes_per_launch"] if t else None
+        if k["bound"] == "hbm":
+            k["frac_of_gather_ceiling"] = k["achieved"] / GATHER_CEILING_GBS
+        rx = _family_regex(k["kernel"])
+        calls = sum(c for n_, (c, _) in ref_rows.items() if rx.search(n_))
+        tot = sum(t_ for n_, (_, t_) in ref_rows.items() if rx.search(n_))
+        if calls:
+            k["rocprof_avg_us"] = tot / calls / 1e3
+    out = {"metric": "field-samples/sec (rays + RIR STFT bins), eval render", "mode": "eval",
+           "value": m["value"], "unit": "field-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+           "data": "synthetic",
+           "rays_per_s": m["rays_per_s"] * world, "fps": m["fps"] * world, "bins_per_s": m["bins_per_s"] * world,
+           "fps_audio": m["fps_audio"] * world, "ms_per_frame": m["ms_per_frame"], "us_per_rir": m["us_per_rir"],
+           "batched_rirs": m["batched_rirs"],
+           "config": {"workload": ("BASELINE configs[4] (full eval render) per GPU, no grad: a step = one 684x1024 RAF frame (700,416 rays) through "
+                                   "NeRAFVisionModel.get_outputs_for_camera(camera, None, eval=True) -- OPENCV camera -> rays -> %d chunks of 32,768 "
+                                   "(sampler, 2 proposal nets, 2 PDF resamplings, fused field query with the mean appearance embedding, "
+                                   "composite) -> [H,W,.] images, rgb clipped -- plus %d RIRs through NeRAFAudioModel.get_outputs_for_camera(None, "
+                                   "None, batch_audio), one call each (T = %d time queries -> prologue -> NAcF MLP -> [T,%d,%d] + the "
+                                   "per-channel panels copied to the host as the reference builds them), ResNet3D scene feature cached (static "
+                                   "grid).  rays_per_s / bins_per_s time each half alone (the reference's num_rays_per_sec / "
+                                   "num_rays_per_sec_audio, NeRAF_pipeline.py:341-344, :384-387, without its metric code).  Random-init "
+                                   "weights, trained-like hash-table magnitudes; cameras with the RAF intrinsics incl. distortion.")
+                                  % (m["chunks_per_frame"], a.rirs, T_, C_, F_),
+                      "rays_per_frame": m["rays_per_frame"], "rirs_per_step": a.rirs, "bins_per_rir": m["bins_per_rir"],
+                      "parallelism": f"dp{world} (eval items dealt round-robin, no collective)"}}
+    if fams:
+        dom = max(fams, key=lambda k: k["ms_per_step"])
+        fq = next((k for k in fams if k["kernel"].startswith("field_query_kernel")), None)
+        out["roofline"] = {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
+                           "frac": dom["frac"], "traffic": dom.get("traffic"),
+                           "frac_of_gather_ceiling": dom.get("frac_of_gather_ceiling"), "gather_ceiling_gbs": GATHER_CEILING_GBS,
+                           "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
+                           "algorithmic_work_per_launch": dom["work_per_launch"],
+                           "selection": "family with the largest share of the eval step among the instrumented families",
+                           "durations": "HIP events on the launch stream, as recorded",
+                           "traffic_source": os.path.basename(pmc_files[-1]) if pmc and dom.get("traffic") is not None else None,
+                           "rocprof_reference": os.path.basename(ref[-1]) if ref else None,
+                           "field_query_inference": fq,
+                           "algorithmic_bytes": "proposal density: samples x 5 levels x 8 corners x 4 B = 160 B/sample (352 samples/ray); "
+                                                "field query: samples x 16 x 8 x 4 B = 512 B/sample (48 samples/ray) -- SURVEY 8(d): 80,896 B/ray",
+                           "all_kernel_families": fams}
+    if not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = eval_cpu_baseline()
+    print(json.dumps(out))
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -394,7 +719,13 @@ def main():
     else:
         R_local, B_local = a.rays, a.slices
         R_global, B_global = a.rays * world, a.slices * world
-    st = JointStep(dev, R_local, B_local, world, dataset=a.dataset)
+    if a.mode == "eval":
+        run_eval_mode(a, dev, rank, local, world)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+    st = JointStep(dev, R_local, B_local, world, dataset=a.dataset, rotate=a.rotate)
     # Setup, before the W warm-up steps: the first steps of a run build the optimizer launch plans (the step with the first
     # proposal-network update builds a second one), capture the ResNet3D hipGraphs and grow the allocator pools --
     # tools/step_trace.py shows them as 10-400 ms steps -- and a full Python garbage collection over the module graph costs
@@ -444,6 +775,18 @@ def main():
             dist.destroy_process_group()
         return
 
+    # ---- the round-3 form of the same step, for the record: ONE resident batch served every step (identical hash-table rows and
+    # scatter targets each step) -- two windows alternated with two rotating ones, so that clock drift does not read as a difference
+    fixed_ms, rot_ms = [], []
+    if a.rotate > 1:
+        for _ in range(2):
+            st.pin_batch(0)
+            st.step()
+            fixed_ms.append(timed_steps(a.steps) / a.steps * 1e3)
+            st.pin_batch(None)
+            st.step()
+            rot_ms.append(timed_steps(a.steps) / a.steps * 1e3)
+
     # ---- the other proposal-update regime (not the headline value): the first 5000 iterations back-propagate through the proposal
     # networks on EVERY step (ProposalNetworkSampler's warm-up schedule); the steady state above does so every 6th step
     steady_i = st.i
@@ -480,34 +823,22 @@ def main():
         st.step()
     torch.cuda.synchronize()
     ref_name, ref_rows = _rocprof_reference()
-    fams = []
-    kid = 0
-    while lib.neraf_prof_kernel_name(kid):
-        ms, n, w, ex = C.c_double(), C.c_int(), C.c_double(), C.c_double()
-        _lib.check(lib.neraf_prof_summary_ex(h, kid, C.byref(ms), C.byref(n), C.byref(w), C.byref(ex)), local)
-        if n.value:
-            name = lib.neraf_prof_kernel_name(kid).decode()
-            is_bytes = kid in (2, 3, 5, 6, 7)     # gather / scatter kernels are priced in bytes against HBM (ids: csrc/common.h PROF_*)
-            peak = HBM_PEAK_GBS if is_bytes else MFMA_PEAK_TFLOPS
-            rate = w.value / (ms.value * 1e-3) / (1e9 if is_bytes else 1e12) if ms.value > 0 else 0.0
-            fam = {"kernel": name, "bound": "hbm" if is_bytes else "mfma", "launches_per_step": n.value / nprof,
-                   "avg_us": ms.value * 1e3 / n.value, "ms_per_step": ms.value / nprof, "achieved": rate,
-                   "unit": "GB/s" if is_bytes else "TFLOP/s", "peak": peak, "frac": rate / peak, "work_per_launch": w.value / n.value,
-                   # `work` / `frac` are ALGORITHMIC (a conv, its dgrad and its wgrad = 2 dout^3 taps cin cout each, real
-                   # channels and taps); `executed` is what the grid multiplied (padded K / channels / voxel rows, zero-page taps)
-                   "executed_per_launch": ex.value / n.value, "executed_frac": (ex.value / (ms.value * 1e-3) / (1e9 if is_bytes else 1e12) / peak) if ms.value > 0 else 0.0,
-                   "work_per_step": w.value / nprof}
-            if ref_rows:
-                rx = _family_regex(name)
-                calls = sum(c for k, (c, _) in ref_rows.items() if rx.search(k))
-                tot = sum(t for k, (_, t) in ref_rows.items() if rx.search(k))
-                if calls:
-                    fam["rocprof_avg_us"] = tot / calls / 1e3
-                    fam["rocprof_frac"] = (w.value / n.value) / (tot / calls * 1e-9) / (1e9 if is_bytes else 1e12) / peak
-            fams.append(fam)
-        kid += 1
+    fams = _prof_families(lib, h, local, nprof, ref_rows)
     lib.neraf_prof_enable(h, 0)
     sync()
+
+    eval_line = None
+    if not a.no_eval_line and world == 1 and a.dataset == "raf":
+        # configs[4] in short (the full line: `bench.py --mode eval`): 3 frames + 3 x 16 RIRs after one warm-up step
+        try:
+            er = EvalRender(dev, dataset=a.dataset)
+            eval_line, _ = measure_eval(er, 3, 1, 16, lib, h, local, sync, full=False)
+            eval_line["note"] = ("BASELINE configs[4] shape on one GPU, short form (3 steps of one 684x1024 frame in 22 chunks + 16 RIRs through "
+                                 "the eval branch with the cached scene feature); `bench.py --mode eval` prints the full line with roofline "
+                                 "and cpu_baseline (profiles/r04_eval_*)")
+            del er
+        except Exception as e:                          # a side measurement must not take the training line down
+            eval_line = {"error": repr(e)}
 
     if rank == 0:
         bins = B_global * C_ * F_
@@ -535,6 +866,12 @@ def main():
             "repeat_windows": {"n": len(repeat_ms), "steps_each": a.steps, "ms_per_step": [round(v, 4) for v in repeat_ms],
                                "median": _median(repeat_ms), "min": min(repeat_ms), "max": max(repeat_ms),
                                "note": "window 0 is the headline (value, ms_per_step); the others repeat it back to back"},
+            "ms_per_step_median": _median(repeat_ms), "ms_per_step_min": min(repeat_ms), "ms_per_step_max": max(repeat_ms),
+            "batches": {"distinct_resident_batches": a.rotate, "rotating_ms_per_step": rot_ms, "fixed_batch_ms_per_step": fixed_ms,
+                        "fixed_minus_rotating_ms": (sum(fixed_ms) / len(fixed_ms) - sum(rot_ms) / len(rot_ms)) if fixed_ms else None,
+                        "note": "the timed steps cycle through `distinct_resident_batches` different ray bundles / slice batches (the "
+                                "reference draws a fresh batch per step, NeRAF_pipeline.py:175, :187); fixed_batch = the round-3 form, "
+                                "batch 0 every step, in windows alternated with rotating ones"},
             "higher_is_better": True,
             "scaling": a.scaling,
             "vs_baseline": None,
@@ -561,10 +898,12 @@ def main():
                              "(lr 1e-4 -> 1e-8, 2000 warm-up), as NeRAF_pipeline.py:487 / NeRAF_config.py:115-132 group and schedule them -> "
                              "scheduler steps; the camera optimizer (SO3xR3, NeRAF_config.py:97) is on: pose deltas applied to the ray bundle, "
                              "their photometric + regulariser gradients computed, camera_opt Adam group stepped (lr 1e-3 -> 1e-4 @5k).  "
-                             "Not inside: data loading (batches are resident).")
-                             % (R_local, B_local, 4096, ", sharded over the ranks" if world > 1 else "", "RCCL all-reduce -> " if world > 1 else ""),
+                             "The steps cycle through %d distinct resident batches.  Not inside: data loading (batches are resident).")
+                             % (R_local, B_local, 4096, ", sharded over the ranks" if world > 1 else "", "RCCL all-reduce -> " if world > 1 else "",
+                                a.rotate),
                 "rays_per_gpu": R_local, "slices_per_gpu": B_local, "global_rays": R_global, "global_slices": B_global,
-                "parallelism": f"dp{world}",
+                "parallelism": f"dp{world}", "distinct_resident_batches": a.rotate,
+                "repeat_windows_ms_per_step": {"n": len(repeat_ms), "median": _median(repeat_ms), "min": min(repeat_ms), "max": max(repeat_ms)},
             },
         }
         if dom:
@@ -591,6 +930,8 @@ def main():
         g_cap, g_launch = C.c_int(), C.c_int()
         out["hip_graphs"] = {"enabled": bool(lib.neraf_graph_stats(h, C.byref(g_cap), C.byref(g_launch))), "captures": g_cap.value,
                              "launches": g_launch.value}
+        if eval_line is not None:
+            out["eval_render"] = eval_line
         if not a.no_parity and world == 1:
             try:
                 out["parity"] = trajectory_parity(dev)

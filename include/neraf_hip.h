@@ -405,6 +405,16 @@ int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_real, int co
  * d origins_out / d dirs_out (rows g_stride floats apart: 3 = two [R,3] arrays, 6 = the halves of neraf_field_backward_rays' [R,6]
  * d_rays; both NULL = regulariser only).
  * ---------------------------------------------------------------------------------- */
+/* Camera -> ray bundle (nerfstudio Cameras.generate_rays as Model.get_outputs_for_camera calls it, NeRAF_model.py:70-79 [NS-recall]):
+ * c2w fp32 [n_cams,3,4] (OpenGL camera frame), fx / fy / cx / cy fp32 [n_cams] each, distortion fp32 [n_cams,6] =
+ * (k1,k2,k3,k4,p1,p2) or NULL.  Ray i belongs to camera cam_idx[i] (int64, as nerfstudio's RayBundle.camera_indices) or, with
+ * cam_idx NULL, to camera cam_single; its pixel is coords[i] = (row, col) fp32 or, with coords NULL, the centre of pixel i of a
+ * `width`-wide image in row-major order (a whole frame: R = height * width).  Writes origins / dirs fp32 [R,3] (unit directions)
+ * and, when cam_out != NULL, the int64 camera index per ray. */
+int neraf_camera_rays(neraf_ctx* ctx, const float* c2w, const float* fx, const float* fy, const float* cx, const float* cy,
+                      const float* distortion, int n_cams,
+                      const int64_t* cam_idx, int cam_single, const float* coords, int R, int width, float* origins, float* dirs,
+                      int64_t* cam_out, neraf_stream_t stream);
 int neraf_camera_apply(neraf_ctx* ctx, const float* pose_adjustment, const int32_t* cam_idx, const float* origins, const float* dirs,
                        int R, float* origins_out, float* dirs_out, int n_cameras, float w_trans, float w_rot, float* reg_out3,
                        neraf_stream_t stream);

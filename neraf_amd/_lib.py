@@ -148,6 +148,8 @@ SIGNATURES = {
     "neraf_resnet3d_pack_weights_bwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), c_fpp, C.c_void_p, C.c_void_p]),
     "neraf_resnet3d_bwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, c_fpp, C.c_void_p, C.c_void_p,
                                      C.c_void_p, c_fpp, c_fpp, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "neraf_camera_rays": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_camera_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "neraf_camera_apply_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -10,8 +10,9 @@
     camera (translation | so(3) log), applied to the ray bundle in training, with nerfacto's L2 regulariser.
 
 Both are restated from nerfstudio's published behaviour [NS-recall] (its source is not under /root/reference): parity
-unpinned, guarded by the property tests in tests/test_cameras.py.  They are plain PyTorch on purpose ("keep in
-PyTorch-ROCm; not hot"): 700k rays per eval frame are one batched tensor expression, not a kernel worth writing.
+unpinned, guarded by the property tests in tests/test_cameras.py.  The tensor expressions below are the CPU form (data
+preparation, tests); on the device ``generate_rays`` is one HIP launch (csrc/camera.hip): as a tensor expression the 700k rays of
+an eval frame cost ~150 small launches and a 700k-batch 3x3 matmul -- 12 ms of a 34 ms frame (profiles/r04_a_eval_kernel_stats.csv).
 """
 from __future__ import annotations
 
@@ -110,12 +111,47 @@ class Cameras:
                                 torch.arange(self.width, device=self.device, dtype=torch.float32), indexing="ij")
         return torch.stack([ys, xs], dim=-1) + 0.5
 
+    def _generate_rays_hip(self, camera_indices, coords: Optional[torch.Tensor]) -> RayBundle:
+        """``generate_rays`` on the device as ONE launch (csrc/camera.hip ``camera_rays_kernel``): a 684 x 1024 eval frame is 700,416
+        rays -- as a tensor expression that is ~150 element-wise launches plus a 700k-batch 3x3 matmul (12 ms of a 34 ms frame)."""
+        from . import _lib
+        from .field import _dev_index, _stream_ptr
+        lib = _lib.load()
+        dev = self.device
+        d = _dev_index(self.camera_to_worlds)
+        c2w = self.camera_to_worlds.float().contiguous()                # contiguous fp32 views of a Cameras slice: no launches
+        fx, fy, cx, cy = (t.float().contiguous() for t in (self.fx, self.fy, self.cx, self.cy))
+        dist = self.distortion_params.float().contiguous() if self.distortion_params is not None else None
+        cam_t, cam_single = None, 0
+        if isinstance(camera_indices, int):
+            cam_single = camera_indices
+        else:
+            cam_t = torch.as_tensor(camera_indices, device=dev).reshape(-1).long()
+        if coords is None:
+            R, width, co = self.height * self.width, self.width, None
+        else:
+            co = coords.reshape(-1, 2).to(dev).float().contiguous()
+            R, width = co.shape[0], self.width
+        if cam_t is not None:
+            cam_t = cam_t.expand(R).contiguous()
+        o = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        dd = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        cam_out = torch.empty((R, 1), dtype=torch.int64, device=dev)
+        _lib.check(lib.neraf_camera_rays(_lib.ctx(d), c2w.data_ptr(), fx.data_ptr(), fy.data_ptr(), cx.data_ptr(), cy.data_ptr(),
+                                         dist.data_ptr() if dist is not None else None,
+                                         self.size, cam_t.data_ptr() if cam_t is not None else None, int(cam_single),
+                                         co.data_ptr() if co is not None else None, R, width, o.data_ptr(), dd.data_ptr(), cam_out.data_ptr(),
+                                         _stream_ptr()), d)
+        return RayBundle(origins=o, directions=dd, camera_indices=cam_out)
+
     def generate_rays(self, camera_indices, coords: Optional[torch.Tensor] = None,
                       camera_opt_to_camera: Optional[torch.Tensor] = None) -> RayBundle:
         """Rays of camera(s) ``camera_indices`` (int, or int tensor [R]) through ``coords`` [..., 2] = (row, col) in pixels
         (default: every pixel centre of one camera, row-major [H*W]).  Directions are unit vectors; ``camera_indices`` of the
         bundle is [R,1] as nerfstudio's.  ``camera_opt_to_camera`` [R,3,4] right-multiplies the poses (pose refinement)."""
         dev = self.device
+        if dev.type == "cuda" and camera_opt_to_camera is None:
+            return self._generate_rays_hip(camera_indices, coords)
         if coords is None:
             coords = self.get_image_coords().reshape(-1, 2)
         coords = coords.reshape(-1, 2).to(dev)

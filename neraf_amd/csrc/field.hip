@@ -50,6 +50,8 @@ struct PropArgs {
   const float* origins; const float* dirs; const float* e_bins;
   int R, S; float avg_density;
   float* density;
+  int ray_tiles;   // 1: a wave holds the SAME sample index of 64 consecutive rays (coherent rays of an eval frame: neighbouring pixels
+                   // at equal depth fall into the same few grid cells, so a gather instruction touches a handful of lines instead of 64)
 };
 
 __global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
@@ -58,9 +60,17 @@ __global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
   for (int i = threadIdx.x; i < 256; i += 256) w0[i >> 4][i & 15] = (float)a.w[i];
   if (threadIdx.x < 16) w1[threadIdx.x] = (float)a.w[256 + threadIdx.x];
   __syncthreads();
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)a.R * a.S) return;
-  const int ray = (int)(idx / a.S), s = (int)(idx % a.S);
+  long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  int ray, s;
+  if (a.ray_tiles) {           // tile = 64 rays x S samples; inside a tile the ray index runs fastest
+    const long tile = idx / (64L * a.S), within = idx % (64L * a.S);
+    ray = (int)(tile * 64 + (within & 63)); s = (int)(within >> 6);
+    if (ray >= a.R) return;
+    idx = (long)ray * a.S + s;
+  } else {
+    if (idx >= (long)a.R * a.S) return;
+    ray = (int)(idx / a.S); s = (int)(idx % a.S);
+  }
   const float t = 0.5f * (a.e_bins[(size_t)ray * (a.S + 1) + s] + a.e_bins[(size_t)ray * (a.S + 1) + s + 1]);
   float x = fmaf(a.dirs[ray * 3 + 0], t, a.origins[ray * 3 + 0]);
   float y = fmaf(a.dirs[ray * 3 + 1], t, a.origins[ray * 3 + 1]);
@@ -196,6 +206,7 @@ struct FieldArgs {
                                  // it back instead of walking the hash table again at one wave per SIMD
   half_t* denc_out;              // optional fp16 [N][4][24]: d enc / d mapped position of each lane's 4 levels x 2 features x 3 axes
                                  // (the camera-pose edge of the backward)
+  int ray_tiles;                 // 1: a group's 16 points are the SAME sample index of 16 consecutive rays (coherent rays, eval frames)
 };
 
 constexpr int NFRAG = 24;   // base0: 0-3, base1: 4-5, head0: 6-13 (ob*2+s), head1: 14-21, head2: 22-23
@@ -222,12 +233,21 @@ __global__ __launch_bounds__(256, SAVE == 2 ? 2 : 3) void field_query_kernel(Fie
 #define wf(f) wfp[(f) * 64]
 
   const long N = (long)a.R * a.S;
-  const long ngroups = (N + 15) / 16;
+  const long ngroups = a.ray_tiles ? (long)((a.R + 15) / 16) * a.S : (N + 15) / 16;
   const long gstride = (long)gridDim.x * 4;
   for (long grp = (long)blockIdx.x * 4 + (threadIdx.x >> 6); grp < ngroups; grp += gstride) {
-    long n = grp * 16 + p;
-    const bool valid = n < N;
-    if (!valid) n = N - 1;                       // MFMA needs every lane: clamp, compute, do not store
+    long n;
+    bool valid;
+    if (a.ray_tiles) {                           // group = (tile of 16 rays, sample index): consecutive groups walk the tile's samples
+      int r = (int)(grp / a.S) * 16 + p;
+      valid = r < a.R;
+      if (!valid) r = a.R - 1;
+      n = (long)r * a.S + (grp % a.S);
+    } else {
+      n = grp * 16 + p;
+      valid = n < N;
+      if (!valid) n = N - 1;                     // MFMA needs every lane: clamp, compute, do not store
+    }
     const int ray = (int)(n / a.S), s = (int)(n % a.S);
     const float t = 0.5f * (a.e_bins[(size_t)ray * (a.S + 1) + s] + a.e_bins[(size_t)ray * (a.S + 1) + s + 1]);
     const float dx = a.dirs[ray * 3 + 0], dy = a.dirs[ray * 3 + 1], dz = a.dirs[ray * 3 + 2];
@@ -520,8 +540,10 @@ extern "C" int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, 
     return neraf_fail(ctx, NERAF_EINVAL, "proposal_density: bad arguments");
   a.table = (const unsigned*)table_f16; a.w = (const half_t*)mlp_f16; a.origins = origins; a.dirs = dirs; a.e_bins = e_bins;
   a.R = R; a.S = S; a.avg_density = avg_density; a.density = density;
-  const long n = (long)R * S;
+  long n = (long)R * S;
   ProfScope prof(ctx, (hipStream_t)stream, PROF_PROP_DENSITY, (double)n * a.g.n_levels * 8 * 4);   // gathered table bytes
+  { const char* e = getenv("NERAF_RAY_TILES"); a.ray_tiles = e ? atoi(e) & 1 : 0; }
+  if (a.ray_tiles) n = (long)((R + 63) / 64) * 64 * S;
   hipLaunchKernelGGL(proposal_density_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
@@ -574,7 +596,8 @@ static int field_query_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void
   for (int i = 0; i < 6; ++i) a.aabb[i] = aabb_host ? aabb_host[i] : 0.f;
   a.avg_density = avg_density; a.avg_row = avg_row; a.rgb = rgb; a.density = density;
   const long n = (long)R * S;
-  const long groups = (n + 15) / 16;
+  { const char* e = getenv("NERAF_RAY_TILES"); a.ray_tiles = e ? (atoi(e) >> 1) & 1 : 0; }
+  const long groups = a.ray_tiles ? (long)((R + 15) / 16) * S : (n + 15) / 16;
   long blocks = (groups + 3) / 4;
   const long cap = (long)(ctx ? ctx->num_cus : 256) * 8;
   if (blocks > cap) blocks = cap;

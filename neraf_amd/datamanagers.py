@@ -9,6 +9,7 @@ scope: these managers serve DEVICE-RESIDENT data -- sy
 from __future__ import annotations
 
 import math
+import warnings
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -31,6 +32,38 @@ class FixedBatchDataManager:
 
     def next_train(self, step: int):
         return self.ray_bundle, self.batch
+
+    next_eval = next_train
+
+    def get_param_groups(self):
+        return {}
+
+
+class RotatingBatchDataManager:
+    """``next_train`` cycles through K distinct resident (ray_bundle, batch) pairs: every step gathers other hash-table rows and
+    scatters into other gradient rows, as a training run that draws a fresh batch per step does (NeRAF_pipeline.py:175, :187),
+    without any host work inside the step.  ``pin(i)`` freezes the rotation on pair i (the fixed-batch A/B of bench.py)."""
+
+    def __init__(self, ray_bundles, batches, train_num_rays_per_batch: Optional[int] = None):
+        if len(ray_bundles) != len(batches) or not batches:
+            raise ValueError("need as many ray bundles (or None entries) as batches, at least one")
+        self.ray_bundles, self.batches = list(ray_bundles), list(batches)
+        if train_num_rays_per_batch is None:
+            train_num_rays_per_batch = len(ray_bundles[0]) if ray_bundles[0] is not None else 4096
+        self.train_num_rays_per_batch = train_num_rays_per_batch
+        self._pinned: Optional[int] = None
+        self._calls = 0
+
+    def __len__(self):
+        return len(self.batches)
+
+    def pin(self, i: Optional[int]):
+        self._pinned = i
+
+    def next_train(self, step: int):
+        i = self._pinned if self._pinned is not None else self._calls % len(self.batches)
+        self._calls += 1
+        return self.ray_bundles[i], self.batches[i]
 
     next_eval = next_train
 
@@ -81,6 +114,17 @@ def synthetic_cameras(n: int, width: int = 684, height: int = 1024, tag: str = "
                    511.3341668407641 * sy, width, height, dist)
 
 
+def _global_rank(local_rank: int) -> int:
+    """The GLOBAL rank seeds per-rank generators (on a multi-node job local ranks repeat and would duplicate batches)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return int(dist.get_rank())
+    except Exception:
+        pass
+    return int(local_rank)
+
+
 class _VisionDataset:
     def __init__(self, cameras: Cameras, images: torch.Tensor, scene_box: SceneBox):
         self.cameras, self.images, self.scene_box, self.metadata = cameras, images, scene_box, {}
@@ -105,7 +149,7 @@ class SyntheticVisionDataManager:
         self.train_num_rays_per_batch = train_num_rays_per_batch
         self.eval_num_rays_per_batch = train_num_rays_per_batch
         self.device = torch.device(device)
-        self.generator = torch.Generator(device="cpu").manual_seed(seed + 7919 * local_rank)
+        self.generator = torch.Generator(device="cpu").manual_seed(seed + 7919 * _global_rank(local_rank))
         self._eval_i = 0
         self.to(device)
 
@@ -181,13 +225,7 @@ class _BankDataManager:
         summed over the ranks as if the batches were distinct.  Single process: torch's default generator, as before."""
         if self.world_size <= 1:
             return None
-        rank = self.local_rank
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                rank = dist.get_rank()
-        except Exception:
-            pass
+        rank = _global_rank(self.local_rank)
         dev = torch.device(device)
         g = torch.Generator(device=dev if dev.type == "cuda" else "cpu")
         g.manual_seed(int(self.seed) + 7919 * int(rank))
@@ -198,8 +236,14 @@ class _BankDataManager:
             b = ds.bank
             b.log_mag, b.mic_pose, b.source_pose, b.rot = b.log_mag.to(device), b.mic_pose.to(device), b.source_pose.to(device), b.rot.to(device)
             ds.waveforms = ds.waveforms.to(device)
-        if getattr(self, "world_size", 1) > 1 and (self.generator is None or self.generator.device != torch.device(device)):
-            self.generator = self._rank_generator(device)
+        if getattr(self, "world_size", 1) > 1:
+            # the per-rank generator is created ONCE per device: 'cuda' and 'cuda:0' name the same device, and re-creating it on
+            # every .to() would re-seed it and restart the rank's audio batch sequence
+            dev = torch.device(device)
+            if dev.type == "cuda" and dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            if self.generator is None or self.generator.device != dev:
+                self.generator = self._rank_generator(dev)
         return self
 
     def next_train(self, step: int):
@@ -281,10 +325,21 @@ class DiskAudioDataManager(_BankDataManager):
             def make(split):
                 bank, out = bank_from_soundspaces(data, split, max_len=frames)
                 waves = torch.zeros((len(out.audios_filenames), 2, n_time))
+                missing = []
                 for i, name in enumerate(out.audios_filenames):
                     path = os.path.join(data, "binaural_rirs", name + ".wav")
-                    if os.path.exists(path):                                              # training splits may ship without the wavs
+                    if os.path.exists(path):
                         waves[i] = torch.from_numpy(load_soundspaces_waveform(path, fs, n_time))
+                    else:
+                        missing.append(name)
+                if missing:
+                    # training splits may ship without the wavs (nothing reads them there); an EVAL split without them would have its
+                    # T60 / EDT / C50 computed against silence
+                    if split != "train":
+                        raise FileNotFoundError(f"SoundSpaces split '{split}': {len(missing)} ground-truth waveform(s) missing under "
+                                                f"{os.path.join(data, 'binaural_rirs')} (first: {missing[0]}.wav)")
+                    warnings.warn(f"SoundSpaces split 'train': {len(missing)} of {len(out.audios_filenames)} binaural_rirs wavs are "
+                                  "missing; their waveforms are zeros (not read in training)")
                 return _AudioDataset(bank, waves, out.scene_box), out
         else:
             raise ValueError("dataset must be 'RAF' or 'SoundSpaces'")

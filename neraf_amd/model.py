@@ -378,6 +378,23 @@ class NeRAFAudioModel(nn.Module):
         stft["raw_output"] = out                                                        # :725-726
         return stft
 
+    @torch.no_grad()
+    def get_outputs_for_rirs(self, mic_pose: torch.Tensor, source_pose: torch.Tensor, rot: torch.Tensor) -> torch.Tensor:
+        """The eval branch (:648-694) for N RIRs in ONE field call: every RIR is the same T time queries at its own (microphone,
+        source, orientation), so N RIRs are N*T independent rows of ``h`` (:560) -- the batch the MFMA GEMMs want (the reference
+        evaluates one RIR = T rows per call, NeRAF_pipeline.py:355-362).  mic / source / rot [N,3] -> log-magnitude STFTs
+        [N,T,C,F]; row n equals ``get_outputs_for_camera(None, None, batch_n)['raw_output']``."""
+        dev = self.aabb.device
+        T = self.max_len
+        N = int(mic_pose.shape[0])
+        tq = torch.arange(0, T, 1, device=dev).repeat(N)
+
+        def rows(p):
+            return p.to(dev).reshape(N, 1, 3).expand(N, T, 3).reshape(N * T, 3)
+        feat = self.scene_feature() if self.use_grid else torch.zeros(0, device=dev)
+        out = self.field.forward_queries(feat, tq, rows(mic_pose), rows(source_pose), rows(rot), self.aabb, T)
+        return out.reshape(N, T, out.shape[1], out.shape[2])
+
     # ---- metrics (SURVEY 8f rank 1) --------------------------------------------------------------
     def get_metrics_dict(self, outputs: torch.Tensor, batch: Dict[str, torch.Tensor]):   # :568-581
         with torch.no_grad():
