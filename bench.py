@@ -846,7 +846,7 @@ def main():
         # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot wrap itself from inside):
         # tools/gpu_pmc.sh -> profiles/*_pmc_traffic.json (FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE)
         import glob
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+        pmc_files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")) if "_eval_" not in os.path.basename(f))
         default_shape = a.rays == 4096 and a.slices == 2048 and a.dataset == "raf" and world == 1
         pmc = json.load(open(pmc_files[-1]))["families"] if pmc_files and default_shape else {}
         for k in fams:

@@ -199,21 +199,28 @@ typedef struct neraf_grid_desc {
 int neraf_grid_layout(const neraf_grid_desc* g, float* scales, int* resolutions, uint32_t* sizes, uint32_t* offsets);
 
 /* Initial samples: S bins uniform in piecewise lin-disp spacing between near and far, optional
- * single jitter per ray (jitter [R] in [0,1), NULL = deterministic / eval). */
-int neraf_sample_uniform(neraf_ctx* ctx, int R, int S, float near, float far, const float* jitter,
+ * single jitter per ray: jitter [R] in [0,1) given by the caller, or -- jitter NULL and jitter_seed != 0 -- drawn inside the
+ * kernel as a pure function of (jitter_seed, ray) (training: no random-number launch in front of the sampler; the host layer passes a
+ * fresh seed per call and stage); both NULL / 0 = deterministic (eval).  The same pair of arguments in neraf_pdf_resample. */
+int neraf_sample_uniform(neraf_ctx* ctx, int R, int S, float near, float far, const float* jitter, uint64_t jitter_seed,
                          float* s_bins, float* e_bins, neraf_stream_t stream);
 
 /* Proposal density: contraction -> hash grid -> MLP(2L -> 16 -> 1) -> avg_density * exp.
  * table_f16: fp16 [rows, 2]; mlp_f16: fp16 [16*16 + 16] = layer-0 [hidden][input] then layer-1 row.
- * density: fp32 [R, S]. */
+ * density: fp32 [R, S].
+ * coherent_rays != 0 (here and in neraf_field_query) declares that CONSECUTIVE RAYS ARE NEIGHBOURS IN SPACE -- the pixels of one
+ * camera in row-major order, i.e. the chunks of Model.get_outputs_for_camera (NeRAF_model.py:70-79) -- and changes only the order
+ * in which samples are assigned to lanes: a wavefront then holds the same sample index of 64 (proposal) / 16 (field) consecutive
+ * rays, whose positions fall into the same few grid cells, so one gather instruction touches a handful of cache lines instead of
+ * 64.  Results are bit-identical to coherent_rays == 0; on a 684 x 1024 frame the two kernels take 0.75x / 0.60x the time. */
 int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                            const float* origins, const float* dirs, const float* e_bins, int R, int S,
-                           float avg_density, float* density, neraf_stream_t stream);
+                           float avg_density, int coherent_rays, float* density, neraf_stream_t stream);
 
 /* get_weights + PDF resampling of n_new bins (n_new+1 edges) from annealed weights; weights
  * (fp32 [R,S], may be NULL) are the un-annealed volume-rendering weights of the S input bins. */
 int neraf_pdf_resample(neraf_ctx* ctx, const float* density, const float* s_bins, const float* e_bins, int R, int S,
-                       float anneal, const float* jitter, int n_new, float near, float far, float* weights,
+                       float anneal, const float* jitter, uint64_t jitter_seed, int n_new, float near, float far, float* weights,
                        float* s_new, float* e_new, neraf_stream_t stream);
 
 /* Fused nerfacto field query: position map (mode 0: L-inf scene contraction, mode 1: AABB
@@ -224,7 +231,7 @@ int neraf_pdf_resample(neraf_ctx* ctx, const float* density, const float* s_bins
 int neraf_field_query(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
                       const void* emb_f16, const float* origins, const float* dirs, const float* e_bins,
                       const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host, float avg_density,
-                      int avg_row, float* rgb, float* density, neraf_stream_t stream);
+                      int avg_row, int coherent_rays, float* rgb, float* density, neraf_stream_t stream);
 
 /* Training form of the query: additionally stores the interpolated encoding enc_out fp16 [R*S, 32] (required) and, when denc_out is
  * not NULL, its derivatives w.r.t. the mapped sample position denc_out fp16 [R*S, 4, 24] (lane quarter, then level x feature x axis).
@@ -235,10 +242,12 @@ int neraf_field_query_train(neraf_ctx* ctx, const neraf_grid_desc* g, const void
                             int avg_row, float* rgb, float* density, void* enc_out, void* denc_out, neraf_stream_t stream);
 
 /* Weights + composite for S <= 64 samples per ray: rgb = sum w c + c_last (1 - sum w) (clipped to
- * [0,1], NeRAF_model.py:67), median depth, expected depth (needs scratch8: 8 bytes), accumulation. */
+ * [0,1], NeRAF_model.py:67), median depth, expected depth, accumulation.  scratch (device, scratch_bytes >= 8 when `expected` is
+ * asked for, <= 248, multiple of 4): bytes 0..7 hold the batch's {min, max} step of the expected-depth clip; bytes 8.. are ZEROED
+ * by the same launch that seeds them -- a training step's loss node takes its four fp32 `sums` (neraf_render_loss) from there. */
 int neraf_composite(neraf_ctx* ctx, const float* density, const float* rgb, const float* e_bins, int R, int S,
                     int training, float* weights, float* rgb_out, float* depth, float* expected, float* acc,
-                    void* scratch8, neraf_stream_t stream);
+                    void* scratch, size_t scratch_bytes, neraf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Radiance half, training: losses (V4) and backward.  These replace autograd through nerfstudio's
@@ -315,7 +324,22 @@ int neraf_field_backward_ex(neraf_ctx* ctx, const neraf_grid_desc* g, const void
                             float avg_density, int avg_row, const float* density, const float* d_rgb, const float* d_density,
                             float* table_grad, float* emb_grad, float* const* w_grads, void* dump, void* splitk_ws,
                             size_t splitk_bytes, int pos_run, float* d_rays, const void* enc_saved, const void* denc_saved,
-                            neraf_stream_t stream);
+                            void* acc_scratch, int accumulate, int emb_rows, neraf_stream_t stream);
+/* acc_scratch / accumulate / emb_rows (neraf_field_backward_ex; acc_scratch also neraf_proposal_backward_ex): how the outputs start.
+ *   acc_scratch == NULL (and every other entry point of the family): table_grad doubles as the 64-bit fixed-point accumulator and
+ *     is converted in place -- the CALLER zeroes table_grad and emb_grad before the call.
+ *   acc_scratch != NULL: 8 bytes per table row, ZERO on entry, left ZERO on exit (the conversion pass clears what it reads), so one
+ *     persistent buffer serves every call without a fill launch.  accumulate == 0: table_grad, the five w_grads and emb_grad
+ *     [emb_rows, 32] are WRITTEN (need no initialisation); accumulate != 0: the call ADDS to all of them -- the second producer of
+ *     the same parameters' gradients in one backward pass (NeRAF's grid refresh next to the render batch, NeRAF_model.py:395-400)
+ *     adds in place instead of handing autograd a second set of tensors to sum. */
+/* neraf_proposal_backward(_rays) with the outputs in the parameters' own layouts and nothing for the caller to zero: w0_grad fp32
+ * [16,16], w1_grad fp32 [16,16] (row 0 = the used output row, rows 1..15 written as zeros), table_grad written through acc_scratch
+ * (see above); d_rays NULL or the ACCUMULATED fp32 [R,6] ray gradients.  scratch: neraf_proposal_backward_scratch_bytes. */
+int neraf_proposal_backward_ex(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
+                               const float* origins, const float* dirs, const float* e_bins, const float* d_density, int R, int S,
+                               float avg_density, float* table_grad, float* w0_grad, float* w1_grad, void* scratch,
+                               size_t scratch_bytes, void* acc_scratch, float* d_rays, neraf_stream_t stream);
 int neraf_proposal_backward_rays(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                                  const float* origins, const float* dirs, const float* e_bins, const float* d_density, int R,
                                  int S, float avg_density, float* table_grad, float* w_grad, void* scratch, size_t scratch_bytes,
@@ -329,9 +353,11 @@ int neraf_grid_refresh_write(neraf_ctx* ctx, const float* rgb, const float* dens
 
 /* The same epilogue as a differentiable node (the reference keeps the autograd edge of the refreshed cells,
  * NeRAF_model.py:395-400): vals fp32 [4][n] = (mean rgb, alpha); cell_major = 1: query k = i*ndirs + j, 0: k = j*n + i.
+ * With grid != NULL the same launch also writes the values into channels 0..3 of grid fp32 [7, nvox] at flat cells [start, start+n)
+ * (the detached slab write of :395-400).
  * The backward maps dvals [4][n] to d_rgb [n*ndirs,3] / d_density [n*ndirs] (alpha's clip passes no gradient where active). */
 int neraf_grid_refresh_vals(neraf_ctx* ctx, const float* rgb, const float* density, int n, int ndirs, int cell_major, float delta,
-                            float* vals, neraf_stream_t stream);
+                            float* vals, float* grid, size_t nvox, size_t start, neraf_stream_t stream);
 int neraf_grid_refresh_vals_bwd(neraf_ctx* ctx, const float* dvals, const float* density, int n, int ndirs, int cell_major,
                                 float delta, float* d_rgb, float* d_density, neraf_stream_t stream);
 
@@ -370,9 +396,11 @@ int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_desc* d, co
 int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed, const float* const* bn,
                        const float* grid, void* workspace, float* feat, int use_batch_stats, size_t win_start, int win_cells,
                        neraf_stream_t stream);
-/* After a train-mode forward: running_mean/var <- (1-m) running + m batch (unbiased var), as nn.BatchNorm3d. */
+/* After a train-mode forward: running_mean/var <- (1-m) running + m batch (unbiased var), as nn.BatchNorm3d; with
+ * num_batches_tracked != NULL (HOST array of the 43 BatchNorms' int64 device scalars) each counter is incremented by the same launch. */
 int neraf_resnet3d_update_running_stats(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* workspace,
-                                        float* const* bn, float momentum, neraf_stream_t stream);
+                                        float* const* bn, float momentum, int64_t* const* num_batches_tracked,
+                                        neraf_stream_t stream);
 
 /* Backward of neraf_resnet3d_fwd (train-mode BatchNorm).  `workspace` is the forward's (its activations and
  * BN statistics are read); packed_t comes from neraf_resnet3d_pack_weights_bwd.  dfeat fp32 [1024] ->

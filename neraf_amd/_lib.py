@@ -85,16 +85,16 @@ SIGNATURES = {
     "neraf_prof_kernel_name": (C.c_char_p, [C.c_int]),
     "neraf_grid_layout": (C.c_int, [C.POINTER(GridDesc), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32)]),
-    "neraf_sample_uniform": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+    "neraf_sample_uniform": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_uint64, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "neraf_proposal_density": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                         C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+                                         C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "neraf_pdf_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
-                                     C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_uint64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "neraf_field_query": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
-                                    C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                    C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_field_query_train": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                           C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -123,14 +123,17 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_float), C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, c_fpp, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
-                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "neraf_proposal_backward_ex": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_proposal_backward_rays": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "neraf_grid_refresh_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                            C.c_size_t, C.c_size_t, C.c_void_p]),
     "neraf_grid_refresh_vals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
-                                          C.c_void_p]),
+                                          C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "neraf_grid_refresh_vals_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                               C.c_void_p, C.c_void_p]),
     "neraf_refresh_origins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
@@ -141,7 +144,7 @@ SIGNATURES = {
     "neraf_resnet3d_pack_weights": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), c_fpp, C.c_void_p, C.c_void_p]),
     "neraf_resnet3d_fwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p]),
-    "neraf_resnet3d_update_running_stats": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, C.c_float,
+    "neraf_resnet3d_update_running_stats": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, C.c_float, c_fpp,
                                                       C.c_void_p]),
     "neraf_resnet3d_bwd_packed_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),
     "neraf_resnet3d_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),
@@ -165,7 +168,7 @@ SIGNATURES = {
                                               C.POINTER(C.c_int)]),
     "neraf_debug_conv_bn_relu_stage": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 11),
     "neraf_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 

@@ -287,14 +287,16 @@ class CameraOptimizer(nn.Module):
         if self.mode == "off" or ray_bundle.camera_indices is None:
             return ray_bundle
         if ray_bundle.origins.is_cuda and not ray_bundle.origins.requires_grad and not ray_bundle.directions.requires_grad:
-            cam = ray_bundle.camera_indices.reshape(-1).to(torch.int32).contiguous()
+            cam = ray_bundle.camera_indices_i32()
             o, d, reg, norms = _CameraApplyFn.apply(self.pose_adjustment, cam, ray_bundle.origins.float().contiguous(),
                                                     ray_bundle.directions.float().contiguous(),
                                                     self.trans_l2_penalty / self.num_cameras, self.rot_l2_penalty / self.num_cameras)
             # the regulariser and the pose norms of THIS parameter state came with the launch: get_loss_dict / get_metrics_dict of
             # the same iteration pick them up (consumed once each; without them they fall back to the torch expressions)
             self._fused = {"reg": reg, "norms": norms, "key": (self.pose_adjustment.data_ptr(), self.pose_adjustment._version, _update_epoch())}
-            return RayBundle(o, d, ray_bundle.camera_indices, ray_bundle.nears, ray_bundle.fars)
+            out = RayBundle(o, d, ray_bundle.camera_indices, ray_bundle.nears, ray_bundle.fars)
+            out._cam_i32 = getattr(ray_bundle, "_cam_i32", None)
+            return out
         corr = self(ray_bundle.camera_indices)
         origins = ray_bundle.origins + corr[:, :3, 3]
         directions = torch.bmm(corr[:, :3, :3], ray_bundle.directions[..., None]).squeeze(-1)

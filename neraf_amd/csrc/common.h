@@ -196,6 +196,7 @@ struct GemmParams {
   half_t* C16; int ldc16;            // optional row-major fp16 out [Mpad, >=Npad]
   half_t* C16T; int ldc16t;          // optional transposed fp16 out [Npad, >=Mpad]
   float* C32; int ldc32;             // optional fp32 out, masked to M x N
+  int c32_beta;                      // != 0: C32 += result instead of C32 = result (a second producer of the same gradient)
   float* colsum;                     // optional [Npad] fp32: atomically += column sums of the final values
   float* colsumsq;                   // optional [Npad] fp32: atomically += column sums of squares (BatchNorm statistics)
   int stat_rep, stat_stride;         // colsum/colsumsq are replicated stat_rep (power of two, 0 = 1) times, stat_stride floats apart; a

@@ -21,21 +21,22 @@ namespace {
 
 // ---- sampler level 0: UniformLinDispPiecewiseSampler with single jitter -----------------------------------
 __global__ __launch_bounds__(256) void sample_uniform_kernel(int R, int S, float near, float far, const float* __restrict__ jitter,
-                                                            float* __restrict__ s_bins, float* __restrict__ e_bins) {
+                                                            unsigned long long jitter_seed, float* __restrict__ s_bins,
+                                                            float* __restrict__ e_bins) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)R * (S + 1)) return;
   const int ray = (int)(idx / (S + 1)), i = (int)(idx % (S + 1));
   const float step = 1.0f / (float)S;
   float b = (float)i * step;
   if (i == S) b = 1.0f;
-  if (jitter) {
+  if (jitter || jitter_seed) {
     // bins = lower + (upper-lower)*u ; lower/upper = neighbouring bin centres (ends clamp to 0 / 1)
     const float cl = i > 0 ? ((float)(i - 1) * step + b) * 0.5f : 0.f;      // centre below (or bins[0])
     const float bn = (i + 1 == S) ? 1.0f : (float)(i + 1) * step;
     const float cu = i < S ? (b + bn) * 0.5f : 1.0f;                         // centre above (or bins[-1])
     const float lower = i == 0 ? 0.f : cl;
     const float upper = i == S ? 1.f : cu;
-    b = lower + (upper - lower) * jitter[ray];
+    b = lower + (upper - lower) * (jitter ? jitter[ray] : jitter_u01(jitter_seed, ray));
   }
   const float sn = spacing_fn(near), sf = spacing_fn(far);
   s_bins[idx] = b;
@@ -104,6 +105,7 @@ struct PdfArgs {
   const float* density; const float* s_bins; const float* e_bins;
   int R, S; float anneal; const float* jitter; int n_new; float near, far;
   float* weights; float* s_new; float* e_new;
+  unsigned long long jitter_seed;   // jitter == null and seed != 0: the per-ray jitter is drawn in the kernel (jitter_u01)
 };
 
 constexpr int PDF_MAX_S = 256;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void pdf_resample_kernel(PdfArgs a) {
   for (int j = lane; j < nb; j += 64) {
     float u = (float)j * ((1.f - 1.f / (float)nb) / (float)(nb - 1));    // linspace(0, 1-1/nb, nb)
     if (j == nb - 1) u = 1.f - 1.f / (float)nb;
-    u += a.jitter ? a.jitter[ray] / (float)nb : 1.f / (2.f * (float)nb);
+    u += a.jitter ? a.jitter[ray] / (float)nb : (a.jitter_seed ? jitter_u01(a.jitter_seed, ray) / (float)nb : 1.f / (2.f * (float)nb));
     // searchsorted(cdf, u, side='right'): first index with cdf[idx] > u, over S+1 entries
     int lo = 0, hi = S + 1;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] > u) hi = mid; else lo = mid + 1; }
@@ -334,7 +336,13 @@ struct CompArgs {
 // global min / max of the sample mid-points (positive floats order like their bit patterns)
 // seeds the {min, max} pair of steps_minmax_kernel on the device (a host-side 8-byte copy would come from pageable memory:
 // host-synchronous, and not capturable into a graph)
-__global__ void minmax_seed_kernel(unsigned* __restrict__ mm) { if (threadIdx.x < 2 && blockIdx.x == 0) mm[threadIdx.x] = threadIdx.x ? 0u : 0x7f7fffffu; }
+// words 2 .. 2 + extra_zero of the scratch are cleared by the same launch: the loss node that follows the composite in a training step
+// accumulates its three sums there (one launch fewer than a fill of its own)
+__global__ void minmax_seed_kernel(unsigned* __restrict__ mm, int extra_zero) {
+  if (blockIdx.x) return;
+  if (threadIdx.x < 2) mm[threadIdx.x] = threadIdx.x ? 0u : 0x7f7fffffu;
+  else if ((int)threadIdx.x < 2 + extra_zero) mm[threadIdx.x] = 0u;
+}
 
 __global__ __launch_bounds__(256) void steps_minmax_kernel(const float* __restrict__ e_bins, int R, int S, unsigned* __restrict__ mm) {
   const int ray = blockIdx.x * 256 + threadIdx.x;
@@ -416,7 +424,8 @@ __global__ __launch_bounds__(256) void grid_refresh_write_kernel(const float* __
 // differentiable form of the same epilogue: vals [4][n] = (mean rgb, alpha) instead of the grid write, queries laid out
 // cell-major (k = i*ndirs + j) or direction-major (k = j*n + i)
 __global__ __launch_bounds__(256) void grid_refresh_vals_kernel(const float* __restrict__ rgb, const float* __restrict__ density,
-                                                               int n, int ndirs, int cell_major, float delta, float* __restrict__ vals) {
+                                                               int n, int ndirs, int cell_major, float delta, float* __restrict__ vals,
+                                                               float* __restrict__ grid, size_t nvox, size_t start) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float r = 0.f, g = 0.f, b = 0.f, d = 0.f;
@@ -425,10 +434,17 @@ __global__ __launch_bounds__(256) void grid_refresh_vals_kernel(const float* __r
     r += rgb[k * 3 + 0]; g += rgb[k * 3 + 1]; b += rgb[k * 3 + 2]; d += density[k];
   }
   const float inv = 1.f / (float)ndirs;
+  const float alpha = fminf(fmaxf(1.f - expf(-delta * (d * inv)), 0.f), 1.f);
   vals[0 * (size_t)n + i] = r * inv;
   vals[1 * (size_t)n + i] = g * inv;
   vals[2 * (size_t)n + i] = b * inv;
-  vals[3 * (size_t)n + i] = fminf(fmaxf(1.f - expf(-delta * (d * inv)), 0.f), 1.f);
+  vals[3 * (size_t)n + i] = alpha;
+  if (grid) {      // the slab write of the same values (NeRAF_model.py:395-400) in the same launch
+    grid[0 * nvox + start + i] = r * inv;
+    grid[1 * nvox + start + i] = g * inv;
+    grid[2 * nvox + start + i] = b * inv;
+    grid[3 * nvox + start + i] = alpha;
+  }
 }
 
 // its backward: d rgb = dvals[0..2] / ndirs for every direction; d density = dvals[3] * delta * exp(-delta * mean) / ndirs where
@@ -468,10 +484,11 @@ __global__ __launch_bounds__(256) void refresh_origins_kernel(const float* __res
 
 // =================================================================================================
 extern "C" int neraf_grid_refresh_vals(neraf_ctx* ctx, const float* rgb, const float* density, int n, int ndirs, int cell_major,
-                                       float delta, float* vals, neraf_stream_t stream) {
-  if (!rgb || !density || !vals || n <= 0 || ndirs <= 0) return neraf_fail(ctx, NERAF_EINVAL, "grid_refresh_vals: bad arguments");
+                                       float delta, float* vals, float* grid, size_t nvox, size_t start, neraf_stream_t stream) {
+  if (!rgb || !density || !vals || n <= 0 || ndirs <= 0 || (grid && start + (size_t)n > nvox))
+    return neraf_fail(ctx, NERAF_EINVAL, "grid_refresh_vals: bad arguments");
   hipLaunchKernelGGL(grid_refresh_vals_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rgb, density, n, ndirs,
-                     cell_major, delta, vals);
+                     cell_major, delta, vals, grid, nvox, start);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
@@ -521,19 +538,19 @@ extern "C" int neraf_grid_layout(const neraf_grid_desc* g, float* scales, int* r
   return NERAF_OK;
 }
 
-extern "C" int neraf_sample_uniform(neraf_ctx* ctx, int R, int S, float near, float far, const float* jitter,
+extern "C" int neraf_sample_uniform(neraf_ctx* ctx, int R, int S, float near, float far, const float* jitter, uint64_t jitter_seed,
                                     float* s_bins, float* e_bins, neraf_stream_t stream) {
   if (R <= 0 || S <= 0 || !s_bins || !e_bins) return neraf_fail(ctx, NERAF_EINVAL, "sample_uniform: bad arguments");
   const long n = (long)R * (S + 1);
   hipLaunchKernelGGL(sample_uniform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, R, S, near, far,
-                     jitter, s_bins, e_bins);
+                     jitter, (unsigned long long)jitter_seed, s_bins, e_bins);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
 
 extern "C" int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                                       const float* origins, const float* dirs, const float* e_bins, int R, int S,
-                                      float avg_density, float* density, neraf_stream_t stream) {
+                                      float avg_density, int coherent_rays, float* density, neraf_stream_t stream) {
   PropArgs a{};
   if (make_grid_layout(g, &a.g) || a.g.n_levels > 8) return neraf_fail(ctx, NERAF_EINVAL, "proposal_density: bad grid (<= 8 levels)");
   if (R <= 0 || S <= 0 || !table_f16 || !mlp_f16 || !origins || !dirs || !e_bins || !density)
@@ -542,7 +559,7 @@ extern "C" int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, 
   a.R = R; a.S = S; a.avg_density = avg_density; a.density = density;
   long n = (long)R * S;
   ProfScope prof(ctx, (hipStream_t)stream, PROF_PROP_DENSITY, (double)n * a.g.n_levels * 8 * 4);   // gathered table bytes
-  { const char* e = getenv("NERAF_RAY_TILES"); a.ray_tiles = e ? atoi(e) & 1 : 0; }
+  a.ray_tiles = coherent_rays ? 1 : 0;
   if (a.ray_tiles) n = (long)((R + 63) / 64) * 64 * S;
   hipLaunchKernelGGL(proposal_density_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
@@ -550,11 +567,11 @@ extern "C" int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, 
 }
 
 extern "C" int neraf_pdf_resample(neraf_ctx* ctx, const float* density, const float* s_bins, const float* e_bins, int R, int S,
-                                  float anneal, const float* jitter, int n_new, float near, float far, float* weights,
-                                  float* s_new, float* e_new, neraf_stream_t stream) {
+                                  float anneal, const float* jitter, uint64_t jitter_seed, int n_new, float near, float far,
+                                  float* weights, float* s_new, float* e_new, neraf_stream_t stream) {
   if (R <= 0 || S <= 0 || S > PDF_MAX_S || n_new <= 0 || !density || !s_bins || !e_bins || !s_new || !e_new)
     return neraf_fail(ctx, NERAF_EINVAL, "pdf_resample: bad arguments (S <= 256)");
-  PdfArgs a{density, s_bins, e_bins, R, S, anneal, jitter, n_new, near, far, weights, s_new, e_new};
+  PdfArgs a{density, s_bins, e_bins, R, S, anneal, jitter, n_new, near, far, weights, s_new, e_new, (unsigned long long)jitter_seed};
   hipLaunchKernelGGL(pdf_resample_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
@@ -563,14 +580,15 @@ extern "C" int neraf_pdf_resample(neraf_ctx* ctx, const float* density, const fl
 static int field_query_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
                             const void* emb_f16, const float* origins, const float* dirs, const float* e_bins,
                             const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host, float avg_density,
-                            int avg_row, float* rgb, float* density, void* enc_out, void* denc_out, neraf_stream_t stream);
+                            int avg_row, int coherent_rays, float* rgb, float* density, void* enc_out, void* denc_out,
+                            neraf_stream_t stream);
 
 extern "C" int neraf_field_query(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
                                  const void* emb_f16, const float* origins, const float* dirs, const float* e_bins,
                                  const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host, float avg_density,
-                                 int avg_row, float* rgb, float* density, neraf_stream_t stream) {
+                                 int avg_row, int coherent_rays, float* rgb, float* density, neraf_stream_t stream) {
   return field_query_impl(ctx, g, table_f16, wfrag_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode, aabb_host, avg_density,
-                          avg_row, rgb, density, nullptr, nullptr, stream);
+                          avg_row, coherent_rays, rgb, density, nullptr, nullptr, stream);
 }
 
 extern "C" int neraf_field_query_train(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
@@ -579,13 +597,14 @@ extern "C" int neraf_field_query_train(neraf_ctx* ctx, const neraf_grid_desc* g,
                                        int avg_row, float* rgb, float* density, void* enc_out, void* denc_out, neraf_stream_t stream) {
   if (!enc_out) return neraf_fail(ctx, NERAF_EINVAL, "field_query_train: enc_out required");
   return field_query_impl(ctx, g, table_f16, wfrag_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode, aabb_host, avg_density,
-                          avg_row, rgb, density, enc_out, denc_out, stream);
+                          avg_row, 0, rgb, density, enc_out, denc_out, stream);
 }
 
 static int field_query_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
                             const void* emb_f16, const float* origins, const float* dirs, const float* e_bins,
                             const int32_t* cam_idx, int R, int S, int mode, const float* aabb_host, float avg_density,
-                            int avg_row, float* rgb, float* density, void* enc_out, void* denc_out, neraf_stream_t stream) {
+                            int avg_row, int coherent_rays, float* rgb, float* density, void* enc_out, void* denc_out,
+                            neraf_stream_t stream) {
   FieldArgs a{};
   if (make_grid_layout(g, &a.g) || a.g.n_levels != 16) return neraf_fail(ctx, NERAF_EINVAL, "field_query: grid must have 16 levels");
   if (R <= 0 || S <= 0 || !table_f16 || !wfrag_f16 || !emb_f16 || !origins || !dirs || !e_bins || !rgb || !density ||
@@ -596,7 +615,7 @@ static int field_query_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void
   for (int i = 0; i < 6; ++i) a.aabb[i] = aabb_host ? aabb_host[i] : 0.f;
   a.avg_density = avg_density; a.avg_row = avg_row; a.rgb = rgb; a.density = density;
   const long n = (long)R * S;
-  { const char* e = getenv("NERAF_RAY_TILES"); a.ray_tiles = e ? (atoi(e) >> 1) & 1 : 0; }
+  a.ray_tiles = coherent_rays ? 1 : 0;
   const long groups = a.ray_tiles ? (long)((R + 15) / 16) * S : (n + 15) / 16;
   long blocks = (groups + 3) / 4;
   const long cap = (long)(ctx ? ctx->num_cus : 256) * 8;
@@ -612,12 +631,13 @@ static int field_query_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void
 
 extern "C" int neraf_composite(neraf_ctx* ctx, const float* density, const float* rgb, const float* e_bins, int R, int S,
                                int training, float* weights, float* rgb_out, float* depth, float* expected, float* acc,
-                               void* scratch8, neraf_stream_t stream) {
-  if (R <= 0 || S <= 0 || S > 64 || !density || !rgb || !e_bins || !rgb_out || (expected && !scratch8))
-    return neraf_fail(ctx, NERAF_EINVAL, "composite: bad arguments (S <= 64; scratch8 needed for expected depth)");
-  unsigned* mm = (unsigned*)scratch8;
+                               void* scratch, size_t scratch_bytes, neraf_stream_t stream) {
+  if (R <= 0 || S <= 0 || S > 64 || !density || !rgb || !e_bins || !rgb_out || (expected && (!scratch || scratch_bytes < 8)) ||
+      scratch_bytes > 8 + 4 * 60 || (scratch_bytes & 3))
+    return neraf_fail(ctx, NERAF_EINVAL, "composite: bad arguments (S <= 64; >= 8 scratch bytes needed for expected depth, <= 248)");
+  unsigned* mm = (unsigned*)scratch;
   if (expected) {
-    hipLaunchKernelGGL(minmax_seed_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mm);
+    hipLaunchKernelGGL(minmax_seed_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mm, (int)((scratch_bytes - 8) / 4));
     hipLaunchKernelGGL(steps_minmax_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, e_bins, R, S, mm);
   }
   CompArgs a{density, rgb, e_bins, R, S, training, weights, rgb_out, depth, expected, acc, mm};

@@ -373,7 +373,10 @@ __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
 
 // w_grad[i] += sum over workgroups of part[b][i], i < 272: 34 workgroups of 8 outputs x 32 row slices (five 64-thread workgroups
 // walking 2048 rows each were a 60-80 us latency chain)
-__global__ __launch_bounds__(256) void prop_wgrad_fold_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ w_grad) {
+__global__ __launch_bounds__(256) void prop_wgrad_fold_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ w_grad,
+                                                             float* __restrict__ w0_out, float* __restrict__ w1_out) {
+  // w0_out / w1_out (both or neither): STORE the result in the parameters' own layouts -- w0 [16][16] and w1 [16][16] whose row 0 is
+  // the used output row (rows 1..15 have no gradient: written as zeros) -- instead of adding into the flat w_grad[272]
   __shared__ float red[32][9];
   const int o = threadIdx.x & 7, sl = threadIdx.x >> 3;
   const int i = blockIdx.x * 8 + o;
@@ -389,8 +392,11 @@ __global__ __launch_bounds__(256) void prop_wgrad_fold_kernel(const float* __res
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
-    w_grad[blockIdx.x * 8 + threadIdx.x] += s;
+    const int k = blockIdx.x * 8 + threadIdx.x;
+    if (w0_out) { if (k < 256) w0_out[k] = s; else w1_out[k - 256] = s; }
+    else w_grad[k] += s;
   }
+  if (w1_out && blockIdx.x == 0 && threadIdx.x >= 16) w1_out[threadIdx.x] = 0.f;      // rows 1..15 of w1 (240 floats)
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1070,26 +1076,40 @@ __global__ __launch_bounds__(OWN_THREADS) void field_scatter_owner_kernel(FieldO
   }
 }
 
-// packed fixed point -> fp32 pair, in place:  (lo, hi) * (1 / F_l) * (1 / S)
+// packed fixed point -> fp32 pair:  (lo, hi) * (1 / F_l) * (1 / S).  dst == acc: in place (the legacy form: the gradient buffer
+// doubles as the accumulator).  dst != acc: the accumulator is a persistent scratch that this kernel leaves ZERO again for the next
+// call (no fill launch per call), and dst is written (beta == 0: every entry, zeros included) or added to (beta != 0: entries
+// with a contribution only) -- the second producer of a parameter's gradient in one backward pass adds in place instead of
+// handing autograd a second tensor to sum (a 49 MB add per step for the radiance table: render batch + grid refresh)
 __global__ __launch_bounds__(256) void field_unpack_grad_kernel(GridLayout g, const float* __restrict__ lvl, const float* __restrict__ scale,
-                                                               unsigned long long* __restrict__ acc) {
+                                                               unsigned long long* __restrict__ acc, float2* __restrict__ dst, int beta) {
   const int l = blockIdx.y;
   const float m = lvl[16 + l] * scale[1];
   const unsigned size = g.size[l], off = g.offset[l];
+  const bool inplace = reinterpret_cast<void*>(dst) == reinterpret_cast<void*>(acc);
   for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < size; i += gridDim.x * 256) {
     const long long v = (long long)acc[off + i];
-    if (v == 0) continue;                                   // bit pattern 0 is also fp32 (0, 0)
+    if (v == 0) {                                           // bit pattern 0 is also fp32 (0, 0)
+      if (!inplace && !beta) dst[off + i] = make_float2(0.f, 0.f);
+      continue;
+    }
     const int lo = (int)(v & 0xffffffffll);
     const int hi = (int)((v - (long long)lo) >> 32);
     float2 o = make_float2((float)lo * m, (float)hi * m);
-    reinterpret_cast<float2*>(acc)[off + i] = o;
+    if (!inplace) {
+      acc[off + i] = 0ull;
+      if (beta) { const float2 old = dst[off + i]; o.x += old.x; o.y += old.y; }
+    }
+    dst[off + i] = o;
   }
 }
 
 // amax of the upstream gradients entering the fp16 chain -> power-of-two scale {S, 1/S}
 __global__ __launch_bounds__(256) void field_amax_kernel(const float* __restrict__ d_rgb, const float* __restrict__ d_density,
                                                         const float* __restrict__ density, long N, float avg_density,
-                                                        unsigned* __restrict__ amax_bits) {
+                                                        unsigned* __restrict__ amax_bits, float* __restrict__ zero_p, long zero_n) {
+  // first launch of the backward: also clears the (small) embedding-gradient buffer the later kernels add into
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_n; i += (long)gridDim.x * 256) zero_p[i] = 0.f;
   // |d logit| = |d sigma| * avg * exp(clamp(logit, -15, 15)): the forward density with the trunc_exp clamp applied to it (an
   // un-clamped density of 1e20 would push the scale so low that every clamped gradient underflows the fp16 chain)
   const float dlo = avg_density * 3.0590232e-7f, dhi = avg_density * 3269017.4f;       // avg * e^-15, avg * e^15
@@ -1110,6 +1130,7 @@ __global__ __launch_bounds__(256) void field_amax_kernel(const float* __restrict
 __global__ void field_make_scale_kernel(float* __restrict__ scale) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const float amax = __uint_as_float(reinterpret_cast<unsigned*>(scale)[2]);
+    reinterpret_cast<unsigned*>(scale)[2] = 0u;      // consumed: the atomic-max word is zero again for the next call (the dump starts zeroed)
     float S = 1.f;
     if (amax > 0.f && amax < 3.0e38f) {
       int e = 6 - (int)floorf(log2f(amax));       // max |dY| of the last layer -> [64, 128)
@@ -1150,7 +1171,8 @@ extern "C" int neraf_interlevel_loss(neraf_ctx* ctx, const float* c_bins, const 
 static int proposal_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                                   const float* origins, const float* dirs, const float* e_bins, const float* d_density,
                                   int R, int S, float avg_density, float* table_grad, float* w_grad, void* scratch,
-                                  size_t scratch_bytes, float* d_rays, neraf_stream_t stream);
+                                  size_t scratch_bytes, float* d_rays, float* w0_out, float* w1_out, void* acc_scratch,
+                                  neraf_stream_t stream);
 
 extern "C" size_t neraf_proposal_backward_scratch_bytes(int R, int S, int n_levels) {
   const size_t npad = ((size_t)R * S + 63) / 64 * 64;
@@ -1162,7 +1184,18 @@ extern "C" int neraf_proposal_backward(neraf_ctx* ctx, const neraf_grid_desc* g,
                                        int R, int S, float avg_density, float* table_grad, float* w_grad, void* scratch,
                                        size_t scratch_bytes, neraf_stream_t stream) {
   return proposal_backward_impl(ctx, g, table_f16, mlp_f16, origins, dirs, e_bins, d_density, R, S, avg_density, table_grad, w_grad,
-                                scratch, scratch_bytes, nullptr, stream);
+                                scratch, scratch_bytes, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int neraf_proposal_backward_ex(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
+                                          const float* origins, const float* dirs, const float* e_bins, const float* d_density,
+                                          int R, int S, float avg_density, float* table_grad, float* w0_grad, float* w1_grad,
+                                          void* scratch, size_t scratch_bytes, void* acc_scratch, float* d_rays,
+                                          neraf_stream_t stream) {
+  if (!w0_grad || !w1_grad || !acc_scratch || !scratch || scratch_bytes < neraf_proposal_backward_scratch_bytes(R, S, g ? g->n_levels : 0))
+    return neraf_fail(ctx, NERAF_EINVAL, "proposal_backward_ex: w0_grad, w1_grad, acc_scratch and the full scratch are required");
+  return proposal_backward_impl(ctx, g, table_f16, mlp_f16, origins, dirs, e_bins, d_density, R, S, avg_density, table_grad, w0_grad,
+                                scratch, scratch_bytes, d_rays, w0_grad, w1_grad, acc_scratch, stream);
 }
 
 extern "C" int neraf_proposal_backward_rays(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
@@ -1171,13 +1204,14 @@ extern "C" int neraf_proposal_backward_rays(neraf_ctx* ctx, const neraf_grid_des
                                             size_t scratch_bytes, float* d_rays, neraf_stream_t stream) {
   if (!d_rays) return neraf_fail(ctx, NERAF_EINVAL, "proposal_backward_rays: d_rays required");
   return proposal_backward_impl(ctx, g, table_f16, mlp_f16, origins, dirs, e_bins, d_density, R, S, avg_density, table_grad, w_grad,
-                                scratch, scratch_bytes, d_rays, stream);
+                                scratch, scratch_bytes, d_rays, nullptr, nullptr, nullptr, stream);
 }
 
 static int proposal_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                                   const float* origins, const float* dirs, const float* e_bins, const float* d_density,
                                   int R, int S, float avg_density, float* table_grad, float* w_grad, void* scratch,
-                                  size_t scratch_bytes, float* d_rays, neraf_stream_t stream) {
+                                  size_t scratch_bytes, float* d_rays, float* w0_out, float* w1_out, void* acc_scratch,
+                                  neraf_stream_t stream) {
   PropBwdArgs a{};
   if (make_grid_layout(g, &a.g) || a.g.n_levels > 8) return neraf_fail(ctx, NERAF_EINVAL, "proposal_backward: bad grid (<= 8 levels)");
   if (R <= 0 || S <= 0 || !table_f16 || !mlp_f16 || !origins || !dirs || !e_bins || !d_density || !table_grad || !w_grad)
@@ -1207,7 +1241,8 @@ static int proposal_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, cons
       hipLaunchKernelGGL(field_finalize_kernel, dim3(16), dim3(256), 0, st, a.t_part, (int)blocks, lvl, nullptr, nullptr, nullptr);
       FieldScatterArgs sa{};
       sa.g = a.g; sa.origins = origins; sa.dirs = dirs; sa.e_bins = e_bins; sa.R = R; sa.S = S; sa.mode = 0;
-      sa.npad = npad; sa.lvl = lvl; sa.acc = reinterpret_cast<unsigned long long*>(table_grad); sa.l_end = a.g.n_levels; sa.run = 1;
+      sa.npad = npad; sa.lvl = lvl; sa.acc = reinterpret_cast<unsigned long long*>(acc_scratch ? acc_scratch : (void*)table_grad);
+      sa.l_end = a.g.n_levels; sa.run = 1;
       sa.d32 = a.d32;
       long sblocks = ((n + 63) / 64 + 3) / 4;
       const long cap = (long)(ctx ? ctx->num_cus : 256) * 8;
@@ -1216,10 +1251,10 @@ static int proposal_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, cons
       unsigned maxsize = 0;
       for (int l = 0; l < a.g.n_levels; ++l) maxsize = a.g.size[l] > maxsize ? a.g.size[l] : maxsize;
       hipLaunchKernelGGL(field_unpack_grad_kernel, dim3((maxsize + 1023) / 1024, a.g.n_levels), dim3(256), 0, st, a.g, lvl, a.one2,
-                         reinterpret_cast<unsigned long long*>(table_grad));
-    }
+                         sa.acc, reinterpret_cast<float2*>(table_grad), 0);
+    } else if (acc_scratch) return neraf_fail(ctx, NERAF_EINVAL, "proposal_backward_ex: packed table gradient unavailable");
   }
-  if (a.w_part) hipLaunchKernelGGL(prop_wgrad_fold_kernel, dim3(34), dim3(256), 0, st, a.w_part, (int)blocks, w_grad);
+  if (a.w_part) hipLaunchKernelGGL(prop_wgrad_fold_kernel, dim3(34), dim3(256), 0, st, a.w_part, (int)blocks, w_grad, w0_out, w1_out);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
@@ -1235,7 +1270,7 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
                                float avg_density, int avg_row, const float* density, const float* d_rgb,
                                const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
                                void* splitk_ws, size_t splitk_bytes, int pos_run, float* d_rays, const void* enc_in, const void* denc_in,
-                               neraf_stream_t stream);
+                               void* acc_scratch, int accumulate, int emb_rows, neraf_stream_t stream);
 
 extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
                                     const void* wfrag_bwd_f16, const void* emb_f16, const float* origins, const float* dirs,
@@ -1245,7 +1280,7 @@ extern "C" int neraf_field_backward(neraf_ctx* ctx, const neraf_grid_desc* g, co
                                     size_t splitk_bytes, neraf_stream_t stream) {
   return field_backward_impl(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
                              aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
-                             splitk_ws, splitk_bytes, 1, nullptr, nullptr, nullptr, stream);
+                             splitk_ws, splitk_bytes, 1, nullptr, nullptr, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
@@ -1256,7 +1291,7 @@ extern "C" int neraf_field_backward_runs(neraf_ctx* ctx, const neraf_grid_desc* 
                                          void* splitk_ws, size_t splitk_bytes, int pos_run, neraf_stream_t stream) {
   return field_backward_impl(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
                              aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
-                             splitk_ws, splitk_bytes, pos_run, nullptr, nullptr, nullptr, stream);
+                             splitk_ws, splitk_bytes, pos_run, nullptr, nullptr, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int neraf_field_backward_rays(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
@@ -1268,7 +1303,7 @@ extern "C" int neraf_field_backward_rays(neraf_ctx* ctx, const neraf_grid_desc* 
   if (!d_rays) return neraf_fail(ctx, NERAF_EINVAL, "field_backward_rays: d_rays required");
   return field_backward_impl(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
                              aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
-                             splitk_ws, splitk_bytes, 1, d_rays, nullptr, nullptr, stream);
+                             splitk_ws, splitk_bytes, 1, d_rays, nullptr, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int neraf_field_backward_ex(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
@@ -1277,11 +1312,11 @@ extern "C" int neraf_field_backward_ex(neraf_ctx* ctx, const neraf_grid_desc* g,
                                       float avg_density, int avg_row, const float* density, const float* d_rgb,
                                       const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
                                       void* splitk_ws, size_t splitk_bytes, int pos_run, float* d_rays, const void* enc_saved,
-                                      const void* denc_saved, neraf_stream_t stream) {
+                                      const void* denc_saved, void* acc_scratch, int accumulate, int emb_rows, neraf_stream_t stream) {
   if (d_rays && pos_run != 1) return neraf_fail(ctx, NERAF_EINVAL, "field_backward_ex: ray gradients need pos_run == 1");
   return field_backward_impl(ctx, g, table_f16, wfrag_f16, wfrag_bwd_f16, emb_f16, origins, dirs, e_bins, cam_idx, R, S, mode,
                              aabb_host, avg_density, avg_row, density, d_rgb, d_density, table_grad, emb_grad, w_grads, dump,
-                             splitk_ws, splitk_bytes, pos_run, d_rays, enc_saved, denc_saved, stream);
+                             splitk_ws, splitk_bytes, pos_run, d_rays, enc_saved, denc_saved, acc_scratch, accumulate, emb_rows, stream);
 }
 
 static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
@@ -1290,7 +1325,9 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
                                float avg_density, int avg_row, const float* density, const float* d_rgb,
                                const float* d_density, float* table_grad, float* emb_grad, float* const* w_grads, void* dump,
                                void* splitk_ws, size_t splitk_bytes, int pos_run, float* d_rays, const void* enc_in, const void* denc_in,
-                               neraf_stream_t stream) {
+                               void* acc_scratch, int accumulate, int emb_rows, neraf_stream_t stream) {
+  if (accumulate && !acc_scratch)
+    return neraf_fail(ctx, NERAF_EINVAL, "field_backward: accumulate needs acc_scratch (the gradient buffer cannot double as the accumulator)");
   if (pos_run < 1 || (pos_run > 1 && (S != 1 || R % pos_run != 0)))
     return neraf_fail(ctx, NERAF_EINVAL, "field_backward_runs: pos_run > 1 needs S == 1 and R a multiple of pos_run");
   FieldBwdArgs a{};
@@ -1342,11 +1379,15 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
     }
     a.pos = reinterpret_cast<float*>((half_t*)dump + (size_t)4 * 128 * npad + (size_t)64 * npad);   // slot 4, rows 64..: pos [3][npad], ids
   }
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(scale, 0, 16, st));
+  // scale[2] (the atomic-max word) is zero on entry: the dump is zero-initialised by the caller once, and field_make_scale_kernel
+  // clears the word after reading it
   {
     long blocks = (N + 1023) / 1024; if (blocks > 256) blocks = 256;
+    // with a separate accumulator the library owns the initial state of the outputs: a first producer (accumulate == 0) starts the
+    // embedding gradient from zero here; the legacy form (acc_scratch == NULL) expects the caller to have zeroed both buffers
+    const bool zero_emb = acc_scratch && !accumulate && emb_grad && avg_row < 0 && emb_rows > 0;
     hipLaunchKernelGGL(field_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_rgb, d_density, density, N, avg_density,
-                       reinterpret_cast<unsigned*>(scale) + 2);
+                       reinterpret_cast<unsigned*>(scale) + 2, zero_emb ? emb_grad : nullptr, zero_emb ? (long)emb_rows * 32 : 0l);
     hipLaunchKernelGGL(field_make_scale_kernel, dim3(1), dim3(64), 0, st, scale);
   }
   {
@@ -1371,7 +1412,8 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
     FieldScatterArgs sa{};
     sa.g = a.g; sa.origins = origins; sa.dirs = dirs; sa.e_bins = e_bins; sa.R = R; sa.S = S; sa.mode = mode;
     for (int i = 0; i < 6; ++i) sa.aabb[i] = a.aabb[i];
-    sa.d_enc = a.d_enc; sa.npad = npad; sa.lvl = lvl; sa.acc = reinterpret_cast<unsigned long long*>(table_grad);
+    sa.d_enc = a.d_enc; sa.npad = npad; sa.lvl = lvl;
+    sa.acc = reinterpret_cast<unsigned long long*>(acc_scratch ? acc_scratch : (void*)table_grad);
     sa.l_end = 16;
     sa.run = pos_run;
     long sblocks = ((N + 63) / 64 + 3) / 4;
@@ -1404,7 +1446,7 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
     unsigned maxsize = 0;
     for (int l = 0; l < 16; ++l) maxsize = a.g.size[l] > maxsize ? a.g.size[l] : maxsize;
     hipLaunchKernelGGL(field_unpack_grad_kernel, dim3((maxsize + 1023) / 1024, 16), dim3(256), 0, st, a.g, lvl, scale,
-                       reinterpret_cast<unsigned long long*>(table_grad));
+                       sa.acc, reinterpret_cast<float2*>(table_grad), accumulate);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
   }
   // weight gradients: dW_l [out,in] = (1/S) dY_l [out,N] . X_l [in,N]^T   (NT GEMM, K = points, split-K)
@@ -1414,6 +1456,7 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
   gp.lda = (int)npad; gp.ldb = (int)npad; gp.K = (int)npad; gp.Mpad = 64; gp.Npad = 64; gp.alpha = 1.f; gp.alpha_dev = scale + 1;
   gp.splitk_ws = (float*)splitk_ws; gp.splitk_ws_bytes = splitk_bytes;
   gp.ngroups = 5;
+  gp.c32_beta = accumulate;
   for (int l = 0; l < 5; ++l) {
     gp.grp[l].A = (const half_t*)dump + (size_t)(2 * l + 1) * 128 * npad;
     gp.grp[l].B = (const half_t*)dump + (size_t)(2 * l) * 128 * npad;

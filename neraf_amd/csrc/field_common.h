@@ -41,6 +41,16 @@ int make_grid_layout(const neraf_grid_desc* g, GridLayout* L) {
 __device__ __forceinline__ float spacing_fn(float x) { return x < 1.f ? 0.5f * x : 1.f - 1.f / (2.f * x); }
 __device__ __forceinline__ float spacing_inv(float x) { return x < 0.5f ? 2.f * x : 1.f / (2.f - 2.f * x); }
 
+// One uniform [0,1) draw per (seed, ray): the sampler's single jitter per ray and stage, generated where it is consumed (splitmix64
+// finaliser over seed + golden-ratio * (ray + 1); the top 24 bits).  The host layer derives a fresh seed per call and stage.
+__device__ __forceinline__ float jitter_u01(unsigned long long seed, int ray) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(ray + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
 // ---- shared point helpers ---------------------------------------------------------------------------------
 __device__ __forceinline__ bool map_position(float& x, float& y, float& z, int mode, const float* aabb) {
   if (mode == 0) {   // SceneContraction(L-inf) then (x+2)/4

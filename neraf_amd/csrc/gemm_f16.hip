@@ -255,7 +255,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
           for (int c0 = 0; c0 < WN; c0 += 64) {
             const int n = n_w0 + c0 + lane;
-            if (n < N) C32[(size_t)m * ldc32 + n] = im[row * T::IMG32_LD + c0 + lane];
+            if (n < N) {
+              float* dst = C32 + (size_t)m * ldc32 + n;
+              *dst = im[row * T::IMG32_LD + c0 + lane] + (p.c32_beta ? *dst : 0.f);
+            }
           }
         }
       } else {
@@ -265,7 +268,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         for (int it = 0; it < ROWS * WN / 64; ++it) {
           const int idx = it * 64 + lane, row = idx / WN, col = idx - row * WN;
           const int m = m_p0 + row, n = n_w0 + col;
-          if (m < M && n < N) C32[(size_t)m * ldc32 + n] = im[row * T::IMG32_LD + col];
+          if (m < M && n < N) {
+            float* dst = C32 + (size_t)m * ldc32 + n;
+            *dst = im[row * T::IMG32_LD + col] + (p.c32_beta ? *dst : 0.f);
+          }
         }
       }
     }
@@ -745,10 +751,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
   }
   if (C32 && m < M) {
     float* dst = C32 + (size_t)m * ldc32 + n;
-    if (n + 3 < N && (reinterpret_cast<size_t>(dst) & 15) == 0) *reinterpret_cast<f32x4*>(dst) = v;
-    else {
+    if (n + 3 < N && (reinterpret_cast<size_t>(dst) & 15) == 0) {
+      f32x4 o = v;
+      if (p.c32_beta) o += *reinterpret_cast<const f32x4*>(dst);
+      *reinterpret_cast<f32x4*>(dst) = o;
+    } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) if (n + r < N) dst[r] = v[r];
+      for (int r = 0; r < 4; ++r) if (n + r < N) dst[r] = v[r] + (p.c32_beta ? dst[r] : 0.f);
     }
   }
   __syncthreads();

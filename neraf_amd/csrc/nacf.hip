@@ -246,10 +246,12 @@ __global__ __launch_bounds__(256) void dfeat_kernel(const float* __restrict__ W0
 
 // dW0[:, :n_feat] = outer(db0, feat)
 __global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ db0, const float* __restrict__ feat, int N,
-                                                   int n_feat, float* __restrict__ dW0, int ldw) {
+                                                   int n_feat, float* __restrict__ dW0, int ldw, float* __restrict__ zero_nfeat) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y;
   if (k < n_feat && n < N) dW0[(size_t)n * ldw + k] = db0[n] * feat[k];
+  // row 0 of the grid also clears d feat, which the next launch (dfeat_kernel) accumulates into: no fill launch in between
+  if (zero_nfeat && n == 0 && k < n_feat) zero_nfeat[k] = 0.f;
 }
 
 // Query prologue, NeRAF_model.py:533-551.  One thread per (row, column) of q[B,192]; `tmajor`
@@ -617,7 +619,7 @@ static int nacf_bwd_body(neraf_ctx* ctx, const neraf_nacf_desc* d, const Dims& D
                          int* slot0, hipStream_t st) {
   const int M = WL.Mpad;
   // the six column-sum rows and the scale block are adjacent in the workspace (make_ws_layout): one fill
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(ws + WL.colsum[0], 0, WL.scale + 256 - WL.colsum[0], st));
+  neraf_zero_async(st, ws + WL.colsum[0], WL.scale + 256 - WL.colsum[0]);
   // heads: dz5 = dout * (10 - out^2/10)  -> fp16 [Mpad][np5] and transposed [np5(+128)][Mpad]
   float* scale = (float*)(ws + WL.scale);
   const float* inv_scale = scale + 1;
@@ -708,9 +710,8 @@ extern "C" int neraf_nacf_bwd(neraf_ctx* ctx, const neraf_nacf_desc* d, const vo
   const float* db0 = grads[1];   // un-scaled layer-0 bias gradient
   if (d->n_feat > 0) {
     hipLaunchKernelGGL(outer_kernel, dim3((d->n_feat + 255) / 256, D.n[0]), dim3(256), 0, st, db0, feat, D.n[0], d->n_feat,
-                       grads[0], D.kdense);
+                       grads[0], D.kdense, dfeat);
     if (dfeat) {
-      NERAF_HIP_CHECK(ctx, hipMemsetAsync(dfeat, 0, (size_t)d->n_feat * 4, st));
       hipLaunchKernelGGL(dfeat_kernel, dim3((d->n_feat + 255) / 256, 64), dim3(256), 0, st, Wptr(w, 0), D.kdense, db0,
                          D.n[0], d->n_feat, dfeat);
     }
@@ -757,7 +758,7 @@ extern "C" int neraf_stft_loss_sums(neraf_ctx* ctx, const float* pred, const flo
                                     float* sums, neraf_stream_t stream) {
   if (!pred || !gt || !sums || n == 0) return neraf_fail(ctx, NERAF_EINVAL, "stft_loss_sums: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  NERAF_HIP_CHECK(ctx, hipMemsetAsync(sums, 0, 16, st));
+  neraf_zero_async(st, sums, 16);
   int blocks = (int)((n + 1023) / 1024);
   if (blocks > 256) blocks = 256;   // 3 same-address atomics per block: keep the count low
   hipLaunchKernelGGL(stft_loss_sums_kernel, dim3(blocks), dim3(256), 0, st, pred, gt, n, loss_type, sums);

@@ -48,9 +48,11 @@ struct RunTable {
   int cpad[48];
   float unbias[48];
   float* rmean[48]; float* rvar[48];
+  long long* nbt[48];                // num_batches_tracked of each BatchNorm (or null): += 1 in the same launch
 };
 
 __global__ __launch_bounds__(256) void bn_update_running_all_kernel(RunTable t, const char* __restrict__ ws, float mom) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < t.n && t.nbt[threadIdx.x]) *t.nbt[threadIdx.x] += 1;    // BatchNorm3d.num_batches_tracked
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= t.begin[t.n]) return;
   int lo = 0, hi = t.n - 1;
@@ -324,7 +326,8 @@ extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
 }
 
 extern "C" int neraf_resnet3d_update_running_stats(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* workspace,
-                                                   float* const* bn, float momentum, neraf_stream_t stream) {
+                                                   float* const* bn, float momentum, int64_t* const* num_batches_tracked,
+                                                   neraf_stream_t stream) {
   Arch A; Layout L;
   if (make_arch(d, &A) || !workspace || !bn) return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_update_running_stats: bad arguments");
   make_layout(A, &L);
@@ -338,6 +341,7 @@ extern "C" int neraf_resnet3d_update_running_stats(neraf_ctx* ctx, const neraf_r
     t.begin[i] = acc; t.stat_off[i] = L.fin[i]; t.cpad[i] = round_up(c.cout, 128);
     t.unbias[i] = m / (m - 1.f);
     t.rmean[i] = bn[4 * i + 2]; t.rvar[i] = bn[4 * i + 3];
+    t.nbt[i] = num_batches_tracked ? (long long*)num_batches_tracked[i] : nullptr;
     acc += c.cout;
   }
   t.begin[A.nconv] = acc;

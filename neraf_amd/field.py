@@ -50,6 +50,9 @@ class _NacfSplitFn(torch.autograd.Function):
         _lib.check(lib.neraf_nacf_fwd(h, C.byref(field._desc), packed.data_ptr(), wptr, feat.data_ptr(), B,
                                       out.data_ptr(), ws.data_ptr(), int(training), _stream_ptr()), dev)
         ctx.field, ctx.B, ctx.dev = field, B, dev
+        # optional hand-off: the producer of `feat` names the buffer it wants d loss / d feat in (ResNet3D.dfeat_buffer)
+        gb = getattr(feat, "_neraf_grad_buffer", None)
+        ctx.dfeat_out = gb if (gb is not None and gb.shape == feat.shape and gb.dtype == feat.dtype and gb.device == feat.device) else None
         ctx.save_for_backward(feat, ws, out, packed, *params)
         return out
 
@@ -60,7 +63,7 @@ class _NacfSplitFn(torch.autograd.Function):
         lib = _lib.load()
         dout = dout.contiguous().float()
         grads = [torch.empty_like(p) for p in params]
-        dfeat = torch.empty_like(feat)
+        dfeat = ctx.dfeat_out if ctx.dfeat_out is not None else torch.empty_like(feat)
         _lib.check(lib.neraf_nacf_bwd(_lib.ctx(ctx.dev), C.byref(field._desc), packed.data_ptr(), _lib.ptr_array(params),
                                       feat.data_ptr(), ctx.B, out.data_ptr(), dout.data_ptr(), _lib.ptr_array(grads),
                                       dfeat.data_ptr(), ws.data_ptr(), _stream_ptr()), ctx.dev)
@@ -177,7 +180,10 @@ class NeRAFAudioSoundField(nn.Module):
         lib = _lib.load()
         dev = _dev_index(mic_pose)
         B = int(time_query.shape[0])
+        gb = getattr(feat, "_neraf_grad_buffer", None)
         feat = feat.reshape(-1).float().contiguous()
+        if gb is not None:                    # the view made above is a new tensor object: carry the producer's hand-off along
+            feat._neraf_grad_buffer = gb
         if feat.numel() != self._desc.n_feat:
             raise ValueError(f"feat must have {self._desc.n_feat} elements")
         tq = time_query.to(torch.int64).contiguous()

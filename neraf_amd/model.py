@@ -68,9 +68,10 @@ class _RefreshFn(torch.autograd.Function):
     (NeRAF_model.py:339-357, :386).  Forward = fused field query in AABB mode; backward = fused field backward."""
 
     @staticmethod
-    def forward(ctx, field, coords, aabb, dirs, nd: int, delta: float, consts, *params: torch.Tensor):
+    def forward(ctx, field, coords, aabb, dirs, nd: int, delta: float, consts, slab, *params: torch.Tensor):
         """coords [n,3] cell centres in (0,1)^3 (a window of coordinates_to_render), aabb the radiance field's box, dirs [nd,3];
-        consts = (dd [n*nd,3], z [n*nd,2], cam [n*nd]) are the per-shape constants of the query.  The nd*n queries are laid out
+        consts = (dd [n*nd,3], z [n*nd,2], cam [n*nd]) are the per-shape constants of the query; slab = (grid tensor, first cell) or None:
+        the launch that forms the values also writes them into the grid window (the detached write of NeRAF_model.py:395-400).  The nd*n queries are laid out
         CELL-major (the nd directions of a cell adjacent) -- the result does not depend on the order, and the backward's
         hash-gradient pre-reduction then merges the nd identical positions into one update per table entry."""
         lib = _lib.load()
@@ -83,8 +84,10 @@ class _RefreshFn(torch.autograd.Function):
         packed = field.packed(with_average=False)       # the refresh queries with camera index 0's embedding (:334)
         rgb, den, saved = field.query(oris, dd, z, cam, use_average_embedding=False, packed=packed, save=1)    # [n*nd,1,3], [n*nd,1]
         vals = torch.empty((4, n), dtype=torch.float32, device=coords.device)
+        grid, start = slab if slab is not None else (None, 0)
+        nvox = grid.shape[1] * grid.shape[2] * grid.shape[3] if grid is not None else 0
         _lib.check(lib.neraf_grid_refresh_vals(_lib.ctx(dev), rgb.data_ptr(), den.data_ptr(), n, nd, 1, delta, vals.data_ptr(),
-                                               _stream_ptr()), dev)                        # :352-357, :386
+                                               grid.data_ptr() if grid is not None else None, nvox, int(start), _stream_ptr()), dev)   # :352-357, :386
         ctx.field, ctx.nd, ctx.delta, ctx.packed, ctx.dev, ctx.saved = field, nd, delta, packed, dev, saved
         ctx.save_for_backward(oris, dd, z, cam, den)
         return vals
@@ -100,8 +103,9 @@ class _RefreshFn(torch.autograd.Function):
         d_den = torch.empty((nd * n, 1), dtype=torch.float32, device=oris.device)
         _lib.check(lib.neraf_grid_refresh_vals_bwd(_lib.ctx(ctx.dev), dvals.data_ptr(), den.data_ptr(), n, nd, 1, delta,
                                                    d_rgb.data_ptr(), d_den.data_ptr(), _stream_ptr()), ctx.dev)
-        grads = ctx.field.backward_query(ctx.packed, oris, dd, z, cam, den, d_rgb, d_den, pos_run=nd, saved=ctx.saved)   # cell-major: nd rays per position
-        return (None, None, None, None, None, None, None, *grads)
+        grads = ctx.field.backward_query(ctx.packed, oris, dd, z, cam, den, d_rgb, d_den, pos_run=nd, saved=ctx.saved,
+                                         in_autograd=all(ctx.needs_input_grad[8:15]))          # cell-major: nd rays per position
+        return (None, None, None, None, None, None, None, None, *grads)
 
 
 class NeRAFAudioModel(nn.Module):
@@ -234,9 +238,11 @@ class NeRAFAudioModel(nn.Module):
             if differentiable:
                 # the grid is detached and the fresh values keep their graph (:395-400): vals is an autograd node over the
                 # radiance-field parameters, consumed by the ResNet3D node in scene_feature()
+                vb = self.grid._version
                 if dp is None:
+                    # the kernel that forms the values writes the grid window too (a raw-pointer write: the version counter stays)
                     vals = _RefreshFn.apply(module, coords, aabb, dirs, nd, self._delta, self._refresh_consts(dirs, batch_size),
-                                            *module.grad_params())
+                                            (self.grid, i), *module.grad_params())
                 else:
                     # data parallel (SURVEY 8e "Partitioning"): every rank holds the same field, so rank r queries only its
                     # share of the window's cells (and back-propagates only through those); the shares are assembled into the
@@ -246,11 +252,10 @@ class NeRAFAudioModel(nn.Module):
                     group, rank, world = dp
                     lo, hi = shard_range(batch_size, rank, world)
                     local = _RefreshFn.apply(module, coords[lo:hi], aabb, dirs, nd, self._delta, self._refresh_consts(dirs, hi - lo),
-                                             *module.grad_params()) if hi > lo else torch.zeros((4, 0), device=coords.device)
+                                             None, *module.grad_params()) if hi > lo else torch.zeros((4, 0), device=coords.device)
                     vals = gather_shards(local, lo, hi, batch_size, group)
-                vb = self.grid._version
-                with torch.no_grad():
-                    self.grid.view(7, nvox)[0:4, i:i + batch_size] = vals
+                    with torch.no_grad():
+                        self.grid.view(7, nvox)[0:4, i:i + batch_size] = vals
                 self.mark_grid_written(i, batch_size, vb)
                 self._window = (i, batch_size, vals)
             else:
@@ -315,10 +320,14 @@ class NeRAFAudioModel(nn.Module):
         d = self._grid_dirty
         gs = d if (d is not None and d[0] == self._grid_gen) else (self._grid_gen, -1, 0, 0, -1, -1)
         if self.training and win is not None:
-            feat = self.resnet3d(self.grid.unsqueeze(0), window=(win[0], win[1], 4), window_vals=win[2], grid_state=gs).flatten()
+            out = self.resnet3d(self.grid.unsqueeze(0), window=(win[0], win[1], 4), window_vals=win[2], grid_state=gs)
             self._window = None
         else:
-            feat = self.resnet3d(self.grid.unsqueeze(0), grid_state=gs).flatten()       # :554-557
+            out = self.resnet3d(self.grid.unsqueeze(0), grid_state=gs)                  # :554-557
+        feat = out.flatten()
+        gb = getattr(out, "_neraf_grad_buffer", None)
+        if gb is not None:                   # where the encoder's backward wants d loss / d feature written (ResNet3D.dfeat_buffer)
+            feat._neraf_grad_buffer = gb
         if not self.training:
             self._feat_cache, self._feat_key = feat, True
         return feat
@@ -364,17 +373,23 @@ class NeRAFAudioModel(nn.Module):
         feat = self.scene_feature() if self.use_grid else torch.zeros(0, device=dev)
         out = self.field.forward_queries(feat, tq, mic, src, rot, self.aabb, T)         # [T,C,F]
         stft: Dict[str, torch.Tensor] = {}
+        host = out.cpu()                           # ONE device-to-host copy of [T,C,F]; the panels below are host-side views of it
         for ch in range(out.shape[1]):                                                  # :695-700
-            v = out[:, ch, :].transpose(0, 1).unsqueeze(-1).cpu()
-            stft["stft_ch_" + str(ch)] = torch.flip(v, [0])
-        gt = self.eval_gt.to(dev)
+            stft["stft_ch_" + str(ch)] = torch.flip(host[:, ch, :].transpose(0, 1).unsqueeze(-1), [0])
+        gt = self.eval_gt.cpu()
         for ch in range(gt.shape[0]):                                                   # :703-714
-            stft["gt_ch_" + str(ch)] = torch.flip(gt[ch, :, :].unsqueeze(-1).cpu(), [0])
+            stft["gt_ch_" + str(ch)] = torch.flip(gt[ch, :, :].unsqueeze(-1), [0])
         for ch in range(gt.shape[0]):
             stft["comparison_ch_" + str(ch)] = torch.cat([stft["stft_ch_" + str(ch)], stft["gt_ch_" + str(ch)]], dim=1)
         if self.use_grid:                                                               # :716-723
-            stft["grid"] = self.grid[0:3].mean(dim=3).permute(1, 2, 0)
-            stft["grid_density"] = self.grid[3].mean(dim=2).unsqueeze(-1)
+            # two full reductions over the 128^3 grid per call in the reference; the grid is static in eval, so the panels are
+            # cached per write generation of the grid (mark_grid_written) and tensor version
+            key = (self._grid_gen, self.grid._version, self.grid.data_ptr())
+            pc = getattr(self, "_grid_panels", None)
+            if pc is None or pc[0] != key:
+                pc = (key, self.grid[0:3].mean(dim=3).permute(1, 2, 0), self.grid[3].mean(dim=2).unsqueeze(-1))
+                self._grid_panels = pc
+            stft["grid"], stft["grid_density"] = pc[1], pc[2]
         stft["raw_output"] = out                                                        # :725-726
         return stft
 

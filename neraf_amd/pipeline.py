@@ -20,6 +20,18 @@ from .checkpoint import pipeline_state_dict
 from .datamanagers import FixedBatchDataManager, RIRBankDataManager  # noqa: F401  (re-exported)
 
 
+_UNITS: Dict[Any, torch.Tensor] = {}
+
+
+def _unit_scalar(device) -> torch.Tensor:
+    """A persistent 0-d one per device: the seed of ``backward`` (torch fills a fresh ones tensor per call otherwise)."""
+    t = _UNITS.get(device)
+    if t is None:
+        t = torch.ones((), dtype=torch.float32, device=device)
+        _UNITS[device] = t
+    return t
+
+
 class _ScaledLossSum(torch.autograd.Function):
     """(scale * sum_i loss_i, sum_i loss_i) of 0-d device losses -- Trainer.train_iteration's ``functools.reduce(add, loss_dict.values())``
     and ``grad_scaler.scale(loss)`` [NS-recall] -- as ONE launch (csrc/glue.hip: terms added left to right, as ``reduce`` does) with a
@@ -55,7 +67,13 @@ class _ScaledLossSum(torch.autograd.Function):
     def backward(ctx, g, _g_total):
         if g is None:
             return (None,) * (ctx.n + 1)
-        gi = g if ctx.scale is None else g * ctx.scale
+        if ctx.scale is None:
+            gi = g
+        elif g.data_ptr() == _unit_scalar(g.device).data_ptr():
+            gi = ctx.scale                       # seeded with the persistent one (train_iteration): 1 * scale, no launch.  A view of
+                                                 # the scaler's own tensor: shared storage, so autograd never accumulates into it in place
+        else:
+            gi = g * ctx.scale
         return (None,) + (gi,) * ctx.n
 
 
@@ -391,7 +409,7 @@ class NeRAFPipeline(nn.Module):
         _, loss_dict, _ = self.get_train_loss_dict(step)
         # Trainer.train_iteration: loss = reduce(add, loss_dict.values()); grad_scaler.scale(loss).backward() -- as one node
         scaled, loss = _ScaledLossSum.apply(scaler, *loss_dict.values())
-        scaled.backward()
+        scaled.backward(gradient=_unit_scalar(scaled.device) if scaled.is_cuda else None)
         if self._reducer is not None:
             self._reducer.finish()
         for o in optimizers:

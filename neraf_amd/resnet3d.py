@@ -40,9 +40,11 @@ class _ResNet3DFn(torch.autograd.Function):
         # the forward kernels already ran (ResNet3D.forward); this node only attaches the backward.  ``window_vals``
         # ([n_ch, n_cells], may be None) are the grad-carrying values that were written into the grid window this step
         # (NeRAF_model.py:395-400): their gradient is the grid gradient at those cells.
+        # ``feat`` is one of the module's two alternating output buffers (no copy): it stays valid until the training forward
+        # after the next one, i.e. through this iteration's backward and beyond.
         ctx.net, ctx.window, ctx.sink = net, window, sink
         ctx.has_vals = window_vals is not None
-        return feat.clone()
+        return feat.detach()
 
     @staticmethod
     def backward(ctx, dfeat: torch.Tensor):
@@ -71,7 +73,6 @@ class _ResNet3DFn(torch.autograd.Function):
                 net._grad_bufs.append(dict(flat=flat, views=views, lo=flat.data_ptr(), hi=flat.data_ptr() + flat.numel() * 4,
                                            ptrs=(_lib.ptr_array(views[:nconv]), _lib.ptr_array(views[nconv:]))))
             net._grad_turn = 0
-            net._dfeat_buf = torch.empty(1024, dtype=torch.float32, device=device)
         # pick the buffer that no live gradient aliases (normally they simply alternate)
         g0 = params[0].grad
         k = net._grad_turn
@@ -82,7 +83,9 @@ class _ResNet3DFn(torch.autograd.Function):
         start, n_cells, n_ch = ctx.window if ctx.window is not None else (0, 0, 0)
         if n_cells > 0 and (net._dgrid_buf is None or tuple(net._dgrid_buf.shape) != (n_ch, n_cells) or net._dgrid_buf.device != device):
             net._dgrid_buf = torch.empty((n_ch, n_cells), dtype=torch.float32, device=device)
-        net._dfeat_buf.copy_(dfeat.reshape(-1))
+        net.dfeat_buffer(device)
+        if dfeat.data_ptr() != net._dfeat_buf.data_ptr():      # the consumer wrote its gradient straight into the buffer: see dfeat_buffer
+            net._dfeat_buf.copy_(dfeat.reshape(-1))
         if net.dp_group is not None:
             # data parallel, OPT-IN: every rank holds the same grid and weights and the backward is linear in d feat, so
             # averaging these 1024 floats (4 KiB) replaces the all-reduce of 17 M ResNet3D gradients (68 MB).  Exact only if the
@@ -112,7 +115,9 @@ class _ResNet3DFn(torch.autograd.Function):
             torch._foreach_add_([p.grad for p, _ in live], [v for _, v in live])
         if net.grads_ready_hook is not None:       # e.g. the data-parallel reducer: this group's gradients are final
             net.grads_ready_hook()
-        dgrid = net._dgrid_buf.clone() if n_cells > 0 else None
+        # the module's persistent buffer itself (no copy): valid until this module's next backward; its consumer (the grid refresh's
+        # backward node) reads it inside this pass
+        dgrid = net._dgrid_buf.detach() if n_cells > 0 else None
         if ctx.sink is not None and dgrid is not None:
             ctx.sink(dgrid)
         return (None, None, None, None, dgrid if ctx.has_vals else None, None)
@@ -186,6 +191,14 @@ class ResNet3D(nn.Module):
         self.grid_window = None      # (cell_start, n_cells, n_channels): grid cells whose gradient the backward should produce
         self.grid_grad_sink = None   # callable(dgrid_cells fp32 [n_ch, n_cells]) invoked inside the backward
 
+    def dfeat_buffer(self, device) -> torch.Tensor:
+        """The persistent fp32 [1024] buffer the backward sequence reads d loss / d feature from (its pointer is part of the captured
+        hipGraph).  A consumer of the feature that is handed this buffer (``feature._neraf_grad_buffer``, set by ``forward``) may write
+        its gradient w.r.t. the feature directly into it and return it as that gradient: the backward then skips its 4 KB copy."""
+        if self._dfeat_buf is None or self._dfeat_buf.device != torch.device(device):
+            self._dfeat_buf = torch.empty(1024, dtype=torch.float32, device=device)
+        return self._dfeat_buf
+
     def conv_bn_pairs(self):
         pairs = [(self.conv1, self.bn1)]
         for li in (1, 2, 3):
@@ -207,10 +220,11 @@ class ResNet3D(nn.Module):
         live: List[torch.Tensor] = [cv.weight for cv, _ in pairs]
         for _, b in pairs:
             bn += [b.weight.detach(), b.bias.detach(), b.running_mean, b.running_var]
-            live += [b.weight, b.bias, b.running_mean, b.running_var]
+            live += [b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked]
         self._tables = c = dict(pairs=pairs, conv_w=conv_w, bn=bn, live=live, ptrs=[t.data_ptr() for t in live],
                                 conv_w_ptrs=_lib.ptr_array(conv_w), bn_ptrs=_lib.ptr_array(bn),
                                 nbt=[b.num_batches_tracked for _, b in pairs],
+                                nbt_ptrs=_lib.ptr_array([b.num_batches_tracked for _, b in pairs]),
                                 params=[cv.weight for cv, _ in pairs] + [t for _, b in pairs for t in (b.weight, b.bias)])
         return c
 
@@ -255,23 +269,28 @@ class ResNet3D(nn.Module):
         packed = self._packed
         if self._ws is None or self._ws.device != x.device:
             self._ws = torch.empty(lib.neraf_resnet3d_workspace_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
-        if self._feat_buf is None or self._feat_buf.device != x.device:
-            self._feat_buf = torch.empty(1024, dtype=torch.float32, device=x.device)
+        if self._feat_buf is None or self._feat_buf[0].device != x.device:
+            self._feat_buf = [torch.empty(1024, dtype=torch.float32, device=x.device) for _ in range(2)]
+            self._feat_turn = 0
+        # two output buffers alternate (two captured forward graphs): the feature handed out is not copied, and stays intact while
+        # the next forward writes the other buffer
+        self._feat_turn ^= 1
+        feat_buf = self._feat_buf[self._feat_turn]
         key = (grid.data_ptr(), self._ws.data_ptr(), bool(self.training))
         win = (0, 0)
         if (grid_state is not None and _GRID_WINDOW and getattr(self, "_x0_state", None) == (key, grid_state[1], grid_state[4])
                 and grid_state[0] == grid_state[1] + 1 and x._version == grid_state[5] and 0 < grid_state[3] <= S ** 3 - grid_state[2]):
             win = (int(grid_state[2]), int(grid_state[3]))
         _lib.check(lib.neraf_resnet3d_fwd(h, C.byref(self._desc), packed.data_ptr(), tb["bn_ptrs"], grid.data_ptr(),
-                                          self._ws.data_ptr(), self._feat_buf.data_ptr(), int(self.training), win[0], win[1], st), dev)
+                                          self._ws.data_ptr(), feat_buf.data_ptr(), int(self.training), win[0], win[1], st), dev)
         self._x0_state = (key, grid_state[0], x._version) if grid_state is not None else None
-        feat = self._feat_buf
+        feat = feat_buf
         if self.training:
             mom = pairs[0][1].momentum if pairs[0][1].momentum is not None else 0.1
             if mom > 0:
+                # running statistics and the 43 num_batches_tracked counters in one launch
                 _lib.check(lib.neraf_resnet3d_update_running_stats(h, C.byref(self._desc), self._ws.data_ptr(),
-                                                                   tb["bn_ptrs"], float(mom), st), dev)
-                torch._foreach_add_(tb["nbt"], 1)   # one launch for the 43 counters
+                                                                   tb["bn_ptrs"], float(mom), tb["nbt_ptrs"], st), dev)
         if self.training and torch.is_grad_enabled() and any(c.weight.requires_grad for c, _ in pairs):
             if window is None:
                 window = self.grid_window
@@ -279,10 +298,11 @@ class ResNet3D(nn.Module):
                 window_vals = None
             if self._anchor is None or self._anchor.device != x.device:
                 self._anchor = torch.zeros(1, dtype=torch.float32, device=x.device, requires_grad=True)
-            feat = _ResNet3DFn.apply(self, feat, window, self.grid_grad_sink, window_vals, self._anchor)    # returns a copy
-        else:
-            feat = feat.clone()                 # never hand out the persistent output buffer
-        return feat.reshape(1, 1024, 1, 1, 1)
+            feat = _ResNet3DFn.apply(self, feat, window, self.grid_grad_sink, window_vals, self._anchor)    # the buffer itself, see there
+            out = feat.reshape(1, 1024, 1, 1, 1)
+            out._neraf_grad_buffer = self.dfeat_buffer(x.device)
+            return out
+        return feat.clone().reshape(1, 1024, 1, 1, 1)      # inference: callers cache this (never the persistent buffer)
 
 
 class ResNet3D_helper(nn.Module):

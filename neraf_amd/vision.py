@@ -43,6 +43,19 @@ class RayBundle:
     def __len__(self):
         return self.origins.shape[0]
 
+    def camera_indices_i32(self) -> Optional[torch.Tensor]:
+        """``camera_indices`` as the flat int32 vector the kernels index with, converted ONCE per bundle (nerfstudio hands over int64
+        [R,1]); a resident bundle (bench, tests) or one that already carries int32 indices costs no launch at all."""
+        ci = self.camera_indices
+        if ci is None:
+            return None
+        key = (ci.data_ptr(), ci._version, ci.dtype)
+        c = getattr(self, "_cam_i32", None)
+        if c is None or c[0] != key:
+            c = (key, ci.reshape(-1).to(torch.int32).contiguous())
+            self._cam_i32 = c
+        return c[1]
+
 
 @dataclass
 class Frustums:
@@ -188,6 +201,14 @@ class HashMLPDensityField(nn.Module):
         self.w1 = nn.Parameter(torch.empty(16, 16).uniform_(-0.43, 0.43))
         self.average_init_density = average_init_density
 
+    def acc_scratch(self, device) -> torch.Tensor:
+        """Persistent fixed-point accumulator of the table gradient, zero between calls (see NerfactoField.acc_scratch)."""
+        a = getattr(self, "_acc_scratch", None)
+        if a is None or a.device != torch.device(device):
+            a = torch.zeros(self.table.shape[0], dtype=torch.int64, device=device)
+            self._acc_scratch = a
+        return a
+
     def packed(self):
         """fp16 copies for the kernels, cached until the parameters change (see ``_param_key``)."""
         key = _param_key((self.table, self.w0, self.w1))
@@ -198,7 +219,7 @@ class HashMLPDensityField(nn.Module):
             self._pack_cache = c
         return c[1]
 
-    def density(self, origins, directions, e_bins, packed=None):
+    def density(self, origins, directions, e_bins, packed=None, coherent_rays: bool = False):
         lib = _lib.load()
         dev = _dev_index(origins)
         R, S = e_bins.shape[0], e_bins.shape[1] - 1
@@ -206,7 +227,7 @@ class HashMLPDensityField(nn.Module):
         out = torch.empty((R, S), dtype=torch.float32, device=origins.device)
         _lib.check(lib.neraf_proposal_density(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), w.data_ptr(),
                                               origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(), R, S,
-                                              self.average_init_density, out.data_ptr(), _stream_ptr()), dev)
+                                              self.average_init_density, int(coherent_rays), out.data_ptr(), _stream_ptr()), dev)
         return out
 
 
@@ -290,20 +311,53 @@ class NerfactoField(nn.Module):
             self._splitk[key] = torch.empty(4 << 20, dtype=torch.float32, device=device)
         return self._splitk[key]
 
+    def acc_scratch(self, device) -> torch.Tensor:
+        """Persistent 64-bit fixed-point accumulator of the hash-table gradient (8 bytes per table row): zeroed ONCE here; every
+        backward leaves it zero again (csrc/field_bwd.hip ``field_unpack_grad_kernel``), so no call pays a 49 MB fill."""
+        a = getattr(self, "_acc_scratch", None)
+        if a is None or a.device != torch.device(device) or a.numel() != self.table.shape[0]:
+            a = torch.zeros(self.table.shape[0], dtype=torch.int64, device=device)
+            self._acc_scratch = a
+        return a
+
     def backward_query(self, packed, origins, directions, e_bins, camera_indices, density, d_rgb, d_density, pos_run: int = 1,
-                       d_rays: Optional[torch.Tensor] = None, saved=None):
+                       d_rays: Optional[torch.Tensor] = None, saved=None, in_autograd: bool = False, accumulate_into=None):
         """Gradients of the field parameters for upstream d_rgb [R,S,3] / d_density [R,S] of a structured query.
         Returns [d table, d base_w0, d base_w1, d head_w0, d head_w1, d head_w2, d embedding].  ``pos_run`` > 1: runs of that many
-        consecutive rays share their single sample position (the grid refresh), see neraf_field_backward_runs."""
+        consecutive rays share their single sample position (the grid refresh), see neraf_field_backward_runs.
+
+        ``in_autograd`` (set by the autograd nodes, which call this from inside a backward pass with every field parameter
+        requiring a gradient): the FIRST call of a backward pass writes fresh tensors and returns them; every LATER call of the same
+        pass (NeRAF: the render batch's node after the grid refresh's, NeRAF_model.py:395-400) ADDS into those tensors in place
+        (``accumulate`` of neraf_field_backward_ex) and returns Nones -- autograd then receives ONE gradient per parameter instead of
+        two to sum (seven add launches per step, one of them over the 49 MB table gradient).  Only raw pointers are remembered
+        between the calls (a reference would stop AccumulateGrad from adopting the tensors without a copy); they stay valid because
+        autograd holds the first contribution in the parameter's input buffer until every producer of the pass has run.  An
+        end-of-pass engine callback forgets them.  ``accumulate_into`` = a previous call's seven tensors: the explicit form of the same
+        thing for direct callers (adds into them, returns them)."""
         lib = _lib.load()
         dev = _dev_index(origins)
         device = origins.device
         R, S = e_bins.shape[0], e_bins.shape[1] - 1
         tab, wfrag, emb = packed
         wfrag_b = self.packed_bwd()
-        g_table = torch.zeros_like(self.table)
-        g_emb = torch.zeros_like(self.embedding)
-        g_w = [torch.empty_like(p) for p in (self.base_w0, self.base_w1, self.head_w0, self.head_w1, self.head_w2)]
+        first = getattr(self, "_pass_ptrs", None) if in_autograd else None
+        if accumulate_into is not None:
+            first = (accumulate_into[0].data_ptr(), accumulate_into[6].data_ptr(), [t.data_ptr() for t in accumulate_into[1:6]])
+        if first is None:
+            g_table = torch.empty_like(self.table)
+            g_emb = torch.empty_like(self.embedding) if camera_indices is not None else torch.zeros_like(self.embedding)
+            g_w = [torch.empty_like(p) for p in (self.base_w0, self.base_w1, self.head_w0, self.head_w1, self.head_w2)]
+            ptrs = (g_table.data_ptr(), g_emb.data_ptr(), [t.data_ptr() for t in g_w])
+            if in_autograd:
+                self._pass_ptrs = ptrs
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward_pass)
+            accumulate = 0
+        else:
+            ptrs, accumulate = first, 1
+            if camera_indices is None:
+                raise RuntimeError("a later producer of the pass must index real embedding rows (camera indices)")
+        w_ptrs = (C.c_void_p * 5)(*ptrs[2])
         dump = self.dump_buffer(R, S, device)
         splitk = self.splitk_buffer(device)
         cam = camera_indices.reshape(-1).to(torch.int32).contiguous() if camera_indices is not None else None
@@ -313,8 +367,8 @@ class NerfactoField(nn.Module):
                   emb.data_ptr(), origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(),
                   cam.data_ptr() if cam is not None else None, R, S, mode, ab, self.average_init_density,
                   -1 if cam is not None else self.embedding.shape[0], density.data_ptr(),
-                  d_rgb.data_ptr(), d_density.data_ptr(), g_table.data_ptr(),
-                  g_emb.data_ptr() if cam is not None else None, _lib.ptr_array(g_w), dump.data_ptr(),
+                  d_rgb.data_ptr(), d_density.data_ptr(), ptrs[0],
+                  ptrs[1] if cam is not None else None, w_ptrs, dump.data_ptr(),
                   splitk.data_ptr(), splitk.numel() * 4)
         # d_rays: camera-pose edge, also accumulate d loss / d (origin, direction) per ray (fp32 [R,6]); saved = (enc, denc | None) as
         # stored by query(save=...) for this batch and parameter state: no second walk of the hash table
@@ -323,16 +377,26 @@ class NerfactoField(nn.Module):
         enc, denc = saved if saved is not None else (None, None)
         _lib.check(lib.neraf_field_backward_ex(*common, int(pos_run), d_rays.data_ptr() if d_rays is not None else None,
                                                enc.data_ptr() if enc is not None else None,
-                                               denc.data_ptr() if (denc is not None and d_rays is not None) else None, _stream_ptr()), dev)
+                                               denc.data_ptr() if (denc is not None and d_rays is not None) else None,
+                                               self.acc_scratch(device).data_ptr(), accumulate, self.embedding.shape[0], _stream_ptr()), dev)
+        if accumulate_into is not None:
+            return list(accumulate_into)
+        if first is not None:
+            return [None] * 7
         return [g_table] + g_w + [g_emb]
+
+    def _end_of_backward_pass(self):
+        self._pass_ptrs = None
 
     def grad_params(self):
         return [self.table, self.base_w0, self.base_w1, self.head_w0, self.head_w1, self.head_w2, self.embedding]
 
-    def query(self, origins, directions, e_bins, camera_indices=None, use_average_embedding: bool = False, packed=None, save: int = 0):
+    def query(self, origins, directions, e_bins, camera_indices=None, use_average_embedding: bool = False, packed=None, save: int = 0,
+              coherent_rays: bool = False):
         """Structured query: R rays x S samples.  Returns (rgb [R,S,3], density [R,S]); with ``save`` = 1 / 2 also
         ``(enc fp16 [R*S,32], denc fp16 [R*S,4,24] | None)``: the interpolated encoding (and its position derivatives) for
-        ``backward_query(saved=...)``."""
+        ``backward_query(saved=...)``.  ``coherent_rays``: consecutive rays are neighbouring pixels of one camera (inference only;
+        include/neraf_hip.h, neraf_proposal_density)."""
         lib = _lib.load()
         dev = _dev_index(origins)
         R, S = e_bins.shape[0], e_bins.shape[1] - 1
@@ -348,13 +412,14 @@ class NerfactoField(nn.Module):
         args = (_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), wfrag.data_ptr(), emb.data_ptr(),
                 origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(),
                 cam.data_ptr() if cam is not None else None, R, S, mode, ab,
-                self.average_init_density, avg_row, rgb.data_ptr(), den.data_ptr())
+                self.average_init_density, avg_row)
         if save:
             enc = torch.empty((R * S, 32), dtype=torch.float16, device=origins.device)
             denc = torch.empty((R * S, 4, 24), dtype=torch.float16, device=origins.device) if save >= 2 else None
-            _lib.check(lib.neraf_field_query_train(*args, enc.data_ptr(), denc.data_ptr() if denc is not None else None, _stream_ptr()), dev)
+            _lib.check(lib.neraf_field_query_train(*args, rgb.data_ptr(), den.data_ptr(), enc.data_ptr(),
+                                                   denc.data_ptr() if denc is not None else None, _stream_ptr()), dev)
             return rgb, den, (enc, denc)
-        _lib.check(lib.neraf_field_query(*args, _stream_ptr()), dev)
+        _lib.check(lib.neraf_field_query(*args, int(coherent_rays), rgb.data_ptr(), den.data_ptr(), _stream_ptr()), dev)
         return rgb, den
 
     def forward(self, ray_samples: RaySamples, compute_normals: bool = False) -> Dict[str, torch.Tensor]:
@@ -391,7 +456,9 @@ class _VisionLossFn(torch.autograd.Function):
         h, stream = _lib.ctx(dev), _stream_ptr()
         fine = st["samples"][-1]
         R, S2 = st["dens"].shape
-        sums = torch.zeros(4, dtype=torch.float32, device=gt.device)
+        sums = st.pop("loss_sums", None)             # zeroed by the composite's seeding launch; one use (a second loss call: own fill)
+        if sums is None:
+            sums = torch.zeros(4, dtype=torch.float32, device=gt.device)
         # values and UNIT gradients in one pass (the backward only scales them by the upstream scalars)
         need_grad = any(ctx.needs_input_grad[3:])
         f32 = dict(dtype=torch.float32, device=gt.device)
@@ -446,7 +513,7 @@ class _VisionLossFn(torch.autograd.Function):
                                                  R * 6 if d_rays is not None else 0, sums.data_ptr(), stream), dev)
         # ---- main field (+ the camera-pose edge: d loss / d (origin, direction) per ray)
         grads = field.backward_query(st["field_packed"], st["o"], st["d"], fine.e_bins, st["cam"], st["dens"], d_rgb_s, d_dens,
-                                     d_rays=d_rays, saved=st.get("field_saved"))
+                                     d_rays=d_rays, saved=st.get("field_saved"), in_autograd=all(ctx.needs_input_grad[5:12]))
         ray_grads = (d_rays[:, :3], d_rays[:, 3:]) if ctx.need_rays else (None, None)
         # ---- proposal networks (interlevel loss); densities were computed under no_grad when not `updated`
         if not st["prop_updated"]:
@@ -459,20 +526,16 @@ class _VisionLossFn(torch.autograd.Function):
                                                  ps.e_bins.data_ptr(), st["prop_dens"][i].data_ptr(), Sp, R, model.interlevel_loss_mult,
                                                  up.data_ptr(), d_pd.data_ptr(), sums.data_ptr(), stream), dev)
             ptab, pw = st["prop_packed"][i]
-            g_pt = torch.zeros_like(pn.table)
-            g_pw = torch.zeros(16 * 16 + 16, **f32)
+            # outputs in the parameters' own layouts, written (not accumulated) by the kernels: nothing to zero, nothing to copy
+            g_pt, g_w0, g_w1 = torch.empty_like(pn.table), torch.empty_like(pn.w0), torch.empty_like(pn.w1)
             # per-workgroup weight-gradient partials + the two-pass table gradient's per-sample encoding gradients and level masses
             scratch = torch.empty((int(lib.neraf_proposal_backward_scratch_bytes(R, Sp, pn.desc.n_levels)) + 3) // 4, **f32)
-            pargs = (h, C.byref(pn.desc), ptab.data_ptr(), pw.data_ptr(), st["o"].data_ptr(), st["d"].data_ptr(), ps.e_bins.data_ptr(),
-                     d_pd.data_ptr(), R, Sp, pn.average_init_density, g_pt.data_ptr(), g_pw.data_ptr(), scratch.data_ptr(),
-                     scratch.numel() * 4)
-            if ctx.need_rays:
-                _lib.check(lib.neraf_proposal_backward_rays(*pargs, d_rays.data_ptr(), stream), dev)
-            else:
-                _lib.check(lib.neraf_proposal_backward(*pargs, stream), dev)
-            g_w1 = torch.zeros_like(pn.w1)
-            g_w1[0] = g_pw[256:]
-            grads += [g_pt, g_pw[:256].reshape(16, 16), g_w1]
+            _lib.check(lib.neraf_proposal_backward_ex(h, C.byref(pn.desc), ptab.data_ptr(), pw.data_ptr(), st["o"].data_ptr(),
+                                                      st["d"].data_ptr(), ps.e_bins.data_ptr(), d_pd.data_ptr(), R, Sp,
+                                                      pn.average_init_density, g_pt.data_ptr(), g_w0.data_ptr(), g_w1.data_ptr(),
+                                                      scratch.data_ptr(), scratch.numel() * 4, pn.acc_scratch(device).data_ptr(),
+                                                      d_rays.data_ptr() if ctx.need_rays else None, stream), dev)
+            grads += [g_pt, g_w0, g_w1]
         return (None, None, None, *ray_grads, *grads)
 
 
@@ -576,6 +639,20 @@ class NeRAFVisionModel(nn.Module):
         for pn, k, pk in zip(self.proposal_networks, pkeys, prop):
             pn._pack_cache = (k, pk)
 
+    def _next_jitter_seed(self) -> int:
+        """Next value of a splitmix64 stream (never 0: 0 means "no jitter" to the kernels)."""
+        M = (1 << 64) - 1
+        st = getattr(self, "_jitter_state", None)
+        if st is None:
+            st = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & M
+        st = (st + 0x9E3779B97F4A7C15) & M
+        self._jitter_state = st
+        z = st
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        return z or 1
+
     def _proposal_updated(self) -> bool:
         """ProposalNetworkSampler's schedule [NS-recall]: the proposal networks receive gradients on every step during
         warm-up and then only when more than ``update_sched(step)`` (-> proposal_update_every) steps have passed."""
@@ -593,10 +670,15 @@ class NeRAFVisionModel(nn.Module):
         b = self.proposal_weights_anneal_slope
         return (b * x) / ((b - 1) * x + 1)
 
-    def get_outputs(self, ray_bundle: RayBundle, jitters: Optional[List[torch.Tensor]] = None):
+    def get_outputs(self, ray_bundle: RayBundle, jitters: Optional[List[torch.Tensor]] = None, coherent_rays: bool = False,
+                    _out: Optional[Dict[str, torch.Tensor]] = None):
         """NerfactoModel.get_outputs + rgb clip (NeRAF_model.py:65-68).  ``jitters`` (3 tensors [R]) override the
-        training-time single jitter of the three sampling stages (tests pass the oracle's values)."""
+        training-time single jitter of the three sampling stages (tests pass the oracle's values).  ``coherent_rays``: the bundle is
+        a run of neighbouring pixels of one camera (the chunks of ``get_outputs_for_camera``): the gather kernels then put
+        neighbouring RAYS, not neighbouring samples of a ray, into a wavefront (same results, fewer cache lines per instruction).
+        ``_out``: preallocated rgb / depth / expected_depth / accumulation rows to write into (the chunked frame render)."""
         lib = _lib.load()
+        cam32 = ray_bundle.camera_indices_i32()
         if self.training:
             ray_bundle = self.camera_optimizer.apply_to_raybundle(ray_bundle)     # NerfactoModel.get_outputs [NS-recall]
         ray_o, ray_d = ray_bundle.origins, ray_bundle.directions      # carry the camera optimizer's graph when it is on
@@ -606,16 +688,21 @@ class NeRAFVisionModel(nn.Module):
         h, st = _lib.ctx(dev), _stream_ptr()
         R = o.shape[0]
         near, far = self.near_plane, self.far_plane
+        seeds = [0, 0, 0]
         if self.training and jitters is None:
-            jitters = (self.jitter_fn(self.step, R, o.device) if self.jitter_fn is not None
-                       else [torch.rand(R, device=o.device) for _ in range(3)])
+            if self.jitter_fn is not None:
+                jitters = self.jitter_fn(self.step, R, o.device)
+            else:
+                # the single jitter per ray and stage is drawn INSIDE the sampler kernels from (seed, ray): three seeds per call from a
+                # host-side splitmix64 stream started at torch.initial_seed() -- reproducible under torch.manual_seed, no launch
+                seeds = [self._next_jitter_seed() for _ in range(3)]
         jit = [j.reshape(-1).float().contiguous() if j is not None else None for j in (jitters or [None] * 3)]
         jp = [j.data_ptr() if j is not None else None for j in jit]
         S0, S1 = self.num_proposal_samples_per_ray
         S2 = self.num_nerf_samples_per_ray
         f32 = dict(dtype=torch.float32, device=o.device)
         s0, e0 = torch.empty((R, S0 + 1), **f32), torch.empty((R, S0 + 1), **f32)
-        _lib.check(lib.neraf_sample_uniform(h, R, S0, near, far, jp[0], s0.data_ptr(), e0.data_ptr(), st), dev)
+        _lib.check(lib.neraf_sample_uniform(h, R, S0, near, far, jp[0], seeds[0], s0.data_ptr(), e0.data_ptr(), st), dev)
         anneal = self._anneal()
         prop_updated = self._proposal_updated() if self.training else False
         weights_list, samples_list = [], []
@@ -625,33 +712,37 @@ class NeRAFVisionModel(nn.Module):
         prop_packed = [pn.packed() for pn in self.proposal_networks]
         prop_dens = []
         for i, S_next in enumerate((S1, S2)):
-            dens = self.proposal_networks[i].density(o, d, e_prev, packed=prop_packed[i])
+            dens = self.proposal_networks[i].density(o, d, e_prev, packed=prop_packed[i], coherent_rays=coherent_rays and not self.training)
             prop_dens.append(dens)
             S_cur = e_prev.shape[1] - 1
             w = torch.empty((R, S_cur), **f32)
             s_n, e_n = torch.empty((R, S_next + 1), **f32), torch.empty((R, S_next + 1), **f32)
             _lib.check(lib.neraf_pdf_resample(h, dens.data_ptr(), s_prev.data_ptr(), e_prev.data_ptr(), R, S_cur, anneal,
-                                              jp[i + 1], S_next, near, far, w.data_ptr(), s_n.data_ptr(), e_n.data_ptr(), st), dev)
+                                              jp[i + 1], seeds[i + 1], S_next, near, far, w.data_ptr(), s_n.data_ptr(), e_n.data_ptr(), st), dev)
             weights_list.append(w)
             samples_list.append(RaySamples(None, ray_bundle.camera_indices, s_prev, e_prev))
             s_prev, e_prev = s_n, e_n
         field = self.field.module
-        field_packed = field.packed(with_average=not self.training or ray_bundle.camera_indices is None)
+        field_packed = field.packed(with_average=not self.training or cam32 is None)
         saved = None
         if self.training and torch.is_grad_enabled():
             # keep the encoding for the backward; with trainable poses (the rays carry the camera optimizer's graph) its derivatives too
-            rgb_s, dens, saved = field.query(o, d, e_prev, ray_bundle.camera_indices, use_average_embedding=False, packed=field_packed,
+            rgb_s, dens, saved = field.query(o, d, e_prev, cam32, use_average_embedding=False, packed=field_packed,
                                              save=2 if (ray_o.requires_grad or ray_d.requires_grad) else 1)
         else:
-            rgb_s, dens = field.query(o, d, e_prev, ray_bundle.camera_indices, use_average_embedding=not self.training,
-                                      packed=field_packed)
+            rgb_s, dens = field.query(o, d, e_prev, cam32, use_average_embedding=not self.training,
+                                      packed=field_packed, coherent_rays=coherent_rays and not self.training)
         w = torch.empty((R, S2), **f32)
-        rgb, depth = torch.empty((R, 3), **f32), torch.empty((R, 1), **f32)
-        expd, acc = torch.empty((R, 1), **f32), torch.empty((R, 1), **f32)
-        scratch = torch.empty(2, dtype=torch.int32, device=o.device)
+        if _out is not None:
+            rgb, depth, expd, acc = _out["rgb"], _out["depth"], _out["expected_depth"], _out["accumulation"]
+        else:
+            rgb, depth = torch.empty((R, 3), **f32), torch.empty((R, 1), **f32)
+            expd, acc = torch.empty((R, 1), **f32), torch.empty((R, 1), **f32)
+        # {min step, max step} of the expected-depth clip + (training) the loss node's four sums, zeroed by the seeding launch
+        scratch = torch.empty(6 if self.training else 2, dtype=torch.float32, device=o.device)
         _lib.check(lib.neraf_composite(h, dens.data_ptr(), rgb_s.data_ptr(), e_prev.data_ptr(), R, S2, int(self.training),
                                        w.data_ptr(), rgb.data_ptr(), depth.data_ptr(), expd.data_ptr(), acc.data_ptr(),
-                                       scratch.data_ptr(), st), dev)
+                                       scratch.data_ptr(), scratch.numel() * 4, st), dev)
         weights_list.append(w)
         samples_list.append(RaySamples(None, ray_bundle.camera_indices, s_prev, e_prev))
         out = {"rgb": rgb, "accumulation": acc, "depth": depth, "expected_depth": expd}
@@ -659,9 +750,9 @@ class NeRAFVisionModel(nn.Module):
             out["weights_list"] = weights_list
             out["ray_samples_list"] = samples_list
             # everything the fused loss/backward node needs (same packed fp16 parameter copies as the forward used)
-            out["_state"] = dict(o=o, d=d, ray_o=ray_o, ray_d=ray_d, cam=ray_bundle.camera_indices, samples=samples_list, prop_dens=prop_dens,
+            out["_state"] = dict(o=o, d=d, ray_o=ray_o, ray_d=ray_d, cam=cam32, samples=samples_list, prop_dens=prop_dens,
                                  prop_packed=prop_packed, field_packed=field_packed, field_saved=saved, rgb_s=rgb_s, dens=dens, w_fine=w,
-                                 prop_updated=prop_updated)
+                                 prop_updated=prop_updated, loss_sums=scratch[2:6])
         out["rgb_samples"], out["density"] = rgb_s, dens
         return out
 
@@ -715,12 +806,15 @@ class NeRAFVisionModel(nn.Module):
     forward = get_outputs
 
     @torch.no_grad()
-    def get_outputs_for_camera_ray_bundle(self, ray_bundle: RayBundle):
+    def get_outputs_for_camera_ray_bundle(self, ray_bundle: RayBundle, coherent_rays: bool = False):
         """Full-image render in chunks of eval_num_rays_per_chunk rays (NeRAF_config.py:95), as nerfstudio's
         Model.get_outputs_for_camera_ray_bundle does; NeRAFVisionModel.get_outputs_for_camera (NeRAF_model.py:70-79)
-        then clips rgb (already applied by the composite kernel)."""
+        then clips rgb (already applied by the composite kernel).  Every chunk writes its rows of the frame-sized outputs directly
+        (no concatenation); ``coherent_rays``: the bundle is one camera's pixels in row-major order (see ``get_outputs``)."""
         R = len(ray_bundle)
-        outs: Dict[str, List[torch.Tensor]] = {}
+        f32 = dict(dtype=torch.float32, device=ray_bundle.origins.device)
+        full = {"rgb": torch.empty((R, 3), **f32), "accumulation": torch.empty((R, 1), **f32), "depth": torch.empty((R, 1), **f32),
+                "expected_depth": torch.empty((R, 1), **f32)}
         was = self.training
         self.eval()
         try:
@@ -728,12 +822,10 @@ class NeRAFVisionModel(nn.Module):
                 sl = slice(i, min(R, i + self.eval_num_rays_per_chunk))
                 rb = RayBundle(ray_bundle.origins[sl], ray_bundle.directions[sl],
                                ray_bundle.camera_indices[sl] if ray_bundle.camera_indices is not None else None)
-                o = self.get_outputs(rb)
-                for k in ("rgb", "accumulation", "depth", "expected_depth"):
-                    outs.setdefault(k, []).append(o[k])
+                self.get_outputs(rb, coherent_rays=coherent_rays, _out={k: v[sl] for k, v in full.items()})
         finally:
             self.train(was)
-        return {k: torch.cat(v, 0) for k, v in outs.items()}
+        return full
 
     @torch.no_grad()
     def get_outputs_for_camera(self, camera, obb_box=None, eval: bool = False):
@@ -746,11 +838,10 @@ class NeRAFVisionModel(nn.Module):
             raise NotImplementedError("viewer branch (NeRAF_model.py:73-77) is UI code, out of scope (SURVEY.md row 15)")
         cam = camera.to(self.device)
         rb = cam.generate_rays(0)
-        out = self.get_outputs_for_camera_ray_bundle(rb)
+        out = self.get_outputs_for_camera_ray_bundle(rb, coherent_rays=True)                  # row-major pixels of one camera
         H, W = cam.height, cam.width
-        img = {k: v.reshape(H, W, -1) for k, v in out.items()}
-        img["rgb"] = torch.clip(img["rgb"], 0.0, 1.0)                                        # :78
-        return img
+        # rgb is already clipped to [0,1] by the composite kernel (:78; csrc/field.hip composite_kernel)
+        return {k: v.reshape(H, W, -1) for k, v in out.items()}
 
     @torch.no_grad()
     def get_image_metrics_and_images(self, outputs, batch):

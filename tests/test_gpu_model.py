@@ -161,7 +161,7 @@ def test_refresh_gradient_edge_vs_oracle(models):
     try:
         dirs_d = dirs.to(dev).contiguous()
         vals = _RefreshFn.apply(f, coords.float().to(dev).contiguous(), f.aabb, dirs_d, 18, 1e-2, am._refresh_consts(dirs_d, n),
-                                *f.grad_params())
+                                None, *f.grad_params())
         assert float((vals.detach().cpu() - vals_o.detach()).abs().max()) <= 4e-3
         (vals * dvals.to(dev)).sum().backward()
     finally:

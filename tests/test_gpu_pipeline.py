@@ -80,7 +80,7 @@ def test_joint_training_converges_without_skipped_steps():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     torch.manual_seed(0)
-    js = bench.JointStep(torch.device("cuda:0"), 512, 256, 1)
+    js = bench.JointStep(torch.device("cuda:0"), 512, 256, 1, rotate=1)     # one fixed batch: the loss must FALL on it
     losses = []
     for _ in range(40):
         js.i += 1

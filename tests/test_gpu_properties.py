@@ -127,7 +127,7 @@ def test_bad_arguments_return_einval_with_message():
     x = torch.zeros(128 * 64, dtype=torch.float16, device="cuda:0")
     rc = lib.neraf_gemm_f16(h, x.data_ptr(), 64, x.data_ptr(), 64, 128, 128, 60, 128, 128, 1.0, None, 0, None, 0, None, 0, None, 0, st)
     assert rc != 0 and b"K must be" in lib.neraf_last_error(h)
-    rc = lib.neraf_sample_uniform(h, 0, 48, 0.05, 1000.0, None, None, None, st)
+    rc = lib.neraf_sample_uniform(h, 0, 48, 0.05, 1000.0, None, 0, None, None, st)
     assert rc != 0 and len(lib.neraf_last_error(h)) > 0
     d = _lib.ResnetDesc(96, 7, 1024)                                  # unsupported grid size
     assert lib.neraf_resnet3d_workspace_bytes(C.byref(d)) == 0 and lib.neraf_resnet3d_num_convs(C.byref(d)) == -1

@@ -76,7 +76,7 @@ def test_sample_uniform(dev, setup, jit):
     ref = V.sample_uniform(T(rb["origins"]), T(rb["directions"]), torch.full((R, 1), 0.05), torch.full((R, 1), 1000.0), S, j)
     s, e = torch.empty((R, S + 1), device=dev), torch.empty((R, S + 1), device=dev)
     jd = j.reshape(-1).to(dev) if jit else None
-    _lib.check(lib.neraf_sample_uniform(_lib.ctx(0), R, S, 0.05, 1000.0, jd.data_ptr() if jit else None, s.data_ptr(),
+    _lib.check(lib.neraf_sample_uniform(_lib.ctx(0), R, S, 0.05, 1000.0, jd.data_ptr() if jit else None, 0, s.data_ptr(),
                                         e.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     np.testing.assert_allclose(s.cpu().numpy(), ref.s_bins.numpy(), atol=2e-6)
     np.testing.assert_allclose(e.cpu().numpy(), ref.e_bins.numpy(), rtol=2e-4)     # 1/(2-2s) amplifies near s=1
@@ -115,7 +115,7 @@ def test_pdf_resample(dev, setup, S, n_new, anneal, jit):
     jd = j.reshape(-1).to(dev) if jit else None
     dens_d, sb_d, eb_d = dens.to(dev), ray.s_bins.to(dev).contiguous(), ray.e_bins.to(dev).contiguous()   # keep alive
     _lib.check(lib.neraf_pdf_resample(_lib.ctx(0), dens_d.data_ptr(), sb_d.data_ptr(),
-                                      eb_d.data_ptr(), R, S, anneal, jd.data_ptr() if jit else None,
+                                      eb_d.data_ptr(), R, S, anneal, jd.data_ptr() if jit else None, 0,
                                       n_new, 0.05, 1000.0, w.data_ptr(), s_n.data_ptr(), e_n.data_ptr(),
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=2e-4, atol=1e-7)
@@ -156,7 +156,7 @@ def test_weights_at_surface_densities(dev, setup):
             w = torch.empty((R, S), device=dev)
             s_n, e_n = torch.empty((R, n_new + 1), device=dev), torch.empty((R, n_new + 1), device=dev)
             j = T(rb["jitters"][1]).reshape(-1).to(dev)
-            _lib.check(lib.neraf_pdf_resample(_lib.ctx(0), dens_d.data_ptr(), sb_d.data_ptr(), eb_d.data_ptr(), R, S, 1.0, j.data_ptr(), n_new,
+            _lib.check(lib.neraf_pdf_resample(_lib.ctx(0), dens_d.data_ptr(), sb_d.data_ptr(), eb_d.data_ptr(), R, S, 1.0, j.data_ptr(), 0, n_new,
                                               0.05, 1000.0, w.data_ptr(), s_n.data_ptr(), e_n.data_ptr(), st))
             np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=2e-4, atol=1e-7)
             assert bool(torch.isfinite(s_n).all()) and bool((s_n[:, 1:] >= s_n[:, :-1]).all())
@@ -167,7 +167,7 @@ def test_weights_at_surface_densities(dev, setup):
             expd, acc = torch.empty((R, 1), device=dev), torch.empty((R, 1), device=dev)
             scratch = torch.empty(2, dtype=torch.int32, device=dev)
             _lib.check(lib.neraf_composite(_lib.ctx(0), dens_d.data_ptr(), rgb_s.data_ptr(), eb_d.data_ptr(), R, S, 1, w.data_ptr(), rgb.data_ptr(),
-                                           depth.data_ptr(), expd.data_ptr(), acc.data_ptr(), scratch.data_ptr(), st))
+                                           depth.data_ptr(), expd.data_ptr(), acc.data_ptr(), scratch.data_ptr(), 8, st))
             np.testing.assert_allclose(w.cpu().numpy(), w_ref.numpy(), rtol=2e-4, atol=1e-7)
             assert float(acc.max()) <= 1.0 + 1e-5 and bool(torch.isfinite(rgb).all())
 

@@ -338,3 +338,103 @@ def test_surface_densities_of_1e15_and_more(setup):
         for p in m.parameters():
             p.grad = None
         assert all(torch.equal(P16[k], keep[k]) for k in keep)
+
+
+def test_second_producer_accumulates_in_place_and_autograd_receives_one_gradient(setup):
+    """NeRAF's step has TWO producers of the radiance field's gradients in one backward pass (render batch + grid refresh,
+    NeRAF_model.py:395-400).  (1) At the C-ABI level a second neraf_field_backward_ex call with accumulate = 1 equals the sum of two
+    separate calls: bit for bit for the table and the five weight gradients (the same fp32 adds), to rounding for the embedding
+    (atomics); the persistent accumulator is zero again after every call.  (2) Through autograd (``in_autograd``): two loss
+    nodes over the same parameters leave in ``p.grad`` the sum of their separate gradients, the first producer's tensor is adopted as
+    ``p.grad`` without a copy, and the pass state is forgotten at the end of the pass."""
+    from neraf_amd.vision import RayBundle
+    m, P16, spec, V, dev = setup
+    f = m.field.module
+    m.train()
+    m.update_to_step(300)
+    sts, ups = [], []
+    for k, R in enumerate((256, 192)):
+        rb = synth.ray_batch(R, tag=f"acc.rays{k}")
+        bundle = RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev))
+        out = m.get_outputs(bundle, jitters=[T(j).to(dev) for j in rb["jitters"]])
+        st = out["_state"]
+        g = torch.Generator(device=dev).manual_seed(11 + k)
+        S = st["dens"].shape[1]
+        ups.append(((torch.rand((R, S, 3), generator=g, device=dev) - 0.5) * 1e-2, (torch.rand((R, S), generator=g, device=dev) - 0.5) * 1e-4))
+        sts.append(st)
+
+    def call(k, **kw):
+        st = sts[k]
+        return f.backward_query(st["field_packed"], st["o"], st["d"], st["samples"][-1].e_bins, st["cam"], st["dens"], ups[k][0], ups[k][1],
+                                saved=st.get("field_saved"), **kw)
+    a, b = call(0), call(1)
+    assert int(f.acc_scratch(dev).count_nonzero()) == 0            # self-cleaning accumulator
+    # the accumulate form (what the second autograd node of a pass does through the remembered pointers)
+    first = call(0)
+    second = call(1, accumulate_into=first)
+    assert all(x is y for x, y in zip(first, second))
+    assert int(f.acc_scratch(dev).count_nonzero()) == 0
+    for i in range(6):
+        assert torch.equal(first[i], a[i] + b[i]), i
+    np.testing.assert_allclose(first[6].cpu().numpy(), (a[6] + b[6]).cpu().numpy(), rtol=1e-5, atol=1e-9)
+
+    # ---- through autograd: two loss nodes in one pass
+    for p in m.parameters():
+        p.grad = None
+    outs = []
+    for k, R in enumerate((256, 192)):
+        rb = synth.ray_batch(R, tag=f"acc.rays{k}")
+        bundle = RayBundle(T(rb["origins"]).to(dev), T(rb["directions"]).to(dev), T(rb["camera_indices"]).to(dev))
+        o = m.get_outputs(bundle, jitters=[T(j).to(dev) for j in rb["jitters"]])
+        outs.append(m.get_loss_dict(o, {"image": T(rb["rgb"]).to(dev)}))
+    sep = []
+    for ld in outs:
+        for p in m.parameters():
+            p.grad = None
+        sum(ld.values()).backward(retain_graph=True)
+        sep.append([p.grad.clone() for p in f.grad_params()])
+        assert f._pass_ptrs is None
+    for p in m.parameters():
+        p.grad = None
+    (sum(outs[0].values()) + sum(outs[1].values())).backward()
+    assert f._pass_ptrs is None
+    for i, p in enumerate(f.grad_params()):
+        ref = sep[0][i] + sep[1][i]
+        if i < 6:
+            assert torch.equal(p.grad, ref), i
+        else:
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_in_kernel_jitter_is_uniform_reproducible_and_fresh_per_call(setup):
+    """Training draws the sampler's single jitter per ray inside the kernels from (seed, ray) (csrc/field_common.h jitter_u01): the
+    bins of two calls differ, a re-seeded model repeats them bit for bit, and the implied jitter values are uniform on [0, 1)."""
+    import ctypes as C
+    from neraf_amd import _lib
+    m, P16, spec, V, dev = setup
+    lib = _lib.load()
+    R, S = 8192, 48
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def bins(seed):
+        s, e = torch.empty((R, S + 1), device=dev), torch.empty((R, S + 1), device=dev)
+        _lib.check(lib.neraf_sample_uniform(_lib.ctx(0), R, S, 0.05, 1000.0, None, seed, s.data_ptr(), e.data_ptr(), st))
+        return s
+    s1, s2, s1b, s0 = bins(12345), bins(12346), bins(12345), bins(0)
+    assert torch.equal(s1, s1b) and not torch.equal(s1, s2)
+    # interior edge i = lower + (upper - lower) u with lower / upper the neighbouring bin centres: u = (s - lower) / (1 / S)
+    u = ((s1[:, 1] - 0.5 / S) * S).cpu().numpy()
+    assert u.min() >= 0.0 and u.max() < 1.0
+    hist, _ = np.histogram(u, bins=16, range=(0.0, 1.0))
+    assert hist.min() > 0.7 * R / 16 and hist.max() < 1.3 * R / 16
+    assert abs(float(u.mean()) - 0.5) < 0.02
+    np.testing.assert_allclose(s0[:, 1].cpu().numpy(), 1.0 / S, rtol=1e-6)          # seed 0: no jitter
+    # the model: fresh seeds per call, the same sequence after re-seeding
+    m.train()
+    m._jitter_state = None
+    torch.manual_seed(77)
+    a = [m._next_jitter_seed() for _ in range(3)]
+    m._jitter_state = None
+    torch.manual_seed(77)
+    b = [m._next_jitter_seed() for _ in range(3)]
+    assert a == b and len(set(a)) == 3 and all(0 < v < (1 << 64) for v in a)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-js = bench.JointStep(torch.device("cuda:0"), 4096, 2048, 1)
+js = bench.JointStep(torch.device("cuda:0"), 4096, 2048, 1, rotate=1)
 hist = []
 for i in range(n):
     loss, ld = js.pipe.train_iteration(js.i + 1, js.optimizers, js.scaler); js.i += 1
