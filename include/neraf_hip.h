@@ -506,14 +506,21 @@ int neraf_resnet3d_debug_locate(const neraf_resnet3d_desc* d, int kind, int inde
  * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps), exactly torch's formula (no weight decay, no amsgrad).
  * ---------------------------------------------------------------------------------- */
 int neraf_fused_adam_chunk(void);
-/* GradScaler's non-finite check over the same tensor table: found_inf[0] = 1.0f if any gradient element is inf / nan, else 0. */
+/* GradScaler's non-finite check over the same tensor table: found_inf[0] = 1.0f if any gradient element is inf / nan, else 0.
+ * g_ptrs_host / n_ptrs (here and in neraf_fused_adam_dual): the per-tensor gradient pointers as a HOST array of n_ptrs <= 256 entries;
+ * they then travel in the kernel arguments and g_ptrs (the same column in DEVICE memory, which costs a host-to-device copy per step
+ * because a step's gradient tensors are new allocations) is not read.  NULL / 0: g_ptrs, or the table's own g fields when that is NULL
+ * too.  found_is_zero != 0: the caller vouches that found_inf[0] is 0 on entry (neraf_amp_update_scale with clear_flags left it so):
+ * no launch to clear it. */
 int neraf_grads_nonfinite(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
-                          int n_blocks, float* found_inf, neraf_stream_t stream);
+                          int n_blocks, float* found_inf, const void* const* g_ptrs_host, int n_ptrs, int found_is_zero,
+                          neraf_stream_t stream);
 /* GradScaler.update for up to 8 optimizers in one launch: torch._amp_update_scale_(scale, growth_tracker, sum of found_infs, ...)
  * -- any flag set: scale *= backoff_factor, tracker = 0; else tracker += 1 and, at growth_interval, scale *= growth_factor (kept
- * finite), tracker = 0.  found_infs: HOST array of n device flags (as neraf_grads_nonfinite writes them). */
+ * finite), tracker = 0.  found_infs: HOST array of n device flags (as neraf_grads_nonfinite writes them); clear_flags != 0: every
+ * flag is reset to 0 after it has been read (the next step's checks then need no clearing launch). */
 int neraf_amp_update_scale(neraf_ctx* ctx, float* scale, int32_t* growth_tracker, const float* const* found_infs, int n,
-                           double growth_factor, double backoff_factor, int growth_interval, neraf_stream_t stream);
+                           double growth_factor, double backoff_factor, int growth_interval, int clear_flags, neraf_stream_t stream);
 int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
                      int n_blocks, const float* group_lr, int n_groups, int n_tensors, double beta1, double beta2, double eps,
                      float* step, const float* grad_scale, const float* found_inf, neraf_stream_t stream);
@@ -529,7 +536,8 @@ int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g_ptrs, cons
 int neraf_fused_adam_dual(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
                           int n_blocks, const float* group_lr, int n_groups, int n_tensors, double beta1, double beta2, double eps,
                           float* step, const float* grad_scale, const float* found_inf, const void* dual, const float* step0,
-                          const float* found_inf0, const float* group_lr0, int n_groups0, neraf_stream_t stream);
+                          const float* found_inf0, const float* group_lr0, int n_groups0, const void* const* g_ptrs_host, int n_ptrs,
+                          neraf_stream_t stream);
 
 #ifdef __cplusplus
 }

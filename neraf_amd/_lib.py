@@ -50,12 +50,13 @@ SIGNATURES = {
     "neraf_gemm_bf16_tn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                      C.c_void_p]),
     "neraf_fused_adam_chunk": (C.c_int, []),
-    "neraf_grads_nonfinite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "neraf_grads_nonfinite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_void_p]),
     "neraf_fused_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                    C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_fused_adam_dual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                         C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "neraf_nacf_packed_bytes": (C.c_size_t, [C.POINTER(NacfDesc)]),
     "neraf_nacf_workspace_bytes": (C.c_size_t, [C.POINTER(NacfDesc), C.c_int, C.c_int]),
     "neraf_nacf_pack_weights": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), c_fpp, C.c_void_p, C.c_void_p]),
@@ -157,7 +158,8 @@ SIGNATURES = {
                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "neraf_camera_apply_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "neraf_amp_update_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_fpp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]),
+    "neraf_amp_update_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_fpp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                         C.c_void_p]),
     "neraf_loss_sum_scale": (C.c_int, [C.c_void_p, c_fpp, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_vision_loss_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_vision_bwd_prologue": (C.c_int, [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

@@ -45,7 +45,15 @@ __device__ __forceinline__ void adam_elem(float& p, float gr, float& m, float& v
   p = __fsub_rn(p, __fdiv_rn(__fmul_rn(step_size, m), denom));
 }
 
+// Up to kArgPtrs gradient pointers travel in the KERNEL ARGUMENTS (2 KiB of the 4 KiB argument segment): the gradient tensors of a
+// step are new allocations, and a pointer column in device memory needs a host-to-device copy per optimizer and step in front of the
+// launch.  A workgroup's tensor index is uniform, so the lookup is one scalar load from the argument segment.
+constexpr int kArgPtrs = 256;
+struct GradPtrArgs { unsigned long long p[kArgPtrs]; int n; };
+
+template <bool ARGP>
 __global__ __launch_bounds__(256) void fused_adam_kernel(const AdamTensor* __restrict__ table, const unsigned long long* __restrict__ g_ptrs,
+                                                        GradPtrArgs gargs,
                                                         const int* __restrict__ blk_tensor,
                                                         const int* __restrict__ blk_chunk, AdamLrs lrs, float beta1, float beta2,
                                                         float omb1, float omb2, float eps,
@@ -58,7 +66,8 @@ __global__ __launch_bounds__(256) void fused_adam_kernel(const AdamTensor* __res
   if (dual) d = dual[blk_tensor[blockIdx.x]];
   const bool first = d.m != nullptr && !(found_inf0 && found_inf0[0] != 0.f);     // the deferred update of the earlier optimizer
   if (skip && !first) return;
-  if (g_ptrs) t.g = reinterpret_cast<const float*>(g_ptrs[blk_tensor[blockIdx.x]]);
+  if (ARGP) t.g = reinterpret_cast<const float*>(gargs.p[blk_tensor[blockIdx.x]]);
+  else if (g_ptrs) t.g = reinterpret_cast<const float*>(g_ptrs[blk_tensor[blockIdx.x]]);
   const long long base = (long long)blk_chunk[blockIdx.x] * kAdamChunk;
   const float inv_scale = grad_scale ? 1.f / grad_scale[0] : 1.f;
   const float step_size = lrs.lr[t.group & 7] * step[4 * t.slot + 1], inv_sqrt_bc2 = step[4 * t.slot + 2];
@@ -137,12 +146,13 @@ __global__ __launch_bounds__(256) void fused_adam_kernel(const AdamTensor* __res
 }
 
 // found[0] = 1 if any gradient element of the table's tensors is inf / nan (GradScaler's check, one launch for all tensors)
+template <bool ARGP>
 __global__ __launch_bounds__(256) void grads_nonfinite_kernel(const AdamTensor* __restrict__ table, const unsigned long long* __restrict__ g_ptrs,
-                                                             const int* __restrict__ blk_tensor, const int* __restrict__ blk_chunk,
-                                                             float* __restrict__ found) {
+                                                             GradPtrArgs gargs, const int* __restrict__ blk_tensor,
+                                                             const int* __restrict__ blk_chunk, float* __restrict__ found) {
   const int ti = blk_tensor[blockIdx.x];
   const long long numel = table[ti].numel;
-  const float* g = g_ptrs ? reinterpret_cast<const float*>(g_ptrs[ti]) : table[ti].g;
+  const float* g = ARGP ? reinterpret_cast<const float*>(gargs.p[ti]) : (g_ptrs ? reinterpret_cast<const float*>(g_ptrs[ti]) : table[ti].g);
   const long long base = (long long)blk_chunk[blockIdx.x] * kAdamChunk;
   bool bad = false;
   const bool vec = (reinterpret_cast<size_t>(g) & 15) == 0;
@@ -166,10 +176,13 @@ __global__ void set_f32_kernel(float* p, float v) { if (threadIdx.x == 0 && bloc
 struct FoundPtrs { const float* p[8]; int n; };
 
 // torch._amp_update_scale_ over the OR of up to 8 per-optimizer found_inf flags (GradScaler.update sums them first: one more launch)
-__global__ void amp_update_scale_kernel(float* scale, int* growth_tracker, FoundPtrs f, float growth, float backoff, int interval) {
+__global__ void amp_update_scale_kernel(float* scale, int* growth_tracker, FoundPtrs f, float growth, float backoff, int interval, int clear) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float found = 0.f;
-  for (int i = 0; i < f.n; ++i) found += *f.p[i];
+  for (int i = 0; i < f.n; ++i) {
+    found += *f.p[i];
+    if (clear) *const_cast<float*>(f.p[i]) = 0.f;       // consumed: the next step's checks find their flags cleared (no launch for it)
+  }
   if (found != 0.f) {
     *scale = *scale * backoff;
     *growth_tracker = 0;
@@ -187,25 +200,39 @@ __global__ void amp_update_scale_kernel(float* scale, int* growth_tracker, Found
 
 }  // namespace
 
+static bool pack_grad_ptrs(const void* const* host, int n, GradPtrArgs* out) {
+  if (!host || n <= 0 || n > kArgPtrs) return false;
+  for (int i = 0; i < n; ++i) out->p[i] = (unsigned long long)(uintptr_t)host[i];
+  out->n = n;
+  return true;
+}
+
 extern "C" int neraf_grads_nonfinite(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
-                                     int n_blocks, float* found_inf, neraf_stream_t stream) {
+                                     int n_blocks, float* found_inf, const void* const* g_ptrs_host, int n_ptrs, int found_is_zero,
+                                     neraf_stream_t stream) {
   if (!table || !blk_tensor || !blk_chunk || n_blocks <= 0 || !found_inf) return neraf_fail(ctx, NERAF_EINVAL, "grads_nonfinite: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(64), 0, st, found_inf, 0.f);
-  hipLaunchKernelGGL(grads_nonfinite_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, (const AdamTensor*)table,
-                     (const unsigned long long*)g_ptrs, blk_tensor, blk_chunk, found_inf);
+  if (!found_is_zero) hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(64), 0, st, found_inf, 0.f);
+  GradPtrArgs ga{};
+  if (pack_grad_ptrs(g_ptrs_host, n_ptrs, &ga))
+    hipLaunchKernelGGL(grads_nonfinite_kernel<true>, dim3((unsigned)n_blocks), dim3(256), 0, st, (const AdamTensor*)table, nullptr, ga, blk_tensor,
+                       blk_chunk, found_inf);
+  else
+    hipLaunchKernelGGL(grads_nonfinite_kernel<false>, dim3((unsigned)n_blocks), dim3(256), 0, st, (const AdamTensor*)table,
+                       (const unsigned long long*)g_ptrs, ga, blk_tensor, blk_chunk, found_inf);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
 
 extern "C" int neraf_amp_update_scale(neraf_ctx* ctx, float* scale, int32_t* growth_tracker, const float* const* found_infs, int n,
-                                      double growth_factor, double backoff_factor, int growth_interval, neraf_stream_t stream) {
+                                      double growth_factor, double backoff_factor, int growth_interval, int clear_flags,
+                                      neraf_stream_t stream) {
   if (!scale || !growth_tracker || !found_infs || n < 1 || n > 8) return neraf_fail(ctx, NERAF_EINVAL, "amp_update_scale: 1..8 found_inf flags");
   FoundPtrs f{};
   f.n = n;
   for (int i = 0; i < n; ++i) { if (!found_infs[i]) return neraf_fail(ctx, NERAF_EINVAL, "amp_update_scale: null flag"); f.p[i] = found_infs[i]; }
   hipLaunchKernelGGL(amp_update_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scale, (int*)growth_tracker, f, (float)growth_factor,
-                     (float)backoff_factor, growth_interval);
+                     (float)backoff_factor, growth_interval, clear_flags);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
@@ -216,14 +243,14 @@ extern "C" int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g
                                 int n_blocks, const float* group_lr, int n_groups, int n_tensors, double beta1, double beta2, double eps,
                                 float* step, const float* grad_scale, const float* found_inf, neraf_stream_t stream) {
   return neraf_fused_adam_dual(ctx, table, g_ptrs, blk_tensor, blk_chunk, n_blocks, group_lr, n_groups, n_tensors, beta1, beta2, eps, step, grad_scale,
-                               found_inf, nullptr, nullptr, nullptr, nullptr, 0, stream);
+                               found_inf, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
 }
 
 extern "C" int neraf_fused_adam_dual(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
                                      int n_blocks, const float* group_lr, int n_groups, int n_tensors, double beta1,
                                      double beta2, double eps, float* step, const float* grad_scale, const float* found_inf,
                                      const void* dual, const float* step0, const float* found_inf0, const float* group_lr0, int n_groups0,
-                                     neraf_stream_t stream) {
+                                     const void* const* g_ptrs_host, int n_ptrs, neraf_stream_t stream) {
   if (!table || n_blocks < 0 || (n_blocks > 0 && (!blk_tensor || !blk_chunk)) || !step || !group_lr || n_groups < 1 || n_groups > 8 || n_tensors < 1 ||
       (dual && (!step0 || !group_lr0 || n_groups0 < 1 || n_groups0 > 8)))
     return neraf_fail(ctx, NERAF_EINVAL, "fused_adam: bad arguments (1..8 parameter groups)");
@@ -235,10 +262,17 @@ extern "C" int neraf_fused_adam_dual(neraf_ctx* ctx, const void* table, const vo
   // next optimizer's launch (their workgroups are simply absent from blk_tensor / blk_chunk)
   hipLaunchKernelGGL(adam_advance_step_kernel, dim3((unsigned)((n_tensors + 63) / 64)), dim3(64), 0, st, step, found_inf, beta1, beta2,
                      (const AdamTensor*)table, n_tensors);
-  if (n_blocks > 0)
-    hipLaunchKernelGGL(fused_adam_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, (const AdamTensor*)table, (const unsigned long long*)g_ptrs,
-                       blk_tensor, blk_chunk, lrs, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, step,
-                       grad_scale, found_inf, (const AdamDual*)dual, step0, found_inf0, lrs0);
+  if (n_blocks > 0) {
+    GradPtrArgs ga{};
+    if (pack_grad_ptrs(g_ptrs_host, n_ptrs, &ga))
+      hipLaunchKernelGGL(fused_adam_kernel<true>, dim3((unsigned)n_blocks), dim3(256), 0, st, (const AdamTensor*)table, nullptr, ga,
+                         blk_tensor, blk_chunk, lrs, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, step,
+                         grad_scale, found_inf, (const AdamDual*)dual, step0, found_inf0, lrs0);
+    else
+      hipLaunchKernelGGL(fused_adam_kernel<false>, dim3((unsigned)n_blocks), dim3(256), 0, st, (const AdamTensor*)table,
+                         (const unsigned long long*)g_ptrs, ga, blk_tensor, blk_chunk, lrs, (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                         (float)(1.0 - beta2), (float)eps, step, grad_scale, found_inf, (const AdamDual*)dual, step0, found_inf0, lrs0);
+  }
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }

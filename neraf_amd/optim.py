@@ -19,6 +19,7 @@ from .field import _dev_index, _stream_ptr
 # Bumped by every FusedAdam.step: the kernel updates parameters in place without touching tensor version counters, so caches of
 # derived data (packed fp16 weights used in eval mode) key on this as well.
 UPDATE_EPOCH = 0
+_ARG_PTRS = 256          # csrc/optim.hip kArgPtrs: gradient pointers that fit the kernel-argument table
 
 _REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("numel", "<i8"), ("group", "<i4"), ("slot", "<i4")])
 assert _REC.itemsize == 48
@@ -206,7 +207,13 @@ class FusedAdam(torch.optim.Optimizer):
         if plan is None:                       # a new set of parameters with gradients: build its device table (synchronises, once)
             plan = self._plans[sig] = self._build(entries, p0.device)
         gp = tuple(gp)
-        if plan.get("gp") != gp:               # gradient tensors are new every step: refresh the pointer column
+        if len(gp) <= _ARG_PTRS:
+            # the gradient pointers travel in the kernel arguments (include/neraf_hip.h, neraf_grads_nonfinite): no device column,
+            # no host-to-device copy per step
+            if plan.get("gp") != gp:
+                plan["gp"], plan["gargs"] = gp, (C.c_void_p * len(gp))(*gp)
+            plan["gdev"] = None
+        elif plan.get("gp") != gp:             # gradient tensors are new every step: refresh the pointer column
             k = plan["ring_i"]
             plan["ring_i"] = (k + 1) % 4
             slot = plan["ring"][k]
@@ -229,12 +236,20 @@ class FusedAdam(torch.optim.Optimizer):
         if self._found is None:
             dev = next(p for g in self.param_groups for p in g["params"]).device
             self._found = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._found_clean = True
         if plan is None:
+            self._found_clean = True
             return self._found.zero_()
         lib = _lib.load()
-        _lib.check(lib.neraf_grads_nonfinite(_lib.ctx(plan["dev"]), plan["table"].data_ptr(), plan["gdev"].data_ptr(),
+        gargs = plan.get("gargs") if plan.get("gdev") is None else None
+        # `_found_clean`: GradScaler.update's launch reset the flag after reading it (neraf_amp_update_scale, clear_flags): no
+        # clearing launch here; any other consumer of the flag leaves it to be cleared by this call
+        _lib.check(lib.neraf_grads_nonfinite(_lib.ctx(plan["dev"]), plan["table"].data_ptr(),
+                                             plan["gdev"].data_ptr() if plan.get("gdev") is not None else None,
                                              plan["blk_tensor"].data_ptr(), plan["blk_chunk"].data_ptr(), int(plan["blk_tensor"].numel()),
-                                             self._found.data_ptr(), _stream_ptr()), plan["dev"])
+                                             self._found.data_ptr(), gargs, len(gargs) if gargs is not None else 0,
+                                             int(bool(getattr(self, "_found_clean", False))), _stream_ptr()), plan["dev"])
+        self._found_clean = False
         return self._found
 
     @torch.no_grad()
@@ -270,13 +285,16 @@ class FusedAdam(torch.optim.Optimizer):
             lrs0, fi0 = first._pending
             first._pending = None
             dual, step0, n0 = plan["dual"], first._step_t, len(first.param_groups)
-        _lib.check(lib.neraf_fused_adam_dual(_lib.ctx(dev), plan["table"].data_ptr(), plan["gdev"].data_ptr(), bt.data_ptr(), bc.data_ptr(),
+        gargs = plan.get("gargs") if plan.get("gdev") is None else None
+        _lib.check(lib.neraf_fused_adam_dual(_lib.ctx(dev), plan["table"].data_ptr(),
+                                             plan["gdev"].data_ptr() if plan.get("gdev") is not None else None, bt.data_ptr(), bc.data_ptr(),
                                              int(bt.numel()), lrs, len(self.param_groups), plan["n_tensors"], float(b1), float(b2),
                                              float(self.param_groups[0]["eps"]), self._step_t.data_ptr(),
                                              gs.data_ptr() if gs is not None else None, fi.data_ptr() if fi is not None else None,
                                              dual.data_ptr() if dual is not None else None,
                                              step0.data_ptr() if step0 is not None else None,
-                                             fi0.data_ptr() if fi0 is not None else None, lrs0, n0, _stream_ptr()), dev)
+                                             fi0.data_ptr() if fi0 is not None else None, lrs0, n0,
+                                             gargs, len(gargs) if gargs is not None else 0, _stream_ptr()), dev)
         return loss
 
 
@@ -289,6 +307,9 @@ class GradScaler(torch.amp.GradScaler):
         if not isinstance(optimizer, FusedAdam):
             return super()._check_inf_per_device(optimizer)
         found = optimizer.check_finite(_keep_plan_for_step=True)
+        if not hasattr(self, "_fused_optimizers"):
+            self._fused_optimizers = {}
+        self._fused_optimizers[id(optimizer)] = optimizer
         state = self._per_optimizer_states[id(optimizer)]
         state["found_inf_per_device"] = {found.device: found}
         return state["found_inf_per_device"]
@@ -333,9 +354,16 @@ class GradScaler(torch.amp.GradScaler):
                 from torch.amp.grad_scaler import _refresh_per_optimizer_state
                 _scale, _growth_tracker = self._check_scale_growth_tracker("update")
                 dev = _dev_index(_scale)
+                # flags that belong to FusedAdam optimizers are reset by the same launch: their next check needs no clearing launch
+                owners = [o for o in getattr(self, "_fused_optimizers", {}).values() if any(o._found is f for f in founds)]
+                clear = len(owners) == len(founds)
                 _lib.check(_lib.load().neraf_amp_update_scale(_lib.ctx(dev), _scale.data_ptr(), _growth_tracker.data_ptr(),
                                                               _lib.ptr_array(founds), len(founds), float(self._growth_factor),
-                                                              float(self._backoff_factor), int(self._growth_interval), _stream_ptr()), dev)
+                                                              float(self._backoff_factor), int(self._growth_interval), int(clear),
+                                                              _stream_ptr()), dev)
+                if clear:
+                    for o in owners:
+                        o._found_clean = True
                 self._per_optimizer_states = defaultdict(_refresh_per_optimizer_state)
                 return
         return super().update(new_scale)
