@@ -156,14 +156,16 @@ int neraf_nacf_bwd_dense(neraf_ctx* ctx, const neraf_nacf_desc* d, const void* p
 
 /* ------------------------------------------------------------------------------------
  * STFT loss (STFTLoss.forward, NeRAF_evaluator.py:88-108; scaling NeRAF_model.py:584-600).
- * loss_type: 0 = 'mse' (SC+SLMSE), 1 = 'l1' (SC+SLL1).  sums (fp32[4], device, zeroed by the
- * call): sum (ymag-xmag)^2, sum ymag^2, sum |x-y|^p, unused.  losses (fp32[2], device):
+ * loss_type: 0 = 'mse' (SC+SLMSE), 1 = 'l1' (SC+SLL1).  sums (device, fp32[NERAF_STFT_SUMS_FLOATS] = 4 + 4 * 256, needs no
+ * initialisation): [0..3] = sum (ymag-xmag)^2, sum ymag^2, sum |x-y|^p, 0; the rest holds per-workgroup partials that a second
+ * launch adds in a fixed order (no atomics: the loss and its gradient are bit-reproducible).  losses (fp32[2], device):
  * {sc, mag}, multiplied by weights[0], weights[1] (device fp32[2], the loss factors of NeRAF_model.py:592-599) when weights != NULL.
  * The *_bwd writes d(total)/dpred into dpred with d total/d sc = *g_sc * weights[0] * extra and d total/d mag = *g_mag * weights[1]
  * * extra: g_sc / g_mag are DEVICE scalars (the upstream gradients, i.e. the grad-scaler scale; NULL = 0), weights as in the forward
  * (NULL = 1), extra a host factor (the data-parallel world size, see neraf_amd/losses.py) -- no host synchronisation and no scalar
  * torch ops between forward and backward.
  * ---------------------------------------------------------------------------------- */
+#define NERAF_STFT_SUMS_FLOATS (4 + 4 * 256)
 int neraf_stft_loss_fwd(neraf_ctx* ctx, const float* pred, const float* gt, size_t n, int loss_type,
                         float* sums, float* losses, neraf_stream_t stream);
 /* The same in two steps for data-parallel training: the spectral-convergence ratio is over the

@@ -157,6 +157,15 @@ static inline void neraf_zero3_async(hipStream_t st, void* p0, size_t b0, void* 
   hipLaunchKernelGGL(neraf_zero3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned*)p0, w0, (unsigned*)p1, w1, (unsigned*)p2, w2);
 }
 
+// NERAF_DETERMINISTIC=1 (read once per process): every floating-point sum whose order the hardware schedules -- BatchNorm statistics
+// and BatchNorm-backward sums, bias gradients, the average pool, d feat, the appearance-embedding gradient -- is formed from
+// per-workgroup partials in a FIXED order instead of by atomics (the hash-table gradients already are integer sums).  A training
+// run is then bit-reproducible; costs launches and bandwidth (tests / debugging: the bench keeps the atomics).
+static inline bool neraf_deterministic() {
+  static const bool d = [] { const char* e = getenv("NERAF_DETERMINISTIC"); return e && atoi(e) != 0; }();
+  return d;
+}
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
@@ -201,6 +210,10 @@ struct GemmParams {
   float* colsumsq;                   // optional [Npad] fp32: atomically += column sums of squares (BatchNorm statistics)
   int stat_rep, stat_stride;         // colsum/colsumsq are replicated stat_rep (power of two, 0 = 1) times, stat_stride floats apart; a
                                      // workgroup adds into replica (m-tile % stat_rep) -- same-line atomics serialise in the memory system
+  int stat_det;                      // deterministic statistics (NERAF_DETERMINISTIC=1): every 32-row block of the result owns a slot
+                                     // (slot = first row / 32, stat_stride floats apart, zero-initialised by the caller) and the workgroup
+                                     // that holds the rows STORES its column sums there -- no atomics; the consumer adds the slots in a
+                                     // fixed order (slot_sum_kernel), so the statistics are bit-reproducible run to run
   // fused BatchNorm-backward reduction (dgrad GEMMs of the small ResNet3D layers): the result g is the gradient w.r.t. a
   // post-activation tensor whose producer is BatchNorm + ReLU; with bnb_x set, g *= (bnb_mask > 0) AFTER add16, and colsum / colsumsq
   // receive sum g and sum g * xhat (xhat = (bnb_x - mean) * rsqrt(var + 1e-5), mean / var = bnb_fin[c] / bnb_fin[bnb_cpad + c])

@@ -244,10 +244,10 @@ struct PropBwdArgs {
 __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
   __shared__ float w0[16][16], w1[16];
   __shared__ float s_dh[4][64][17], s_enc[4][64][17], s_hr[4][64][17];   // per wave: [point][16] (+1 pad)
-  __shared__ float acc[16 * 16 + 16];
+  __shared__ float acc[4][16 * 16 + 16];      // per wave: every lane owns its entries, so no atomics and a fixed summation order
   for (int i = threadIdx.x; i < 256; i += 256) w0[i >> 4][i & 15] = (float)a.w[i];
   if (threadIdx.x < 16) w1[threadIdx.x] = (float)a.w[256 + threadIdx.x];
-  for (int i = threadIdx.x; i < 272; i += 256) acc[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * 272; i += 256) (&acc[0][0])[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long N = (long)a.R * a.S;
@@ -341,18 +341,19 @@ __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
         for (int q = 0; q < 4; ++q) s[q] = fmaf(d, s_enc[wv][p][k0 + q], s[q]);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) atomicAdd(&acc[j * 16 + k0 + q], s[q]);
+      for (int q = 0; q < 4; ++q) acc[wv][j * 16 + k0 + q] += s[q];
       if (lane < 16) {
         float t = 0.f;
         for (int p = 0; p < 64; ++p) t += s_hr[wv][p][lane];
-        atomicAdd(&acc[256 + lane], t);
+        acc[wv][256 + lane] += t;
       }
     }
     __syncthreads();
   }
   for (int i = threadIdx.x; i < 272; i += 256) {
-    if (a.w_part) a.w_part[(size_t)blockIdx.x * 272 + i] = acc[i];
-    else atomicAdd(a.w_grad + i, acc[i]);
+    const float v = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+    if (a.w_part) a.w_part[(size_t)blockIdx.x * 272 + i] = v;
+    else atomicAdd(a.w_grad + i, v);
   }
   if (a.d32) {
     // this workgroup's gradient mass per level -> t_part[block][16] (levels >= n_levels: 0), summed by field_finalize_kernel
@@ -411,6 +412,8 @@ struct FieldBwdArgs {
   half_t* dump; long npad;                         // fp16 [10][128][npad]: X_b0,dY_b0,X_b1,dY_b1,X_h0,dY_h0,X_h1,dY_h1,X_h2,dY_h2
   unsigned* d_enc;                                 // half2 [16 levels][npad]: scaled gradient w.r.t. the encoding (rows 64.. of slot 0)
   float* t_part;                                   // fp32 [blocks][16]: per-workgroup sums of max(|g0|,|g1|) per level (rows 64.. of slot 1)
+  int emb_det;                                     // deterministic mode: e_part / e_part_row are PER 16-POINT GROUP ([npad / 16][32] + row, -1 = none),
+                                                   // stored by the group (no atomics), folded per embedding row in group order
   float* e_part; int* e_part_row;                  // fp32 [blocks][32] + row: per-workgroup appearance-embedding gradient of the
                                                    // workgroup's leading embedding row (rows 64.. of slots 2 / 3)
   float* pos;                                      // optional fp32 [3][npad]: mapped sample positions for the owner scatter (slot 4, rows 64..)
@@ -618,6 +621,8 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
       const int e0 = __shfl(erow, lane & 48);                    // row of point 0 of this group (same q)
       const bool uniform = __all(e0 == erow || !valid);
       const bool to_lds = uniform && __all(e0 == e_blk);
+      const bool det_store = a.emb_det && uniform;               // (a group that mixes rows -- S not a multiple of 16 -- keeps the atomics)
+      if (a.emb_det && lane == 0) a.e_part_row[grp] = (uniform && __shfl(valid ? 1 : 0, 0)) ? e0 : -1;
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
@@ -626,7 +631,9 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
           if (uniform) {
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
-            if (p == 0 && v != 0.f) {
+            if (det_store) {
+              if (p == 0) a.e_part[grp * 32 + 16 * ib + 4 * q + r] = v;
+            } else if (p == 0 && v != 0.f) {
               if (to_lds) atomicAdd(&e_acc[16 * ib + 4 * q + r], v);
               else atomicAdd(a.emb_grad + (size_t)e0 * 32 + 16 * ib + 4 * q + r, v);
             }
@@ -736,8 +743,10 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
   __syncthreads();
   if (threadIdx.x < 16)
     a.t_part[(long)blockIdx.x * 16 + threadIdx.x] = t_sum[0][threadIdx.x] + t_sum[1][threadIdx.x] + t_sum[2][threadIdx.x] + t_sum[3][threadIdx.x];
-  if (threadIdx.x < 32) a.e_part[(long)blockIdx.x * 32 + threadIdx.x] = e_acc[threadIdx.x];
-  if (threadIdx.x == 0) a.e_part_row[blockIdx.x] = e_blk;
+  if (!a.emb_det) {
+    if (threadIdx.x < 32) a.e_part[(long)blockIdx.x * 32 + threadIdx.x] = e_acc[threadIdx.x];
+    if (threadIdx.x == 0) a.e_part_row[blockIdx.x] = e_blk;
+  }
 #undef wf
 }
 
@@ -795,6 +804,24 @@ __global__ __launch_bounds__(256) void field_finalize_kernel(const float* __rest
     acc += vals[i];
   }
   if (cur >= 0 && acc != 0.f) atomicAdd(emb_grad + (size_t)cur * 32 + c, acc);
+}
+
+// Deterministic mode: emb_grad[row] (+)= sum of the group partials of that row, in group order.  One workgroup per embedding row; 8
+// interleaved partial sums per element (threads = 8 x 32), then a fixed tree.
+__global__ __launch_bounds__(256) void field_emb_fold_det_kernel(const float* __restrict__ e_part, const int* __restrict__ e_part_row,
+                                                                long ngroups, float* __restrict__ emb_grad, int beta) {
+  __shared__ float part[8][32];
+  const int row = blockIdx.x, c = threadIdx.x & 31, q = threadIdx.x >> 5;
+  float acc = 0.f;
+  for (long g = q; g < ngroups; g += 8)
+    if (e_part_row[g] == row) acc += e_part[g * 32 + c];
+  part[q][c] = acc;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const float v = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) + ((part[4][c] + part[5][c]) + (part[6][c] + part[7][c]));
+    float* dst = emb_grad + (size_t)row * 32 + c;
+    *dst = beta ? *dst + v : v;
+  }
 }
 
 struct FieldScatterArgs {
@@ -1385,6 +1412,7 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
     long blocks = (N + 1023) / 1024; if (blocks > 256) blocks = 256;
     // with a separate accumulator the library owns the initial state of the outputs: a first producer (accumulate == 0) starts the
     // embedding gradient from zero here; the legacy form (acc_scratch == NULL) expects the caller to have zeroed both buffers
+    a.emb_det = (neraf_deterministic() && acc_scratch && emb_grad && avg_row < 0 && emb_rows > 0) ? 1 : 0;
     const bool zero_emb = acc_scratch && !accumulate && emb_grad && avg_row < 0 && emb_rows > 0;
     hipLaunchKernelGGL(field_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_rgb, d_density, density, N, avg_density,
                        reinterpret_cast<unsigned*>(scale) + 2, zero_emb ? emb_grad : nullptr, zero_emb ? (long)emb_rows * 32 : 0l);
@@ -1406,7 +1434,9 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
     NERAF_HIP_CHECK(ctx, hipGetLastError());
     // hash-grid gradient: per-level fixed-point scale from the gradient mass, packed 64-bit scatter, in-place unpack
     float* lvl = scale + 8;
-    const bool fold_emb = avg_row < 0 && emb_grad;
+    const bool fold_emb = avg_row < 0 && emb_grad && !a.emb_det;
+    if (a.emb_det)
+      hipLaunchKernelGGL(field_emb_fold_det_kernel, dim3((unsigned)emb_rows), dim3(256), 0, st, a.e_part, a.e_part_row, npad / 16, emb_grad, 1);
     hipLaunchKernelGGL(field_finalize_kernel, dim3(16 + (fold_emb ? (unsigned)((blocks + 63) / 64) : 0u)), dim3(256), 0, st, a.t_part,
                        (int)blocks, lvl, a.e_part, a.e_part_row, fold_emb ? emb_grad : nullptr);
     FieldScatterArgs sa{};

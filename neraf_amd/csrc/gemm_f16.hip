@@ -181,8 +181,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
       for (int w = 0; w < WAVES_M; ++w) v += red[(w * 2 + which) * BN + col];
       float* dst = which ? p.colsumsq : p.colsum;
-      const int rep = p.stat_rep > 1 ? (bm & (p.stat_rep - 1)) * p.stat_stride : 0;
-      if (dst) atomicAdd(dst + rep + n_tile0 + col, v);
+      if (p.stat_det) {                 // this workgroup alone holds rows [m_tile0, m_tile0 + BM): a plain store into their first slot
+        if (dst) dst[(size_t)(m_tile0 >> 5) * p.stat_stride + n_tile0 + col] = v;
+      } else {
+        const int rep = p.stat_rep > 1 ? (bm & (p.stat_rep - 1)) * p.stat_stride : 0;
+        if (dst) atomicAdd(dst + rep + n_tile0 + col, v);
+      }
     }
     __syncthreads();
   }
@@ -782,9 +786,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
 #pragma unroll 8
       for (int i = 0; i < 32; ++i) { const float x = tile[i][tx]; cs += x * x; }
     }
-    const int rep = p.stat_rep > 1 ? (blockIdx.y & (p.stat_rep - 1)) * p.stat_stride : 0;
     float* dst = ty == 0 ? p.colsum : p.colsumsq;
-    if (dst) atomicAdd(dst + rep + n0 + tx, cs);
+    if (p.stat_det) {                   // rows [32 blockIdx.y, +32) belong to this workgroup: slot blockIdx.y, plain store
+      if (dst) dst[(size_t)blockIdx.y * p.stat_stride + n0 + tx] = cs;
+    } else {
+      const int rep = p.stat_rep > 1 ? (blockIdx.y & (p.stat_rep - 1)) * p.stat_stride : 0;
+      if (dst) atomicAdd(dst + rep + n0 + tx, cs);
+    }
   }
 }
 
@@ -1458,7 +1466,7 @@ int launch_gemm_f16(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   if (p.K <= 0 || (p.K % BK) != 0) return neraf_fail(ctx, NERAF_EINVAL, "gemm: K must be a positive multiple of 64");
   if ((p.Mpad % 64) != 0 || (p.Npad % 64) != 0 || p.M > p.Mpad || p.N > p.Npad || p.M <= 0 || p.N <= 0)
     return neraf_fail(ctx, NERAF_EINVAL, "gemm: Mpad/Npad must be multiples of 64 covering M/N");
-  if (p.stat_rep > 1 && (p.stat_rep & (p.stat_rep - 1))) return neraf_fail(ctx, NERAF_EINVAL, "gemm: stat_rep must be a power of two");
+  if (!p.stat_det && p.stat_rep > 1 && (p.stat_rep & (p.stat_rep - 1))) return neraf_fail(ctx, NERAF_EINVAL, "gemm: stat_rep must be a power of two");
   if (p.ngroups > 1 && (p.ngroups > 6 || p.conv.loader != 0 || p.C16 || p.C16T || p.colsum || p.colsumsq || p.lmask || p.add16))
     return neraf_fail(ctx, NERAF_EINVAL, "gemm: grouped launches are plain GEMMs with fp32 results only");
   if ((p.conv.loader == 0 && (p.lda % 8)) || (p.ldb % 8) || (p.C16 && (p.ldc16 % 8)) || (p.C16T && (p.ldc16t % 8)) ||

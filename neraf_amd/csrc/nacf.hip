@@ -69,8 +69,10 @@ struct WsLayout {
   size_t h[5], hT[5];      // activations fp16 [Mpad][np], [np][Mpad]
   size_t bias0;            // fp32 [np0] effective layer-0 bias
   size_t dz[2], dzT[2];    // backward ping-pong fp16 [Mpad][5120] / [5120+128][Mpad]
-  size_t colsum[6];        // fp32 [np]
+  size_t colsum[6];        // fp32 [np]; deterministic mode: [Mpad / 32][np] slots (one per 32 rows, GemmParams::stat_det)
   size_t scale;            // fp32 [4]: {S, 1/S, amax bits, -} backward auto-scale
+  size_t dfeat_part;       // deterministic mode: fp32 [64][n_feat] row-slice partials of d feat
+  int col_slots;           // 1, or Mpad / 32 in deterministic mode
   size_t total;
 };
 
@@ -98,8 +100,10 @@ WsLayout make_ws_layout(const neraf_nacf_desc* d, const Dims& D, int B, int trai
       L.dz[i] = take(M * maxw * 2);
       L.dzT[i] = take((size_t)(maxw + 128) * M * 2);
     }
-    for (int l = 0; l < 6; ++l) L.colsum[l] = take((size_t)D.np[l] * 4);
+    L.col_slots = neraf_deterministic() ? L.Mpad / 32 : 1;
+    for (int l = 0; l < 6; ++l) L.colsum[l] = take((size_t)L.col_slots * D.np[l] * 4);
     L.scale = take(256);
+    if (neraf_deterministic()) L.dfeat_part = take((size_t)64 * (d->n_feat > 0 ? d->n_feat : 1) * 4);
   }
   L.total = off;
   return L;
@@ -113,7 +117,7 @@ WsLayout make_ws_layout(const neraf_nacf_desc* d, const Dims& D, int B, int trai
 __global__ __launch_bounds__(256) void cvt_pad_transpose_kernel(
     const float* __restrict__ src, const float* __restrict__ aux, const float* __restrict__ scale, int ld, int R, int Cc,
     int mode, half_t* __restrict__ dst, int ld_dst, int Rpad, int Cpad,
-    half_t* __restrict__ dstT, int ld_dstT, int RpadT, int CpadT, float* __restrict__ colsum) {
+    half_t* __restrict__ dstT, int ld_dstT, int RpadT, int CpadT, float* __restrict__ colsum, int colsum_slot_stride) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -145,7 +149,10 @@ __global__ __launch_bounds__(256) void cvt_pad_transpose_kernel(
 #pragma unroll 8
     for (int i = 0; i < 32; ++i) s += (float)(half_t)tile[i][tx];
     const int c = c0 + tx;
-    if (c < Cpad) atomicAdd(colsum + c, s);
+    if (c < Cpad) {
+      if (colsum_slot_stride > 0) colsum[(size_t)blockIdx.y * colsum_slot_stride + c] = s;      // deterministic mode: this row block's slot
+      else atomicAdd(colsum + c, s);
+    }
   }
 }
 
@@ -191,18 +198,37 @@ __global__ __launch_bounds__(256) void cvt_pad_transpose_grouped_kernel(CvtTable
 }
 
 // up to 16 segments: dst[i] = i < n ? src[i] * (mul ? mul[0] : 1) : 0 for i < npad
-struct SegCopyTable { int n; int begin[17]; const float* src[16]; float* dst[16]; int len[16]; int npad[16]; const float* mul; };
+// nslots > 1 (deterministic mode): the source is [nslots][stride] per-row-block partial sums, added here in slot order
+struct SegCopyTable { int n; int begin[17]; const float* src[16]; float* dst[16]; int len[16]; int npad[16]; int stride[16]; const float* mul;
+                      int nslots; };
 
 __global__ __launch_bounds__(256) void seg_copy_kernel(SegCopyTable t) {
   int si = 0;
   while (si + 1 < t.n && (int)blockIdx.x >= t.begin[si + 1]) ++si;
   const int i = (blockIdx.x - t.begin[si]) * 256 + threadIdx.x;
-  if (i < t.npad[si]) t.dst[si][i] = i < t.len[si] ? t.src[si][i] * (t.mul ? t.mul[0] : 1.f) : 0.f;
+  if (i >= t.npad[si]) return;
+  float v = 0.f;
+  if (i < t.len[si]) {
+    if (t.nslots > 1) {
+      float a = 0.f, b = 0.f, c = 0.f, e = 0.f;
+      int sl = 0;
+      for (; sl + 4 <= t.nslots; sl += 4) {
+        a += t.src[si][(size_t)sl * t.stride[si] + i]; b += t.src[si][(size_t)(sl + 1) * t.stride[si] + i];
+        c += t.src[si][(size_t)(sl + 2) * t.stride[si] + i]; e += t.src[si][(size_t)(sl + 3) * t.stride[si] + i];
+      }
+      for (; sl < t.nslots; ++sl) a += t.src[si][(size_t)sl * t.stride[si] + i];
+      v = (a + b) + (c + e);
+    } else {
+      v = t.src[si][i];
+    }
+    v *= t.mul ? t.mul[0] : 1.f;
+  }
+  t.dst[si][i] = v;
 }
 
-static void seg_copy_add(SegCopyTable& t, float* dst, const float* src, int n, int npad) {
+static void seg_copy_add(SegCopyTable& t, float* dst, const float* src, int n, int npad, int stride = 0) {
   const int k = t.n++;
-  t.src[k] = src; t.dst[k] = dst; t.len[k] = n; t.npad[k] = npad;
+  t.src[k] = src; t.dst[k] = dst; t.len[k] = n; t.npad[k] = npad; t.stride[k] = stride;
   t.begin[k + 1] = t.begin[k] + (npad + 255) / 256;
 }
 
@@ -225,7 +251,7 @@ __global__ __launch_bounds__(256) void feat_gemv_kernel(const float* __restrict_
 
 // dfeat[k] = sum_n db0[n] * W0[n][k]; grid (ceil(n_feat/256), nsplit), atomics into zeroed dfeat.
 __global__ __launch_bounds__(256) void dfeat_kernel(const float* __restrict__ W0, int ldw, const float* __restrict__ db0,
-                                                   int N, int n_feat, float* __restrict__ dfeat) {
+                                                   int N, int n_feat, float* __restrict__ dfeat, float* __restrict__ part) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int per = (N + gridDim.y - 1) / gridDim.y;
   const int n0 = blockIdx.y * per, n1 = min(N, n0 + per);
@@ -241,7 +267,22 @@ __global__ __launch_bounds__(256) void dfeat_kernel(const float* __restrict__ W0
     s2 += db0[n + 2] * w[2] + db0[n + 6] * w[6]; s3 += db0[n + 3] * w[3] + db0[n + 7] * w[7];
   }
   for (; n < n1; ++n) s += db0[n] * W0[(size_t)n * ldw + k];
-  atomicAdd(dfeat + k, (s + s1) + (s2 + s3));
+  // part != null (deterministic mode): row slice blockIdx.y stores its partial, dfeat_fold_kernel adds the slices in order
+  if (part) part[(size_t)blockIdx.y * n_feat + k] = (s + s1) + (s2 + s3);
+  else atomicAdd(dfeat + k, (s + s1) + (s2 + s3));
+}
+
+__global__ __launch_bounds__(256) void dfeat_fold_kernel(const float* __restrict__ part, int nsplit, int n_feat, float* __restrict__ dfeat) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_feat) return;
+  float a = 0.f, b = 0.f, c = 0.f, e = 0.f;
+  int sl = 0;
+  for (; sl + 4 <= nsplit; sl += 4) {
+    a += part[(size_t)sl * n_feat + k]; b += part[(size_t)(sl + 1) * n_feat + k];
+    c += part[(size_t)(sl + 2) * n_feat + k]; e += part[(size_t)(sl + 3) * n_feat + k];
+  }
+  for (; sl < nsplit; ++sl) a += part[(size_t)sl * n_feat + k];
+  dfeat[k] = (a + b) + (c + e);
 }
 
 // dW0[:, :n_feat] = outer(db0, feat)
@@ -377,7 +418,7 @@ __global__ void scale_copy_kernel(float* __restrict__ dst, const float* __restri
 
 // ---- STFT loss -------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stft_loss_sums_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                            size_t n, int l1, float* __restrict__ sums) {
+                                                            size_t n, int l1, float* __restrict__ part) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float xv = x[i], yv = y[i];
@@ -391,10 +432,23 @@ __global__ __launch_bounds__(256) void stft_loss_sums_kernel(const float* __rest
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) { sh[0][w] = s0; sh[1][w] = s1; sh[2][w] = s2; }
   __syncthreads();
-  if (threadIdx.x < 3) {
-    const float t = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
-    atomicAdd(sums + threadIdx.x, t);
+  // this workgroup's partial (no atomics): stft_sums_fold_kernel adds the <= 256 partials in a fixed order
+  if (threadIdx.x < 3) part[(size_t)blockIdx.x * 4 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(64) void stft_sums_fold_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ sums) {
+  const int lane = threadIdx.x;
+  float v[3] = {0.f, 0.f, 0.f};
+  for (int b = lane; b < nblocks; b += 64)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] += part[(size_t)b * 4 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);      // butterfly: every lane ends with the same fixed-order sum
   }
+  if (lane < 3) sums[lane] = v[lane];
+  if (lane == 3) sums[3] = 0.f;
 }
 
 __global__ void stft_loss_final_kernel(const float* __restrict__ sums, float inv_n, const float* __restrict__ weights,
@@ -430,13 +484,13 @@ __global__ __launch_bounds__(256) void stft_loss_bwd_kernel(const float* __restr
 int cvt_pad_transpose(neraf_ctx* ctx, hipStream_t st, const float* src, const float* aux, const float* scale, int ld, int R,
                       int Cc, int mode,
                       half_t* dst, int ld_dst, int Rpad, int Cpad, half_t* dstT, int ld_dstT, int RpadT, int CpadT,
-                      float* colsum) {
+                      float* colsum, int colsum_slot_stride = 0) {
   int rmax = Rpad, cmax = Cpad;
   if (dstT) { rmax = RpadT > rmax ? RpadT : rmax; cmax = CpadT > cmax ? CpadT : cmax; }
   if (!dst) { rmax = RpadT; cmax = CpadT; }
   dim3 grid((cmax + 31) / 32, (rmax + 31) / 32);
   hipLaunchKernelGGL(cvt_pad_transpose_kernel, grid, dim3(256), 0, st, src, aux, scale, ld, R, Cc, mode, dst, ld_dst,
-                     dst ? Rpad : 0, dst ? Cpad : 0, dstT, ld_dstT, RpadT, CpadT, colsum);
+                     dst ? Rpad : 0, dst ? Cpad : 0, dstT, ld_dstT, RpadT, CpadT, colsum, colsum_slot_stride);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
@@ -633,12 +687,14 @@ static int nacf_bwd_body(neraf_ctx* ctx, const neraf_nacf_desc* d, const Dims& D
   // bias gradients = un-scaled column sums: collected here, copied out by ONE launch once the last sum is complete
   SegCopyTable outs{};
   outs.mul = inv_scale;
-  auto copy_out = [&](float* dst, const float* src, int n) { seg_copy_add(outs, dst, src, n, n); };
+  const bool det = WL.col_slots > 1;          // deterministic mode: column sums in [Mpad / 32][np] slots, added in slot order on the way out
+  outs.nslots = WL.col_slots;
+  auto copy_out = [&](float* dst, const float* src, int n, int np) { seg_copy_add(outs, dst, src, n, n, np); };
   int cur = 0;
   half_t* dz = (half_t*)(ws + WL.dz[cur]);
   half_t* dzT = (half_t*)(ws + WL.dzT[cur]);
   if (int e = cvt_pad_transpose(ctx, st, dout, out, scale, D.n[5], B, D.n[5], 1, dz, D.np[5], M, D.np[5], dzT, M, M, D.np[5] + 128,
-                                (float*)(ws + WL.colsum[5])))
+                                (float*)(ws + WL.colsum[5]), det ? D.np[5] : 0))
     return e;
   for (int c = 0; c < d->C; ++c) {
     // dWh_c [F, W] = dz5^T[cF:(c+1)F, :] . h4^T[W, :]^T
@@ -649,7 +705,7 @@ static int nacf_bwd_body(neraf_ctx* ctx, const neraf_nacf_desc* d, const Dims& D
     g.alpha_dev = inv_scale;
     g.C32 = grads[2 * (5 + c)]; g.ldc32 = D.n[4];
     if (int e = launch_gemm_f16(ctx, g, st)) return e;
-    copy_out(grads[2 * (5 + c) + 1], (const float*)(ws + WL.colsum[5]) + (size_t)c * d->F, d->F);
+    copy_out(grads[2 * (5 + c) + 1], (const float*)(ws + WL.colsum[5]) + (size_t)c * d->F, d->F, D.np[5]);
   }
   for (int l = 5; l >= 1; --l) {
     // dz_{l-1} = (dz_l . W_l) * leaky'(h_{l-1})   [Mpad, np_{l-1}]
@@ -664,6 +720,7 @@ static int nacf_bwd_body(neraf_ctx* ctx, const neraf_nacf_desc* d, const Dims& D
     g.C16 = dzn; g.ldc16 = D.np[l - 1];
     g.C16T = dznT; g.ldc16t = M;
     g.colsum = (float*)(ws + WL.colsum[l - 1]);
+    if (det) { g.stat_det = 1; g.stat_stride = D.np[l - 1]; }
     if (int e = launch_gemm_f16(ctx, g, st)) return e;
     cur = nxt;
     if (l - 1 >= 1) {
@@ -675,10 +732,10 @@ static int nacf_bwd_body(neraf_ctx* ctx, const neraf_nacf_desc* d, const Dims& D
       w.alpha_dev = inv_scale;
       w.C32 = grads[2 * (l - 1)]; w.ldc32 = D.k[l - 1];
       if (int e = launch_gemm_f16(ctx, w, st)) return e;
-      copy_out(grads[2 * (l - 1) + 1], (const float*)(ws + WL.colsum[l - 1]), D.n[l - 1]);
+      copy_out(grads[2 * (l - 1) + 1], (const float*)(ws + WL.colsum[l - 1]), D.n[l - 1], D.np[l - 1]);
     }
   }
-  copy_out(grads[1], (const float*)(ws + WL.colsum[0]), D.n[0]);
+  copy_out(grads[1], (const float*)(ws + WL.colsum[0]), D.n[0], D.np[0]);
   hipLaunchKernelGGL(seg_copy_kernel, dim3(outs.begin[outs.n]), dim3(256), 0, st, outs);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   *slot0 = cur;
@@ -712,8 +769,10 @@ extern "C" int neraf_nacf_bwd(neraf_ctx* ctx, const neraf_nacf_desc* d, const vo
     hipLaunchKernelGGL(outer_kernel, dim3((d->n_feat + 255) / 256, D.n[0]), dim3(256), 0, st, db0, feat, D.n[0], d->n_feat,
                        grads[0], D.kdense, dfeat);
     if (dfeat) {
+      float* part = WL.col_slots > 1 ? (float*)(ws + WL.dfeat_part) : nullptr;
       hipLaunchKernelGGL(dfeat_kernel, dim3((d->n_feat + 255) / 256, 64), dim3(256), 0, st, Wptr(w, 0), D.kdense, db0,
-                         D.n[0], d->n_feat, dfeat);
+                         D.n[0], d->n_feat, dfeat, part);
+      if (part) hipLaunchKernelGGL(dfeat_fold_kernel, dim3((d->n_feat + 255) / 256), dim3(256), 0, st, part, 64, d->n_feat, dfeat);
     }
   }
   NERAF_HIP_CHECK(ctx, hipGetLastError());
@@ -758,10 +817,12 @@ extern "C" int neraf_stft_loss_sums(neraf_ctx* ctx, const float* pred, const flo
                                     float* sums, neraf_stream_t stream) {
   if (!pred || !gt || !sums || n == 0) return neraf_fail(ctx, NERAF_EINVAL, "stft_loss_sums: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  neraf_zero_async(st, sums, 16);
+  // sums[0..3] = the three sums (+ a zero); sums[4 .. 4 + 4 * 256) = per-workgroup partials: two launches, no atomics, no
+  // clearing, and a fixed summation order (the loss and its gradient are bit-reproducible)
   int blocks = (int)((n + 1023) / 1024);
-  if (blocks > 256) blocks = 256;   // 3 same-address atomics per block: keep the count low
-  hipLaunchKernelGGL(stft_loss_sums_kernel, dim3(blocks), dim3(256), 0, st, pred, gt, n, loss_type, sums);
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(stft_loss_sums_kernel, dim3(blocks), dim3(256), 0, st, pred, gt, n, loss_type, sums + 4);
+  hipLaunchKernelGGL(stft_sums_fold_kernel, dim3(1), dim3(64), 0, st, sums + 4, blocks, sums);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }

@@ -114,22 +114,32 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnSrc s, int din, 
   }
 }
 
-// AvgPool3d over all remaining voxels (NeRAF_resnet3d.py:143/:149): feat[c] = mean_rows x[row][c]; feat pre-zeroed
-__global__ __launch_bounds__(256) void avgpool_kernel(const half_t* __restrict__ x, int M, int C, int rows_per, float* __restrict__ feat) {
-  const int cpr = C >> 3;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int chunk = idx % cpr, grp = idx / cpr;
-  const int r0 = grp * rows_per;
-  if (r0 >= M) return;
+// AvgPool3d over all remaining voxels (NeRAF_resnet3d.py:143/:149): feat[c] = mean_rows x[row][c].  One workgroup per 64 channels:
+// 32 row groups x 8 channel chunks of threads take every 32nd row, a fixed tree over the groups finishes -- no atomics (the sum's
+// order is fixed: the feature is bit-reproducible given the activations), no pre-zeroed output.
+__global__ __launch_bounds__(256) void avgpool_kernel(const half_t* __restrict__ x, int M, int C, float* __restrict__ feat) {
+  __shared__ float part[32][65];
+  const int chunk = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64 + chunk * 8;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int r = r0; r < min(M, r0 + rows_per); ++r) {
-    const half8 v = *reinterpret_cast<const half8*>(x + (size_t)r * C + chunk * 8);
+  for (int r = grp; r < M; r += 32) {
+    const half8 v = *reinterpret_cast<const half8*>(x + (size_t)r * C + c0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
   }
-  const float inv = 1.f / (float)M;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) atomicAdd(feat + chunk * 8 + j, s[j] * inv);
+  for (int j = 0; j < 8; ++j) part[grp][chunk * 8 + j] = s[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = part[k][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < 32; w <<= 1)
+#pragma unroll
+      for (int k = 0; k < 32; k += 2 * w) v[k] += v[k + w];
+    feat[blockIdx.x * 64 + threadIdx.x] = v[0] * (1.f / (float)M);
+  }
 }
 
 }  // namespace
@@ -296,10 +306,8 @@ static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     x = (const half_t*)(ws + L.out[b]);
   }
   {
-    const int M = (int)cube(A.final_edge), C = 1024, rows_per = 16;
-    const int groups = (M + rows_per - 1) / rows_per;
-    const int threads = groups * (C >> 3);
-    hipLaunchKernelGGL(avgpool_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, x, M, C, rows_per, feat);
+    const int M = (int)cube(A.final_edge), C = 1024;
+    hipLaunchKernelGGL(avgpool_kernel, dim3(C / 64), dim3(256), 0, st, x, M, C, feat);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
   }
   return NERAF_OK;

@@ -81,6 +81,7 @@ struct BnBwdArgs {
   int M, Mpad, C;
   int rows_per_block;         // reduce: rows handled by one workgroup (multiple of 32)
   float* sums; int rep;       // [rep][2][cpad] (replica stride kStatStride): sum dy, sum dy*xhat
+  int det;                    // reduce, deterministic mode: row block b STORES its sums into slot b of [slots][2][cpad] (no atomics)
   bf16_t* dx;                 // apply: gradient w.r.t. the pre-BN conv output [Mpad][C]
   bf16_t* dy_masked;          // apply (optional): g * (act > 0) for the identity residual branch
   float* dgamma; float* dbeta; const float* inv_scale;   // apply (row-block 0 writes the un-scaled affine gradients)
@@ -137,8 +138,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs p) {
     float acc = 0.f;
 #pragma unroll 8
     for (int r = 0; r < 32; ++r) acc += red[which][r][col];
-    const int rep = p.rep > 1 ? (blockIdx.x & (p.rep - 1)) * kStatStride : 0;
-    atomicAdd(p.sums + rep + which * p.s.cpad + c_base + col, acc);
+    if (p.det) {
+      // slot = first row of the block / 32: the layout the fused dgrad epilogues (GemmParams::stat_det) use for the same buffer
+      p.sums[(size_t)(blockIdx.x * (p.rows_per_block >> 5)) * (2 * p.s.cpad) + which * p.s.cpad + c_base + col] = acc;
+    } else {
+      const int rep = p.rep > 1 ? (blockIdx.x & (p.rep - 1)) * kStatStride : 0;
+      atomicAdd(p.sums + rep + which * p.s.cpad + c_base + col, acc);
+    }
   }
 }
 
@@ -153,7 +159,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
     // the replicas of the two sums: four threads per channel take every fourth replica (a chain of rep loads otherwise)
     const int c = c_base + (tid & 63), q = tid >> 6;
     float db = 0.f, dg = 0.f;
-    for (int r = q; r < p.rep; r += 4) { db += p.sums[r * kStatStride + c]; dg += p.sums[r * kStatStride + p.s.cpad + c]; }
+    for (int r = q; r < p.rep; r += 4) {          // produced by atomics: read where they executed (stat_ld, resnet3d_common.h)
+      db += stat_ld(p.sums + r * kStatStride + c, p.s.read_mode); dg += stat_ld(p.sums + r * kStatStride + p.s.cpad + c, p.s.read_mode);
+    }
     part[0][q][tid & 63] = db; part[1][q][tid & 63] = dg;
   }
   __syncthreads();
@@ -324,7 +332,8 @@ struct BwdLayout {
   size_t wt[64];              // dgrad weights (in the packed-dgrad blob)
   size_t packed_total;
   size_t scale;               // fp32[4]
-  size_t sums[64];            // per conv/BN: [rep][2][cpad] fp32 (replica stride kStatStride)
+  size_t sums[64];            // per conv/BN: [rep][2][cpad] fp32 (replica stride kStatStride); deterministic mode: [slots][2][cpad]
+  size_t sums_fin[64];        // deterministic mode: the slots added in a fixed order, [2][cpad] (what bn_bwd_apply reads)
   size_t sums_begin, sums_bytes;
   size_t g[2];                // ping-pong gradient w.r.t. block outputs, fp16, largest activation
   size_t dy[64];              // dY of every convolution [rows_pad(dout)][cout] bf16: all alive until the grouped weight-gradient launch
@@ -365,9 +374,11 @@ void make_bwd_layout(const Arch& A, BwdLayout* L) {
   L->sums_begin = off;
   for (int i = 0; i < A.nconv; ++i) {
     const int rep = bwd_stat_rep(A.conv[i]);
-    L->sums[i] = take(rep > 1 ? (size_t)rep * kStatStride * 4 : (size_t)2 * round_up(A.conv[i].cout, 128) * 4);
+    if (neraf_deterministic()) L->sums[i] = take(det_slots(A.conv[i]) * 2 * round_up(A.conv[i].cout, 128) * 4);
+    else L->sums[i] = take(rep > 1 ? (size_t)rep * kStatStride * 4 : (size_t)2 * round_up(A.conv[i].cout, 128) * 4);
   }
   L->sums_bytes = off - L->sums_begin;
+  for (int i = 0; i < A.nconv; ++i) L->sums_fin[i] = take((size_t)2 * round_up(A.conv[i].cout, 128) * 4);
   size_t max_act = 0, max_wtmp = 0;
   for (int i = 0; i < A.nconv; ++i) {
     const ConvSpec& c = A.conv[i];
@@ -407,8 +418,14 @@ int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const
   p.dx = dx; p.dy_masked = dy_masked;
   p.dgamma = c.bn_grads[2 * ci]; p.dbeta = c.bn_grads[2 * ci + 1]; p.inv_scale = c.inv_scale;
   const int nrb = (p.M + p.rows_per_block - 1) / p.rows_per_block;
+  p.det = neraf_deterministic() ? 1 : 0;
   // sums_done: the dgrad GEMM that produced g16 already reduced sum g and sum g * xhat in its epilogue (fuse_bn_sums below)
   if (!sums_done) hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nrb, p.C / 64), dim3(256), 0, c.st, p);
+  if (p.det) {     // the slots (of the reduce kernel or of the fused epilogue) added in a fixed order; the apply pass reads that
+    float* fin = (float*)(c.bws + c.B->sums_fin[ci]);
+    run_slot_sum(c.st, p.sums, det_slots(cs), p.s.cpad, 0.f, 0, fin);
+    p.sums = fin; p.rep = 1;
+  }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(p.Mpad / 64, p.C / 64), dim3(256), 0, c.st, p);
   NERAF_HIP_CHECK(c.ctx, hipGetLastError());
   return NERAF_OK;
@@ -459,6 +476,7 @@ int conv_dgrad(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* add16, bf16
     float* sums = (float*)(c.bws + c.B->sums[bn_ci]);
     g.colsum = sums; g.colsumsq = sums + round_up(bs.cout, 128);
     g.stat_rep = bwd_stat_rep(bs); g.stat_stride = kStatStride;
+    if (neraf_deterministic()) { g.stat_det = 1; g.stat_rep = 0; g.stat_stride = 2 * round_up(bs.cout, 128); }
     g.bnb_x = (const half_t*)(c.ws + c.L->pre[bn_ci]); g.ldbnb = bs.cout; g.bnb_mask = (const half_t*)bn_act;
     g.bnb_fin = (const float*)(c.ws + c.L->fin[bn_ci]); g.bnb_cpad = round_up(bs.cout, 128);
   }

@@ -61,6 +61,8 @@ inline int stat_rep(const ConvSpec& c) {
   return r;
 }
 
+inline size_t det_slots(const ConvSpec& c) { return rows_pad(c.dout) / 32; }
+
 struct Layout {
   size_t w[64];                 // packed fp16 weights [npad][kpad]
   size_t packed_total;
@@ -91,7 +93,10 @@ void make_layout(const Arch& A, Layout* L) {
   L->stats_begin = off;
   for (int i = 0; i < A.nconv; ++i) {
     const int rep = stat_rep(A.conv[i]);
-    L->stat[i] = take(rep > 1 ? (size_t)rep * kStatStride * 4 : (size_t)2 * round_up(A.conv[i].cout, 128) * 4);
+    if (neraf_deterministic())       // one slot [2][cpad] per 32 result rows (GemmParams::stat_det), summed in a fixed order by slot_sum_kernel
+      L->stat[i] = take(det_slots(A.conv[i]) * 2 * round_up(A.conv[i].cout, 128) * 4);
+    else
+      L->stat[i] = take(rep > 1 ? (size_t)rep * kStatStride * 4 : (size_t)2 * round_up(A.conv[i].cout, 128) * 4);
   }
   L->stats_bytes = off - L->stats_begin;
   for (int i = 0; i < A.nconv; ++i) L->fin[i] = take((size_t)2 * round_up(A.conv[i].cout, 128) * 4);
@@ -127,21 +132,27 @@ struct BnSrc {
   float* fin_w;             // forward BN pass: block 0 writes the finalised statistics here -- or null
   const float* gamma; const float* beta; const float* rmean; const float* rvar;
   int cpad, rep;
-  int read_mode;            // how the accumulators are read (NERAF_BN_STAT_READ): 0 plain loads, 1 atomic fetch-add of 0, 2 system-scope loads
+  int read_mode;            // how atomically produced accumulators are read (stat_ld): 2 system-scope loads (default), 1 atomic fetch-add of 0, 0 plain
 };
 
-// Reading one statistic accumulator.  Modes 1 and 2 go to the point of coherence the producing atomics used; mode 0 (the default)
-// is a plain load, valid because the producer is an earlier kernel of the same stream.
-// DO NOT REMOVE the mode-selected re-read in bn_mean_var below, although mode 0 never takes it: with it compiled in, the BatchNorm
-// kernels are the build that survives a second process on the same GPU -- 0 damaged forwards in 30,000 next to every neighbour
-// tried, against 12-25 % without it (same executed instructions, tools/share_gpu_ab_libs.sh, DESIGN.md section 6 "Two processes on
-// one GPU": the cause is not understood; padding the code, raising the SGPR allocation, dividing on the host, fences and scoped
-// loads on their own do not have the effect).  tools/share_gpu_regression.sh re-checks it.
-
+// Reading one statistic accumulator.  The accumulators are produced by no-return fp32 atomics (GEMM epilogues, bn_bwd_reduce), and
+// on MI355X float atomics execute at the MEMORY SIDE: they leave the issuing XCD's L2 as uncached requests and nothing stays in any
+// L2 (MI355X_MICROARCH.md, "Global float atomics").  The consumer therefore reads them at the same point: mode 2 (the default) is a
+// system-scope load (sc0 sc1: served past the L1 and the L2), mode 1 an atomic fetch-add of zero (a returning atomic at the memory
+// side: exact by construction, but thousands of workgroups re-reading the same lines serialise there), mode 0 a plain load that
+// relies on the kernel boundary alone.  Round 3 shipped mode 0 plus a never-taken re-read that merely changed code generation and
+// happened to survive a second process on the GPU (profiles/r03_gpu_sharing_bisect.txt: single workgroups of bn_apply normalised
+// with wrong tables, cause not understood); modes 1 and 2 measured 0 damaged forwards in the same bisect and do not depend on code
+// placement.  NERAF_BN_STAT_READ selects the mode for A/B (tools/share_gpu_regression.sh re-checks the shared-GPU scenario).
 __device__ __forceinline__ float stat_ld(const float* p, int mode) {
-  if (mode == 1) return atomicAdd(const_cast<float*>(p), 0.f);
   if (mode == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (mode == 1) return atomicAdd(const_cast<float*>(p), 0.f);
   return *p;
+}
+
+inline int bn_stat_read_mode() {
+  static const int m = [] { const char* e = getenv("NERAF_BN_STAT_READ"); const int v = e ? atoi(e) : 2; return (v < 0 || v > 2) ? 2 : v; }();
+  return m;
 }
 
 __device__ __forceinline__ void bn_mean_var(const BnSrc& s, int c, float inv_m, float& mean, float& var) {
@@ -150,18 +161,16 @@ __device__ __forceinline__ void bn_mean_var(const BnSrc& s, int c, float inv_m, 
   } else if (s.stats) {
     // four independent chains: the loop is a latency chain of 2 * rep loads otherwise (rep is 1, 2, 4, 8 or 16)
     float a = 0.f, b = 0.f, a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, a3 = 0.f, b3 = 0.f;
+    const int md = s.read_mode;
+    const float* q = s.stats + c;
     int r = 0;
     for (; r + 4 <= s.rep; r += 4) {
-      a += s.stats[r * kStatStride + c]; b += s.stats[r * kStatStride + s.cpad + c];
-      a1 += s.stats[(r + 1) * kStatStride + c]; b1 += s.stats[(r + 1) * kStatStride + s.cpad + c];
-      a2 += s.stats[(r + 2) * kStatStride + c]; b2 += s.stats[(r + 2) * kStatStride + s.cpad + c];
-      a3 += s.stats[(r + 3) * kStatStride + c]; b3 += s.stats[(r + 3) * kStatStride + s.cpad + c];
+      a += stat_ld(q + r * kStatStride, md); b += stat_ld(q + r * kStatStride + s.cpad, md);
+      a1 += stat_ld(q + (r + 1) * kStatStride, md); b1 += stat_ld(q + (r + 1) * kStatStride + s.cpad, md);
+      a2 += stat_ld(q + (r + 2) * kStatStride, md); b2 += stat_ld(q + (r + 2) * kStatStride + s.cpad, md);
+      a3 += stat_ld(q + (r + 3) * kStatStride, md); b3 += stat_ld(q + (r + 3) * kStatStride + s.cpad, md);
     }
-    for (; r < s.rep; ++r) { a += s.stats[r * kStatStride + c]; b += s.stats[r * kStatStride + s.cpad + c]; }
-    if (s.read_mode) {
-      a = b = a1 = b1 = a2 = b2 = a3 = b3 = 0.f;
-      for (r = 0; r < s.rep; ++r) { a += stat_ld(s.stats + r * kStatStride + c, s.read_mode); b += stat_ld(s.stats + r * kStatStride + s.cpad + c, s.read_mode); }
-    }
+    for (; r < s.rep; ++r) { a += stat_ld(q + r * kStatStride, md); b += stat_ld(q + r * kStatStride + s.cpad, md); }
     a = (a + a1) + (a2 + a3); b = (b + b1) + (b2 + b3);
     mean = a * inv_m;
     var = fmaxf(b * inv_m - mean * mean, 0.f);    // biased variance, as nn.BatchNorm3d normalises with
@@ -180,15 +189,55 @@ __device__ __forceinline__ void bn_scale_shift(const BnSrc& s, int c, float inv_
 }
 
 
+// Deterministic mode: dst[which][c] = sum over the nslots slots of src[slot][which][c] in a FIXED order (16 interleaved partial sums
+// per column, then a fixed tree), which = 0 / 1 the two statistics; to_meanvar: dst = {mean, biased variance} of a BatchNorm over
+// 1 / inv_m rows instead of the raw sums.  grid = cpad / 64 column panels, 1024 threads.
+__global__ __launch_bounds__(1024) void slot_sum_kernel(const float* __restrict__ src, int nslots, int stride, int cpad, float inv_m,
+                                                       int to_meanvar, float* __restrict__ dst) {
+  __shared__ float part[2][16][64];
+  const int col = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + col;
+  float a = 0.f, b = 0.f;
+  for (int sl = q; sl < nslots; sl += 16) { a += src[(size_t)sl * stride + c]; b += src[(size_t)sl * stride + cpad + c]; }
+  part[0][q][col] = a; part[1][q][col] = b;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = part[which][k][col];
+#pragma unroll
+    for (int w = 1; w < 16; w <<= 1)
+#pragma unroll
+      for (int k = 0; k < 16; k += 2 * w) v[k] += v[k + w];
+    part[which][0][col] = v[0];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float s0 = part[0][0][col], s1 = part[1][0][col];
+    if (to_meanvar) {
+      const float mean = s0 * inv_m;
+      dst[c] = mean; dst[cpad + c] = fmaxf(s1 * inv_m - mean * mean, 0.f);
+    } else {
+      dst[c] = s0; dst[cpad + c] = s1;
+    }
+  }
+}
+
+inline void run_slot_sum(hipStream_t st, const float* src, size_t nslots, int cpad, float inv_m, int to_meanvar, float* dst) {
+  hipLaunchKernelGGL(slot_sum_kernel, dim3(cpad / 64), dim3(1024), 0, st, src, (int)nslots, 2 * cpad, cpad, inv_m, to_meanvar, dst);
+}
+
 // forward BN pass: reads the replicated accumulators of conv ci, block 0 publishes mean / variance to L.fin[ci]
+// (deterministic mode: the statistics were finalised into L.fin[ci] by run_conv's slot_sum launch; every pass reads them there)
 inline BnSrc bn_src_fwd(const Arch& A, const Layout& L, char* ws, const float* const* bn, int ci, int use_batch) {
   const ConvSpec& c = A.conv[ci];
   BnSrc s{};
-  static const int stat_read = [] { const char* e = getenv("NERAF_BN_STAT_READ"); return e ? atoi(e) : 0; }();
-  s.read_mode = stat_read;
+  s.read_mode = bn_stat_read_mode();
   s.x = (const half_t*)(ws + L.pre[ci]);
   s.stats = use_batch ? (const float*)(ws + L.stat[ci]) : nullptr;
   s.fin_w = use_batch ? (float*)(ws + L.fin[ci]) : nullptr;
+  if (use_batch && neraf_deterministic()) { s.stats = nullptr; s.fin_w = nullptr; s.fin_r = (const float*)(ws + L.fin[ci]); }
   s.gamma = bn[4 * ci + 0]; s.beta = bn[4 * ci + 1]; s.rmean = bn[4 * ci + 2]; s.rvar = bn[4 * ci + 3];
   s.cpad = round_up(c.cout, 128); s.rep = stat_rep(c);
   return s;
@@ -202,6 +251,7 @@ inline BnSrc bn_src_bwd(const Arch& A, const Layout& L, const char* ws, const fl
   s.fin_r = (const float*)(ws + L.fin[ci]);
   s.gamma = bn[4 * ci + 0]; s.beta = bn[4 * ci + 1]; s.rmean = bn[4 * ci + 2]; s.rvar = bn[4 * ci + 3];
   s.cpad = round_up(c.cout, 128); s.rep = 1;
+  s.read_mode = bn_stat_read_mode();
   return s;
 }
 
@@ -410,8 +460,11 @@ inline int run_conv(neraf_ctx* ctx, hipStream_t st, const Arch& A, const Layout&
   g.alg_flops = 2.0 * (double)cube(c.dout) * (c.k * c.k * c.k) * c.cin_real * c.cout;       // un-padded taps x cin
   g.C16 = (half_t*)(ws + L.pre[ci]); g.ldc16 = c.cout;
   float* stats = (float*)(ws + L.stat[ci]);
-  g.colsum = stats; g.colsumsq = stats + round_up(c.cout, 128);
+  const int cpad = round_up(c.cout, 128);
+  g.colsum = stats; g.colsumsq = stats + cpad;
   g.stat_rep = stat_rep(c); g.stat_stride = kStatStride;
+  const bool det = neraf_deterministic();
+  if (det) { g.stat_det = 1; g.stat_rep = 0; g.stat_stride = 2 * cpad; }
   g.splitk_ws = (float*)(ws + L.splitk); g.splitk_ws_bytes = L.splitk_bytes;
   if (c.k == 1 && c.stride == 1) {
     g.conv.loader = 0;
@@ -420,7 +473,12 @@ inline int run_conv(neraf_ctx* ctx, hipStream_t st, const Arch& A, const Layout&
     g.conv.din = c.din; g.conv.dout = c.dout; g.conv.stride = c.stride; g.conv.pad = c.pad; g.conv.ksize = c.k; g.conv.cin = c.cin;
     g.conv.zero_page = (const half_t*)(ws + L.zero_page);
   }
-  return launch_gemm_f16(ctx, g, st);
+  if (int e = launch_gemm_f16(ctx, g, st)) return e;
+  if (det) {       // {mean, biased variance} of the batch into L.fin[ci], slots added in a fixed order
+    run_slot_sum(st, stats, det_slots(c), cpad, 1.f / (float)M, 1, (float*)(ws + L.fin[ci]));
+    NERAF_HIP_CHECK(ctx, hipGetLastError());
+  }
+  return NERAF_OK;
 }
 
 inline int run_bn_apply(neraf_ctx* ctx, hipStream_t st, const BnApplyArgs& a) {

@@ -28,7 +28,8 @@ class _StftLossFn(torch.autograd.Function):
         y = y_log.contiguous().float()
         if x.shape != y.shape:
             raise ValueError("STFTLoss: prediction / target shape mismatch")
-        sums = torch.empty(4, dtype=torch.float32, device=x.device)
+        buf = torch.empty(4 + 4 * 256, dtype=torch.float32, device=x.device)      # NERAF_STFT_SUMS_FLOATS: the 4 sums + per-workgroup partials
+        sums = buf[:4]
         losses = torch.empty(2, dtype=torch.float32, device=x.device)
         n_total = x.numel()
         world = 1

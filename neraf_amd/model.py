@@ -297,7 +297,9 @@ class NeRAFAudioModel(nn.Module):
             return None
         group = None if pg is True else pg
         world = dist.get_world_size(group)
-        return (group, dist.get_rank(group), world) if world > 1 else None
+        # ``dp_single_rank_collectives`` (tests): keep the data-parallel code path -- sharded refresh, assembled through the collectives --
+        # also in a group of ONE rank, which exercises it on the real backend of a one-GPU box
+        return (group, dist.get_rank(group), world) if (world > 1 or getattr(self, "dp_single_rank_collectives", False)) else None
 
     def _refresh_consts(self, dirs, n):
         """(directions [n*nd,3] cell-major, zero frustum extents [n*nd,2], camera index 0 [n*nd]) of a refresh window: constant

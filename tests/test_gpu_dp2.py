@@ -64,3 +64,27 @@ def _run_two_ranks(tmp_path, attempt):
         assert max(res["audio_grad_rel"]) <= 2e-2, res["audio_grad_rel"]
         sc_dp, sc_ref, mag_dp, mag_ref = res["audio_loss"]
         np.testing.assert_allclose([sc_dp, mag_dp], [sc_ref, mag_ref], rtol=2e-3)
+
+
+def test_rccl_world_size_one_runs_the_data_parallel_plumbing_on_the_real_backend(tmp_path):
+    """RCCL itself (backend "nccl"), with the one rank a one-GPU box has: three training iterations with the gradient reducer
+    attached, the refresh sharded + assembled through ``gather_shards`` and the STFT loss on all-reduced sums must reproduce the run
+    without any group -- every collective of one rank is the identity.  Checks that ReduceOp.AVG exists and averages in place, that
+    the flat ResNet3D gradient buffer survives an in-place collective, and that the reducer's hook order launches every group
+    (tests/tools/nccl1_worker.py)."""
+    out = str(tmp_path / "nccl1.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               NERAF_DETERMINISTIC="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "nccl1_worker.py"), out], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-4000:]
+    r = json.load(open(out))
+    a, b = r["plain"], r["nccl"]
+    assert b["collectives_per_step"] and all(n >= 3 for n in b["collectives_per_step"]), b["collectives_per_step"]
+    for la, lb in zip(a["losses"], b["losses"]):
+        assert set(la) == set(lb)
+        for k in la:
+            np.testing.assert_allclose(lb[k], la[k], rtol=2e-3, atol=1e-9, err_msg=k)
+    worst = max(r["rel"].values())
+    assert worst <= 2e-3, sorted(r["rel"].items(), key=lambda kv: -kv[1])[:5]
+    assert a["scale"] == b["scale"]

@@ -1,0 +1,36 @@
+"""Worker of tests/test_gpu_trajectory.py: ONE single-process training run of a trajectory scenario in a fresh process, so that the
+test can choose the library's summation mode (NERAF_DETERMINISTIC, read once per process by libneraf_hip) without touching the
+rest of the GPU suite, which runs in the default (atomics) mode.
+
+    python tests/tools/trajectory_worker.py <scenario> <out.npz>
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import numpy as np
+import torch
+
+
+def main():
+    scenario, out_path = sys.argv[1], sys.argv[2]
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import trajectory_common as TC
+    torch.manual_seed(0)
+    curves, img, stft, pipe, evb = TC.run_hip_trajectory(dev, cfg=TC.SCENARIOS[scenario])
+    extra = {}
+    if TC.SCENARIOS[scenario]["camera_opt"]:
+        extra["pose"] = pipe.model.camera_optimizer.pose_adjustment.detach().cpu().double().numpy()
+    tab = pipe.model.field.module.table.detach().cpu().numpy()
+    w1 = pipe.audio_model.field.soundfield[1].weight.detach().cpu().numpy()
+    cv = pipe.audio_model.resnet3d.backbone_net.layer3[5].conv3.weight.detach().cpu().numpy()
+    np.savez(out_path, curves=curves, image=img, stft_eval=stft["eval"], stft_batch_stats=stft["batch_stats"], table=tab, nacf_w1=w1,
+             conv=cv, deterministic=int(os.environ.get("NERAF_DETERMINISTIC", "0")), **extra)
+
+
+if __name__ == "__main__":
+    main()
