@@ -200,6 +200,12 @@ typedef struct neraf_grid_desc {
  * the stack agrees): scales/resolutions/sizes [n_levels], offsets [n_levels+1] in table rows. */
 int neraf_grid_layout(const neraf_grid_desc* g, float* scales, int* resolutions, uint32_t* sizes, uint32_t* offsets);
 
+/* Multiresolution hash encoding on its own (tiny-cuda-nn HashGrid forward [TCNN-recall]; the fused kernels below contain it): x01 fp32
+ * [n_points,3] in [0,1]^3 (positions are used as given: no contraction, no selector) -> enc fp32 [n_points, 2 * n_levels], level-major
+ * pairs, the trilinear interpolation of the level's fp16 table entries (table_f16: fp16 [rows, 2], rows from neraf_grid_layout). */
+int neraf_hash_encode(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const float* x01, long long n_points,
+                      float* enc, neraf_stream_t stream);
+
 /* Initial samples: S bins uniform in piecewise lin-disp spacing between near and far, optional
  * single jitter per ray: jitter [R] in [0,1) given by the caller, or -- jitter NULL and jitter_seed != 0 -- drawn inside the
  * kernel as a pure function of (jitter_seed, ray) (training: no random-number launch in front of the sampler; the host layer passes a
@@ -534,7 +540,9 @@ int neraf_fused_adam(neraf_ctx* ctx, const void* table, const void* g_ptrs, cons
  * (m == NULL: none) naming the FIRST optimizer's moments, parameter group (index into group_lr0, its HOST learning rates) and counter slot in `step0` (the first optimizer's step
  * table, already advanced by its own call) and its non-finite flag `found_inf0` (may be NULL).  For such a tensor the kernel applies
  * update 0 (unless *found_inf0) and then update 1 (unless *found_inf) in registers: the same fp32 operations in the same order as
- * the two launches, bit for bit.  n_blocks may be 0 (nothing but deferred tensors).  dual == NULL: plain neraf_fused_adam. */
+ * the two launches, bit for bit.  n_blocks may be 0 (nothing but deferred tensors).  dual == NULL: plain neraf_fused_adam.
+ * n_tensors == 0: the per-tensor counters are NOT advanced (they were, by an earlier call over this table: the host layer's flush of
+ * an update that was deferred to an optimizer which then never stepped). */
 int neraf_fused_adam_dual(neraf_ctx* ctx, const void* table, const void* g_ptrs, const int* blk_tensor, const int* blk_chunk,
                           int n_blocks, const float* group_lr, int n_groups, int n_tensors, double beta1, double beta2, double eps,
                           float* step, const float* grad_scale, const float* found_inf, const void* dual, const float* step0,

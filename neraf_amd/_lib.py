@@ -86,6 +86,7 @@ SIGNATURES = {
     "neraf_prof_kernel_name": (C.c_char_p, [C.c_int]),
     "neraf_grid_layout": (C.c_int, [C.POINTER(GridDesc), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32)]),
+    "neraf_hash_encode": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]),
     "neraf_sample_uniform": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_uint64, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "neraf_proposal_density": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -136,8 +136,9 @@ class Optimizers:
             self.parameters[n] = param_groups[n]
         # tensors held by two consecutive fused optimizers (the radiance field: "fields", then "audio_fields") get both updates in
         # the later optimizer's launch (one pass over p and g instead of two; bit-identical, neraf_amd/optim.py)
+        # (pairs only: an optimizer that is already the second of a pair is not linked onwards)
         for a, b in zip(self._steppers[:-1], self._steppers[1:]):
-            if isinstance(a, FusedAdam) and isinstance(b, FusedAdam):
+            if isinstance(a, FusedAdam) and isinstance(b, FusedAdam) and a._dual_from is None and a._defer_to is None:
                 a.fuse_shared_updates_into(b)
         # one LambdaLR per optimizer object, one lambda per param group (LambdaLR accepts a list)
         for opt in self._steppers:

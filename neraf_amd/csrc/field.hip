@@ -99,6 +99,20 @@ __global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
   a.density[idx] = sel ? a.avg_density * __expf(out) : 0.f;
 }
 
+// ---- stand-alone multiresolution hash encoding (tiny-cuda-nn HashGrid forward; SURVEY 8b op list) ------------------------------
+// One thread per (point, level): x01 [N,3] already mapped to [0,1]^3 -> enc [N][2 L] fp32, the trilinear interpolation of the fp16
+// table entries of each level (the fused kernels compute exactly this per lane and feed it to the MLP as fp16).
+__global__ __launch_bounds__(256) void hash_encode_kernel(GridLayout g, const unsigned* __restrict__ table, const float* __restrict__ x01,
+                                                         long N, float* __restrict__ enc) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * g.n_levels) return;
+  const long n = idx / g.n_levels; const int l = (int)(idx % g.n_levels);
+  float f0, f1;
+  encode_level(table, x01[n * 3], x01[n * 3 + 1], x01[n * 3 + 2], g.scale[l], g.res[l], g.size[l], g.offset[l], g.hashed[l], f0, f1);
+  enc[n * 2 * g.n_levels + 2 * l] = f0;
+  enc[n * 2 * g.n_levels + 2 * l + 1] = f1;
+}
+
 // ---- weights + PDF resampling, one wavefront per ray ------------------------------------------------------
 // RaySamples.get_weights then PDFSampler.generate_ray_samples (single jitter, include_original=False).
 struct PdfArgs {
@@ -535,6 +549,18 @@ extern "C" int neraf_grid_layout(const neraf_grid_desc* g, float* scales, int* r
     if (offsets) offsets[l] = L.offset[l];
   }
   if (offsets) offsets[L.n_levels] = L.offset[L.n_levels];
+  return NERAF_OK;
+}
+
+extern "C" int neraf_hash_encode(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const float* x01, long long n_points,
+                                 float* enc, neraf_stream_t stream) {
+  GridLayout L;
+  if (make_grid_layout(g, &L)) return neraf_fail(ctx, NERAF_EINVAL, "hash_encode: bad grid descriptor");
+  if (!table_f16 || !x01 || !enc || n_points <= 0) return neraf_fail(ctx, NERAF_EINVAL, "hash_encode: bad arguments");
+  const long total = (long)n_points * L.n_levels;
+  hipLaunchKernelGGL(hash_encode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, L,
+                     (const unsigned*)table_f16, x01, (long)n_points, enc);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
 

@@ -251,7 +251,7 @@ extern "C" int neraf_fused_adam_dual(neraf_ctx* ctx, const void* table, const vo
                                      double beta2, double eps, float* step, const float* grad_scale, const float* found_inf,
                                      const void* dual, const float* step0, const float* found_inf0, const float* group_lr0, int n_groups0,
                                      const void* const* g_ptrs_host, int n_ptrs, neraf_stream_t stream) {
-  if (!table || n_blocks < 0 || (n_blocks > 0 && (!blk_tensor || !blk_chunk)) || !step || !group_lr || n_groups < 1 || n_groups > 8 || n_tensors < 1 ||
+  if (!table || n_blocks < 0 || (n_blocks > 0 && (!blk_tensor || !blk_chunk)) || !step || !group_lr || n_groups < 1 || n_groups > 8 || n_tensors < 0 ||
       (dual && (!step0 || !group_lr0 || n_groups0 < 1 || n_groups0 > 8)))
     return neraf_fail(ctx, NERAF_EINVAL, "fused_adam: bad arguments (1..8 parameter groups)");
   AdamLrs lrs{}, lrs0{};
@@ -260,8 +260,10 @@ extern "C" int neraf_fused_adam_dual(neraf_ctx* ctx, const void* table, const vo
   hipStream_t st = (hipStream_t)stream;
   // counters of EVERY record of the table advance here -- also those of tensors whose element update this optimizer defers to the
   // next optimizer's launch (their workgroups are simply absent from blk_tensor / blk_chunk)
-  hipLaunchKernelGGL(adam_advance_step_kernel, dim3((unsigned)((n_tensors + 63) / 64)), dim3(64), 0, st, step, found_inf, beta1, beta2,
-                     (const AdamTensor*)table, n_tensors);
+  // n_tensors == 0: the counters were advanced by an earlier call over this table (the flush of a deferred update, neraf_amd/optim.py)
+  if (n_tensors > 0)
+    hipLaunchKernelGGL(adam_advance_step_kernel, dim3((unsigned)((n_tensors + 63) / 64)), dim3(64), 0, st, step, found_inf, beta1, beta2,
+                       (const AdamTensor*)table, n_tensors);
   if (n_blocks > 0) {
     GradPtrArgs ga{};
     if (pack_grad_ptrs(g_ptrs_host, n_ptrs, &ga))

@@ -290,6 +290,10 @@ static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     a2.a = bn_src_fwd(A, L, ws, bn, i1, use_batch_stats);
     a2.M = (int)cube(c1.dout); a2.Mpad = (int)rows_pad(c1.dout); a2.C = c1.cout; a2.relu = 1; a2.out = (half_t*)(ws + L.a2[b]);
     a2.out_bf = shadow ? (bf16_t*)(ws + L.a2_bf[b]) : nullptr;
+    // MEASUREMENT ONLY (NERAF_SKIP_SMALL_BN=1, results are garbage): upper bound of what fusing the BatchNorm apply of a 1x1x1
+    // consumer into that consumer's operand load could save -- the launch is simply dropped for the <= 4096-voxel layers
+    static const int skip_small = [] { const char* e = getenv("NERAF_SKIP_SMALL_BN"); return e ? atoi(e) : 0; }();
+    if (!(skip_small && cube(c1.dout) <= 4096))
     if (int e = run_bn_apply(ctx, st, a2)) return e;
     if (int e = run_conv(ctx, st, A, L, i2, packed, ws, (const half_t*)(ws + L.a2[b]))) return e;
     BnApplyArgs a3{};

@@ -421,6 +421,8 @@ int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const
   p.det = neraf_deterministic() ? 1 : 0;
   // sums_done: the dgrad GEMM that produced g16 already reduced sum g and sum g * xhat in its epilogue (fuse_bn_sums below)
   if (!sums_done) hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nrb, p.C / 64), dim3(256), 0, c.st, p);
+  static const int skip_small = [] { const char* e = getenv("NERAF_SKIP_SMALL_BN"); return e ? atoi(e) : 0; }();      // measurement only, see resnet3d.hip
+  if (skip_small >= 2 && cube(cs.dout) <= 4096 && cs.k == 1) return NERAF_OK;     // BatchNorms of 1x1x1 convolutions: their dgrad consumer is a plain GEMM
   if (p.det) {     // the slots (of the reduce kernel or of the fused epilogue) added in a fixed order; the apply pass reads that
     float* fin = (float*)(c.bws + c.B->sums_fin[ci]);
     run_slot_sum(c.st, p.sums, det_slots(cs), p.s.cpad, 0.f, 0, fin);

@@ -57,6 +57,10 @@ class FusedAdam(torch.optim.Optimizer):
         second ``first.step()`` before ``second.step()`` raises (the deferred update's gradient would be gone)."""
         if later is self or not isinstance(later, FusedAdam):
             raise ValueError("fuse_shared_updates_into needs another FusedAdam")
+        if self._dual_from is not None or self._defer_to is not None or later._dual_from is not None or later._defer_to is not None:
+            # chains (a -> b -> c) are not supported: b would both apply a's deferred update and defer its own, and a tensor held by
+            # all three would have a's pending update consumed by a launch that does not contain the tensor
+            raise ValueError("fuse_shared_updates_into links PAIRS: one of the two optimizers is already part of a fused pair")
         if self.param_groups[0]["betas"] != later.param_groups[0]["betas"] or self.param_groups[0]["eps"] != later.param_groups[0]["eps"]:
             raise ValueError("fused double updates need equal betas / eps in both optimizers")
         mine = {id(p) for p, _ in self._flat}
@@ -66,6 +70,41 @@ class FusedAdam(torch.optim.Optimizer):
         self._defer_to, later._dual_from = later, self
         self._plans, later._plans = {}, {}
         self._fresh_plan = later._fresh_plan = None
+
+    def flush_pending(self) -> bool:
+        """Apply a deferred update of the shared tensors that the later optimizer never consumed (it was not stepped this iteration: an
+        exception, a caller stepping this optimizer alone, a state load in between) with a plain launch over those tensors -- their
+        counters were already advanced by this optimizer's ``step``, and their gradients are still the ones of that step as long as
+        this is called before they are dropped (``zero_grad`` does).  Returns whether there was anything to flush."""
+        if self._pending is None:
+            return False
+        lrs, fi = self._pending
+        plan, gs, b1, b2 = self._pending_flush
+        self._pending = None
+        first = self._defer_to
+        bt, bc = plan["sh_blk_tensor"], plan["sh_blk_chunk"]
+        if int(bt.numel()) == 0 or any(p.grad is None for p, _ in self._flat if id(p) in self._shared):
+            return False
+        global UPDATE_EPOCH
+        UPDATE_EPOCH += 1
+        lib = _lib.load()
+        gargs = plan.get("gargs") if plan.get("gdev") is None else None
+        _lib.check(lib.neraf_fused_adam_dual(_lib.ctx(plan["dev"]), plan["table"].data_ptr(),
+                                             plan["gdev"].data_ptr() if plan.get("gdev") is not None else None, bt.data_ptr(), bc.data_ptr(),
+                                             int(bt.numel()), lrs, len(self.param_groups), 0, b1, b2, float(self.param_groups[0]["eps"]),
+                                             self._step_t.data_ptr(), gs.data_ptr() if gs is not None else None,
+                                             fi.data_ptr() if fi is not None else None, None, None, None, None, 0,
+                                             gargs, len(gargs) if gargs is not None else 0, _stream_ptr()), plan["dev"])
+        del first
+        return True
+
+    def zero_grad(self, set_to_none: bool = True):
+        self.flush_pending()             # the gradients about to be dropped are the deferred update's
+        return super().zero_grad(set_to_none=set_to_none)
+
+    def state_dict(self):
+        self.flush_pending()
+        return super().state_dict()
 
     def _reindex(self):
         self._flat = [(p, gi) for gi, group in enumerate(self.param_groups) for p in group["params"]]
@@ -103,6 +142,8 @@ class FusedAdam(torch.optim.Optimizer):
         """After ``load_state_dict`` / unpickling: the loaded per-parameter ``step`` values become the device counters again (the
         kernel advances those, and every parameter's ``state['step']`` is a view of its slot), moments move to the parameter's
         device, and every cached launch plan -- which holds raw moment pointers -- is dropped."""
+        if getattr(self, "_pending", None) is not None and getattr(self, "_step_t", None) is not None:
+            self.flush_pending()                # a deferred update is applied, not discarded (the loaded state then replaces it, as torch's would)
         self._plans, self._fresh_plan = {}, None
         for other in (getattr(self, "_defer_to", None), getattr(self, "_dual_from", None)):
             if other is not None:               # the partner's plans hold raw pointers to this optimizer's moments / expect them
@@ -168,9 +209,15 @@ class FusedAdam(torch.optim.Optimizer):
             keep = [i for i, (p, _) in enumerate(entries) if id(p) not in self._shared]
             ubt = [bt[i] for i in keep] or [np.zeros(0, np.int32)]
             ubc = [bc[i] for i in keep] or [np.zeros(0, np.int32)]
+            shared = [i for i, (p, _) in enumerate(entries) if id(p) in self._shared]
+            sbt = [bt[i] for i in shared] or [np.zeros(0, np.int32)]
+            sbc = [bc[i] for i in shared] or [np.zeros(0, np.int32)]
             extra.update(upd_blk_tensor=torch.from_numpy(np.concatenate(ubt)).to(device),
                          upd_blk_chunk=torch.from_numpy(np.concatenate(ubc)).to(device),
-                         deferred=any(id(p) in self._shared for p, _ in entries))
+                         # the shared tensors alone: launched by flush_pending() when the later optimizer never stepped
+                         sh_blk_tensor=torch.from_numpy(np.concatenate(sbt)).to(device),
+                         sh_blk_chunk=torch.from_numpy(np.concatenate(sbc)).to(device),
+                         deferred=bool(shared))
         if self._dual_from is not None:        # the earlier optimizer's moments / group / counter slot of the shared tensors
             first = self._dual_from
             dual = np.zeros(n, dtype=_DUAL)
@@ -274,10 +321,13 @@ class FusedAdam(torch.optim.Optimizer):
         if self._defer_to is not None and plan.get("deferred"):
             if self._pending is not None:
                 raise RuntimeError("FusedAdam: this optimizer's shared tensors are updated by the optimizer it was fused into "
-                                   "(fuse_shared_updates_into): step that one before stepping this one again")
+                                   "(fuse_shared_updates_into): step that one (or call zero_grad / flush_pending) before stepping "
+                                   "this one again")
             bt, bc = plan["upd_blk_tensor"], plan["upd_blk_chunk"]
             # what the later optimizer needs to apply this update: the learning rates as of NOW and this step's non-finite flag
+            # (+ what flush_pending needs should that optimizer never step: this plan, the scale, the betas)
             self._pending = (lrs, fi)
+            self._pending_flush = (plan, gs, float(b1), float(b2))
         dual = step0 = fi0 = lrs0 = None
         n0 = 0
         first = self._dual_from

@@ -157,19 +157,8 @@ class NeRAFPipeline(nn.Module):
         return self.model.device
 
     # ---- the hot path ------------------------------------------------------------------------------------------------
-    def _side_stream(self):
-        """The stream of the radiance half when ``overlap_radiance`` is on (see ``get_train_loss_dict``); created on first use,
-        optionally restricted to a subset of the compute units (``side_cu_mask`` = number of CUs)."""
-        if getattr(self, "_side", None) is None:
-            from . import _streams
-            self._side = _streams.make_stream(self.device, getattr(self, "side_cu_mask", 0))
-        return self._side
-
     def get_train_loss_dict(self, step: int):
         ray_bundle, batch = self.datamanager.next_train(step)
-        audio_on = step > self.start_step_audio
-        if getattr(self, "overlap_radiance", False) and audio_on and torch.cuda.is_available():
-            return self._get_train_loss_dict_overlapped(step, ray_bundle, batch)
         model_outputs = self._model(ray_bundle)                                                  # :176
         metrics_dict = self.model.get_metrics_dict(model_outputs, batch)
         loss_dict = self.model.get_loss_dict(model_outputs, batch, metrics_dict)                # :178
@@ -180,42 +169,6 @@ class NeRAFPipeline(nn.Module):
             _, batch_audio = self.audio_datamanager.next_train(step)
             model_audio_outputs = self.audio_model.get_outputs(batch_audio)
             loss_dict.update(self.audio_model.get_loss_dict(model_audio_outputs, batch_audio, {}))
-        return model_outputs, loss_dict, metrics_dict
-
-    def _get_train_loss_dict_overlapped(self, step: int, ray_bundle, batch):
-        """The same loss dict with the two independent halves of the step on two HIP streams: the radiance half (vision forward,
-        its three losses and -- because autograd replays a node on its forward's stream -- the proposal / field backward) on a side
-        stream, the acoustic half (grid refresh -> ResNet3D -> NAcF -> STFT loss and their backward: a dependent chain of ~400 small
-        kernels that leaves most of the chip idle) on the caller's stream.  They share only the radiance-field parameters (read)
-        and their gradients (summed by autograd's AccumulateGrad, which orders the two streams itself).  Values are identical to the
-        serial form: the same kernels run on the same data."""
-        main = torch.cuda.current_stream()
-        side = self._side_stream()
-        if self.model.training:
-            self.model._refresh_packs()            # fp16 working copies made ONCE, on the main stream, before the fork: both halves read them
-        side.wait_stream(main)
-        late = getattr(self, "overlap_loss_late", False)
-        with torch.cuda.stream(side):
-            model_outputs = self._model(ray_bundle)                                              # :176
-            metrics_dict = self.model.get_metrics_dict(model_outputs, batch)
-            if not late:
-                loss_dict = self.model.get_loss_dict(model_outputs, batch, metrics_dict)        # :178
-        if self.audio_model.use_grid:                                                            # :181-184
-            self.audio_model.query_grid_one_batch(step, self.model.field, renderer_rgb=self.model.renderer_rgb,
-                                                  batch_size=getattr(self.datamanager, "train_num_rays_per_batch", 4096))
-        _, batch_audio = self.audio_datamanager.next_train(step)                                 # :186-199
-        model_audio_outputs = self.audio_model.get_outputs(batch_audio)
-        audio_losses = self.audio_model.get_loss_dict(model_audio_outputs, batch_audio, {})
-        if late:
-            # the radiance loss node is created LAST, so the backward pass issues it FIRST (autograd runs nodes in reverse creation
-            # order): its kernels are queued on the side stream before the host starts issuing the acoustic chain
-            with torch.cuda.stream(side):
-                loss_dict = self.model.get_loss_dict(model_outputs, batch, metrics_dict)        # :178
-        loss_dict.update(audio_losses)
-        main.wait_stream(side)                      # the loss scalars of the radiance half are summed on the caller's stream
-        for v in loss_dict.values():
-            if torch.is_tensor(v) and v.is_cuda:
-                v.record_stream(main)
         return model_outputs, loss_dict, metrics_dict
 
     def forward(self):

@@ -97,6 +97,19 @@ def grid_layout(desc: _lib.GridDesc):
     return list(sc), list(rs), list(sz), list(off)
 
 
+def hash_encode(desc: _lib.GridDesc, table: torch.Tensor, x01: torch.Tensor) -> torch.Tensor:
+    """tiny-cuda-nn's HashGrid forward on its own (``neraf_hash_encode``): positions ``x01`` [N,3] in [0,1]^3 and a table [rows,2]
+    (rounded to fp16 as the kernels read it) -> [N, 2 * n_levels] fp32.  The fused field / proposal kernels contain the same
+    arithmetic; this entry exists for callers that want the encoding itself (SURVEY 8b op list) and as its stand-alone parity point."""
+    lib = _lib.load()
+    dev = _dev_index(x01)
+    x = x01.reshape(-1, 3).float().contiguous()
+    t16 = table.detach().half().contiguous()
+    out = torch.empty((x.shape[0], 2 * desc.n_levels), dtype=torch.float32, device=x.device)
+    _lib.check(lib.neraf_hash_encode(_lib.ctx(dev), C.byref(desc), t16.data_ptr(), x.data_ptr(), x.shape[0], out.data_ptr(), _stream_ptr()), dev)
+    return out
+
+
 # ---- MFMA weight-fragment packing of the field MLPs ----------------------------------------------------
 def _dperm(s: int, q: int, j: int) -> int:
     """k index held by (lane quarter q, element j) of k-step s when the B operand is built from two
@@ -302,9 +315,9 @@ class NerfactoField(nn.Module):
         return self._dumps[key]
 
     def splitk_buffer(self, device) -> torch.Tensor:
-        """Split-K scratch of the weight-gradient GEMMs: one per (device, stream) -- the render batch's backward and the grid
-        refresh's backward may run on different streams (two-stream step, neraf_amd/pipeline.py)."""
-        key = (str(device), torch.cuda.current_stream().cuda_stream)
+        """Split-K scratch of the weight-gradient GEMMs: one per (device, stream) -- a caller that runs two backward passes of this
+        field on two streams must not share it."""
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
         if not isinstance(getattr(self, "_splitk", None), dict):
             self._splitk = {}
         if key not in self._splitk:

@@ -88,3 +88,8 @@ def test_rccl_world_size_one_runs_the_data_parallel_plumbing_on_the_real_backend
     worst = max(r["rel"].values())
     assert worst <= 2e-3, sorted(r["rel"].items(), key=lambda kv: -kv[1])[:5]
     assert a["scale"] == b["scale"]
+    # deterministic summation (NERAF_DETERMINISTIC=1 above) and no camera optimizer: the two runs are the SAME computation -- every
+    # parameter and the voxel grid bit for bit
+    diff = [k for k in a["digest"] if a["digest"][k] != b["digest"][k]]
+    assert not diff, f"{len(diff)} tensors differ between the plain and the RCCL run, e.g. {diff[:5]}"
+    assert a["grid"] == b["grid"]

@@ -74,12 +74,14 @@ def test_amp_update_scale_matches_torch():
     pattern = [(0, 0), (0, 0), (0, 0), (1, 0), (0, 0), (0, 1), (0, 0), (0, 0), (0, 0), (1, 1), (0, 0)]
     for f1, f2 in pattern:
         fa = [torch.tensor([float(f1)], device=dev), torch.tensor([float(f2)], device=dev)]
-        _lib.check(lib.neraf_amp_update_scale(h, sa.data_ptr(), ta.data_ptr(), _lib.ptr_array(fa), 2, 2.0, 0.5, 3, _st()), 0)
+        clear = int(f1 == 0)              # clear_flags: both flags are reset by the launch after it has read them
+        _lib.check(lib.neraf_amp_update_scale(h, sa.data_ptr(), ta.data_ptr(), _lib.ptr_array(fa), 2, 2.0, 0.5, 3, clear, _st()), 0)
         torch._amp_update_scale_(sb, tb, torch.tensor([float(f1 + f2)], device=dev), 2.0, 0.5, 3)
         assert float(sa) == float(sb) and int(ta) == int(tb), (f1, f2, float(sa), float(sb))
+        assert [float(f) for f in fa] == ([0.0, 0.0] if clear else [float(f1), float(f2)])
     # growth that would overflow keeps the scale (torch: only a finite product is adopted)
     big = torch.tensor(3.0e38, device=dev)
     trk = torch.tensor(2, dtype=torch.int32, device=dev)
     z = [torch.zeros(1, device=dev)]
-    _lib.check(lib.neraf_amp_update_scale(h, big.data_ptr(), trk.data_ptr(), _lib.ptr_array(z), 1, 2.0, 0.5, 3, _st()), 0)
+    _lib.check(lib.neraf_amp_update_scale(h, big.data_ptr(), trk.data_ptr(), _lib.ptr_array(z), 1, 2.0, 0.5, 3, 0, _st()), 0)
     assert float(big) == pytest.approx(3.0e38) and int(trk) == 0

@@ -210,3 +210,46 @@ def test_fused_double_update_of_shared_tensors_is_bit_identical_to_two_steps():
     a0.step()
     with pytest.raises(RuntimeError, match="fused into"):
         a0.step()
+
+
+def test_deferred_update_is_flushed_not_lost_when_the_second_optimizer_never_steps():
+    """after ``first.fuse_shared_updates_into(second)`` the first optimizer's ``step`` defers the shared tensors' update to
+    the second's launch.  If the second is not stepped that iteration (an exception, a caller stepping "fields" alone), the update must
+    not be dropped: ``zero_grad`` (and ``state_dict`` / a state load) applies it with a plain launch over those tensors -- equal, bit
+    for bit, to what an un-linked optimizer does.  And chains are refused: an optimizer is part of ONE pair."""
+    from neraf_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+
+    def build(linked):
+        ps = _params(dev, 6)
+        shared, only0, only1 = ps[:2], ps[2:4], ps[4:]
+        o0 = FusedAdam([{"params": only0, "lr": 1e-2}, {"params": shared, "lr": 5e-3}], eps=1e-15)
+        o1 = FusedAdam([{"params": only1 + shared, "lr": 1e-4}], eps=1e-15)
+        if linked:
+            o0.fuse_shared_updates_into(o1)
+        return ps, o0, o1
+    (pa, a0, a1), (pb, b0, b1) = build(True), build(False)
+    g = torch.Generator().manual_seed(5)
+    for it in range(3):
+        grads = [torch.randn(x.shape, generator=g).to(dev) for x in pa]
+        for ps in (pa, pb):
+            for x, gr in zip(ps, grads):
+                x.grad = gr.clone()
+        a0.step(); b0.step()
+        if it != 1:                        # iteration 1: the second optimizer never steps
+            a1.step(); b1.step()
+        if it == 1:
+            assert not torch.equal(pa[0], pb[0])          # the shared update is still pending on the linked side ...
+        a0.zero_grad(); a1.zero_grad(); b0.zero_grad(); b1.zero_grad()
+        for x, y in zip(pa, pb):                           # ... and applied by zero_grad: both sides agree again, bit for bit
+            assert torch.equal(x, y), it
+    for o, q in ((a0, b0), (a1, b1)):
+        for (px, sx), (py, sy) in zip(o.state.items(), q.state.items()):
+            assert torch.equal(sx["exp_avg"], sy["exp_avg"]) and torch.equal(sx["exp_avg_sq"], sy["exp_avg_sq"])
+            assert float(sx["step"]) == float(sy["step"])
+    # chains are refused
+    ps = _params(dev, 3)
+    c0, c1, c2 = (FusedAdam([{"params": ps, "lr": 1e-3}], eps=1e-15) for _ in range(3))
+    c0.fuse_shared_updates_into(c1)
+    with pytest.raises(ValueError):
+        c1.fuse_shared_updates_into(c2)

@@ -54,6 +54,31 @@ def setup(dev):
     return m.to(dev), P16, spec, V
 
 
+def test_hash_encode_standalone_vs_oracle(dev, setup):
+    """neraf_hash_encode (the stand-alone encoding of SURVEY 8b's op list) against oracle.vision.hash_encode on the three grids of the
+    model: dense and hashed levels, positions on cell faces and at the box corners included."""
+    from neraf_amd import _lib
+    from neraf_amd.vision import hash_encode
+    m, P16, spec, V = setup
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand((4096, 3), generator=g)
+    x[:64] = torch.randint(0, 17, (64, 3), generator=g).float() / 16.0          # faces / corners of the coarsest level, 0 and 1 included
+    for gs, d, key in ((spec.main_grid, _lib.GridDesc(16, 16, 2048, 19, 2), "field.table"),
+                       (spec.prop_grids[0], _lib.GridDesc(5, 16, 128, 17, 2), "prop0.table"),
+                       (spec.prop_grids[1], _lib.GridDesc(5, 16, 256, 17, 2), "prop1.table")):
+        ref = V.hash_encode(x, P16[key], gs)
+        out = hash_encode(d, P16[key].to(dev), x.to(dev))
+        assert out.shape == ref.shape == (4096, 2 * gs.n_levels)
+        # the kernels form the cell coordinate with one rounding (fmaf(scale, x, 0.5), as tiny-cuda-nn does), the oracle with two
+        # (x * scale + 0.5): at the finest levels the coordinate is ~2e3 and one fp32 ulp of it is 1.2e-4 of a cell, which moves an
+        # interpolated value by up to that times the local table contrast (entries in +-0.5 here)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=3e-4)
+        lvl0 = slice(0, 2)              # the coarsest level (coordinate < 17: ulp 1e-6) agrees to rounding
+        np.testing.assert_allclose(out.cpu().numpy()[:, lvl0], ref.numpy()[:, lvl0], rtol=0, atol=2e-6)
+    rc = _lib.load().neraf_hash_encode(_lib.ctx(0), None, None, None, 0, None, None)
+    assert rc != 0
+
+
 def test_grid_layout_matches_oracle(setup):
     from neraf_amd import _lib
     from neraf_amd.vision import grid_layout
