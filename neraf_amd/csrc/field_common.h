@@ -70,29 +70,78 @@ __device__ __forceinline__ bool map_position(float& x, float& y, float& z, int m
   return sel;
 }
 
+// ---- one hash-grid level: cell, corner indices, gathers ---------------------------------------------------------------------------
+// The eight corner entries of the cell that contains (x,y,z) at one level.  Index arithmetic shared between the corners: the hashed
+// index is (cx ^ cy P1 ^ cz P2) & (size - 1) and (cy + 1) P1 = cy P1 + P1 in uint32 arithmetic, so the four (y, z) corner hashes
+// cost two multiplies and four xors for the cell, and a corner one xor + and (v_bitop3); the dense index is base + {0,1} + {0,res} +
+// {0,res^2}.  Gathers are raw BUFFER loads (32-bit byte offset from a scalar resource for the table: no 64-bit address arithmetic
+// per corner -- the generic-pointer form spent two v_mad_u64_u32 / v_lshl_add_u64 per corner on it).
+struct LevelCell { float wx, wy, wz; unsigned idx[8]; };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const unsigned* __restrict__ table) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(table), 0, 0xFFFFFFFFu, 0x00020000);
+}
+
+__device__ __forceinline__ void level_cell(float x, float y, float z, float scale, int res, unsigned size, int hashed, LevelCell& c) {
+  const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+  const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+  c.wx = px - flx; c.wy = py - fly; c.wz = pz - flz;
+  const unsigned ix = (unsigned)(int)flx, iy = (unsigned)(int)fly, iz = (unsigned)(int)flz;
+  if (hashed) {                     // hashed levels have size = 2^log2_T
+    const unsigned m = size - 1u;
+    const unsigned hy0 = iy * 2654435761u, hy1 = hy0 + 2654435761u;
+    const unsigned hz0 = iz * 805459861u, hz1 = hz0 + 805459861u;
+    const unsigned t00 = hy0 ^ hz0, t10 = hy1 ^ hz0, t01 = hy0 ^ hz1, t11 = hy1 ^ hz1;
+    const unsigned x0 = ix, x1 = ix + 1u;
+    c.idx[0] = (x0 ^ t00) & m; c.idx[1] = (x1 ^ t00) & m; c.idx[2] = (x0 ^ t10) & m; c.idx[3] = (x1 ^ t10) & m;
+    c.idx[4] = (x0 ^ t01) & m; c.idx[5] = (x1 ^ t01) & m; c.idx[6] = (x0 ^ t11) & m; c.idx[7] = (x1 ^ t11) & m;
+  } else {
+    // dense level: tcnn's `index % size`; corners of the last cell reach res, so idx < res^3+res^2+res < 2*size
+    const unsigned r = (unsigned)res, r2 = r * r;
+    const unsigned base = ix + iy * r + iz * r2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      unsigned i = base + (k & 1) + ((k & 2) ? r : 0u) + ((k & 4) ? r2 : 0u);
+      if (i >= size) i -= size;
+      c.idx[k] = i;
+    }
+  }
+}
+
+// trilinear weight of corner k = (fx * fy) * fz with f = w or 1 - w per axis bit (the product order every consumer shares)
+__device__ __forceinline__ void corner_weights(const LevelCell& c, float (&w)[8]) {
+  const float fx0 = 1.f - c.wx, fy0 = 1.f - c.wy, fz0 = 1.f - c.wz;
+  const float xy[4] = {fx0 * fy0, c.wx * fy0, fx0 * c.wy, c.wx * c.wy};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = xy[k & 3] * ((k & 4) ? c.wz : fz0);
+}
+
+// (Tried and reverted, round 4: ONE 8-byte gather for the two x-corners of a (y, z) pair whenever their indices differ by one --
+// always on dense levels, for even cell x on hashed ones: 40 -> 24 gather instructions per proposal sample.  The per-lane choice
+// between the 8-byte and the two 4-byte forms is a divergent branch around every load: proposal density 128 -> 144 us, field query
+// on frames 233 -> 405 us, training 63 -> 72 us.  Eight independent 4-byte loads in flight beat fewer, serialised ones.)
+__device__ __forceinline__ void gather_corners(const unsigned* __restrict__ table, unsigned offset, const LevelCell& c, unsigned (&raw)[8]) {
+  const __amdgpu_buffer_rsrc_t rs = table_rsrc(table);
+  const unsigned off4 = offset << 2;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) raw[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (c.idx[k] << 2) + off4, 0, 0);
+}
+
 // one hash-grid level, trilinear; table entries are half2 (2 features)
 __device__ __forceinline__ void encode_level(const unsigned* __restrict__ table, float x, float y, float z, float scale, int res,
                                              unsigned size, unsigned offset, int hashed, float& f0, float& f1) {
-  const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
-  const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-  const float wx = px - flx, wy = py - fly, wz = pz - flz;
-  const unsigned ix = (unsigned)(int)flx, iy = (unsigned)(int)fly, iz = (unsigned)(int)flz;
+  LevelCell c;
+  level_cell(x, y, z, scale, res, size, hashed, c);
+  unsigned raw[8];
+  gather_corners(table, offset, c, raw);
+  float w[8];
+  corner_weights(c, w);
   f0 = 0.f; f1 = 0.f;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const unsigned cx = ix + (c & 1), cy = iy + ((c >> 1) & 1), cz = iz + ((c >> 2) & 1);
-    const float w = ((c & 1) ? wx : 1.f - wx) * ((c & 2) ? wy : 1.f - wy) * ((c & 4) ? wz : 1.f - wz);
-    unsigned idx;
-    if (hashed) idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1u);   // hashed levels have size = 2^log2_T
-    else {
-      // dense level: tcnn's `index % size`; corners of the last cell reach res, so idx < res^3+res^2+res < 2*size
-      idx = cx + cy * (unsigned)res + cz * (unsigned)res * (unsigned)res;
-      if (idx >= size) idx -= size;
-    }
-    const unsigned raw = table[offset + idx];
-    const half2v v = *reinterpret_cast<const half2v*>(&raw);
-    f0 = fmaf(w, (float)v[0], f0);
-    f1 = fmaf(w, (float)v[1], f1);
+  for (int k = 0; k < 8; ++k) {
+    const half2v v = *reinterpret_cast<const half2v*>(&raw[k]);
+    f0 = fmaf(w[k], (float)v[0], f0);
+    f1 = fmaf(w[k], (float)v[1], f1);
   }
 }
 
@@ -103,28 +152,21 @@ __device__ __forceinline__ void encode_level(const unsigned* __restrict__ table,
 __device__ __forceinline__ void encode_level_grad(const unsigned* __restrict__ table, float x, float y, float z, float scale, int res,
                                                   unsigned size, unsigned offset, int hashed, float& f0, float& f1,
                                                   float (&d0)[3], float (&d1)[3]) {
-  const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
-  const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-  const float wx = px - flx, wy = py - fly, wz = pz - flz;
-  const unsigned ix = (unsigned)(int)flx, iy = (unsigned)(int)fly, iz = (unsigned)(int)flz;
+  LevelCell c;
+  level_cell(x, y, z, scale, res, size, hashed, c);
+  unsigned raw[8];
+  gather_corners(table, offset, c, raw);
+  const float wx = c.wx, wy = c.wy, wz = c.wz;
   f0 = 0.f; f1 = 0.f;
   float a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const unsigned cx = ix + (c & 1), cy = iy + ((c >> 1) & 1), cz = iz + ((c >> 2) & 1);
-    unsigned idx;
-    if (hashed) idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1u);
-    else {
-      idx = cx + cy * (unsigned)res + cz * (unsigned)res * (unsigned)res;
-      if (idx >= size) idx -= size;
-    }
-    const unsigned raw = table[offset + idx];
-    const half2v v = *reinterpret_cast<const half2v*>(&raw);
+  for (int k = 0; k < 8; ++k) {
+    const half2v v = *reinterpret_cast<const half2v*>(&raw[k]);
     const float v0 = (float)v[0], v1 = (float)v[1];
-    const float fx = (c & 1) ? wx : 1.f - wx, fy = (c & 2) ? wy : 1.f - wy, fz = (c & 4) ? wz : 1.f - wz;
+    const float fx = (k & 1) ? wx : 1.f - wx, fy = (k & 2) ? wy : 1.f - wy, fz = (k & 4) ? wz : 1.f - wz;
     const float w = fx * fy * fz;
     f0 = fmaf(w, v0, f0); f1 = fmaf(w, v1, f1);
-    const float gx = ((c & 1) ? 1.f : -1.f) * fy * fz, gy = ((c & 2) ? 1.f : -1.f) * fx * fz, gz = ((c & 4) ? 1.f : -1.f) * fx * fy;
+    const float gx = ((k & 1) ? 1.f : -1.f) * fy * fz, gy = ((k & 2) ? 1.f : -1.f) * fx * fz, gz = ((k & 4) ? 1.f : -1.f) * fx * fy;
     a0x = fmaf(gx, v0, a0x); a0y = fmaf(gy, v0, a0y); a0z = fmaf(gz, v0, a0z);
     a1x = fmaf(gx, v1, a1x); a1y = fmaf(gy, v1, a1y); a1z = fmaf(gz, v1, a1z);
   }
@@ -138,27 +180,20 @@ __device__ __forceinline__ void encode_level_grad(const unsigned* __restrict__ t
 __device__ __forceinline__ void encode_level_dpos(const unsigned* __restrict__ table, float x, float y, float z, float scale, int res,
                                                   unsigned size, unsigned offset, int hashed, float g0, float g1,
                                                   float& dx, float& dy, float& dz) {
-  const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
-  const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-  const float wx = px - flx, wy = py - fly, wz = pz - flz;
-  const unsigned ix = (unsigned)(int)flx, iy = (unsigned)(int)fly, iz = (unsigned)(int)flz;
+  LevelCell c;
+  level_cell(x, y, z, scale, res, size, hashed, c);
+  unsigned raw[8];
+  gather_corners(table, offset, c, raw);
+  const float wx = c.wx, wy = c.wy, wz = c.wz;
   float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const unsigned cx = ix + (c & 1), cy = iy + ((c >> 1) & 1), cz = iz + ((c >> 2) & 1);
-    unsigned idx;
-    if (hashed) idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (size - 1u);
-    else {
-      idx = cx + cy * (unsigned)res + cz * (unsigned)res * (unsigned)res;
-      if (idx >= size) idx -= size;
-    }
-    const unsigned raw = table[offset + idx];
-    const half2v v = *reinterpret_cast<const half2v*>(&raw);
+  for (int k = 0; k < 8; ++k) {
+    const half2v v = *reinterpret_cast<const half2v*>(&raw[k]);
     const float val = g0 * (float)v[0] + g1 * (float)v[1];
-    const float fx = (c & 1) ? wx : 1.f - wx, fy = (c & 2) ? wy : 1.f - wy, fz = (c & 4) ? wz : 1.f - wz;
-    ax = fmaf(((c & 1) ? 1.f : -1.f) * fy * fz, val, ax);
-    ay = fmaf(((c & 2) ? 1.f : -1.f) * fx * fz, val, ay);
-    az = fmaf(((c & 4) ? 1.f : -1.f) * fx * fy, val, az);
+    const float fx = (k & 1) ? wx : 1.f - wx, fy = (k & 2) ? wy : 1.f - wy, fz = (k & 4) ? wz : 1.f - wz;
+    ax = fmaf(((k & 1) ? 1.f : -1.f) * fy * fz, val, ax);
+    ay = fmaf(((k & 2) ? 1.f : -1.f) * fx * fz, val, ay);
+    az = fmaf(((k & 4) ? 1.f : -1.f) * fx * fy, val, az);
   }
   dx = fmaf(scale, ax, dx); dy = fmaf(scale, ay, dy); dz = fmaf(scale, az, dz);
 }

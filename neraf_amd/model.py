@@ -371,9 +371,17 @@ class NeRAFAudioModel(nn.Module):
         mic = batch_audio["mic_pose"].to(dev).reshape(1, 3).expand(T, -1)
         src = batch_audio["source_pose"].to(dev).reshape(1, 3).expand(T, -1)
         rot = batch_audio["rot"].to(dev).reshape(1, 3).expand(T, -1)
-        self.set_eval_data(mic[0], src[0], rot[0], batch_audio["data"])                 # :653 (argument order as written there)
         feat = self.scene_feature() if self.use_grid else torch.zeros(0, device=dev)
         out = self.field.forward_queries(feat, tq, mic, src, rot, self.aabb, T)         # [T,C,F]
+        return self.eval_outputs_from_raw(out, batch_audio)
+
+    @torch.no_grad()
+    def eval_outputs_from_raw(self, out: torch.Tensor, batch_audio) -> Dict[str, torch.Tensor]:
+        """The output dict of the eval branch (:695-726) from the raw log-magnitudes ``out`` [T,C,F] of one RIR -- the per-channel panels,
+        the ground-truth panels, the grid views.  ``get_outputs_for_camera`` ends here; a caller that evaluated many RIRs in one
+        field call (``get_outputs_for_rirs``) builds each item's dict with it."""
+        self.set_eval_data(batch_audio["mic_pose"], batch_audio["source_pose"], batch_audio["rot"], batch_audio["data"])    # :653
+        dev = self.aabb.device
         stft: Dict[str, torch.Tensor] = {}
         host = out.cpu()                           # ONE device-to-host copy of [T,C,F]; the panels below are host-side views of it
         for ch in range(out.shape[1]):                                                  # :695-700
