@@ -49,6 +49,7 @@ def main():
     js = bench.JointStep(dev, 4096, 2048, 1, rotate=1, camera_opt=False)
     vm = js.vm
     vm.train()
+    vm.update_to_step(js.i)        # the bench's operating point (step 20000: proposal-weight annealing finished)
     with torch.no_grad():
         out = vm.get_outputs(js.bundle)
     fine = out["ray_samples_list"][-1]
