@@ -53,38 +53,54 @@ struct PropArgs {
   float* density;
   int ray_tiles;   // 1: a wave holds the SAME sample index of 64 consecutive rays (coherent rays of an eval frame: neighbouring pixels
                    // at equal depth fall into the same few grid cells, so a gather instruction touches a handful of lines instead of 64)
+  FastDiv divS;    // division by S
 };
 
+// VALU-bound (rocprofv3 SQ_INSTS_VALU x 4 cycles = 89 % of its duration on a frame, tools/gpu_r4_valu.sh): what counts is the number
+// of vector instructions per sample.  The sample's (ray, index) pair comes from WAVE-uniform scalar arithmetic plus the lane number
+// (no per-lane 64-bit division); the table offsets of a level ride in the gathers' scalar offset; the 2 NL -> 16 layer is
+// v_dot2c_f32_f16 on the fp16 feature pairs tcnn hands to its MLP (two exact fp16 x fp16 products per instruction, fp32 accumulation).
+template <int NL>    // levels compiled in (5: both nerfacto proposal networks; 8: any n_levels <= 8)
 __global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
-  __shared__ float w0[16][16];
+  __shared__ unsigned w0h[16][8];      // layer 0 as half2 pairs: [hidden unit][level] = columns (2 l, 2 l + 1)
   __shared__ float w1[16];
-  for (int i = threadIdx.x; i < 256; i += 256) w0[i >> 4][i & 15] = (float)a.w[i];
+  if (threadIdx.x < 128) w0h[threadIdx.x >> 3][threadIdx.x & 7] = reinterpret_cast<const unsigned*>(a.w)[threadIdx.x];
   if (threadIdx.x < 16) w1[threadIdx.x] = (float)a.w[256 + threadIdx.x];
   __syncthreads();
-  long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  int ray, s;
-  if (a.ray_tiles) {           // tile = 64 rays x S samples; inside a tile the ray index runs fastest
-    const long tile = idx / (64L * a.S), within = idx % (64L * a.S);
-    ray = (int)(tile * 64 + (within & 63)); s = (int)(within >> 6);
-    if (ray >= a.R) return;
-    idx = (long)ray * a.S + s;
-  } else {
-    if (idx >= (long)a.R * a.S) return;
-    ray = (int)(idx / a.S); s = (int)(idx % a.S);
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+  const unsigned S = (unsigned)a.S;
+  unsigned ray, s;
+  if (a.ray_tiles) {           // tile = 64 rays x S samples; a wave is one sample index of the tile's 64 rays
+    const unsigned tile = fastdiv(wave, a.divS);
+    ray = tile * 64u + lane; s = wave - tile * S;
+  } else {                     // 64 consecutive samples in ray-major order
+    const unsigned n = wave * 64u + lane;
+    ray = fastdiv(n, a.divS); s = n - ray * S;
   }
-  const float t = 0.5f * (a.e_bins[(size_t)ray * (a.S + 1) + s] + a.e_bins[(size_t)ray * (a.S + 1) + s + 1]);
-  float x = fmaf(a.dirs[ray * 3 + 0], t, a.origins[ray * 3 + 0]);
-  float y = fmaf(a.dirs[ray * 3 + 1], t, a.origins[ray * 3 + 1]);
-  float z = fmaf(a.dirs[ray * 3 + 2], t, a.origins[ray * 3 + 2]);
+  if (ray >= (unsigned)a.R) return;
+  const unsigned eb = ray * (S + 1u) + s;
+  const float t = 0.5f * (a.e_bins[eb] + a.e_bins[eb + 1u]);
+  float x = fmaf(a.dirs[ray * 3u + 0u], t, a.origins[ray * 3u + 0u]);
+  float y = fmaf(a.dirs[ray * 3u + 1u], t, a.origins[ray * 3u + 1u]);
+  float z = fmaf(a.dirs[ray * 3u + 2u], t, a.origins[ray * 3u + 2u]);
   const bool sel = map_position(x, y, z, 0, nullptr);
-  float enc[2 * 8];
+  half2v enc[NL];
+  LevelCell cell[NL];
+  unsigned raw[NL][8];
 #pragma unroll
-  for (int l = 0; l < 8; ++l) {
-    enc[2 * l] = 0.f; enc[2 * l + 1] = 0.f;
-    if (l < a.g.n_levels) {
+  for (int l = 0; l < NL; ++l)
+    if (NL == 5 || l < a.g.n_levels) {
+      level_cell(x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.hashed[l], cell[l]);
+      gather_corners<true>(a.table, a.g.offset[l], cell[l], raw[l]);
+    }
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    enc[l] = half2v{(half_t)0.f, (half_t)0.f};
+    if (NL == 5 || l < a.g.n_levels) {
       float f0, f1;
-      encode_level(a.table, x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.offset[l], a.g.hashed[l], f0, f1);
-      enc[2 * l] = (float)(half_t)f0; enc[2 * l + 1] = (float)(half_t)f1;   // tcnn hands fp16 features to the MLP
+      interpolate_level(cell[l], raw[l], f0, f1);
+      enc[l] = half2v{(half_t)f0, (half_t)f1};               // tcnn hands fp16 features to the MLP
     }
   }
   float out = 0.f;
@@ -92,11 +108,11 @@ __global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
   for (int j = 0; j < 16; ++j) {
     float h = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) h = fmaf(w0[j][k], enc[k], h);
+    for (int l = 0; l < NL; ++l) h = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w0h[j][l]), enc[l], h, false);
     h = fmaxf(h, 0.f);
     out = fmaf(w1[j], h, out);
   }
-  a.density[idx] = sel ? a.avg_density * __expf(out) : 0.f;
+  a.density[ray * S + s] = sel ? a.avg_density * __expf(out) : 0.f;
 }
 
 // ---- stand-alone multiresolution hash encoding (tiny-cuda-nn HashGrid forward; SURVEY 8b op list) ------------------------------
@@ -223,12 +239,16 @@ struct FieldArgs {
   half_t* denc_out;              // optional fp16 [N][4][24]: d enc / d mapped position of each lane's 4 levels x 2 features x 3 axes
                                  // (the camera-pose edge of the backward)
   int ray_tiles;                 // 1: a group's 16 points are the SAME sample index of 16 consecutive rays (coherent rays, eval frames)
+  FastDiv divS;                  // division by S
 };
 
 constexpr int NFRAG = 24;   // base0: 0-3, base1: 4-5, head0: 6-13 (ob*2+s), head1: 14-21, head2: 22-23
 
+#ifndef NERAF_FQ_OCC
+#define NERAF_FQ_OCC 3     // workgroups per CU the inference / encoding-saving forms are compiled for (A/B knob of tools/gpu_r4_occ.sh)
+#endif
 template <int SAVE>   // 0: outputs only; 1: also the encoding; 2: the encoding and its position derivatives
-__global__ __launch_bounds__(256, SAVE == 2 ? 2 : 3) void field_query_kernel(FieldArgs a) {
+__global__ __launch_bounds__(256, SAVE == 2 ? 2 : NERAF_FQ_OCC) void field_query_kernel(FieldArgs a) {
   __shared__ float l_scale[MAX_LEVELS];
   __shared__ int l_res[MAX_LEVELS];
   __shared__ unsigned l_size[MAX_LEVELS], l_off[MAX_LEVELS];
@@ -248,39 +268,50 @@ __global__ __launch_bounds__(256, SAVE == 2 ? 2 : 3) void field_query_kernel(Fie
   const half8* wfp = wf_s + lane;
 #define wf(f) wfp[(f) * 64]
 
-  const long N = (long)a.R * a.S;
-  const long ngroups = a.ray_tiles ? (long)((a.R + 15) / 16) * a.S : (N + 15) / 16;
-  const long gstride = (long)gridDim.x * 4;
-  for (long grp = (long)blockIdx.x * 4 + (threadIdx.x >> 6); grp < ngroups; grp += gstride) {
-    long n;
+  // 32-bit sample arithmetic (the entry point refuses R * S >= 2^31); the group index is wave-uniform: its division by S is scalar
+  const unsigned N = (unsigned)a.R * (unsigned)a.S, S = (unsigned)a.S;
+  const unsigned ngroups = a.ray_tiles ? ((unsigned)(a.R + 15) / 16u) * S : (N + 15u) / 16u;
+  const unsigned gstride = gridDim.x * 4u;
+  for (unsigned grp = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)); grp < ngroups; grp += gstride) {
+    unsigned n, ray, s;
     bool valid;
     if (a.ray_tiles) {                           // group = (tile of 16 rays, sample index): consecutive groups walk the tile's samples
-      int r = (int)(grp / a.S) * 16 + p;
-      valid = r < a.R;
-      if (!valid) r = a.R - 1;
-      n = (long)r * a.S + (grp % a.S);
+      const unsigned tile = fastdiv(grp, a.divS);
+      s = grp - tile * S;
+      ray = tile * 16u + (unsigned)p;
+      valid = ray < (unsigned)a.R;
+      if (!valid) ray = (unsigned)a.R - 1u;
+      n = ray * S + s;
     } else {
-      n = grp * 16 + p;
+      n = grp * 16u + (unsigned)p;
       valid = n < N;
-      if (!valid) n = N - 1;                     // MFMA needs every lane: clamp, compute, do not store
+      if (!valid) n = N - 1u;                    // MFMA needs every lane: clamp, compute, do not store
+      ray = fastdiv(n, a.divS); s = n - ray * S;
     }
-    const int ray = (int)(n / a.S), s = (int)(n % a.S);
-    const float t = 0.5f * (a.e_bins[(size_t)ray * (a.S + 1) + s] + a.e_bins[(size_t)ray * (a.S + 1) + s + 1]);
-    const float dx = a.dirs[ray * 3 + 0], dy = a.dirs[ray * 3 + 1], dz = a.dirs[ray * 3 + 2];
-    float x = fmaf(dx, t, a.origins[ray * 3 + 0]);
-    float y = fmaf(dy, t, a.origins[ray * 3 + 1]);
-    float z = fmaf(dz, t, a.origins[ray * 3 + 2]);
+    const unsigned eb = ray * (S + 1u) + s;
+    const float t = 0.5f * (a.e_bins[eb] + a.e_bins[eb + 1u]);
+    const float dx = a.dirs[ray * 3u + 0u], dy = a.dirs[ray * 3u + 1u], dz = a.dirs[ray * 3u + 2u];
+    float x = fmaf(dx, t, a.origins[ray * 3u + 0u]);
+    float y = fmaf(dy, t, a.origins[ray * 3u + 1u]);
+    float z = fmaf(dz, t, a.origins[ray * 3u + 2u]);
     const bool sel = map_position(x, y, z, a.mode, a.aabb);
     // --- hash encode: this lane's 4 levels -> B fragment of the first layer (k = 8q + 2*li + f)
     half8 xin;
+    LevelCell cell[4];
+    unsigned raw[4][8];
+#pragma unroll
+    for (int li = 0; li < 4; ++li) {               // all 32 gathers of the lane in flight before the first is consumed
+      const int l = 4 * q + li;
+      level_cell(x, y, z, l_scale[l], l_res[l], l_size[l], l_hash[l], cell[li]);
+      gather_corners<false>(a.table, l_off[l], cell[li], raw[li]);
+    }
     if (SAVE == 2) {
       half8 dh[3];                                 // [li][feature][axis] = 24 halfs
       half_t* dp = reinterpret_cast<half_t*>(dh);
 #pragma unroll
       for (int li = 0; li < 4; ++li) {
-        const int l = 4 * q + li;
         float f0, f1, d0[3], d1_[3];
-        encode_level_grad(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1, d0, d1_);
+        interpolate_level_grad(cell[li], raw[li], l_scale[4 * q + li], f0, f1, d0, d1_);
         xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { dp[li * 6 + k] = (half_t)(sel ? d0[k] : 0.f); dp[li * 6 + 3 + k] = (half_t)(sel ? d1_[k] : 0.f); }
@@ -292,9 +323,8 @@ __global__ __launch_bounds__(256, SAVE == 2 ? 2 : 3) void field_query_kernel(Fie
     } else {
 #pragma unroll
       for (int li = 0; li < 4; ++li) {
-        const int l = 4 * q + li;
         float f0, f1;
-        encode_level(a.table, x, y, z, l_scale[l], l_res[l], l_size[l], l_off[l], l_hash[l], f0, f1);
+        interpolate_level(cell[li], raw[li], f0, f1);
         xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
       }
     }
@@ -333,7 +363,7 @@ __global__ __launch_bounds__(256, SAVE == 2 ? 2 : 3) void field_query_kernel(Fie
     d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(23), pack_relu(d4[2], d4[3], true), d5, 0, 0, 0);
     if (q == 0 && valid) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) a.rgb[(size_t)n * 3 + c] = 1.f / (1.f + __expf(-d5[c]));
+      for (int c = 0; c < 3; ++c) a.rgb[(size_t)n * 3 + c] = __builtin_amdgcn_rcpf(1.f + __expf(-d5[c]));   // v_rcp_f32: 1 ulp
     }
   }
 }
@@ -587,7 +617,10 @@ extern "C" int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, 
   ProfScope prof(ctx, (hipStream_t)stream, PROF_PROP_DENSITY, (double)n * a.g.n_levels * 8 * 4);   // gathered table bytes
   a.ray_tiles = coherent_rays ? 1 : 0;
   if (a.ray_tiles) n = (long)((R + 63) / 64) * 64 * S;
-  hipLaunchKernelGGL(proposal_density_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if (n + 256 >= (1L << 31) || (long)R * (S + 1) >= (1L << 31)) return neraf_fail(ctx, NERAF_EINVAL, "proposal_density: R * S must stay below 2^31");
+  a.divS = make_fastdiv((unsigned)S);
+  if (a.g.n_levels == 5) hipLaunchKernelGGL(proposal_density_kernel<5>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(proposal_density_kernel<8>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }
@@ -641,6 +674,8 @@ static int field_query_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void
   for (int i = 0; i < 6; ++i) a.aabb[i] = aabb_host ? aabb_host[i] : 0.f;
   a.avg_density = avg_density; a.avg_row = avg_row; a.rgb = rgb; a.density = density;
   const long n = (long)R * S;
+  if ((long)(R + 16) * (S + 1) >= (1L << 31)) return neraf_fail(ctx, NERAF_EINVAL, "field_query: R * S must stay below 2^31");
+  a.divS = make_fastdiv((unsigned)S);
   a.ray_tiles = coherent_rays ? 1 : 0;
   const long groups = a.ray_tiles ? (long)((R + 15) / 16) * S : (n + 15) / 16;
   long blocks = (groups + 3) / 4;

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
     if (q == 0 && valid) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float o = 1.f / (1.f + __expf(-d5[c]));
+        const float o = __builtin_amdgcn_rcpf(1.f + __expf(-d5[c]));   // as the forward
         dy5[c] = a.d_rgb[(size_t)n * 3 + c] * o * (1.f - o) * gscale;
       }
     }

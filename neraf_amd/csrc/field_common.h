@@ -38,6 +38,23 @@ int make_grid_layout(const neraf_grid_desc* g, GridLayout* L) {
   return NERAF_OK;
 }
 
+// n / d for any 32-bit n by a multiply-high, one subtraction, one addition and two shifts (Granlund & Montgomery 1994, fig. 4.1): the
+// sample -> (ray, index) maps of the gather kernels divide by the runtime samples-per-ray; on a wave-uniform n this is five SCALAR
+// instructions, on a per-lane n five vector ones (the compiler's 32-bit udiv is ~25, its 64-bit one far more).
+struct FastDiv { unsigned d, m, sh1, sh2; };
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f{d, 0u, 0u, 0u};
+  unsigned L = 0;
+  while ((1ull << L) < d) ++L;                                                   // ceil(log2 d)
+  f.m = (unsigned)(((1ull << 32) * ((1ull << L) - d)) / d + 1ull);
+  f.sh1 = L < 1u ? L : 1u; f.sh2 = L > 0u ? L - 1u : 0u;
+  return f;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
+  const unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 __device__ __forceinline__ float spacing_fn(float x) { return x < 1.f ? 0.5f * x : 1.f - 1.f / (2.f * x); }
 __device__ __forceinline__ float spacing_inv(float x) { return x < 0.5f ? 2.f * x : 1.f / (2.f - 2.f * x); }
 
@@ -76,86 +93,109 @@ __device__ __forceinline__ bool map_position(float& x, float& y, float& z, int m
 // cost two multiplies and four xors for the cell, and a corner one xor + and (v_bitop3); the dense index is base + {0,1} + {0,res} +
 // {0,res^2}.  Gathers are raw BUFFER loads (32-bit byte offset from a scalar resource for the table: no 64-bit address arithmetic
 // per corner -- the generic-pointer form spent two v_mad_u64_u32 / v_lshl_add_u64 per corner on it).
-struct LevelCell { float wx, wy, wz; unsigned idx[8]; };
+struct LevelCell { float wx, wy, wz; unsigned off[8]; };   // off = BYTE offset of the corner's entry inside its level (index * 4)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const unsigned* __restrict__ table) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(table), 0, 0xFFFFFFFFu, 0x00020000);
 }
 
 __device__ __forceinline__ void level_cell(float x, float y, float z, float scale, int res, unsigned size, int hashed, LevelCell& c) {
+  // p >= 0.5: the cell is the truncation of p and the in-cell weight its fractional part (v_fract_f32 == p - floor(p) exactly here)
   const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
-  const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
-  c.wx = px - flx; c.wy = py - fly; c.wz = pz - flz;
-  const unsigned ix = (unsigned)(int)flx, iy = (unsigned)(int)fly, iz = (unsigned)(int)flz;
+  c.wx = __builtin_amdgcn_fractf(px); c.wy = __builtin_amdgcn_fractf(py); c.wz = __builtin_amdgcn_fractf(pz);
+  const unsigned ix = (unsigned)px, iy = (unsigned)py, iz = (unsigned)pz;
   if (hashed) {                     // hashed levels have size = 2^log2_T
-    const unsigned m = size - 1u;
+    // ((x ^ t) & m) << 2 = ((x << 2) ^ (t << 2)) & (m << 2): the hash is taken in byte space, a corner is ONE v_bitop3
+    const unsigned m4 = (size - 1u) << 2;
     const unsigned hy0 = iy * 2654435761u, hy1 = hy0 + 2654435761u;
     const unsigned hz0 = iz * 805459861u, hz1 = hz0 + 805459861u;
-    const unsigned t00 = hy0 ^ hz0, t10 = hy1 ^ hz0, t01 = hy0 ^ hz1, t11 = hy1 ^ hz1;
-    const unsigned x0 = ix, x1 = ix + 1u;
-    c.idx[0] = (x0 ^ t00) & m; c.idx[1] = (x1 ^ t00) & m; c.idx[2] = (x0 ^ t10) & m; c.idx[3] = (x1 ^ t10) & m;
-    c.idx[4] = (x0 ^ t01) & m; c.idx[5] = (x1 ^ t01) & m; c.idx[6] = (x0 ^ t11) & m; c.idx[7] = (x1 ^ t11) & m;
+    const unsigned t00 = (hy0 ^ hz0) << 2, t10 = (hy1 ^ hz0) << 2, t01 = (hy0 ^ hz1) << 2, t11 = (hy1 ^ hz1) << 2;
+    const unsigned x0 = ix << 2, x1 = x0 + 4u;
+    c.off[0] = (x0 ^ t00) & m4; c.off[1] = (x1 ^ t00) & m4; c.off[2] = (x0 ^ t10) & m4; c.off[3] = (x1 ^ t10) & m4;
+    c.off[4] = (x0 ^ t01) & m4; c.off[5] = (x1 ^ t01) & m4; c.off[6] = (x0 ^ t11) & m4; c.off[7] = (x1 ^ t11) & m4;
   } else {
     // dense level: tcnn's `index % size`; corners of the last cell reach res, so idx < res^3+res^2+res < 2*size
-    const unsigned r = (unsigned)res, r2 = r * r;
-    const unsigned base = ix + iy * r + iz * r2;
+    const unsigned r4 = (unsigned)res << 2, r24 = r4 * (unsigned)res, size4 = size << 2;
+    const unsigned base = (ix << 2) + iy * r4 + iz * r24;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      unsigned i = base + (k & 1) + ((k & 2) ? r : 0u) + ((k & 4) ? r2 : 0u);
-      if (i >= size) i -= size;
-      c.idx[k] = i;
+      const unsigned i = base + ((k & 1) ? 4u : 0u) + ((k & 2) ? r4 : 0u) + ((k & 4) ? r24 : 0u);
+      c.off[k] = min(i, i - size4);          // i >= size4 ? i - size4 : i   (unsigned wrap makes i - size4 huge when i < size4)
     }
   }
 }
 
 // trilinear weight of corner k = (fx * fy) * fz with f = w or 1 - w per axis bit (the product order every consumer shares)
+// (pairs of products as 2-wide vectors: v_pk_mul_f32 does two fp32 multiplies per instruction)
 __device__ __forceinline__ void corner_weights(const LevelCell& c, float (&w)[8]) {
-  const float fx0 = 1.f - c.wx, fy0 = 1.f - c.wy, fz0 = 1.f - c.wz;
-  const float xy[4] = {fx0 * fy0, c.wx * fy0, fx0 * c.wy, c.wx * c.wy};
-#pragma unroll
-  for (int k = 0; k < 8; ++k) w[k] = xy[k & 3] * ((k & 4) ? c.wz : fz0);
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const float fy0 = 1.f - c.wy, fz0 = 1.f - c.wz;
+  const f32x2 fx = {1.f - c.wx, c.wx};
+  const f32x2 xy0 = fx * fy0, xy1 = fx * c.wy;
+  const f32x2 w01 = xy0 * fz0, w23 = xy1 * fz0, w45 = xy0 * c.wz, w67 = xy1 * c.wz;
+  w[0] = w01[0]; w[1] = w01[1]; w[2] = w23[0]; w[3] = w23[1]; w[4] = w45[0]; w[5] = w45[1]; w[6] = w67[0]; w[7] = w67[1];
 }
 
 // (Tried and reverted, round 4: ONE 8-byte gather for the two x-corners of a (y, z) pair whenever their indices differ by one --
 // always on dense levels, for even cell x on hashed ones: 40 -> 24 gather instructions per proposal sample.  The per-lane choice
 // between the 8-byte and the two 4-byte forms is a divergent branch around every load: proposal density 128 -> 144 us, field query
 // on frames 233 -> 405 us, training 63 -> 72 us.  Eight independent 4-byte loads in flight beat fewer, serialised ones.)
+// UNIFORM: `offset` (the level's first entry) is the same for every lane of the wave: it rides in the instruction's scalar offset;
+// otherwise (a wave whose lanes hold different levels: the fused field kernels) it is added per lane.
+template <bool UNIFORM>
 __device__ __forceinline__ void gather_corners(const unsigned* __restrict__ table, unsigned offset, const LevelCell& c, unsigned (&raw)[8]) {
   const __amdgpu_buffer_rsrc_t rs = table_rsrc(table);
   const unsigned off4 = offset << 2;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) raw[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (c.idx[k] << 2) + off4, 0, 0);
+  for (int k = 0; k < 8; ++k)
+    raw[k] = UNIFORM ? __builtin_amdgcn_raw_buffer_load_b32(rs, c.off[k], __builtin_amdgcn_readfirstlane(off4), 0)
+                     : __builtin_amdgcn_raw_buffer_load_b32(rs, c.off[k] + off4, 0, 0);
 }
 
-// one hash-grid level, trilinear; table entries are half2 (2 features)
-__device__ __forceinline__ void encode_level(const unsigned* __restrict__ table, float x, float y, float z, float scale, int res,
-                                             unsigned size, unsigned offset, int hashed, float& f0, float& f1) {
-  LevelCell c;
-  level_cell(x, y, z, scale, res, size, hashed, c);
-  unsigned raw[8];
-  gather_corners(table, offset, c, raw);
+// acc + w * (fp32 of the low / high fp16 of `raw`) in ONE instruction: v_fma_mix_f32 reads an fp16 operand in place (the conversion is
+// exact, the result is the fused multiply-add of the converted value: bit-identical to fmaf(w, (float)h, acc))
+__device__ __forceinline__ float fma_f16lo(float w, unsigned raw, float acc) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(raw), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ float fma_f16hi(float w, unsigned raw, float acc) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(raw), "v"(acc));
+  return r;
+}
+
+// trilinear interpolation of a gathered cell; table entries are half2 (2 features).  Kernels that walk several levels per lane call
+// level_cell + gather_corners for ALL of them first and interpolate afterwards: every gather of the lane is then in flight at once
+// (written as one encode_level per level, the compiler waits for each level's eight loads before it starts the next level's).
+__device__ __forceinline__ void interpolate_level(const LevelCell& c, const unsigned (&raw)[8], float& f0, float& f1) {
   float w[8];
   corner_weights(c, w);
   f0 = 0.f; f1 = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const half2v v = *reinterpret_cast<const half2v*>(&raw[k]);
-    f0 = fmaf(w[k], (float)v[0], f0);
-    f1 = fmaf(w[k], (float)v[1], f1);
+    f0 = fma_f16lo(w[k], raw[k], f0);
+    f1 = fma_f16hi(w[k], raw[k], f1);
   }
 }
 
-// encode_level that also returns d f0 / d(x,y,z) and d f1 / d(x,y,z) (in mapped [0,1] coordinates) from the SAME eight gathers: the
-// field backward recomputes the encoding anyway.  Measured on the 196,608-sample render batch (the kernel runs at one wave per SIMD):
-// baseline 210 us; a second gather pass inside the kernel +75 us; the position gradient as its own high-occupancy kernel on the
-// stored d enc +103 us (a second full table walk); this form +27 us.
-__device__ __forceinline__ void encode_level_grad(const unsigned* __restrict__ table, float x, float y, float z, float scale, int res,
-                                                  unsigned size, unsigned offset, int hashed, float& f0, float& f1,
-                                                  float (&d0)[3], float (&d1)[3]) {
+// one hash-grid level, trilinear
+template <bool UNIFORM = false>
+__device__ __forceinline__ void encode_level(const unsigned* __restrict__ table, float x, float y, float z, float scale, int res,
+                                             unsigned size, unsigned offset, int hashed, float& f0, float& f1) {
   LevelCell c;
   level_cell(x, y, z, scale, res, size, hashed, c);
   unsigned raw[8];
-  gather_corners(table, offset, c, raw);
+  gather_corners<UNIFORM>(table, offset, c, raw);
+  interpolate_level(c, raw, f0, f1);
+}
+
+// interpolation that also returns d f0 / d(x,y,z) and d f1 / d(x,y,z) (in mapped [0,1] coordinates) from the SAME eight gathers: the
+// field backward recomputes the encoding anyway.  Measured on the 196,608-sample render batch (the kernel runs at one wave per SIMD):
+// baseline 210 us; a second gather pass inside the kernel +75 us; the position gradient as its own high-occupancy kernel on the
+// stored d enc +103 us (a second full table walk); this form +27 us.
+__device__ __forceinline__ void interpolate_level_grad(const LevelCell& c, const unsigned (&raw)[8], float scale, float& f0, float& f1,
+                                                       float (&d0)[3], float (&d1)[3]) {
   const float wx = c.wx, wy = c.wy, wz = c.wz;
   f0 = 0.f; f1 = 0.f;
   float a0x = 0.f, a0y = 0.f, a0z = 0.f, a1x = 0.f, a1y = 0.f, a1z = 0.f;
@@ -174,6 +214,16 @@ __device__ __forceinline__ void encode_level_grad(const unsigned* __restrict__ t
   d1[0] = scale * a1x; d1[1] = scale * a1y; d1[2] = scale * a1z;
 }
 
+__device__ __forceinline__ void encode_level_grad(const unsigned* __restrict__ table, float x, float y, float z, float scale, int res,
+                                                  unsigned size, unsigned offset, int hashed, float& f0, float& f1,
+                                                  float (&d0)[3], float (&d1)[3]) {
+  LevelCell c;
+  level_cell(x, y, z, scale, res, size, hashed, c);
+  unsigned raw[8];
+  gather_corners<false>(table, offset, c, raw);
+  interpolate_level_grad(c, raw, scale, f0, f1, d0, d1);
+}
+
 // d/d(x,y,z) of  g0 * f0 + g1 * f1  for one level (f = the trilinear interpolation of encode_level), ACCUMULATED into (dx,dy,dz):
 // the hash-grid input gradient (tiny-cuda-nn computes it for its inputs; here it feeds the camera-pose optimizer).  The weights
 // are products of (w | 1-w) per axis, so the derivative along an axis replaces that axis' factor by (+1 | -1) * scale.
@@ -183,7 +233,7 @@ __device__ __forceinline__ void encode_level_dpos(const unsigned* __restrict__ t
   LevelCell c;
   level_cell(x, y, z, scale, res, size, hashed, c);
   unsigned raw[8];
-  gather_corners(table, offset, c, raw);
+  gather_corners<false>(table, offset, c, raw);
   const float wx = c.wx, wy = c.wy, wz = c.wz;
   float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
@@ -358,14 +408,23 @@ __device__ __forceinline__ void sh4_quarter(int q, float dx, float dy, float dz,
   }
 }
 
+// two accumulator blocks -> one fp16 B fragment, ReLU applied AFTER the conversion on the packed pairs (round-to-nearest is monotonic
+// and maps 0 to 0, so relu(round(x)) == round(relu(x)); v_pk_max_f16 with 0 returns 0 for a NaN like fmaxf): 4 conversions + 4
+// packed maxima for 8 values instead of 8 canonicalising maxima + 4 conversions
 __device__ __forceinline__ half8 pack_relu(const f32x4& a, const f32x4& b, bool relu) {
-  half8 h;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 u;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    h[r] = (half_t)(relu ? fmaxf(a[r], 0.f) : a[r]);
-    h[4 + r] = (half_t)(relu ? fmaxf(b[r], 0.f) : b[r]);
+  for (int r = 0; r < 2; ++r) {
+    const half2v lo = {(half_t)a[2 * r], (half_t)a[2 * r + 1]}, hi = {(half_t)b[2 * r], (half_t)b[2 * r + 1]};
+    unsigned ul = __builtin_bit_cast(unsigned, lo), uh = __builtin_bit_cast(unsigned, hi);
+    if (relu) {
+      asm("v_pk_max_f16 %0, %1, 0" : "=v"(ul) : "v"(ul));
+      asm("v_pk_max_f16 %0, %1, 0" : "=v"(uh) : "v"(uh));
+    }
+    u[r] = ul; u[2 + r] = uh;
   }
-  return h;
+  return __builtin_bit_cast(half8, u);
 }
 
 }  // namespace
