@@ -217,10 +217,15 @@ int neraf_sample_uniform(neraf_ctx* ctx, int R, int S, float near, float far, co
  * table_f16: fp16 [rows, 2]; mlp_f16: fp16 [16*16 + 16] = layer-0 [hidden][input] then layer-1 row.
  * density: fp32 [R, S].
  * coherent_rays != 0 (here and in neraf_field_query) declares that CONSECUTIVE RAYS ARE NEIGHBOURS IN SPACE -- the pixels of one
- * camera in row-major order, i.e. the chunks of Model.get_outputs_for_camera (NeRAF_model.py:70-79) -- and changes only the order
- * in which samples are assigned to lanes: a wavefront then holds the same sample index of 64 (proposal) / 16 (field) consecutive
- * rays, whose positions fall into the same few grid cells, so one gather instruction touches a handful of cache lines instead of
- * 64.  Results are bit-identical to coherent_rays == 0; on a 684 x 1024 frame the two kernels take 0.75x / 0.60x the time. */
+ * camera in row-major order, i.e. the chunks of Model.get_outputs_for_camera (NeRAF_model.py:70-79) -- and changes only how samples
+ * are assigned to lanes: a wavefront owns a TILE of 64 (proposal) / 16 (field) neighbouring rays and walks a run of 16 consecutive
+ * sample indices, so at every step its lanes fall into the same few grid cells (a gather touches a handful of cache lines instead
+ * of 64), the rays' data are loaded once per run and the outputs leave as whole cache lines.
+ *   coherent_rays == 1: a tile is 64 / 16 consecutive rays (a pixel ROW segment);
+ *   coherent_rays  > 1: coherent_rays is the IMAGE WIDTH: the R rays are whole rows of an image that wide (width % 8 == 0,
+ *                       R % width == 0), and a tile is an 8 x 8 / 4 x 4 block of PIXELS.
+ * Takes effect when S % 16 == 0 (nerfacto's 256 / 96 / 48 samples per ray), otherwise the call runs in the general order.
+ * Results are bit-identical to coherent_rays == 0. */
 int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                            const float* origins, const float* dirs, const float* e_bins, int R, int S,
                            float avg_density, int coherent_rays, float* density, neraf_stream_t stream);

@@ -51,39 +51,16 @@ struct PropArgs {
   const float* origins; const float* dirs; const float* e_bins;
   int R, S; float avg_density;
   float* density;
-  int ray_tiles;   // 1: a wave holds the SAME sample index of 64 consecutive rays (coherent rays of an eval frame: neighbouring pixels
-                   // at equal depth fall into the same few grid cells, so a gather instruction touches a handful of lines instead of 64)
   FastDiv divS;    // division by S
+  RayTiles tiles;  // frame kernel only: how a tile's 64 slots map to rays
+  FastDiv divRuns; // frame kernel only: division by S / 16
 };
 
-// VALU-bound (rocprofv3 SQ_INSTS_VALU x 4 cycles = 89 % of its duration on a frame, tools/gpu_r4_valu.sh): what counts is the number
-// of vector instructions per sample.  The sample's (ray, index) pair comes from WAVE-uniform scalar arithmetic plus the lane number
-// (no per-lane 64-bit division); the table offsets of a level ride in the gathers' scalar offset; the 2 NL -> 16 layer is
-// v_dot2c_f32_f16 on the fp16 feature pairs tcnn hands to its MLP (two exact fp16 x fp16 products per instruction, fp32 accumulation).
-template <int NL>    // levels compiled in (5: both nerfacto proposal networks; 8: any n_levels <= 8)
-__global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
-  __shared__ unsigned w0h[16][8];      // layer 0 as half2 pairs: [hidden unit][level] = columns (2 l, 2 l + 1)
-  __shared__ float w1[16];
-  if (threadIdx.x < 128) w0h[threadIdx.x >> 3][threadIdx.x & 7] = reinterpret_cast<const unsigned*>(a.w)[threadIdx.x];
-  if (threadIdx.x < 16) w1[threadIdx.x] = (float)a.w[256 + threadIdx.x];
-  __syncthreads();
-  const unsigned lane = threadIdx.x & 63u;
-  const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-  const unsigned S = (unsigned)a.S;
-  unsigned ray, s;
-  if (a.ray_tiles) {           // tile = 64 rays x S samples; a wave is one sample index of the tile's 64 rays
-    const unsigned tile = fastdiv(wave, a.divS);
-    ray = tile * 64u + lane; s = wave - tile * S;
-  } else {                     // 64 consecutive samples in ray-major order
-    const unsigned n = wave * 64u + lane;
-    ray = fastdiv(n, a.divS); s = n - ray * S;
-  }
-  if (ray >= (unsigned)a.R) return;
-  const unsigned eb = ray * (S + 1u) + s;
-  const float t = 0.5f * (a.e_bins[eb] + a.e_bins[eb + 1u]);
-  float x = fmaf(a.dirs[ray * 3u + 0u], t, a.origins[ray * 3u + 0u]);
-  float y = fmaf(a.dirs[ray * 3u + 1u], t, a.origins[ray * 3u + 1u]);
-  float z = fmaf(a.dirs[ray * 3u + 2u], t, a.origins[ray * 3u + 2u]);
+// density of one sample point from the proposal network: NL hash-grid levels -> 2 NL fp16 features -> 16 (ReLU) -> 1 -> avg * exp
+// (the sample's table offsets ride in the gathers' scalar offset; the 2 NL -> 16 layer is v_dot2c_f32_f16 on the fp16 feature pairs tcnn
+// hands to its MLP: two exact fp16 x fp16 products per instruction, fp32 accumulation)
+template <int NL>
+__device__ __forceinline__ float proposal_point(const PropArgs& a, const unsigned (&w0h)[16][8], const float (&w1)[16], float x, float y, float z) {
   const bool sel = map_position(x, y, z, 0, nullptr);
   half2v enc[NL];
   LevelCell cell[NL];
@@ -92,7 +69,7 @@ __global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
   for (int l = 0; l < NL; ++l)
     if (NL == 5 || l < a.g.n_levels) {
       level_cell(x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.hashed[l], cell[l]);
-      gather_corners<true>(a.table, a.g.offset[l], cell[l], raw[l]);
+      gather_corners<true, true>(a.table, a.g.offset[l], cell[l], raw[l], a.g.hashed[l], a.g.size[l]);
     }
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
@@ -112,7 +89,77 @@ __global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
     h = fmaxf(h, 0.f);
     out = fmaf(w1[j], h, out);
   }
-  a.density[ray * S + s] = sel ? a.avg_density * __expf(out) : 0.f;
+  return sel ? a.avg_density * __expf(out) : 0.f;
+}
+
+// General form (training batches, any S): 64 consecutive samples per wave in ray-major order.  The sample's (ray, index) pair comes
+// from a multiply-high division by S (no per-lane 64-bit division).
+template <int NL>    // levels compiled in (5: both nerfacto proposal networks; 8: any n_levels <= 8)
+__global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
+  __shared__ unsigned w0h[16][8];      // layer 0 as half2 pairs: [hidden unit][level] = columns (2 l, 2 l + 1)
+  __shared__ float w1[16];
+  if (threadIdx.x < 128) w0h[threadIdx.x >> 3][threadIdx.x & 7] = reinterpret_cast<const unsigned*>(a.w)[threadIdx.x];
+  if (threadIdx.x < 16) w1[threadIdx.x] = (float)a.w[256 + threadIdx.x];
+  __syncthreads();
+  const unsigned S = (unsigned)a.S;
+  const unsigned n = blockIdx.x * 256u + threadIdx.x;
+  const unsigned ray = fastdiv(n, a.divS), s = n - ray * S;
+  if (ray >= (unsigned)a.R) return;
+  const unsigned eb = ray * (S + 1u) + s;
+  const float t = 0.5f * (a.e_bins[eb] + a.e_bins[eb + 1u]);
+  const float x = fmaf(a.dirs[ray * 3u + 0u], t, a.origins[ray * 3u + 0u]);
+  const float y = fmaf(a.dirs[ray * 3u + 1u], t, a.origins[ray * 3u + 1u]);
+  const float z = fmaf(a.dirs[ray * 3u + 2u], t, a.origins[ray * 3u + 2u]);
+  a.density[n] = proposal_point<NL>(a, w0h, w1, x, y, z);
+}
+
+// Frame form (coherent rays: the chunks of a camera frame; S % 16 == 0).  A wave owns a TILE of 64 neighbouring rays (an 8 x 8 pixel
+// tile, or 64 consecutive rays) and a RUN of 16 consecutive sample indices, and walks the run: at every step its 64 lanes are the
+// same sample index of neighbouring rays, so a gather instruction touches a handful of cache lines.  What the walk adds over "one
+// wave per sample index" (the first coherent form, 179 -> 135 us): the rays' origins / directions are loaded once per run, the 17 bin
+// edges of a ray as one 68-byte segment (per-step loads of e_bins with lanes 4 (S + 1) bytes apart were 64 cache lines per instruction),
+// and the 16 densities of a ray leave as ONE 64-byte line through an LDS transpose (per-step stores were 64 partial lines per
+// instruction).  Measured by dropping them: stores 13 %, edge loads up to 18 % of the kernel (tools/gpu_r4_propexp.sh).
+template <int NL>
+__global__ __launch_bounds__(256) void proposal_density_frame_kernel(PropArgs a) {
+  __shared__ unsigned w0h[16][8];
+  __shared__ float w1[16];
+  __shared__ float t_s[4][16][64];     // [wave][step][lane]: sample mid-points of the run, each replaced by the step's density once consumed
+  if (threadIdx.x < 128) w0h[threadIdx.x >> 3][threadIdx.x & 7] = reinterpret_cast<const unsigned*>(a.w)[threadIdx.x];
+  if (threadIdx.x < 16) w1[threadIdx.x] = (float)a.w[256 + threadIdx.x];
+  __syncthreads();
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const unsigned task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
+  const unsigned S = (unsigned)a.S, runs = a.divRuns.d;
+  const unsigned tile = fastdiv(task, a.divRuns), s0 = (task - tile * runs) * 16u;
+  if (tile >= a.tiles.n_tiles) return;
+  unsigned ray;
+  if (!tile_ray<8>(a.tiles, tile, lane, (unsigned)a.R, ray)) ray = (unsigned)a.R - 1u;      // computes like its neighbours, stores nothing
+  const float ox = a.origins[ray * 3u + 0u], oy = a.origins[ray * 3u + 1u], oz = a.origins[ray * 3u + 2u];
+  const float dx = a.dirs[ray * 3u + 0u], dy = a.dirs[ray * 3u + 1u], dz = a.dirs[ray * 3u + 2u];
+  const float* eb = a.e_bins + (size_t)ray * (S + 1u) + s0;
+  float e0 = eb[0];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float e1 = eb[i + 1];
+    t_s[wv][i][lane] = 0.5f * (e0 + e1);
+    e0 = e1;
+  }
+#pragma unroll 1
+  for (int j = 0; j < 16; ++j) {
+    asm volatile("" ::: "memory");       // the layer weights are re-read from LDS every step (hoisted out of the loop they cost 100 VGPRs)
+    const float t = t_s[wv][j][lane];
+    t_s[wv][j][lane] = proposal_point<NL>(a, w0h, w1, fmaf(dx, t, ox), fmaf(dy, t, oy), fmaf(dz, t, oz));
+  }
+  // a ray's 16 densities = one aligned 64-byte line of density[ray][s0 ...]: four lanes write it as four float4
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned slot = (lane >> 2) + 16u * i, part = lane & 3u;
+    unsigned r;
+    const bool ok = tile_ray<8>(a.tiles, tile, slot, (unsigned)a.R, r);
+    const float4 v = make_float4(t_s[wv][4u * part][slot], t_s[wv][4u * part + 1u][slot], t_s[wv][4u * part + 2u][slot], t_s[wv][4u * part + 3u][slot]);
+    if (ok) *reinterpret_cast<float4*>(a.density + (size_t)r * S + s0 + 4u * part) = v;
+  }
 }
 
 // ---- stand-alone multiresolution hash encoding (tiny-cuda-nn HashGrid forward; SURVEY 8b op list) ------------------------------
@@ -238,17 +285,82 @@ struct FieldArgs {
                                  // it back instead of walking the hash table again at one wave per SIMD
   half_t* denc_out;              // optional fp16 [N][4][24]: d enc / d mapped position of each lane's 4 levels x 2 features x 3 axes
                                  // (the camera-pose edge of the backward)
-  int ray_tiles;                 // 1: a group's 16 points are the SAME sample index of 16 consecutive rays (coherent rays, eval frames)
   FastDiv divS;                  // division by S
+  RayTiles tiles; FastDiv divRuns;   // frame kernel only (see proposal_density_frame_kernel)
 };
 
 constexpr int NFRAG = 24;   // base0: 0-3, base1: 4-5, head0: 6-13 (ob*2+s), head1: 14-21, head2: 22-23
 
-#ifndef NERAF_FQ_OCC
-#define NERAF_FQ_OCC 3     // workgroups per CU the inference / encoding-saving forms are compiled for (A/B knob of tools/gpu_r4_occ.sh)
-#endif
+// the lane's 4 levels of the point -> B fragment of the first layer (k = 8q + 2*li + f); all 32 gathers of the lane in flight before
+// the first is consumed.  SAVE == 2 also returns d enc / d mapped position (24 halfs: [li][feature][axis]).
+template <int SAVE>
+__device__ __forceinline__ half8 field_encode(const unsigned* __restrict__ table, float x, float y, float z, bool sel, int q, const float* l_scale,
+                                              const int* l_res, const unsigned* l_size, const unsigned* l_off, const int* l_hash, half8 (&dh)[3]) {
+  half8 xin;
+  LevelCell cell[4];
+  unsigned raw[4][8];
+#pragma unroll
+  for (int li = 0; li < 4; ++li) {
+    const int l = 4 * q + li;
+    level_cell(x, y, z, l_scale[l], l_res[l], l_size[l], l_hash[l], cell[li]);
+    gather_corners<false>(table, l_off[l], cell[li], raw[li]);
+  }
+  if (SAVE == 2) {
+    half_t* dp = reinterpret_cast<half_t*>(dh);
+#pragma unroll
+    for (int li = 0; li < 4; ++li) {
+      float f0, f1, d0[3], d1_[3];
+      interpolate_level_grad(cell[li], raw[li], l_scale[4 * q + li], f0, f1, d0, d1_);
+      xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { dp[li * 6 + k] = (half_t)(sel ? d0[k] : 0.f); dp[li * 6 + 3 + k] = (half_t)(sel ? d1_[k] : 0.f); }
+    }
+  } else {
+#pragma unroll
+    for (int li = 0; li < 4; ++li) {
+      float f0, f1;
+      interpolate_level(cell[li], raw[li], f0, f1);
+      xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
+    }
+  }
+  return xin;
+}
+
+// base MLP 32 -> 64 (ReLU) -> 16, colour head [base out | SH | appearance embedding] -> 64 -> 64 -> 3 for the wave's 16 points.
+// d2[0] of the q == 0 lanes is the density logit, d5[0..2] of the q == 0 lanes the colour logits.
+#define wf(f) wfp[(f) * 64]
+__device__ __forceinline__ void field_mlp(const half8* wfp, const half8 xin, int q, const float (&sh)[4], const half8 h1, f32x4& d2, f32x4& d5) {
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 d1[4];
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob) d1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(ob), xin, zero, 0, 0, 0);
+  d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(4), pack_relu(d1[0], d1[1], true), zero, 0, 0, 0);
+  d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(5), pack_relu(d1[2], d1[3], true), d2, 0, 0, 0);
+  // colour head input: k-step 0 = [base out 4q..4q+3 | SH 4q..4q+3], k-step 1 = appearance embedding 8q..8q+7
+  half8 h0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { h0[r] = (half_t)d2[r]; h0[4 + r] = (half_t)sh[r]; }
+  if (q == 0) h0[0] = (half_t)0.f;              // the density logit is not an input of the head (weight column is 0 too)
+  f32x4 d3[4], d4[4];
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob) {
+    d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(6 + ob * 2), h0, zero, 0, 0, 0);
+    d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(7 + ob * 2), h1, d3[ob], 0, 0, 0);
+  }
+  const half8 a0 = pack_relu(d3[0], d3[1], true), a1 = pack_relu(d3[2], d3[3], true);
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob) {
+    d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(14 + ob * 2), a0, zero, 0, 0, 0);
+    d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(15 + ob * 2), a1, d4[ob], 0, 0, 0);
+  }
+  d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(22), pack_relu(d4[0], d4[1], true), zero, 0, 0, 0);
+  d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(23), pack_relu(d4[2], d4[3], true), d5, 0, 0, 0);
+}
+#undef wf
+
+// General form (training batches, the grid refresh, any S): a wave takes 16 consecutive samples in ray-major order per step.
 template <int SAVE>   // 0: outputs only; 1: also the encoding; 2: the encoding and its position derivatives
-__global__ __launch_bounds__(256, SAVE == 2 ? 2 : NERAF_FQ_OCC) void field_query_kernel(FieldArgs a) {
+__global__ __launch_bounds__(256, SAVE == 2 ? 2 : 3) void field_query_kernel(FieldArgs a) {
   __shared__ float l_scale[MAX_LEVELS];
   __shared__ int l_res[MAX_LEVELS];
   __shared__ unsigned l_size[MAX_LEVELS], l_off[MAX_LEVELS];
@@ -257,37 +369,22 @@ __global__ __launch_bounds__(256, SAVE == 2 ? 2 : NERAF_FQ_OCC) void field_query
     const int l = threadIdx.x;
     l_scale[l] = a.g.scale[l]; l_res[l] = a.g.res[l]; l_size[l] = a.g.size[l]; l_off[l] = a.g.offset[l]; l_hash[l] = a.g.hashed[l];
   }
-  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int p = lane & 15, q = lane >> 4;
-  // the 24 weight fragments live in LDS (24 KiB per workgroup), not in 96 VGPRs: the kernel is bound by the latency of its 32
-  // table gathers per lane, and what hides that is waves per SIMD (202 VGPRs allowed two; now four)
+  // the 24 weight fragments live in LDS (24 KiB per workgroup), not in 96 VGPRs: what hides the latency of the lane's 32 table
+  // gathers is waves per SIMD
   __shared__ half8 wf_s[NFRAG * 64];
   for (int i = threadIdx.x; i < NFRAG * 64; i += 256) wf_s[i] = a.wfrag[i];
   __syncthreads();
   const half8* wfp = wf_s + lane;
-#define wf(f) wfp[(f) * 64]
-
-  // 32-bit sample arithmetic (the entry point refuses R * S >= 2^31); the group index is wave-uniform: its division by S is scalar
+  // 32-bit sample arithmetic (the entry point refuses R * S >= 2^31)
   const unsigned N = (unsigned)a.R * (unsigned)a.S, S = (unsigned)a.S;
-  const unsigned ngroups = a.ray_tiles ? ((unsigned)(a.R + 15) / 16u) * S : (N + 15u) / 16u;
-  const unsigned gstride = gridDim.x * 4u;
+  const unsigned ngroups = (N + 15u) / 16u, gstride = gridDim.x * 4u;
   for (unsigned grp = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)); grp < ngroups; grp += gstride) {
-    unsigned n, ray, s;
-    bool valid;
-    if (a.ray_tiles) {                           // group = (tile of 16 rays, sample index): consecutive groups walk the tile's samples
-      const unsigned tile = fastdiv(grp, a.divS);
-      s = grp - tile * S;
-      ray = tile * 16u + (unsigned)p;
-      valid = ray < (unsigned)a.R;
-      if (!valid) ray = (unsigned)a.R - 1u;
-      n = ray * S + s;
-    } else {
-      n = grp * 16u + (unsigned)p;
-      valid = n < N;
-      if (!valid) n = N - 1u;                    // MFMA needs every lane: clamp, compute, do not store
-      ray = fastdiv(n, a.divS); s = n - ray * S;
-    }
+    unsigned n = grp * 16u + (unsigned)p;
+    const bool valid = n < N;
+    if (!valid) n = N - 1u;                      // MFMA needs every lane: clamp, compute, do not store
+    const unsigned ray = fastdiv(n, a.divS), s = n - ray * S;
     const unsigned eb = ray * (S + 1u) + s;
     const float t = 0.5f * (a.e_bins[eb] + a.e_bins[eb + 1u]);
     const float dx = a.dirs[ray * 3u + 0u], dy = a.dirs[ray * 3u + 1u], dz = a.dirs[ray * 3u + 2u];
@@ -295,79 +392,98 @@ __global__ __launch_bounds__(256, SAVE == 2 ? 2 : NERAF_FQ_OCC) void field_query
     float y = fmaf(dy, t, a.origins[ray * 3u + 1u]);
     float z = fmaf(dz, t, a.origins[ray * 3u + 2u]);
     const bool sel = map_position(x, y, z, a.mode, a.aabb);
-    // --- hash encode: this lane's 4 levels -> B fragment of the first layer (k = 8q + 2*li + f)
-    half8 xin;
-    LevelCell cell[4];
-    unsigned raw[4][8];
-#pragma unroll
-    for (int li = 0; li < 4; ++li) {               // all 32 gathers of the lane in flight before the first is consumed
-      const int l = 4 * q + li;
-      level_cell(x, y, z, l_scale[l], l_res[l], l_size[l], l_hash[l], cell[li]);
-      gather_corners<false>(a.table, l_off[l], cell[li], raw[li]);
-    }
-    if (SAVE == 2) {
-      half8 dh[3];                                 // [li][feature][axis] = 24 halfs
-      half_t* dp = reinterpret_cast<half_t*>(dh);
-#pragma unroll
-      for (int li = 0; li < 4; ++li) {
-        float f0, f1, d0[3], d1_[3];
-        interpolate_level_grad(cell[li], raw[li], l_scale[4 * q + li], f0, f1, d0, d1_);
-        xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { dp[li * 6 + k] = (half_t)(sel ? d0[k] : 0.f); dp[li * 6 + 3 + k] = (half_t)(sel ? d1_[k] : 0.f); }
-      }
-      if (valid) {
-        half8* dst = reinterpret_cast<half8*>(a.denc_out + ((size_t)n * 4 + q) * 24);
-        dst[0] = dh[0]; dst[1] = dh[1]; dst[2] = dh[2];
-      }
-    } else {
-#pragma unroll
-      for (int li = 0; li < 4; ++li) {
-        float f0, f1;
-        interpolate_level(cell[li], raw[li], f0, f1);
-        xin[2 * li] = (half_t)f0; xin[2 * li + 1] = (half_t)f1;
-      }
+    half8 dh[3];
+    const half8 xin = field_encode<SAVE>(a.table, x, y, z, sel, q, l_scale, l_res, l_size, l_off, l_hash, dh);
+    if (SAVE == 2 && valid) {
+      half8* dst = reinterpret_cast<half8*>(a.denc_out + ((size_t)n * 4 + q) * 24);
+      dst[0] = dh[0]; dst[1] = dh[1]; dst[2] = dh[2];
     }
     if (SAVE >= 1 && valid) *reinterpret_cast<half8*>(a.enc_out + ((size_t)n * 4 + q) * 8) = xin;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    // --- base MLP 32 -> 64 (ReLU) -> 16
-    f32x4 d1[4];
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) d1[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(ob), xin, zero, 0, 0, 0);
-    f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(4), pack_relu(d1[0], d1[1], true), zero, 0, 0, 0);
-    d2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(5), pack_relu(d1[2], d1[3], true), d2, 0, 0, 0);
-    // density = avg * trunc_exp(logit) * selector ; logit = base output 0 -> lane q == 0, register 0
-    if (q == 0 && valid) a.density[n] = sel ? a.avg_density * __expf(d2[0]) : 0.f;
-    // --- colour head input: k-step 0 = [base out 4q..4q+3 | SH 4q..4q+3], k-step 1 = appearance embedding 8q..8q+7
     float sh[4];
     sh4_quarter(q, dx, dy, dz, sh);
-    half8 h0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { h0[r] = (half_t)d2[r]; h0[4 + r] = (half_t)sh[r]; }
-    if (q == 0) h0[0] = (half_t)0.f;              // the density logit is not an input of the head (weight column is 0 too)
     const int erow = a.avg_row >= 0 ? a.avg_row : a.cam_idx[ray];
     const half8 h1 = *reinterpret_cast<const half8*>(a.emb + (size_t)erow * 32 + 8 * q);
-    f32x4 d3[4], d4[4];
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) {
-      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(6 + ob * 2), h0, zero, 0, 0, 0);
-      d3[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(7 + ob * 2), h1, d3[ob], 0, 0, 0);
-    }
-    const half8 a0 = pack_relu(d3[0], d3[1], true), a1 = pack_relu(d3[2], d3[3], true);
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) {
-      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(14 + ob * 2), a0, zero, 0, 0, 0);
-      d4[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(15 + ob * 2), a1, d4[ob], 0, 0, 0);
-    }
-    f32x4 d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(22), pack_relu(d4[0], d4[1], true), zero, 0, 0, 0);
-    d5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf(23), pack_relu(d4[2], d4[3], true), d5, 0, 0, 0);
+    f32x4 d2, d5;
+    field_mlp(wfp, xin, q, sh, h1, d2, d5);
     if (q == 0 && valid) {
+      // density = avg * trunc_exp(logit) * selector ; logit = base output 0 -> lane q == 0, register 0
+      a.density[n] = sel ? a.avg_density * __expf(d2[0]) : 0.f;
 #pragma unroll
       for (int c = 0; c < 3; ++c) a.rgb[(size_t)n * 3 + c] = __builtin_amdgcn_rcpf(1.f + __expf(-d5[c]));   // v_rcp_f32: 1 ulp
     }
   }
 }
-#undef wf
+
+// Frame form (coherent rays, S % 16 == 0; see proposal_density_frame_kernel): a wave owns a tile of 16 neighbouring rays (a 4 x 4 pixel
+// tile, or 16 consecutive rays) and a run of 16 sample indices.  Per run and ray: origin, direction, SH of the direction and the
+// appearance-embedding fragment once; the run's bin edges as one segment; its 16 densities as one 64-byte line and its 48 colour values
+// as three, through LDS (per-step stores with lanes 4 S bytes apart were 16 partial lines per instruction, four instructions a step).
+__global__ __launch_bounds__(256, 3) void field_query_frame_kernel(FieldArgs a) {
+  __shared__ float l_scale[MAX_LEVELS];
+  __shared__ int l_res[MAX_LEVELS];
+  __shared__ unsigned l_size[MAX_LEVELS], l_off[MAX_LEVELS];
+  __shared__ int l_hash[MAX_LEVELS];
+  __shared__ half8 wf_s[NFRAG * 64];
+  __shared__ float t_s[4][16][16];       // [wave][step][ray slot]
+  __shared__ float den_s[4][16][17];     // [wave][ray slot][step] (+1: conflict-free column writes)
+  __shared__ float rgb_s[4][16][49];     // [wave][ray slot][3 step + c]
+  if (threadIdx.x < MAX_LEVELS) {
+    const int l = threadIdx.x;
+    l_scale[l] = a.g.scale[l]; l_res[l] = a.g.res[l]; l_size[l] = a.g.size[l]; l_off[l] = a.g.offset[l]; l_hash[l] = a.g.hashed[l];
+  }
+  for (int i = threadIdx.x; i < NFRAG * 64; i += 256) wf_s[i] = a.wfrag[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int p = lane & 15, q = lane >> 4;
+  const half8* wfp = wf_s + lane;
+  const unsigned S = (unsigned)a.S, runs = a.divRuns.d, ntasks = a.tiles.n_tiles * runs, gstride = gridDim.x * 4u;
+  for (unsigned task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv); task < ntasks; task += gstride) {
+    const unsigned tile = fastdiv(task, a.divRuns), s0 = (task - tile * runs) * 16u;
+    unsigned ray;
+    const bool valid = tile_ray<4>(a.tiles, tile, (unsigned)p, (unsigned)a.R, ray);
+    if (!valid) ray = (unsigned)a.R - 1u;
+    const float ox = a.origins[ray * 3u + 0u], oy = a.origins[ray * 3u + 1u], oz = a.origins[ray * 3u + 2u];
+    const float dx = a.dirs[ray * 3u + 0u], dy = a.dirs[ray * 3u + 1u], dz = a.dirs[ray * 3u + 2u];
+    float sh[4];
+    sh4_quarter(q, dx, dy, dz, sh);
+    const int erow = a.avg_row >= 0 ? a.avg_row : a.cam_idx[ray];
+    const half8 h1 = *reinterpret_cast<const half8*>(a.emb + (size_t)erow * 32 + 8 * q);
+    {                                            // lane (p, q): edges 4q .. 4q+4 of ray p's run -> mid-points 4q .. 4q+3
+      const float* eb = a.e_bins + (size_t)ray * (S + 1u) + s0 + 4u * (unsigned)q;
+      float e0 = eb[0];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float e1 = eb[k + 1];
+        t_s[wv][4 * q + k][p] = 0.5f * (e0 + e1);
+        e0 = e1;
+      }
+    }
+#pragma unroll 1
+    for (int j = 0; j < 16; ++j) {
+      const float t = t_s[wv][j][p];
+      float x = fmaf(dx, t, ox), y = fmaf(dy, t, oy), z = fmaf(dz, t, oz);
+      const bool sel = map_position(x, y, z, a.mode, a.aabb);
+      half8 dh[3];
+      const half8 xin = field_encode<0>(a.table, x, y, z, sel, q, l_scale, l_res, l_size, l_off, l_hash, dh);
+      f32x4 d2, d5;
+      field_mlp(wfp, xin, q, sh, h1, d2, d5);
+      if (q == 0) {
+        den_s[wv][p][j] = sel ? a.avg_density * __expf(d2[0]) : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb_s[wv][p][3 * j + c] = __builtin_amdgcn_rcpf(1.f + __expf(-d5[c]));
+      }
+    }
+    if (valid) {                                 // lane (p, q): quarter q of ray p's density line and of its three colour lines
+      const size_t n0 = (size_t)ray * S + s0;
+      const float* ds = &den_s[wv][p][4 * q];
+      *reinterpret_cast<float4*>(a.density + n0 + 4 * q) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+      const float* rs = &rgb_s[wv][p][12 * q];
+      float4* dst = reinterpret_cast<float4*>(a.rgb + n0 * 3 + 12 * q);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dst[k] = make_float4(rs[4 * k], rs[4 * k + 1], rs[4 * k + 2], rs[4 * k + 3]);
+    }
+  }
+}
 
 // ---- weights + composite, one wavefront per ray (S <= 64) ---------------------------------------------------
 struct CompArgs {
@@ -613,13 +729,19 @@ extern "C" int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, 
     return neraf_fail(ctx, NERAF_EINVAL, "proposal_density: bad arguments");
   a.table = (const unsigned*)table_f16; a.w = (const half_t*)mlp_f16; a.origins = origins; a.dirs = dirs; a.e_bins = e_bins;
   a.R = R; a.S = S; a.avg_density = avg_density; a.density = density;
-  long n = (long)R * S;
+  const long n = (long)R * S;
   ProfScope prof(ctx, (hipStream_t)stream, PROF_PROP_DENSITY, (double)n * a.g.n_levels * 8 * 4);   // gathered table bytes
-  a.ray_tiles = coherent_rays ? 1 : 0;
-  if (a.ray_tiles) n = (long)((R + 63) / 64) * 64 * S;
-  if (n + 256 >= (1L << 31) || (long)R * (S + 1) >= (1L << 31)) return neraf_fail(ctx, NERAF_EINVAL, "proposal_density: R * S must stay below 2^31");
+  if (coherent_rays > 1 && (coherent_rays % 8 || R % coherent_rays))
+    return neraf_fail(ctx, NERAF_EINVAL, "proposal_density: coherent_rays = image width needs width % 8 == 0 and whole rows");
+  if (n + 256 >= (1L << 31) || (long)(R + 64) * (S + 1) >= (1L << 31)) return neraf_fail(ctx, NERAF_EINVAL, "proposal_density: R * S must stay below 2^31");
   a.divS = make_fastdiv((unsigned)S);
-  if (a.g.n_levels == 5) hipLaunchKernelGGL(proposal_density_kernel<5>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if (coherent_rays && S % 16 == 0) {          // frame form: (tile of 64 rays, run of 16 sample indices) per wave
+    a.tiles = make_ray_tiles<8>(R, coherent_rays);
+    a.divRuns = make_fastdiv((unsigned)(S / 16));
+    const long tasks = (long)a.tiles.n_tiles * (S / 16);
+    if (a.g.n_levels == 5) hipLaunchKernelGGL(proposal_density_frame_kernel<5>, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(proposal_density_frame_kernel<8>, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (a.g.n_levels == 5) hipLaunchKernelGGL(proposal_density_kernel<5>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(proposal_density_kernel<8>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
@@ -676,14 +798,18 @@ static int field_query_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void
   const long n = (long)R * S;
   if ((long)(R + 16) * (S + 1) >= (1L << 31)) return neraf_fail(ctx, NERAF_EINVAL, "field_query: R * S must stay below 2^31");
   a.divS = make_fastdiv((unsigned)S);
-  a.ray_tiles = coherent_rays ? 1 : 0;
-  const long groups = a.ray_tiles ? (long)((R + 15) / 16) * S : (n + 15) / 16;
+  if (coherent_rays > 1 && (coherent_rays % 8 || R % coherent_rays))
+    return neraf_fail(ctx, NERAF_EINVAL, "field_query: coherent_rays = image width needs width % 8 == 0 and whole rows");
+  const bool frame = coherent_rays && S % 16 == 0 && !enc_out && !denc_out;
+  if (frame) { a.tiles = make_ray_tiles<4>(R, coherent_rays); a.divRuns = make_fastdiv((unsigned)(S / 16)); }
+  const long groups = frame ? (long)a.tiles.n_tiles * (S / 16) : (n + 15) / 16;      // wave tasks
   long blocks = (groups + 3) / 4;
   const long cap = (long)(ctx ? ctx->num_cus : 256) * 8;
   if (blocks > cap) blocks = cap;
   ProfScope prof(ctx, (hipStream_t)stream, PROF_FIELD_QUERY, (double)n * 16 * 8 * 4);   // gathered table bytes
   a.enc_out = (half_t*)enc_out; a.denc_out = (half_t*)denc_out;
-  if (denc_out) hipLaunchKernelGGL(field_query_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (frame) hipLaunchKernelGGL(field_query_frame_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else if (denc_out) hipLaunchKernelGGL(field_query_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   else if (enc_out) hipLaunchKernelGGL(field_query_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(field_query_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   NERAF_HIP_CHECK(ctx, hipGetLastError());

@@ -55,6 +55,30 @@ __device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) {
   return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
+// How the SIDE x SIDE slots of ray tile `tile` map to rays (the frame kernels of field.hip): with an image width, the tile is a
+// SIDE x SIDE block of pixels of a row-major image (`rows` whole rows, `width` % 8 == 0); without, SIDE^2 consecutive rays.
+struct RayTiles { int width, rows; FastDiv divTX; unsigned n_tiles; };
+template <int SIDE>
+inline RayTiles make_ray_tiles(int R, int width) {
+  RayTiles t{};
+  if (width > 1) {
+    t.width = width; t.rows = R / width; t.divTX = make_fastdiv((unsigned)(width / SIDE));
+    t.n_tiles = (unsigned)(width / SIDE) * (unsigned)((t.rows + SIDE - 1) / SIDE);
+  } else t.n_tiles = (unsigned)((R + SIDE * SIDE - 1) / (SIDE * SIDE));
+  return t;
+}
+template <int SIDE>
+__device__ __forceinline__ bool tile_ray(const RayTiles& t, unsigned tile, unsigned slot, unsigned R, unsigned& ray) {
+  if (t.width) {
+    const unsigned ty = fastdiv(tile, t.divTX), tx = tile - ty * t.divTX.d;
+    const unsigned row = ty * SIDE + slot / SIDE;
+    ray = row * (unsigned)t.width + tx * SIDE + slot % SIDE;
+    return row < (unsigned)t.rows;
+  }
+  ray = tile * (SIDE * SIDE) + slot;
+  return ray < R;
+}
+
 __device__ __forceinline__ float spacing_fn(float x) { return x < 1.f ? 0.5f * x : 1.f - 1.f / (2.f * x); }
 __device__ __forceinline__ float spacing_inv(float x) { return x < 0.5f ? 2.f * x : 1.f / (2.f - 2.f * x); }
 
@@ -136,16 +160,31 @@ __device__ __forceinline__ void corner_weights(const LevelCell& c, float (&w)[8]
   w[0] = w01[0]; w[1] = w01[1]; w[2] = w23[0]; w[3] = w23[1]; w[4] = w45[0]; w[5] = w45[1]; w[6] = w67[0]; w[7] = w67[1];
 }
 
-// (Tried and reverted, round 4: ONE 8-byte gather for the two x-corners of a (y, z) pair whenever their indices differ by one --
-// always on dense levels, for even cell x on hashed ones: 40 -> 24 gather instructions per proposal sample.  The per-lane choice
-// between the 8-byte and the two 4-byte forms is a divergent branch around every load: proposal density 128 -> 144 us, field query
-// on frames 233 -> 405 us, training 63 -> 72 us.  Eight independent 4-byte loads in flight beat fewer, serialised ones.)
+// What a gather costs (tools/microbench/gather_rate.hip, profiles/r04_gather_rate_microbench.txt): with lanes spread over many cache
+// lines, the distinct lines (width and re-reads of the same lines are free); with coherent lanes -- the frame render -- about 20
+// cycles per INSTRUCTION whatever it loads.  So on a DENSE level, where the x-neighbour of a corner is the next entry, the two are
+// fetched by ONE 8-byte load (PAIRS): 4 instructions per level instead of 8.  Only for kernels whose `hashed` flag is wave-uniform
+// (a per-lane choice between the two forms is a divergent branch around every load: tried in round 4 on hashed levels with even
+// cell x, proposal density 128 -> 144 us, field query on frames 233 -> 405 us).  The one exception to "next entry" is an x0 corner
+// that is the level's LAST entry (its neighbour wraps to entry 0: tcnn's `index % size`): a rare lane-level fix-up load.
 // UNIFORM: `offset` (the level's first entry) is the same for every lane of the wave: it rides in the instruction's scalar offset;
 // otherwise (a wave whose lanes hold different levels: the fused field kernels) it is added per lane.
-template <bool UNIFORM>
-__device__ __forceinline__ void gather_corners(const unsigned* __restrict__ table, unsigned offset, const LevelCell& c, unsigned (&raw)[8]) {
+template <bool UNIFORM, bool PAIRS = false>
+__device__ __forceinline__ void gather_corners(const unsigned* __restrict__ table, unsigned offset, const LevelCell& c, unsigned (&raw)[8],
+                                               int hashed = 1, unsigned size = 0) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   const __amdgpu_buffer_rsrc_t rs = table_rsrc(table);
   const unsigned off4 = offset << 2;
+  if (PAIRS && UNIFORM && !hashed) {
+    const unsigned soff = __builtin_amdgcn_readfirstlane(off4), last = (size << 2) - 4u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, c.off[2 * j], soff, 0);
+      raw[2 * j] = v[0]; raw[2 * j + 1] = v[1];
+      if (c.off[2 * j] == last) raw[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b32(rs, 0, soff, 0);
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k)
     raw[k] = UNIFORM ? __builtin_amdgcn_raw_buffer_load_b32(rs, c.off[k], __builtin_amdgcn_readfirstlane(off4), 0)

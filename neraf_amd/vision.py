@@ -23,6 +23,8 @@ from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -232,7 +234,7 @@ class HashMLPDensityField(nn.Module):
             self._pack_cache = c
         return c[1]
 
-    def density(self, origins, directions, e_bins, packed=None, coherent_rays: bool = False):
+    def density(self, origins, directions, e_bins, packed=None, coherent_rays: int = 0):
         lib = _lib.load()
         dev = _dev_index(origins)
         R, S = e_bins.shape[0], e_bins.shape[1] - 1
@@ -683,7 +685,7 @@ class NeRAFVisionModel(nn.Module):
         b = self.proposal_weights_anneal_slope
         return (b * x) / ((b - 1) * x + 1)
 
-    def get_outputs(self, ray_bundle: RayBundle, jitters: Optional[List[torch.Tensor]] = None, coherent_rays: bool = False,
+    def get_outputs(self, ray_bundle: RayBundle, jitters: Optional[List[torch.Tensor]] = None, coherent_rays: int = 0,
                     _out: Optional[Dict[str, torch.Tensor]] = None):
         """NerfactoModel.get_outputs + rgb clip (NeRAF_model.py:65-68).  ``jitters`` (3 tensors [R]) override the
         training-time single jitter of the three sampling stages (tests pass the oracle's values).  ``coherent_rays``: the bundle is
@@ -725,7 +727,7 @@ class NeRAFVisionModel(nn.Module):
         prop_packed = [pn.packed() for pn in self.proposal_networks]
         prop_dens = []
         for i, S_next in enumerate((S1, S2)):
-            dens = self.proposal_networks[i].density(o, d, e_prev, packed=prop_packed[i], coherent_rays=coherent_rays and not self.training)
+            dens = self.proposal_networks[i].density(o, d, e_prev, packed=prop_packed[i], coherent_rays=0 if self.training else int(coherent_rays))
             prop_dens.append(dens)
             S_cur = e_prev.shape[1] - 1
             w = torch.empty((R, S_cur), **f32)
@@ -744,7 +746,7 @@ class NeRAFVisionModel(nn.Module):
                                              save=2 if (ray_o.requires_grad or ray_d.requires_grad) else 1)
         else:
             rgb_s, dens = field.query(o, d, e_prev, cam32, use_average_embedding=not self.training,
-                                      packed=field_packed, coherent_rays=coherent_rays and not self.training)
+                                      packed=field_packed, coherent_rays=0 if self.training else int(coherent_rays))
         w = torch.empty((R, S2), **f32)
         if _out is not None:
             rgb, depth, expd, acc = _out["rgb"], _out["depth"], _out["expected_depth"], _out["accumulation"]
@@ -819,12 +821,15 @@ class NeRAFVisionModel(nn.Module):
     forward = get_outputs
 
     @torch.no_grad()
-    def get_outputs_for_camera_ray_bundle(self, ray_bundle: RayBundle, coherent_rays: bool = False):
+    def get_outputs_for_camera_ray_bundle(self, ray_bundle: RayBundle, coherent_rays: int = 0):
         """Full-image render in chunks of eval_num_rays_per_chunk rays (NeRAF_config.py:95), as nerfstudio's
         Model.get_outputs_for_camera_ray_bundle does; NeRAFVisionModel.get_outputs_for_camera (NeRAF_model.py:70-79)
         then clips rgb (already applied by the composite kernel).  Every chunk writes its rows of the frame-sized outputs directly
-        (no concatenation); ``coherent_rays``: the bundle is one camera's pixels in row-major order (see ``get_outputs``)."""
+        (no concatenation); ``coherent_rays``: the bundle is one camera's pixels in row-major order (see ``get_outputs``) -- 1 / True,
+        or the image WIDTH: chunks that are whole rows of a width divisible by 8 then walk 8 x 8 / 4 x 4 pixel tiles instead of row
+        segments (include/neraf_hip.h, neraf_proposal_density)."""
         R = len(ray_bundle)
+        W = int(coherent_rays)
         f32 = dict(dtype=torch.float32, device=ray_bundle.origins.device)
         full = {"rgb": torch.empty((R, 3), **f32), "accumulation": torch.empty((R, 1), **f32), "depth": torch.empty((R, 1), **f32),
                 "expected_depth": torch.empty((R, 1), **f32)}
@@ -835,7 +840,9 @@ class NeRAFVisionModel(nn.Module):
                 sl = slice(i, min(R, i + self.eval_num_rays_per_chunk))
                 rb = RayBundle(ray_bundle.origins[sl], ray_bundle.directions[sl],
                                ray_bundle.camera_indices[sl] if ray_bundle.camera_indices is not None else None)
-                self.get_outputs(rb, coherent_rays=coherent_rays, _out={k: v[sl] for k, v in full.items()})
+                n = sl.stop - sl.start
+                tiles = W > 1 and W % 8 == 0 and i % W == 0 and n % W == 0
+                self.get_outputs(rb, coherent_rays=W if tiles else min(W, 1), _out={k: v[sl] for k, v in full.items()})
         finally:
             self.train(was)
         return full
@@ -851,8 +858,9 @@ class NeRAFVisionModel(nn.Module):
             raise NotImplementedError("viewer branch (NeRAF_model.py:73-77) is UI code, out of scope (SURVEY.md row 15)")
         cam = camera.to(self.device)
         rb = cam.generate_rays(0)
-        out = self.get_outputs_for_camera_ray_bundle(rb, coherent_rays=True)                  # row-major pixels of one camera
         H, W = cam.height, cam.width
+        # row-major pixels of one camera; NERAF_PIXEL_TILES=0 (measurement toggle): row segments instead of pixel tiles
+        out = self.get_outputs_for_camera_ray_bundle(rb, coherent_rays=int(W) if os.environ.get("NERAF_PIXEL_TILES", "1") != "0" else 1)
         # rgb is already clipped to [0,1] by the composite kernel (:78; csrc/field.hip composite_kernel)
         return {k: v.reshape(H, W, -1) for k, v in out.items()}
 

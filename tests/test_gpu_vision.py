@@ -268,6 +268,30 @@ def test_full_forward_vs_oracle(dev, setup, training):
             assert float((w.cpu() - wr).abs().max()) <= 5e-3
 
 
+@pytest.mark.parametrize("H,W", [(24, 32), (12, 64), (5, 40)])
+def test_coherent_lane_orders_are_bit_identical(dev, setup, H, W):
+    """coherent_rays only re-assigns samples to lanes (include/neraf_hip.h, neraf_proposal_density): 0 (ray-major), 1 (row segments of
+    64 / 16 rays) and the image width (8 x 8 / 4 x 4 pixel tiles; 12 and 5 rows leave partial tiles) give the same bits for a small
+    pinhole frame -- every sampler stage, both gather kernels, the composite."""
+    from neraf_amd.vision import RayBundle
+    m, P16, spec, V = setup
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    d = torch.stack([(xs - W / 2) / W, -(ys - H / 2) / W, -torch.ones_like(xs)], -1).reshape(-1, 3)
+    d = d / d.norm(dim=-1, keepdim=True)
+    o = torch.tensor([0.1, -0.05, 0.3]).expand(H * W, 3).contiguous()
+    rb = RayBundle(o.to(dev), d.to(dev), torch.zeros((H * W, 1), dtype=torch.long, device=dev))
+    m.eval()
+    try:
+        with torch.no_grad():
+            outs = [m.get_outputs(rb, coherent_rays=c) for c in (0, 1, W)]
+    finally:
+        m.train(True)
+    for k in ("rgb", "depth", "expected_depth", "accumulation"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+        assert torch.equal(outs[0][k], outs[2][k]), k
+    assert float(outs[0]["accumulation"].max()) > 0
+
+
 def test_full_size_batch_invariants(dev, setup):
     """BASELINE size: 4096 rays (NeRAF_config.py:87).  Size-independent properties instead of a CPU oracle run."""
     from neraf_amd.vision import RayBundle
