@@ -730,10 +730,12 @@ class NeRAFVisionModel(nn.Module):
             dens = self.proposal_networks[i].density(o, d, e_prev, packed=prop_packed[i], coherent_rays=0 if self.training else int(coherent_rays))
             prop_dens.append(dens)
             S_cur = e_prev.shape[1] - 1
-            w = torch.empty((R, S_cur), **f32)
+            # the proposal levels' rendering weights only feed the interlevel loss: a whole-frame render (_out given) does not ask for them
+            w = torch.empty((R, S_cur), **f32) if _out is None else None
             s_n, e_n = torch.empty((R, S_next + 1), **f32), torch.empty((R, S_next + 1), **f32)
             _lib.check(lib.neraf_pdf_resample(h, dens.data_ptr(), s_prev.data_ptr(), e_prev.data_ptr(), R, S_cur, anneal,
-                                              jp[i + 1], seeds[i + 1], S_next, near, far, w.data_ptr(), s_n.data_ptr(), e_n.data_ptr(), st), dev)
+                                              jp[i + 1], seeds[i + 1], S_next, near, far, w.data_ptr() if w is not None else None,
+                                              s_n.data_ptr(), e_n.data_ptr(), st), dev)
             weights_list.append(w)
             samples_list.append(RaySamples(None, ray_bundle.camera_indices, s_prev, e_prev))
             s_prev, e_prev = s_n, e_n
