@@ -229,12 +229,22 @@ int neraf_sample_uniform(neraf_ctx* ctx, int R, int S, float near, float far, co
 int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                            const float* origins, const float* dirs, const float* e_bins, int R, int S,
                            float avg_density, int coherent_rays, float* density, neraf_stream_t stream);
+/* The same with an explicit row stride of e_bins (floats): S + 1, or 0 = EVERY RAY SHARES ROW 0.  Without jitter the first sampler
+ * stage (neraf_sample_uniform) gives every ray the same S + 1 edges: a frame render then generates ONE row instead of R (0.4 ms and
+ * 2 x 34 MB per 32,768-ray chunk) and the first proposal query / PDF resampling read it with stride 0. */
+int neraf_proposal_density_ex(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
+                              const float* origins, const float* dirs, const float* e_bins, int64_t e_row_stride, int R, int S,
+                              float avg_density, int coherent_rays, float* density, neraf_stream_t stream);
 
 /* get_weights + PDF resampling of n_new bins (n_new+1 edges) from annealed weights; weights
  * (fp32 [R,S], may be NULL) are the un-annealed volume-rendering weights of the S input bins. */
 int neraf_pdf_resample(neraf_ctx* ctx, const float* density, const float* s_bins, const float* e_bins, int R, int S,
                        float anneal, const float* jitter, uint64_t jitter_seed, int n_new, float near, float far, float* weights,
                        float* s_new, float* e_new, neraf_stream_t stream);
+/* ... with an explicit row stride of the INPUT bins s_bins / e_bins (floats): S + 1, or 0 (every ray shares row 0; see above) */
+int neraf_pdf_resample_ex(neraf_ctx* ctx, const float* density, const float* s_bins, const float* e_bins, int64_t bins_row_stride,
+                          int R, int S, float anneal, const float* jitter, uint64_t jitter_seed, int n_new, float near, float far,
+                          float* weights, float* s_new, float* e_new, neraf_stream_t stream);
 
 /* Fused nerfacto field query: position map (mode 0: L-inf scene contraction, mode 1: AABB
  * normalisation with aabb_host[6]) -> 16-level hash grid -> base MLP -> density; SH(dir) +

@@ -91,6 +91,11 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "neraf_proposal_density": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "neraf_proposal_density_ex": (C.c_int, [C.c_void_p, C.POINTER(GridDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "neraf_pdf_resample_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float,
+                                        C.c_void_p, C.c_uint64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "neraf_pdf_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                      C.c_void_p, C.c_uint64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),

@@ -111,7 +111,7 @@ extern "C" int neraf_prof_summary_ex(neraf_ctx* ctx, int kernel_id, double* tota
 extern "C" const char* neraf_prof_kernel_name(int kernel_id) {
   // the rocprofv3 kernel-name prefix each scope covers (template arguments that vary inside a scope are written as *)
   static const char* names[PROF_NUM_KERNELS] = {"gemm_f16_nt_pipe_kernel<128, 128, *, 0, 1, *>", "gemm_f16_nt_pipe_kernel<64|32, 64|32, 4, 0, 1, false>",
-                                                      "proposal_density_kernel", "field_query_kernel",
+                                                      "proposal_density_kernel | proposal_density_frame_kernel", "field_query_kernel | field_query_frame_kernel",
                                                       "gemm_f16_nt_pipe_kernel<64, 64, 4, 1, *, false>", "proposal_backward_kernel",
                                                       "field_backward_kernel", "field_scatter_kernel | field_slice_ids_kernel + field_scatter_owner_kernel",
                                                       "gemm_f16_nt_wide_kernel<*, 160|128, 3, *>", "wgrad_wide_tn_kernel | wgrad_grouped_tn_kernel",

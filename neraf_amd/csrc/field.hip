@@ -49,6 +49,7 @@ struct PropArgs {
   const unsigned* table;        // fp16x2 entries
   const half_t* w;              // [16][16] layer 0 (row = hidden unit, col = input; cols >= 2L ignored) then [16] layer 1 row 0
   const float* origins; const float* dirs; const float* e_bins;
+  unsigned e_stride;   // floats between the bin-edge rows of consecutive rays: S + 1, or 0 when every ray shares row 0
   int R, S; float avg_density;
   float* density;
   FastDiv divS;    // division by S
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
   const unsigned n = blockIdx.x * 256u + threadIdx.x;
   const unsigned ray = fastdiv(n, a.divS), s = n - ray * S;
   if (ray >= (unsigned)a.R) return;
-  const unsigned eb = ray * (S + 1u) + s;
+  const unsigned eb = ray * a.e_stride + s;
   const float t = 0.5f * (a.e_bins[eb] + a.e_bins[eb + 1u]);
   const float x = fmaf(a.dirs[ray * 3u + 0u], t, a.origins[ray * 3u + 0u]);
   const float y = fmaf(a.dirs[ray * 3u + 1u], t, a.origins[ray * 3u + 1u]);
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void proposal_density_frame_kernel(PropArgs a)
   if (!tile_ray<8>(a.tiles, tile, lane, (unsigned)a.R, ray)) ray = (unsigned)a.R - 1u;      // computes like its neighbours, stores nothing
   const float ox = a.origins[ray * 3u + 0u], oy = a.origins[ray * 3u + 1u], oz = a.origins[ray * 3u + 2u];
   const float dx = a.dirs[ray * 3u + 0u], dy = a.dirs[ray * 3u + 1u], dz = a.dirs[ray * 3u + 2u];
-  const float* eb = a.e_bins + (size_t)ray * (S + 1u) + s0;
+  const float* eb = a.e_bins + (size_t)ray * a.e_stride + s0;
   float e0 = eb[0];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -183,6 +184,7 @@ struct PdfArgs {
   int R, S; float anneal; const float* jitter; int n_new; float near, far;
   float* weights; float* s_new; float* e_new;
   unsigned long long jitter_seed;   // jitter == null and seed != 0: the per-ray jitter is drawn in the kernel (jitter_u01)
+  size_t bins_stride;               // floats between the input bin rows of consecutive rays: S + 1, or 0 (every ray shares row 0)
 };
 
 constexpr int PDF_MAX_S = 256;
@@ -197,8 +199,8 @@ __global__ __launch_bounds__(256) void pdf_resample_kernel(PdfArgs a) {
   const int S = a.S;
   const int per = (S + 63) / 64;                 // samples per lane, contiguous chunk [lane*per, ...)
   const float* dens = a.density + (size_t)ray * S;
-  const float* eb = a.e_bins + (size_t)ray * (S + 1);
-  const float* sb = a.s_bins + (size_t)ray * (S + 1);
+  const float* eb = a.e_bins + (size_t)ray * a.bins_stride;
+  const float* sb = a.s_bins + (size_t)ray * a.bins_stride;
   float* cdf = cdf_s[wv];
   float* bins = bins_s[wv];
   for (int i = lane; i <= S; i += 64) bins[i] = sb[i];
@@ -723,7 +725,15 @@ extern "C" int neraf_sample_uniform(neraf_ctx* ctx, int R, int S, float near, fl
 extern "C" int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
                                       const float* origins, const float* dirs, const float* e_bins, int R, int S,
                                       float avg_density, int coherent_rays, float* density, neraf_stream_t stream) {
+  return neraf_proposal_density_ex(ctx, g, table_f16, mlp_f16, origins, dirs, e_bins, (int64_t)S + 1, R, S, avg_density, coherent_rays, density, stream);
+}
+
+extern "C" int neraf_proposal_density_ex(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
+                                         const float* origins, const float* dirs, const float* e_bins, int64_t e_row_stride, int R, int S,
+                                         float avg_density, int coherent_rays, float* density, neraf_stream_t stream) {
   PropArgs a{};
+  if (e_row_stride != 0 && e_row_stride != (int64_t)S + 1) return neraf_fail(ctx, NERAF_EINVAL, "proposal_density: e_row_stride is S + 1 or 0");
+  a.e_stride = (unsigned)e_row_stride;
   if (make_grid_layout(g, &a.g) || a.g.n_levels > 8) return neraf_fail(ctx, NERAF_EINVAL, "proposal_density: bad grid (<= 8 levels)");
   if (R <= 0 || S <= 0 || !table_f16 || !mlp_f16 || !origins || !dirs || !e_bins || !density)
     return neraf_fail(ctx, NERAF_EINVAL, "proposal_density: bad arguments");
@@ -750,9 +760,16 @@ extern "C" int neraf_proposal_density(neraf_ctx* ctx, const neraf_grid_desc* g, 
 extern "C" int neraf_pdf_resample(neraf_ctx* ctx, const float* density, const float* s_bins, const float* e_bins, int R, int S,
                                   float anneal, const float* jitter, uint64_t jitter_seed, int n_new, float near, float far,
                                   float* weights, float* s_new, float* e_new, neraf_stream_t stream) {
+  return neraf_pdf_resample_ex(ctx, density, s_bins, e_bins, (int64_t)S + 1, R, S, anneal, jitter, jitter_seed, n_new, near, far, weights, s_new, e_new, stream);
+}
+
+extern "C" int neraf_pdf_resample_ex(neraf_ctx* ctx, const float* density, const float* s_bins, const float* e_bins, int64_t bins_row_stride,
+                                     int R, int S, float anneal, const float* jitter, uint64_t jitter_seed, int n_new, float near, float far,
+                                     float* weights, float* s_new, float* e_new, neraf_stream_t stream) {
   if (R <= 0 || S <= 0 || S > PDF_MAX_S || n_new <= 0 || !density || !s_bins || !e_bins || !s_new || !e_new)
     return neraf_fail(ctx, NERAF_EINVAL, "pdf_resample: bad arguments (S <= 256)");
-  PdfArgs a{density, s_bins, e_bins, R, S, anneal, jitter, n_new, near, far, weights, s_new, e_new, (unsigned long long)jitter_seed};
+  if (bins_row_stride != 0 && bins_row_stride != (int64_t)S + 1) return neraf_fail(ctx, NERAF_EINVAL, "pdf_resample: bins_row_stride is S + 1 or 0");
+  PdfArgs a{density, s_bins, e_bins, R, S, anneal, jitter, n_new, near, far, weights, s_new, e_new, (unsigned long long)jitter_seed, (size_t)bins_row_stride};
   hipLaunchKernelGGL(pdf_resample_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;

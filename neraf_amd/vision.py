@@ -235,14 +235,16 @@ class HashMLPDensityField(nn.Module):
         return c[1]
 
     def density(self, origins, directions, e_bins, packed=None, coherent_rays: int = 0):
+        """``e_bins`` [R, S+1], or [1, S+1] when every ray shares the same edges (the first sampler stage without jitter)."""
         lib = _lib.load()
         dev = _dev_index(origins)
-        R, S = e_bins.shape[0], e_bins.shape[1] - 1
+        R, S = origins.shape[0], e_bins.shape[1] - 1
+        shared = e_bins.shape[0] == 1 and R > 1
         tab, w = packed if packed is not None else self.packed()
         out = torch.empty((R, S), dtype=torch.float32, device=origins.device)
-        _lib.check(lib.neraf_proposal_density(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), w.data_ptr(),
-                                              origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(), R, S,
-                                              self.average_init_density, int(coherent_rays), out.data_ptr(), _stream_ptr()), dev)
+        _lib.check(lib.neraf_proposal_density_ex(_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), w.data_ptr(),
+                                                 origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(), 0 if shared else S + 1, R, S,
+                                                 self.average_init_density, int(coherent_rays), out.data_ptr(), _stream_ptr()), dev)
         return out
 
 
@@ -716,8 +718,10 @@ class NeRAFVisionModel(nn.Module):
         S0, S1 = self.num_proposal_samples_per_ray
         S2 = self.num_nerf_samples_per_ray
         f32 = dict(dtype=torch.float32, device=o.device)
-        s0, e0 = torch.empty((R, S0 + 1), **f32), torch.empty((R, S0 + 1), **f32)
-        _lib.check(lib.neraf_sample_uniform(h, R, S0, near, far, jp[0], seeds[0], s0.data_ptr(), e0.data_ptr(), st), dev)
+        # without jitter every ray gets the same first-stage edges: a whole-frame render generates ONE row and reads it with stride 0
+        R0 = 1 if (_out is not None and jp[0] is None and seeds[0] == 0) else R
+        s0, e0 = torch.empty((R0, S0 + 1), **f32), torch.empty((R0, S0 + 1), **f32)
+        _lib.check(lib.neraf_sample_uniform(h, R0, S0, near, far, jp[0], seeds[0], s0.data_ptr(), e0.data_ptr(), st), dev)
         anneal = self._anneal()
         prop_updated = self._proposal_updated() if self.training else False
         weights_list, samples_list = [], []
@@ -733,9 +737,10 @@ class NeRAFVisionModel(nn.Module):
             # the proposal levels' rendering weights only feed the interlevel loss: a whole-frame render (_out given) does not ask for them
             w = torch.empty((R, S_cur), **f32) if _out is None else None
             s_n, e_n = torch.empty((R, S_next + 1), **f32), torch.empty((R, S_next + 1), **f32)
-            _lib.check(lib.neraf_pdf_resample(h, dens.data_ptr(), s_prev.data_ptr(), e_prev.data_ptr(), R, S_cur, anneal,
-                                              jp[i + 1], seeds[i + 1], S_next, near, far, w.data_ptr() if w is not None else None,
-                                              s_n.data_ptr(), e_n.data_ptr(), st), dev)
+            _lib.check(lib.neraf_pdf_resample_ex(h, dens.data_ptr(), s_prev.data_ptr(), e_prev.data_ptr(),
+                                                 0 if (e_prev.shape[0] == 1 and R > 1) else S_cur + 1, R, S_cur, anneal,
+                                                 jp[i + 1], seeds[i + 1], S_next, near, far, w.data_ptr() if w is not None else None,
+                                                 s_n.data_ptr(), e_n.data_ptr(), st), dev)
             weights_list.append(w)
             samples_list.append(RaySamples(None, ray_bundle.camera_indices, s_prev, e_prev))
             s_prev, e_prev = s_n, e_n

@@ -153,6 +153,34 @@ def test_pdf_resample(dev, setup, S, n_new, anneal, jit):
     assert float(de.median()) <= 1e-4
 
 
+def test_shared_first_stage_bins_equal_per_ray_rows(dev, setup):
+    """Row stride 0 (neraf_proposal_density_ex / neraf_pdf_resample_ex): one row of first-stage bin edges shared by every ray gives the
+    bits of R identical rows -- the un-jittered frame render generates that single row."""
+    from neraf_amd import _lib
+    m, _, _, _ = setup
+    lib = _lib.load()
+    R, S, n_new = 203, 256, 96
+    rb = synth.ray_batch(R, tag="t.shared")
+    o, d = T(rb["origins"]).to(dev), T(rb["directions"]).to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    s1, e1 = torch.empty((1, S + 1), device=dev), torch.empty((1, S + 1), device=dev)
+    _lib.check(lib.neraf_sample_uniform(_lib.ctx(0), 1, S, 0.05, 1000.0, None, 0, s1.data_ptr(), e1.data_ptr(), st), 0)
+    sR, eR = s1.expand(R, S + 1).contiguous(), e1.expand(R, S + 1).contiguous()
+    pn = m.proposal_networks[0]
+    for coherent in (0, 1):
+        assert torch.equal(pn.density(o, d, e1, coherent_rays=coherent), pn.density(o, d, eR, coherent_rays=coherent))
+    dens = pn.density(o, d, eR)
+    outs = []
+    for sb, eb, stride in ((sR, eR, S + 1), (s1, e1, 0)):
+        w = torch.empty((R, S), device=dev)
+        s_n, e_n = torch.empty((R, n_new + 1), device=dev), torch.empty((R, n_new + 1), device=dev)
+        _lib.check(lib.neraf_pdf_resample_ex(_lib.ctx(0), dens.data_ptr(), sb.data_ptr(), eb.data_ptr(), stride, R, S, 0.7, None, 0, n_new,
+                                             0.05, 1000.0, w.data_ptr(), s_n.data_ptr(), e_n.data_ptr(), st), 0)
+        outs.append((w, s_n, e_n))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_weights_at_surface_densities(dev, setup):
     """Round-3 regression: optical depths of 1e9-1e17 (surface densities of a trained field).  get_weights needs the exclusive
     prefix sum of the PREVIOUS samples (RaySamples.get_weights [NS-recall]); inclusive-minus-self cancelled there and gave the sample

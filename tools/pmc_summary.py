@@ -31,7 +31,9 @@ def fam(n):
         if bm == 128: return "gemm_f16_nt_pipe_kernel<128, 64, 3, 0, 1, *>"
         return "gemm_f16_nt_pipe_kernel<64|32, 64|32, 4, 0, 1, true>" if bf else "gemm_f16_nt_pipe_kernel<64|32, 64|32, 4, 0, 1, false>"
     if "field_scatter" in n or "field_slice_ids" in n: return "field_scatter_kernel | field_slice_ids_kernel + field_scatter_owner_kernel"
-    for k in ("proposal_density_kernel", "field_query_kernel", "proposal_backward_kernel", "field_backward_kernel", "fused_adam_kernel"):
+    if "proposal_density" in n: return "proposal_density_kernel | proposal_density_frame_kernel"
+    if "field_query" in n: return "field_query_kernel | field_query_frame_kernel"
+    for k in ("proposal_backward_kernel", "field_backward_kernel", "fused_adam_kernel"):
         if k in n: return k
     return None
 fams = collections.defaultdict(lambda: [0.0, 0.0, 0, 0])
