@@ -107,7 +107,7 @@ def test_sample_uniform(dev, setup, jit):
     np.testing.assert_allclose(e.cpu().numpy(), ref.e_bins.numpy(), rtol=2e-4)     # 1/(2-2s) amplifies near s=1
 
 
-@pytest.mark.parametrize("i,S", [(0, 256), (1, 96)])
+@pytest.mark.parametrize("i,S", [(0, 256), (1, 96), (0, 7), (1, 33)])
 def test_proposal_density(dev, setup, i, S):
     m, P16, spec, V = setup
     R = 257
@@ -118,6 +118,8 @@ def test_proposal_density(dev, setup, i, S):
     out = m.proposal_networks[i].density(o.to(dev), d.to(dev), ray.e_bins.to(dev).contiguous())
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-2, atol=1e-7)
     assert float(out.min()) >= 0.0
+    # the coherent forms only re-order lanes (frame kernel when S % 16 == 0, the general order otherwise): same bits
+    assert torch.equal(out, m.proposal_networks[i].density(o.to(dev), d.to(dev), ray.e_bins.to(dev).contiguous(), coherent_rays=1))
 
 
 @pytest.mark.parametrize("S,n_new,anneal,jit", [(256, 96, 0.37, True), (96, 48, 1.0, True), (256, 96, 1.0, False)])
@@ -229,7 +231,7 @@ def test_weights_at_surface_densities(dev, setup):
 def test_field_query(dev, setup, mode, training):
     m, P16, spec, V = setup
     f = m.field.module
-    R, S = 301, 48
+    R, S = (301, 48) if mode == "contract" else (301, 13)       # 13: a samples-per-ray count that is no power of two and no run of 16
     rb = synth.ray_batch(R, tag="t.fq")
     o, d = T(rb["origins"]), T(rb["directions"])
     cam = T(rb["camera_indices"])
