@@ -430,7 +430,7 @@ class NeRAFAudioModel(nn.Module):
     def get_audio_metrics(self, outputs: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], generator=None) -> Dict[str, float]:
         """The metric half of get_image_metrics_and_images (:738-761): magnitude STFTs -> Griffin-Lim waveforms (on the model's
         device) -> T60 / EDT / C50 (and RAF's spectral error) against the ground-truth waveform.  batch: 'data' [C,F,T] log-magnitude,
-        'waveform' [C, n].  The image half (colour-mapped spectrogram panels) is viewer code and not built."""
+        'waveform' [C, n]; the image half is in ``get_image_metrics_and_images``."""
         with torch.no_grad():
             stft = outputs["raw_output"].permute(1, 2, 0).detach().cpu()               # [C, F, T]
             data = batch["data"].detach().cpu()
@@ -445,10 +445,27 @@ class NeRAFAudioModel(nn.Module):
 
     def get_image_metrics_and_images(self, outputs: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], generator=None):
         """NeRAF_model.py:738-803 as its callers use it (NeRAF_pipeline.py:278, :364): (metrics_dict, images_dict).  The metric
-        half is ``get_audio_metrics``; the image half returns the raw log-magnitude panels the forward already produced (the
-        reference colour-maps them with matplotlib for tensorboard -- presentation code, not built)."""
+        half is ``get_audio_metrics``.  The image half (:763-803) is the reference's: every channel's predicted and ground-truth
+        log-STFT panels normalised by the min / max over the GROUND-TRUTH panels, colour-mapped with matplotlib's viridis and set
+        side by side as ``comparison_ch_{c}`` [F, 2T, 3]; with the grid in use, ``grid`` (the mean colour view) and the colour-mapped
+        min-max-normalised ``grid_density``.  Host-side presentation code (numpy + matplotlib, imported here)."""
+        from matplotlib import cm
         metrics = self.get_audio_metrics(outputs, batch, generator=generator)
-        images = {k: v for k, v in outputs.items() if k.startswith(("stft_ch_", "gt_ch_", "comparison_ch_"))}
+        images: Dict[str, torch.Tensor] = {}
+        ids = [k.replace("gt_ch_", "") for k in outputs if "gt" in k]                  # :765-773
+        if ids:
+            min_gt = min(float(outputs["gt_ch_" + i].min()) for i in ids)
+            max_gt = max(float(outputs["gt_ch_" + i].max()) for i in ids)
+
+            def panel(v: torch.Tensor) -> np.ndarray:
+                v = (v.detach().cpu().double().numpy().squeeze() - min_gt) / (max_gt - min_gt)
+                return cm.viridis(v)[..., :3]
+            for i in ids:                                                               # :776-793
+                images["comparison_ch_" + i] = torch.from_numpy(np.concatenate([panel(outputs["stft_ch_" + i]), panel(outputs["gt_ch_" + i])], axis=1))
+        if self.use_grid and "grid" in outputs:                                         # :795-801
+            images["grid"] = outputs["grid"]
+            gd = outputs["grid_density"].detach().cpu().double().numpy().squeeze()
+            images["grid_density"] = torch.from_numpy(cm.viridis((gd - gd.min()) / (gd.max() - gd.min()))[..., :3])
         return metrics, images
 
     def get_param_groups(self):                                                         # :730-737

@@ -280,7 +280,7 @@ class NeRAFPipeline(nn.Module):
                         for k, (i, batch) in enumerate(zip(ids, items)):
                             t0 = time()
                             outputs = self.audio_model.eval_outputs_from_raw(raws[k], batch)               # :362
-                            metrics_dict, _ = self.audio_model.get_image_metrics_and_images(outputs, batch)   # :364
+                            metrics_dict = self.audio_model.get_audio_metrics(outputs, batch)   # :364 (its images are dropped there: not built here)
                             if self.save_eval_audio_path is not None:                                          # :366-372
                                 d = os.path.join(self.save_eval_audio_path, str(step))
                                 os.makedirs(d, exist_ok=True)

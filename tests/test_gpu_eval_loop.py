@@ -56,7 +56,7 @@ def test_eval_loss_dict_and_image_metrics(pipe):
     assert met["num_rays"] == 96 * 128 and {"psnr", "ssim", "t60_error", "edt_error", "c50_error"} <= set(met) or \
         {"psnr", "ssim"} <= set(met)
     assert img["img"].shape == (128, 2 * 96, 3)
-    assert any(k.startswith("stft_ch_") for k in img)
+    assert any(k.startswith("comparison_ch_") and img[k].shape[-1] == 3 for k in img)      # colour-mapped, as NeRAF_model.py:776-793
 
 
 def test_average_eval_image_metrics_matches_manual_loop(pipe, tmp_path):

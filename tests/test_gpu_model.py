@@ -125,6 +125,16 @@ def test_get_outputs_loss_and_eval_branch(models):
     met = am.get_audio_metrics(out, mb, generator=torch.Generator(device=dev).manual_seed(0))
     assert set(met) == {"audio_T60", "audio_total_invalids_T60", "audio_stft_error", "audio_EDT", "audio_C50"}
     assert all(np.isfinite(v) for v in met.values())
+    # the image half (NeRAF_model.py:763-803): viridis panels normalised by the ground truth's range, prediction | ground truth
+    from matplotlib import cm
+    met2, img = am.get_image_metrics_and_images(out, mb, generator=torch.Generator(device=dev).manual_seed(0))
+    assert met2 == met and set(img) == {"comparison_ch_0", "grid", "grid_density"}
+    assert img["comparison_ch_0"].shape == (513, 120, 3) and img["grid_density"].shape == (64, 64, 3)
+    g = out["gt_ch_0"].numpy().squeeze().astype(np.float64)
+    lo, hi = g.min(), g.max()
+    np.testing.assert_array_equal(img["comparison_ch_0"][:, 60:].numpy(), cm.viridis((g - lo) / (hi - lo))[..., :3])
+    pr = out["stft_ch_0"].numpy().squeeze().astype(np.float64)
+    np.testing.assert_array_equal(img["comparison_ch_0"][:, :60].numpy(), cm.viridis((pr - lo) / (hi - lo))[..., :3])
     sm = am.get_metrics_dict(out["raw_output"].permute(1, 2, 0), {"data": item["data"]})
     assert set(sm) == {"audio_mag", "audio_spectral_loss"} and np.isfinite(float(sm["audio_mag"]))
     am.train()
