@@ -68,6 +68,32 @@ __global__ __launch_bounds__(256) void camera_apply_kernel(const float* __restri
 
 // d pose[cam] += (d_o | J_w^T d_d); runs of rays with the same camera inside a wave are summed first (the sampler draws rays image
 // by image or at random: either way one atomic per run instead of one per ray)
+// one ray's contribution to d pose[cam]: (d_o | J_w^T d_d)
+__device__ __forceinline__ void ray_pose_grad(const float* __restrict__ pose, int c, const float* __restrict__ d, const float* __restrict__ g_o,
+                                              const float* __restrict__ g_d, int gs, int i, float (&g)[6]) {
+  const float* p = pose + (size_t)c * 6;
+  const float wx = p[3], wy = p[4], wz = p[5];
+  const Rod r = rodrigues(wx, wy, wz);
+  const float dx = d[i * 3], dy = d[i * 3 + 1], dz = d[i * 3 + 2];
+  const float ux = g_d[(size_t)i * gs], uy = g_d[(size_t)i * gs + 1], uz = g_d[(size_t)i * gs + 2];
+  g[0] = g_o[(size_t)i * gs]; g[1] = g_o[(size_t)i * gs + 1]; g[2] = g_o[(size_t)i * gs + 2];
+  float kx, ky, kz, k2x, k2y, k2z;
+  cross(wx, wy, wz, dx, dy, dz, kx, ky, kz);
+  cross(wx, wy, wz, kx, ky, kz, k2x, k2y, k2z);
+  // radial term: (df1 K d + df2 K^2 d) . u * w_i / a   (zero inside the small-angle guard, where a is constant)
+  const float radial = r.clamped ? 0.f : ((r.df1 * kx + r.df2 * k2x) * ux + (r.df1 * ky + r.df2 * k2y) * uy + (r.df1 * kz + r.df2 * k2z) * uz) / r.a;
+  const float w[3] = {wx, wy, wz};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float ex = a == 0 ? 1.f : 0.f, ey = a == 1 ? 1.f : 0.f, ez = a == 2 ? 1.f : 0.f;
+    float t1x, t1y, t1z, t2x, t2y, t2z, t3x, t3y, t3z;
+    cross(ex, ey, ez, dx, dy, dz, t1x, t1y, t1z);          // e_a x d
+    cross(ex, ey, ez, kx, ky, kz, t2x, t2y, t2z);          // e_a x (w x d)
+    cross(wx, wy, wz, t1x, t1y, t1z, t3x, t3y, t3z);       // w x (e_a x d)
+    g[3 + a] = r.f1 * (t1x * ux + t1y * uy + t1z * uz) + r.f2 * ((t2x + t3x) * ux + (t2y + t3y) * uy + (t2z + t3z) * uz) + radial * w[a];
+  }
+}
+
 __global__ __launch_bounds__(256) void camera_apply_bwd_kernel(const float* __restrict__ pose, const int* __restrict__ cam, const float* __restrict__ d,
                                                               const float* __restrict__ g_o, const float* __restrict__ g_d, int gs, int R,
                                                               float* __restrict__ g_pose) {
@@ -76,29 +102,7 @@ __global__ __launch_bounds__(256) void camera_apply_bwd_kernel(const float* __re
   const bool valid = i < R;
   const int c = valid ? cam[i] : -1;
   float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (valid) {
-    const float* p = pose + (size_t)c * 6;
-    const float wx = p[3], wy = p[4], wz = p[5];
-    const Rod r = rodrigues(wx, wy, wz);
-    const float dx = d[i * 3], dy = d[i * 3 + 1], dz = d[i * 3 + 2];
-    const float ux = g_d[(size_t)i * gs], uy = g_d[(size_t)i * gs + 1], uz = g_d[(size_t)i * gs + 2];
-    g[0] = g_o[(size_t)i * gs]; g[1] = g_o[(size_t)i * gs + 1]; g[2] = g_o[(size_t)i * gs + 2];
-    float kx, ky, kz, k2x, k2y, k2z;
-    cross(wx, wy, wz, dx, dy, dz, kx, ky, kz);
-    cross(wx, wy, wz, kx, ky, kz, k2x, k2y, k2z);
-    // radial term: (df1 K d + df2 K^2 d) . u * w_i / a   (zero inside the small-angle guard, where a is constant)
-    const float radial = r.clamped ? 0.f : ((r.df1 * kx + r.df2 * k2x) * ux + (r.df1 * ky + r.df2 * k2y) * uy + (r.df1 * kz + r.df2 * k2z) * uz) / r.a;
-    const float w[3] = {wx, wy, wz};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float ex = a == 0 ? 1.f : 0.f, ey = a == 1 ? 1.f : 0.f, ez = a == 2 ? 1.f : 0.f;
-      float t1x, t1y, t1z, t2x, t2y, t2z, t3x, t3y, t3z;
-      cross(ex, ey, ez, dx, dy, dz, t1x, t1y, t1z);          // e_a x d
-      cross(ex, ey, ez, kx, ky, kz, t2x, t2y, t2z);          // e_a x (w x d)
-      cross(wx, wy, wz, t1x, t1y, t1z, t3x, t3y, t3z);       // w x (e_a x d)
-      g[3 + a] = r.f1 * (t1x * ux + t1y * uy + t1z * uz) + r.f2 * ((t2x + t3x) * ux + (t2y + t3y) * uy + (t2z + t3z) * uz) + radial * w[a];
-    }
-  }
+  if (valid) ray_pose_grad(pose, c, d, g_o, g_d, gs, i, g);
   // segmented sum over runs of equal camera index among consecutive lanes
   const int prev = __shfl_up(c, 1), next = __shfl_down(c, 1);
   int head = (lane == 0 || prev != c) ? 1 : 0;
@@ -120,6 +124,33 @@ __global__ __launch_bounds__(256) void camera_apply_bwd_kernel(const float* __re
   if (valid && tail) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) if (g[k] != 0.f) atomicAdd(g_pose + (size_t)c * 6 + k, g[k]);
+  }
+}
+
+// Deterministic mode: one wavefront per camera walks ALL rays in index order (lane-strided), adds the contributions of its own
+// rays and folds the lanes with a fixed xor-tree: no atomics, the same bits every run (R x n_cams index compares: 0.9 M at the
+// bench shape).
+__global__ __launch_bounds__(256) void camera_apply_bwd_det_kernel(const float* __restrict__ pose, const int* __restrict__ cam, const float* __restrict__ d,
+                                                                  const float* __restrict__ g_o, const float* __restrict__ g_d, int gs, int R, int n_cams,
+                                                                  float* __restrict__ g_pose) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= n_cams) return;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < R; i += 64)
+    if (cam[i] == c) {
+      float g[6];
+      ray_pose_grad(pose, c, d, g_o, g_d, gs, i, g);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] += g[k];
+    }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g_pose[(size_t)c * 6 + k] += acc[k];
   }
 }
 
@@ -215,7 +246,10 @@ extern "C" int neraf_camera_apply_bwd(neraf_ctx* ctx, const float* pose_adjustme
     return neraf_fail(ctx, NERAF_EINVAL, "camera_apply_bwd: bad arguments");
   hipLaunchKernelGGL(camera_reg_bwd_init_kernel, dim3((n_cams * 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose_adjustment, n_cams,
                      w_trans, w_rot, g_reg, d_pose);
-  if (d_origins)
+  if (d_origins && neraf_deterministic())
+    hipLaunchKernelGGL(camera_apply_bwd_det_kernel, dim3((n_cams + 3) / 4), dim3(256), 0, (hipStream_t)stream, pose_adjustment, cam_idx, dirs,
+                       d_origins, d_dirs, g_stride, R, n_cams, d_pose);
+  else if (d_origins)
     hipLaunchKernelGGL(camera_apply_bwd_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose_adjustment, cam_idx, dirs, d_origins,
                        d_dirs, g_stride, R, d_pose);
   NERAF_HIP_CHECK(ctx, hipGetLastError());

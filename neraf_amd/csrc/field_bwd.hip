@@ -223,6 +223,30 @@ __global__ __launch_bounds__(256) void interlevel_kernel(InterlevelArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Deterministic mode: d_ray[ray] += sum_s g6[ray][s] with one wavefront per ray, lanes striding over the samples and a fixed
+// xor-tree over the lanes -- the same bits whatever order the producing waves ran in.
+__global__ __launch_bounds__(256) void ray_fold_kernel(const float* __restrict__ g6, int R, int S, float* __restrict__ d_ray) {
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ray >= R) return;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = lane; s < S; s += 64) {
+    const float* src = g6 + ((size_t)ray * S + s) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] += src[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+  }
+  if (lane < 6) {
+    float v = acc[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) v = lane == k ? acc[k] : v;
+    d_ray[(size_t)ray * 6 + lane] += v;
+  }
+}
+
 struct PropBwdArgs {
   GridLayout g;
   const unsigned* table; const half_t* w;
@@ -233,6 +257,8 @@ struct PropBwdArgs {
   float* w_part;          // optional fp32 [blocks][272]: per-workgroup partials (folded by prop_wgrad_fold_kernel) instead of
                           // 272 atomics per workgroup on nine cache lines (~220 us of same-line serialisation at 2048 workgroups)
   float* d_ray;           // optional fp32 [R][6], ACCUMULATED: d loss / d (ray origin, ray direction)
+  float* g6_out;          // deterministic mode (with d_ray): fp32 [N][6], the per-SAMPLE contributions, STORED; ray_fold_kernel adds each
+                          // ray's S rows in a fixed order instead of waves adding to d_ray with float atomics in arrival order
   // packed two-pass table gradient (all four non-null): this kernel only STORES the per-sample encoding gradient, fp32 pairs
   // [level][npad], and each level's gradient mass sum_samples max(|g0|, |g1|) per workgroup; field_finalize_kernel turns the masses
   // into the power-of-two fixed-point scales, field_scatter_kernel adds both features of a table entry with ONE 64-bit integer
@@ -314,7 +340,12 @@ __global__ __launch_bounds__(256) void proposal_backward_kernel(PropBwdArgs a) {
       map_position_jt(xr, yr, zr, rgx, rgy, rgz);
       float g6[6] = {rgx, rgy, rgz, tmid * rgx, tmid * rgy, tmid * rgz};
       const int ray0 = __shfl(ray_id, 0);
-      if (__all(ray_id == ray0 || !valid)) {
+      if (a.g6_out) {
+        if (valid) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) a.g6_out[(size_t)idx * 6 + k] = g6[k];
+        }
+      } else if (__all(ray_id == ray0 || !valid)) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           float v = valid ? g6[k] : 0.f;
@@ -418,6 +449,7 @@ struct FieldBwdArgs {
                                                    // workgroup's leading embedding row (rows 64.. of slots 2 / 3)
   float* pos;                                      // optional fp32 [3][npad]: mapped sample positions for the owner scatter (slot 4, rows 64..)
   float* d_ray;                                    // optional fp32 [R][6], ACCUMULATED: d loss / d (ray origin, ray direction) -- the camera-pose optimizer's edge
+  float* g6_out;                                   // deterministic mode (with d_ray): per-sample contributions fp32 [N][6], see PropBwdArgs
   const half_t* enc_in;                            // optional fp16 [N][32] saved by the forward (neraf_field_query_train): no table walk here
   const half_t* denc_in;                           // optional fp16 [N][4][24]: saved d enc / d position (with d_ray)
 };
@@ -714,7 +746,12 @@ __global__ __launch_bounds__(256) void field_backward_kernel(FieldBwdArgs a) {
                      fmaf(t, px, sx) * inv_gscale, fmaf(t, py, sy) * inv_gscale, fmaf(t, pz, sz) * inv_gscale};
       const int ray0 = __shfl(ray, lane & 48);
       const bool one_ray = __all(ray == ray0 || !valid);
-      if (one_ray) {
+      if (a.g6_out) {
+        if (valid && q == 0) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) a.g6_out[(size_t)n * 6 + k] = g6[k];
+        }
+      } else if (one_ray) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           float v = valid ? g6[k] : 0.f;
@@ -1203,7 +1240,8 @@ static int proposal_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, cons
 
 extern "C" size_t neraf_proposal_backward_scratch_bytes(int R, int S, int n_levels) {
   const size_t npad = ((size_t)R * S + 63) / 64 * 64;
-  return (size_t)2048 * 272 * sizeof(float) + (size_t)2048 * 16 * sizeof(float) + 64 * sizeof(float) + (size_t)n_levels * npad * sizeof(float2);
+  return (size_t)2048 * 272 * sizeof(float) + (size_t)2048 * 16 * sizeof(float) + 64 * sizeof(float) + (size_t)n_levels * npad * sizeof(float2) +
+         (neraf_deterministic() ? npad * 6 * sizeof(float) : 0);      // deterministic mode: per-sample ray gradients (ray_fold_kernel)
 }
 
 extern "C" int neraf_proposal_backward(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* mlp_f16,
@@ -1259,11 +1297,14 @@ static int proposal_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, cons
     lvl = (float*)sp; sp += 32 * sizeof(float);
     a.one2 = (float*)sp; sp += 32 * sizeof(float);
     a.d32 = (float2*)sp; a.npad = npad;
+    sp += (size_t)a.g.n_levels * npad * sizeof(float2);
+    if (neraf_deterministic() && d_rays) a.g6_out = (float*)sp;
   }
   hipStream_t st = (hipStream_t)stream;
   {
     ProfScope prof(ctx, st, PROF_PROP_BWD, (double)n * a.g.n_levels * 8 * 8);   // 8 bytes added per (sample, level, corner)
     hipLaunchKernelGGL(proposal_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (a.g6_out) hipLaunchKernelGGL(ray_fold_kernel, dim3((R + 3) / 4), dim3(256), 0, st, a.g6_out, R, S, d_rays);
     if (a.d32) {
       hipLaunchKernelGGL(field_finalize_kernel, dim3(16), dim3(256), 0, st, a.t_part, (int)blocks, lvl, nullptr, nullptr, nullptr);
       FieldScatterArgs sa{};
@@ -1288,7 +1329,7 @@ static int proposal_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, cons
 
 extern "C" size_t neraf_field_backward_dump_bytes(int R, int S) {
   const long npad = ((long)R * S + 63) / 64 * 64;
-  return (size_t)10 * 128 * npad * 2 + 256;
+  return (size_t)10 * 128 * npad * 2 + 256 + (neraf_deterministic() ? (size_t)npad * 6 * sizeof(float) : 0);   // + per-sample ray gradients
 }
 
 static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void* table_f16, const void* wfrag_f16,
@@ -1378,6 +1419,7 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
   a.e_part_row = reinterpret_cast<int*>((half_t*)dump + (size_t)3 * 128 * npad + (size_t)64 * npad);  // slot 3, rows 64..
   float* scale = (float*)((char*)dump + (size_t)10 * 128 * npad * 2);
   a.scale = scale;
+  if (neraf_deterministic() && d_rays) a.g6_out = (float*)((char*)dump + (size_t)10 * 128 * npad * 2 + 256);   // neraf_field_backward_dump_bytes
   // owner scatter (no global atomics) for a large batch: every level in <= 32 slices of 2^14 entries, hashed levels of
   // power-of-two size, and every coordinate below the slice size (the hashed slice id must not depend on x)
   constexpr int kOwnLds = (1 << OWN_SLICE_LOG2) * 8 + (OWN_THREADS / 64) * OWN_QUEUE * 4;
@@ -1430,6 +1472,7 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
       else if (d_rays) hipLaunchKernelGGL((field_backward_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
       else if (enc_in) hipLaunchKernelGGL((field_backward_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
       else hipLaunchKernelGGL((field_backward_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+      if (a.g6_out) hipLaunchKernelGGL(ray_fold_kernel, dim3((R + 3) / 4), dim3(256), 0, st, a.g6_out, R, S, d_rays);
     }
     NERAF_HIP_CHECK(ctx, hipGetLastError());
     // hash-grid gradient: per-level fixed-point scale from the gradient mass, packed 64-bit scatter, in-place unpack

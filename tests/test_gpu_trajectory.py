@@ -128,14 +128,17 @@ def test_training_trajectory_matches_the_oracle(golden, scenario, tmp_path_facto
     _check_against_oracle(g, run, scenario)
 
 
-def test_deterministic_mode_is_bit_reproducible(golden, tmp_path_factory):
-    """NERAF_DETERMINISTIC=1: a second run of G7 (100 joint training iterations from the same weights on the same batches, in another
-    fresh process) ends with the SAME bits -- radiance table, a NAcF matrix, the encoder's last convolution, both loss curves, the
-    held-out render and the predicted STFTs.  This is what lets the parity gates above be single-run bounds."""
-    a = _run_worker("g7_trajectory", tmp_path_factory, "1", "a")
-    b = _run_worker("g7_trajectory", tmp_path_factory, "1", "b")
-    for k in ("table", "nacf_w1", "conv", "image", "stft_eval", "stft_batch_stats"):
+@pytest.mark.parametrize("scenario", ["g7_trajectory", "g8_trajectory_pose"])
+def test_deterministic_mode_is_bit_reproducible(golden, tmp_path_factory, scenario):
+    """NERAF_DETERMINISTIC=1: a second run of the scenario (100 joint training iterations from the same weights on the same batches,
+    in another fresh process) ends with the SAME bits -- radiance table, a NAcF matrix, the encoder's last convolution, both loss
+    curves, the held-out render and the predicted STFTs.  This is what lets the parity gates above be single-run bounds.  G8 adds the
+    camera optimizer: its ray gradients (three producers per ray) and the per-camera pose gradients are folded in a fixed order too."""
+    a = _run_worker(scenario, tmp_path_factory, "1", "a")
+    b = _run_worker(scenario, tmp_path_factory, "1", "b")
+    for k in ("table", "nacf_w1", "conv", "image", "stft_eval", "stft_batch_stats") + (("pose",) if "pose" in a else ()):
         assert np.array_equal(a[k], b[k]), k
+    assert ("pose" in a) == (scenario == "g8_trajectory_pose")
     assert np.array_equal(a["curves"][:, 3:], b["curves"][:, 3:], equal_nan=True)          # audio losses (their sums are ordered)
     np.testing.assert_allclose(a["curves"][:, :3], b["curves"][:, :3], rtol=1e-5)          # radiance loss VALUES: atomically summed (reported only)
 
