@@ -70,7 +70,7 @@ __device__ __forceinline__ float proposal_point(const PropArgs& a, const unsigne
   for (int l = 0; l < NL; ++l)
     if (NL == 5 || l < a.g.n_levels) {
       level_cell(x, y, z, a.g.scale[l], a.g.res[l], a.g.size[l], a.g.hashed[l], cell[l]);
-      gather_corners<true, true>(a.table, a.g.offset[l], cell[l], raw[l], a.g.hashed[l], a.g.size[l]);
+      gather_corners<true, true>(a.table, a.g.offset[l], cell[l], raw[l], !a.g.hashed[l] && l + 1 < a.g.n_levels, a.g.size[l]);
     }
 #pragma unroll
   for (int l = 0; l < NL; ++l) {

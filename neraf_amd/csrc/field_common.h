@@ -161,21 +161,22 @@ __device__ __forceinline__ void corner_weights(const LevelCell& c, float (&w)[8]
 }
 
 // What a gather costs (tools/microbench/gather_rate.hip, profiles/r04_gather_rate_microbench.txt): with lanes spread over many cache
-// lines, the distinct lines (width and re-reads of the same lines are free); with coherent lanes -- the frame render -- about 20
-// cycles per INSTRUCTION whatever it loads.  So on a DENSE level, where the x-neighbour of a corner is the next entry, the two are
-// fetched by ONE 8-byte load (PAIRS): 4 instructions per level instead of 8.  Only for kernels whose `hashed` flag is wave-uniform
-// (a per-lane choice between the two forms is a divergent branch around every load: tried in round 4 on hashed levels with even
-// cell x, proposal density 128 -> 144 us, field query on frames 233 -> 405 us).  The one exception to "next entry" is an x0 corner
-// that is the level's LAST entry (its neighbour wraps to entry 0: tcnn's `index % size`): a rare lane-level fix-up load.
+// lines, its distinct lines (width and re-reads of the same lines are free).  On a DENSE level the x-neighbour of a corner is the next
+// entry: PAIRS fetches the two with ONE 8-byte load (4 instructions per level instead of 8) -- worth 2-3 % on the frame's proposal
+// kernel, nothing elsewhere, and only for kernels whose `pairs` flag is wave-uniform (a per-lane choice between the two forms is a
+// divergent branch around every load: tried on hashed levels with even cell x, proposal density 128 -> 144 us, field query on frames
+// 233 -> 405 us).  The one exception to "next entry" is an x0 corner that is the level's LAST entry (its neighbour wraps to entry 0:
+// tcnn's `index % size`): a rare lane-level fix-up load; the 8-byte load then reads 4 bytes of the NEXT level, so the caller never
+// asks for pairs on the table's last level.
 // UNIFORM: `offset` (the level's first entry) is the same for every lane of the wave: it rides in the instruction's scalar offset;
 // otherwise (a wave whose lanes hold different levels: the fused field kernels) it is added per lane.
 template <bool UNIFORM, bool PAIRS = false>
 __device__ __forceinline__ void gather_corners(const unsigned* __restrict__ table, unsigned offset, const LevelCell& c, unsigned (&raw)[8],
-                                               int hashed = 1, unsigned size = 0) {
+                                               bool pairs = false, unsigned size = 0) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   const __amdgpu_buffer_rsrc_t rs = table_rsrc(table);
   const unsigned off4 = offset << 2;
-  if (PAIRS && UNIFORM && !hashed) {
+  if (PAIRS && UNIFORM && pairs) {
     const unsigned soff = __builtin_amdgcn_readfirstlane(off4), last = (size << 2) - 4u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
