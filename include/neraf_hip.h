@@ -130,6 +130,12 @@ int neraf_nacf_encode_queries(neraf_ctx* ctx, const neraf_nacf_desc* d, const in
                               const double* mic_pose, const double* source_pose, const double* rot,
                               const float* aabb_host, int max_len, int B, void* workspace, int training,
                               neraf_stream_t stream);
+/* pose_rows = B (one pose row per query, as above) or 1: every query shares row 0 of mic_pose / source_pose / rot -- the eval branch
+ * (NeRAF_model.py:648-694), where one RIR is T time queries at ONE (microphone, source, orientation); saves the three [T,3] expansions. */
+int neraf_nacf_encode_queries_ex(neraf_ctx* ctx, const neraf_nacf_desc* d, const int64_t* time_query,
+                                 const double* mic_pose, const double* source_pose, const double* rot, int pose_rows,
+                                 const float* aabb_host, int max_len, int B, void* workspace, int training,
+                                 neraf_stream_t stream);
 
 /* Forward with the layer-0 split: feat [n_feat] fp32 is the ResNet3D feature shared by all
  * rows (NeRAF_model.py:557-558); queries must have been encoded into the workspace.

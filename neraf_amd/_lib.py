@@ -63,6 +63,9 @@ SIGNATURES = {
     "neraf_nacf_encode_queries": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p]),
+    "neraf_nacf_encode_queries_ex": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                               C.c_void_p]),
     "neraf_nacf_fwd": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), C.c_void_p, c_fpp, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_int, C.c_void_p]),
     "neraf_nacf_fwd_dense": (C.c_int, [C.c_void_p, C.POINTER(NacfDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,

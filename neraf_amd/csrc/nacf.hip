@@ -301,6 +301,7 @@ struct EncodeArgs {
   const int64_t* tq; const double* mic; const double* src; const double* rot;
   float aabb[6]; float inv_tmax; int B, Mpad;
   half_t* q; half_t* qT;
+  int pstride;      // doubles between the pose rows of consecutive queries: 3, or 0 when every query shares row 0 (one RIR's T time queries)
 };
 
 __global__ __launch_bounds__(256) void encode_queries_kernel(EncodeArgs a, int tmajor) {
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void encode_queries_kernel(EncodeArgs a, int t
       }
     } else if (col < 147) {
       const bool is_mic = col < 84;
-      const double* P = (is_mic ? a.mic : a.src) + (size_t)row * 3;
+      const double* P = (is_mic ? a.mic : a.src) + (size_t)row * a.pstride;
       const int c = is_mic ? col - 21 : col - 84;
       // SceneBox normalisation + in-box selector in float64 (poses are float64, NeRAF_dataset.py:129)
       double xn[3];
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void encode_queries_kernel(EncodeArgs a, int t
       }
     } else {
       // SH degree 4 on d = 2*rot - 1 (tiny-cuda-nn SphericalHarmonics, float)
-      const double* R = a.rot + (size_t)row * 3;
+      const double* R = a.rot + (size_t)row * a.pstride;
       const float x = (float)R[0] * 2.f - 1.f, y = (float)R[1] * 2.f - 1.f, z = (float)R[2] * 2.f - 1.f;
       const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
       switch (col - 147) {
@@ -569,15 +570,23 @@ extern "C" int neraf_nacf_encode_queries(neraf_ctx* ctx, const neraf_nacf_desc* 
                                          const double* mic_pose, const double* source_pose, const double* rot,
                                          const float* aabb_host, int max_len, int B, void* workspace, int training,
                                          neraf_stream_t stream) {
+  return neraf_nacf_encode_queries_ex(ctx, d, time_query, mic_pose, source_pose, rot, B, aabb_host, max_len, B, workspace, training, stream);
+}
+
+extern "C" int neraf_nacf_encode_queries_ex(neraf_ctx* ctx, const neraf_nacf_desc* d, const int64_t* time_query,
+                                            const double* mic_pose, const double* source_pose, const double* rot, int pose_rows,
+                                            const float* aabb_host, int max_len, int B, void* workspace, int training,
+                                            neraf_stream_t stream) {
   if (int e = check_desc(ctx, d)) return e;
   if (B <= 0 || max_len < 2) return neraf_fail(ctx, NERAF_EINVAL, "encode_queries: B>0 and max_len>=2 required");
+  if (pose_rows != B && pose_rows != 1) return neraf_fail(ctx, NERAF_EINVAL, "encode_queries: pose_rows is B or 1");
   const Dims D = make_dims(d);
   const WsLayout L = make_ws_layout(d, D, B, training);
   EncodeArgs a{};
   a.tq = time_query; a.mic = mic_pose; a.src = source_pose; a.rot = rot;
   for (int i = 0; i < 6; ++i) a.aabb[i] = aabb_host[i];
   a.inv_tmax = 1.0f / (float)(max_len - 1.0);
-  a.B = B; a.Mpad = L.Mpad;
+  a.B = B; a.Mpad = L.Mpad; a.pstride = pose_rows == B ? 3 : 0;
   a.q = (half_t*)((char*)workspace + L.q);
   a.qT = (half_t*)((char*)workspace + L.qT);
   hipStream_t st = (hipStream_t)stream;

@@ -39,16 +39,21 @@ class _NacfSplitFn(torch.autograd.Function):
     """out = NAcF(feat, encoded queries) ; grads for feat and the 2*(5+C) parameters."""
 
     @staticmethod
-    def forward(ctx, field: "NeRAFAudioSoundField", feat: torch.Tensor, ws: torch.Tensor, B: int, training: bool,
-                *params: torch.Tensor):
+    def run(field: "NeRAFAudioSoundField", feat: torch.Tensor, ws: torch.Tensor, B: int, training: bool, params):
+        """The forward launch itself; ``forward_queries`` calls it directly when no graph is recorded (the eval branch: one call per
+        RIR, where ``Function.apply`` is a third of the host time of the call)."""
         lib = _lib.load()
         dev = _dev_index(feat)
-        h = _lib.ctx(dev)
         packed = field._packed(params, training)
         out = torch.empty((B, field.sound_rez, field.N_frequencies), dtype=torch.float32, device=feat.device)
-        wptr = _lib.ptr_array(params)
-        _lib.check(lib.neraf_nacf_fwd(h, C.byref(field._desc), packed.data_ptr(), wptr, feat.data_ptr(), B,
+        _lib.check(lib.neraf_nacf_fwd(_lib.ctx(dev), C.byref(field._desc), packed.data_ptr(), _lib.ptr_array(params), feat.data_ptr(), B,
                                       out.data_ptr(), ws.data_ptr(), int(training), _stream_ptr()), dev)
+        return out, packed, dev
+
+    @staticmethod
+    def forward(ctx, field: "NeRAFAudioSoundField", feat: torch.Tensor, ws: torch.Tensor, B: int, training: bool,
+                *params: torch.Tensor):
+        out, packed, dev = _NacfSplitFn.run(field, feat, ws, B, training, params)
         ctx.field, ctx.B, ctx.dev = field, B, dev
         # optional hand-off: the producer of `feat` names the buffer it wants d loss / d feat in (ResNet3D.dfeat_buffer)
         gb = getattr(feat, "_neraf_grad_buffer", None)
@@ -187,15 +192,21 @@ class NeRAFAudioSoundField(nn.Module):
         if feat.numel() != self._desc.n_feat:
             raise ValueError(f"feat must have {self._desc.n_feat} elements")
         tq = time_query.to(torch.int64).contiguous()
+        # poses: one row per query [B,3], or ONE row [1,3] / [3] shared by all queries (the eval branch: T time queries of one RIR)
+        shared = mic_pose.numel() == 3 and B > 1
         mic = mic_pose.to(torch.float64).contiguous()
         src = source_pose.to(torch.float64).contiguous()
         r = rot.to(torch.float64).contiguous()
+        if (src.numel() == 3) != (mic.numel() == 3) or (r.numel() == 3) != (mic.numel() == 3):
+            raise ValueError("mic_pose, source_pose and rot are all per query [B,3] or all shared [1,3]")
         training = torch.is_grad_enabled() and (feat.requires_grad or any(p.requires_grad for p in self.parameters()))
         ws = self._workspace(B, training, mic.device)
         ab = _lib.host_f32(aabb)
-        _lib.check(lib.neraf_nacf_encode_queries(_lib.ctx(dev), C.byref(self._desc), tq.data_ptr(), mic.data_ptr(),
-                                                 src.data_ptr(), r.data_ptr(), ab, int(max_len), B, ws.data_ptr(),
-                                                 int(training), _stream_ptr()), dev)
+        _lib.check(lib.neraf_nacf_encode_queries_ex(_lib.ctx(dev), C.byref(self._desc), tq.data_ptr(), mic.data_ptr(),
+                                                    src.data_ptr(), r.data_ptr(), 1 if shared else B, ab, int(max_len), B, ws.data_ptr(),
+                                                    int(training), _stream_ptr()), dev)
+        if not training:
+            return _NacfSplitFn.run(self, feat, ws, B, False, self.flat_params())[0]
         return _NacfSplitFn.apply(self, feat, ws, B, training, *self.flat_params())
 
 

@@ -358,7 +358,8 @@ class NeRAFAudioModel(nn.Module):
         return self.criterion(pred, gt, w)
 
     def set_eval_data(self, eval_source_pose, eval_mic_pose, eval_rot, eval_gt):        # :602-607
-        self.eval_source_pose, self.eval_mic_pose, self.eval_rot, self.eval_gt = eval_source_pose, eval_mic_pose, eval_rot, eval_gt
+        # plain attributes, set once per evaluated RIR: nn.Module.__setattr__'s parameter / buffer / module bookkeeping is 10 us for the four
+        self.__dict__.update(eval_source_pose=eval_source_pose, eval_mic_pose=eval_mic_pose, eval_rot=eval_rot, eval_gt=eval_gt)
 
     # ---- A7: eval branch -------------------------------------------------------------------------
     @torch.no_grad()
@@ -367,10 +368,14 @@ class NeRAFAudioModel(nn.Module):
             raise NotImplementedError("viewer camera branch (:611-646) is UI code, out of scope (SURVEY.md row 15)")
         dev = self.aabb.device
         T = self.max_len
-        tq = torch.arange(0, T, 1, device=dev)                                          # :649
-        mic = batch_audio["mic_pose"].to(dev).reshape(1, 3).expand(T, -1)
-        src = batch_audio["source_pose"].to(dev).reshape(1, 3).expand(T, -1)
-        rot = batch_audio["rot"].to(dev).reshape(1, 3).expand(T, -1)
+        tq = getattr(self, "_eval_tq", None)                                            # :649 (the same T indices for every RIR)
+        if tq is None or tq.numel() != T or tq.device != dev:
+            tq = self._eval_tq = torch.arange(0, T, 1, device=dev)
+        # one (microphone, source, orientation) for all T time queries (:650-652, :676-678 expand them to [T,3]; the prologue kernel
+        # reads the single row for every query instead)
+        mic = batch_audio["mic_pose"].to(dev).reshape(1, 3)
+        src = batch_audio["source_pose"].to(dev).reshape(1, 3)
+        rot = batch_audio["rot"].to(dev).reshape(1, 3)
         feat = self.scene_feature() if self.use_grid else torch.zeros(0, device=dev)
         out = self.field.forward_queries(feat, tq, mic, src, rot, self.aabb, T)         # [T,C,F]
         return self.eval_outputs_from_raw(out, batch_audio)
