@@ -87,24 +87,35 @@ struct BnBwdArgs {
   float* dgamma; float* dbeta; const float* inv_scale;   // apply (row-block 0 writes the un-scaled affine gradients)
 };
 
-__device__ __forceinline__ void bn_bwd_load(const BnBwdArgs& p, size_t off, float (&xv)[8], float (&g)[8]) {
-  const half8 x = *reinterpret_cast<const half8*>(p.s.x + off);
+// One thread's 8 channels of a row: the loads (bn_bwd_issue) and their conversion (bn_bwd_finish) are separate so that a kernel can
+// have the tile in flight while it still waits for the statistics it needs to use it (every dependent memory round trip of these
+// 5-7 us kernels is 1.5-2 us).
+struct BnBwdRaw { half8 x; bf16x8 g16; f32x4 g0, g1; half8 act; };
+__device__ __forceinline__ void bn_bwd_issue(const BnBwdArgs& p, size_t off, BnBwdRaw& r) {
+  r.x = *reinterpret_cast<const half8*>(p.s.x + off);
+  if (p.g16) r.g16 = *reinterpret_cast<const bf16x8*>(p.g16 + off);
+  else { r.g0 = *reinterpret_cast<const f32x4*>(p.g32 + off); r.g1 = *reinterpret_cast<const f32x4*>(p.g32 + off + 4); }
+  if (p.act) r.act = *reinterpret_cast<const half8*>(p.act + off);
+}
+__device__ __forceinline__ void bn_bwd_finish(const BnBwdArgs& p, const BnBwdRaw& r, float (&xv)[8], float (&g)[8]) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) xv[j] = (float)x[j];
+  for (int j = 0; j < 8; ++j) xv[j] = (float)r.x[j];
   if (p.g16) {
-    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(p.g16 + off);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = (float)gv[j];
+    for (int j = 0; j < 8; ++j) g[j] = (float)r.g16[j];
   } else {
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g32 + off), g1 = *reinterpret_cast<const f32x4*>(p.g32 + off + 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { g[j] = g0[j]; g[4 + j] = g1[j]; }
+    for (int j = 0; j < 4; ++j) { g[j] = r.g0[j]; g[4 + j] = r.g1[j]; }
   }
   if (p.act) {
-    const half8 av = *reinterpret_cast<const half8*>(p.act + off);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (!((float)av[j] > 0.f)) g[j] = 0.f;
+    for (int j = 0; j < 8; ++j) if (!((float)r.act[j] > 0.f)) g[j] = 0.f;
   }
+}
+__device__ __forceinline__ void bn_bwd_load(const BnBwdArgs& p, size_t off, float (&xv)[8], float (&g)[8]) {
+  BnBwdRaw r;
+  bn_bwd_issue(p, off, r);
+  bn_bwd_finish(p, r, xv, g);
 }
 
 // grid (row blocks, C / 64)
@@ -113,17 +124,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs p) {
   __shared__ float red[2][32][65];
   const int c_base = blockIdx.y * 64;
   const int tid = threadIdx.x;
+  const int ch = tid & 7, rsub = tid >> 3;
+  const int r_begin = blockIdx.x * p.rows_per_block;
+  const int r_end = min(p.M, r_begin + p.rows_per_block);
+  // the first row of this thread is in flight while the forward statistics arrive (two dependent round trips otherwise)
+  BnBwdRaw first;
+  const bool has_first = r_begin + rsub < r_end;
+  if (has_first) bn_bwd_issue(p, (size_t)(r_begin + rsub) * p.C + c_base + ch * 8, first);
   if (tid < 64) { float m, v; bn_mean_var(p.s, c_base + tid, 0.f, m, v); mean[tid] = m; rstd[tid] = rsqrtf(v + 1e-5f); }
   __syncthreads();
-  const int ch = tid & 7, rsub = tid >> 3;
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-  const int r_begin = blockIdx.x * p.rows_per_block;
-  const int r_end = min(p.M, r_begin + p.rows_per_block);
   for (int row = r_begin + rsub; row < r_end; row += 32) {
     float xv[8], g[8];
-    bn_bwd_load(p, (size_t)row * p.C + c_base + ch * 8, xv, g);
+    if (row == r_begin + rsub) bn_bwd_finish(p, first, xv, g);
+    else bn_bwd_load(p, (size_t)row * p.C + c_base + ch * 8, xv, g);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       s1[j] += g[j];
@@ -155,6 +171,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
   const int c_base = blockIdx.y * 64, m0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
   const float inv_m = 1.f / (float)p.M;
+  // Everything this workgroup reads is addressed by its block index alone, so all of it is requested up front: its two rows of the
+  // tile, the forward statistics and gamma of its 64 channels, the replicas of the two backward sums.  Written in the order they are
+  // consumed (sums -> barrier -> statistics -> barrier -> tile) this was three dependent memory round trips in a 7 us kernel.
+  BnBwdRaw raw[2];
+  size_t offs[2];
+  bool in[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = it * 256 + tid, row = e >> 3, ch = e & 7;
+    const int m = m0 + row;
+    offs[it] = (size_t)m * p.C + c_base + ch * 8;
+    in[it] = m < p.M;
+    if (in[it]) bn_bwd_issue(p, offs[it], raw[it]);
+  }
+  float fm = 0.f, fv = 0.f, gam = 0.f;
+  if (tid < 64) { bn_mean_var(p.s, c_base + tid, 0.f, fm, fv); gam = p.s.gamma[c_base + tid]; }
   {
     // the replicas of the two sums: four threads per channel take every fourth replica (a chain of rep loads otherwise)
     const int c = c_base + (tid & 63), q = tid >> 6;
@@ -167,25 +199,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
   __syncthreads();
   if (tid < 64) {
     const int c = c_base + tid;
-    float m, v;
-    bn_mean_var(p.s, c, 0.f, m, v);
-    const float rs = rsqrtf(v + 1e-5f);
+    const float rs = rsqrtf(fv + 1e-5f);
     const float dbeta = (part[0][0][tid] + part[0][1][tid]) + (part[0][2][tid] + part[0][3][tid]);
     const float dgamma = (part[1][0][tid] + part[1][1][tid]) + (part[1][2][tid] + part[1][3][tid]);
-    mean[tid] = m; rstd[tid] = rs;
-    k1[tid] = p.s.gamma[c] * rs; k2[tid] = dbeta * inv_m; k3[tid] = dgamma * inv_m;
+    mean[tid] = fm; rstd[tid] = rs;
+    k1[tid] = gam * rs; k2[tid] = dbeta * inv_m; k3[tid] = dgamma * inv_m;
     if (blockIdx.x == 0 && p.dgamma) { p.dgamma[c] = dgamma * p.inv_scale[0]; p.dbeta[c] = dbeta * p.inv_scale[0]; }
   }
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    const int e = it * 256 + tid, row = e >> 3, ch = e & 7;
-    const int m = m0 + row;
-    const size_t off = (size_t)m * p.C + c_base + ch * 8;
+    const int ch = (it * 256 + tid) & 7;
+    const size_t off = offs[it];
     bf16x8 o, om;
-    if (m < p.M) {
+    if (in[it]) {
       float xv[8], g[8];
-      bn_bwd_load(p, off, xv, g);
+      bn_bwd_finish(p, raw[it], xv, g);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = ch * 8 + j;

@@ -402,21 +402,30 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];            // scale[C] shift[C] (+ scale_r[C] shift_r[C])
   float* sc = sm; float* sh = sm + p.C; float* scr = sm + 2 * p.C; float* shr = sm + 3 * p.C;
   const float inv_m = 1.f / (float)p.M;
+  const int cpr = p.C >> 3;                 // 16-B chunks per row
+  const size_t total = (size_t)p.Mpad * cpr;
+  // the thread's first chunk (in the layers where the launch latency counts, its only one) is requested BEFORE the statistics the
+  // table is built from: one memory round trip instead of two dependent ones
+  size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  half8 x, rr;
+  auto issue = [&](size_t i) {
+    const size_t row = i / cpr; const int c0 = (int)(i % cpr) * 8;
+    if (row < (size_t)p.M) {
+      x = *reinterpret_cast<const half8*>(p.a.x + row * p.C + c0);
+      if (p.r.x) rr = *reinterpret_cast<const half8*>(p.r.x + row * p.C + c0);
+      else if (p.res) rr = *reinterpret_cast<const half8*>(p.res + row * p.C + c0);
+    }
+  };
+  if (idx < total) issue(idx);
   for (int c = threadIdx.x; c < p.C; c += 256) {
     bn_scale_shift(p.a, c, inv_m, sc[c], sh[c]);
     if (p.r.x) bn_scale_shift(p.r, c, inv_m, scr[c], shr[c]);
   }
   __syncthreads();
-  const int cpr = p.C >> 3;                 // 16-B chunks per row
-  const size_t total = (size_t)p.Mpad * cpr;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+  while (idx < total) {
     const size_t row = idx / cpr; const int c0 = (int)(idx % cpr) * 8;
     half8 o;
     if (row < (size_t)p.M) {
-      const half8 x = *reinterpret_cast<const half8*>(p.a.x + row * p.C + c0);
-      half8 rr;
-      if (p.r.x) rr = *reinterpret_cast<const half8*>(p.r.x + row * p.C + c0);
-      else if (p.res) rr = *reinterpret_cast<const half8*>(p.res + row * p.C + c0);
       // the 8 scale / shift values of this thread as two 16-byte LDS reads each: element-wise reads put the lanes of a wave 32 bytes
       // apart on every access, an 8-way bank conflict (SQ_LDS_BANK_CONFLICT was 83 % of the kernel's LDS cycles)
       float scv[8], shv[8], scrv[8], shrv[8];
@@ -445,6 +454,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
       for (int j = 0; j < 8; ++j) ob[j] = (bf16_t)(float)o[j];
       *reinterpret_cast<bf16x8*>(p.out_bf + row * p.C + c0) = ob;
     }
+    idx += (size_t)gridDim.x * 256;
+    if (idx < total) issue(idx);
   }
 }
 
