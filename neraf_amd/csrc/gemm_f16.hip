@@ -705,6 +705,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
   const size_t slab = (size_t)p.Mpad * p.Npad;
   const int m = m0 + row, n = n0 + c4;
   const float* src = p.splitk_ws + (size_t)grp * splits * slab + (size_t)m * p.Npad + n;
+  // every optional operand of the epilogue is requested BEFORE the slab sums (their addresses depend on the thread alone): behind the
+  // uniform branches below each was a further dependent memory round trip of a 6 us kernel
+  f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f}, mu = bias4, var = bias4;
+  E4 mk_l, ad, mk_b;
+  half4 xv;
+  if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+  if (p.lmask) mk_l = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.lmask) + (size_t)m * p.ldmask + n);
+  if (p.add16) ad = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.add16) + (size_t)m * p.ldadd + n);
+  if (p.bnb_mask) mk_b = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.bnb_mask) + (size_t)m * p.ldbnb + n);
+  if (p.bnb_x) {
+    xv = *reinterpret_cast<const half4*>(p.bnb_x + (size_t)m * p.ldbnb + n);
+    mu = *reinterpret_cast<const f32x4*>(p.bnb_fin + n);
+    var = *reinterpret_cast<const f32x4*>(p.bnb_fin + p.bnb_cpad + n);
+  }
   f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
   int s = 0;
   for (; s + 8 <= splits; s += 8) {
@@ -716,23 +730,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
   }
   for (; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * slab);
   v *= alpha;
-  if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+  if (p.bias) v += bias4;
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act);
   if (p.lmask) {
-    const E4 mk = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.lmask) + (size_t)m * p.ldmask + n);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] *= ((float)mk[r] > 0.f) ? 1.f : p.mask_slope;
+    for (int r = 0; r < 4; ++r) v[r] *= ((float)mk_l[r] > 0.f) ? 1.f : p.mask_slope;
   }
   if (p.add16) {
-    const E4 ad = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.add16) + (size_t)m * p.ldadd + n);
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] += (float)ad[r];
   }
   if (p.bnb_mask) {
-    const E4 mk = *reinterpret_cast<const E4*>(reinterpret_cast<const E*>(p.bnb_mask) + (size_t)m * p.ldbnb + n);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) if (!((float)mk[r] > 0.f)) v[r] = 0.f;
+    for (int r = 0; r < 4; ++r) if (!((float)mk_b[r] > 0.f)) v[r] = 0.f;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -741,9 +752,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
   }
   __shared__ float tile2[32][33];                 // g * xhat (fused BatchNorm-backward sums): one coalesced 8-byte load per thread
   if (p.bnb_x) {
-    const half4 xv = *reinterpret_cast<const half4*>(p.bnb_x + (size_t)m * p.ldbnb + n);
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bnb_fin + n);
-    const f32x4 var = *reinterpret_cast<const f32x4*>(p.bnb_fin + p.bnb_cpad + n);
 #pragma unroll
     for (int r = 0; r < 4; ++r) tile2[row][c4 + r] = v[r] * (((float)xv[r] - mu[r]) * rsqrtf(var[r] + 1e-5f));
   }
