@@ -16,4 +16,4 @@ for h in hist:
     print(f"step {h[0]:4d} loss {h[1]:.6f} scale {h[3]:.0f} " + " ".join(f"{k}={v:.3e}" for k, v in h[2].items()))
 bad = [n_ for n_, p in list(js.vm.named_parameters()) + list(js.am.named_parameters()) if not bool(torch.isfinite(p).all())]
 print("non-finite parameters:", bad)
-print("optimizer steps taken per parameter group:", [[float(o.group_steps(gi).max()) for gi in range(len(o.param_groups))] for o in js.optimizers.steppers], "of", n)
+print("optimizer steps taken per parameter group:", [[float(o.group_steps(gi).max()) for gi in range(len(o.param_groups))] for o in js.optimizers], "of", n)
