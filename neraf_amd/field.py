@@ -25,7 +25,16 @@ from . import _lib
 N_QUERY = 163  # 21 (time) + 63 (mic) + 63 (source) + 16 (SH rot)  NeRAF_model.py:169-171
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream_ptr() -> C.c_void_p:
+    """The current torch stream of the current device as the ABI's ``neraf_stream_t``.  ``torch.cuda.current_stream()`` builds a
+    Stream object per call (~10 us; a training step asks a few hundred times, one audio eval call twice): the raw-handle query torch
+    itself uses is ~1 us."""
+    if _raw_stream is not None and _raw_device is not None:
+        return C.c_void_p(_raw_stream(_raw_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
