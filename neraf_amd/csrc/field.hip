@@ -81,15 +81,45 @@ __device__ __forceinline__ float proposal_point(const PropArgs& a, const unsigne
       enc[l] = half2v{(half_t)f0, (half_t)f1};               // tcnn hands fp16 features to the MLP
     }
   }
-  float out = 0.f;
+  // 2 NL -> 16 (ReLU) -> 1 on the matrix pipe: v_mfma_f32_4x4x4_16b_f16 is sixteen independent 4 x 4 x 4 products per wave with
+  // A = (lane % 4 = row, 4 k-values per lane) and D = (lane % 4 = column, 4 rows per lane) inside each group of four lanes
+  // (tools/microbench/mfma4_layout.hip).  Rows = the four SAMPLES of a lane quad (a lane's own features are its A row: no cross-lane
+  // traffic to form the operands), columns = four hidden units, B = their weights (the same for every quad, read from LDS by
+  // lane % 4).  Four column groups x ceil(2 NL / 4) k-steps = 12 MFMAs for NL = 5 instead of 80 v_dot2c; lane (quad, j) then holds
+  // hidden units {j, 4 + j, 8 + j, 12 + j} of its quad's four samples, and a two-step transpose-reduce over the quad (DPP) leaves
+  // every lane with the layer-2 sum of its own sample.
+  constexpr int NS = (2 * NL + 3) / 4;
+  typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+  half4v av[NS];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    float h = 0.f;
-#pragma unroll
-    for (int l = 0; l < NL; ++l) h = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w0h[j][l]), enc[l], h, false);
-    h = fmaxf(h, 0.f);
-    out = fmaf(w1[j], h, out);
+  for (int ks = 0; ks < NS; ++ks) {
+    const half2v lo = enc[2 * ks], hi = (2 * ks + 1 < NL) ? enc[2 * ks + 1] : half2v{(half_t)0.f, (half_t)0.f};
+    av[ks] = half4v{lo[0], lo[1], hi[0], hi[1]};
   }
+  const unsigned j = threadIdx.x & 3u;
+  const char* wrow = reinterpret_cast<const char*>(&w0h[0][0]) + j * 32u;      // row (4 g + j) of the [16][16] fp16 layer-0 matrix
+  float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      const half4v bv = *reinterpret_cast<const half4v*>(wrow + g * 128 + ks * 8);
+      acc = __builtin_amdgcn_mfma_f32_4x4x4f16(av[ks], bv, acc, 0, 0, 0);
+    }
+    const float wj = w1[4 * g + j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = fmaf(wj, fmaxf(acc[i], 0.f), p[i]);
+  }
+  // p[i] = this lane's four hidden units' share of sample i of the quad; sum over the quad's lanes, sample j stays in lane j
+  const bool o1 = (j & 1u) != 0u, o2 = (j & 2u) != 0u;
+  float k0 = o1 ? p[1] : p[0], k1 = o1 ? p[3] : p[2];
+  const float s0 = o1 ? p[0] : p[1], s1 = o1 ? p[2] : p[3];
+  k0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  k1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, false));
+  float out = o2 ? k1 : k0;
+  const float snd = o2 ? k0 : k1;
+  out += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, snd), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
   return sel ? a.avg_density * __expf(out) : 0.f;
 }
 
@@ -103,15 +133,17 @@ __global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
   if (threadIdx.x < 16) w1[threadIdx.x] = (float)a.w[256 + threadIdx.x];
   __syncthreads();
   const unsigned S = (unsigned)a.S;
-  const unsigned n = blockIdx.x * 256u + threadIdx.x;
+  unsigned n = blockIdx.x * 256u + threadIdx.x;
+  const bool valid = n < (unsigned)a.R * S;
+  if (!valid) n = (unsigned)a.R * S - 1u;            // the layer arithmetic runs on whole lane quads (MFMA + DPP): compute, do not store
   const unsigned ray = fastdiv(n, a.divS), s = n - ray * S;
-  if (ray >= (unsigned)a.R) return;
   const unsigned eb = ray * a.e_stride + s;
   const float t = 0.5f * (a.e_bins[eb] + a.e_bins[eb + 1u]);
   const float x = fmaf(a.dirs[ray * 3u + 0u], t, a.origins[ray * 3u + 0u]);
   const float y = fmaf(a.dirs[ray * 3u + 1u], t, a.origins[ray * 3u + 1u]);
   const float z = fmaf(a.dirs[ray * 3u + 2u], t, a.origins[ray * 3u + 2u]);
-  a.density[n] = proposal_point<NL>(a, w0h, w1, x, y, z);
+  const float dens = proposal_point<NL>(a, w0h, w1, x, y, z);
+  if (valid) a.density[n] = dens;
 }
 
 // Frame form (coherent rays: the chunks of a camera frame; S % 16 == 0).  A wave owns a TILE of 64 neighbouring rays (an 8 x 8 pixel
