@@ -282,7 +282,11 @@ __global__ __launch_bounds__(256) void pdf_resample_kernel(PdfArgs a) {
     const int i = lane * per + k;
     if (k < per && i < S) { c += wts[k]; cdf[i + 1] = fminf(1.f, c); }
   }
-  __syncthreads();   // uniform: every wave of the block reaches it
+  // cdf / bins are per-wave arrays: the wave's own LDS operations execute in order, so no workgroup barrier is needed -- only that the
+  // compiler keeps the stores above the loads below (a barrier here made the four waves of a block wait for the slowest ray)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   // --- inverse-CDF sampling of n_new+1 bin edges
   const int nb = a.n_new + 1;
   const float sn = spacing_fn(a.near), sf = spacing_fn(a.far);
