@@ -517,6 +517,10 @@ int neraf_gather_f16(neraf_ctx* ctx, const float* const* src, const long long* s
  * output of convolution `index`; 6: fp32 [2][cols] batch mean / biased variance of BatchNorm `index`. */
 int neraf_resnet3d_debug_locate(const neraf_resnet3d_desc* d, int kind, int index, size_t* offset, int* rows, int* cols);
 
+/* Test hook (host only, no GPU needed): n / d as the gather kernels compute it -- the division-by-invariant constants of csrc/field_common.h
+ * (make_fastdiv) with the multiply-high evaluated on the host.  d == 0 returns 0xFFFFFFFF. */
+uint32_t neraf_debug_fastdiv(uint32_t n, uint32_t d);
+
 /* ------------------------------------------------------------------------------------
  * Optimizer step (SURVEY 8f "optimizer fusion"): torch.optim.Adam as nerfstudio's Optimizers apply it to the
  * `fields` and `audio_fields` groups (NeRAF_config.py:116-127), one launch per optimizer.  `table` is a device

@@ -175,6 +175,7 @@ SIGNATURES = {
                                             C.c_void_p, C.c_void_p]),
     "neraf_cvt_f16_segments": (C.c_int, [C.c_void_p, c_fpp, c_fpp, C.POINTER(C.c_longlong), C.c_int, C.c_void_p]),
     "neraf_gather_f16": (C.c_int, [C.c_void_p, c_fpp, C.POINTER(C.c_longlong), C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "neraf_debug_fastdiv": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "neraf_resnet3d_debug_locate": (C.c_int, [C.POINTER(ResnetDesc), C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int),
                                               C.POINTER(C.c_int)]),
     "neraf_debug_conv_bn_relu_stage": (C.c_int, [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 11),

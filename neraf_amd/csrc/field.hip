@@ -722,6 +722,15 @@ extern "C" int neraf_grid_refresh_write(neraf_ctx* ctx, const float* rgb, const 
   return NERAF_OK;
 }
 
+// Host-side evaluation of the kernels' division-by-invariant (make_fastdiv + the arithmetic of fastdiv, with the multiply-high as a
+// 64-bit product): lets a CPU test check the Granlund-Montgomery constants against n / d for any 32-bit n.
+extern "C" uint32_t neraf_debug_fastdiv(uint32_t n, uint32_t d) {
+  if (d == 0) return 0xFFFFFFFFu;
+  const FastDiv f = make_fastdiv(d);
+  const uint32_t t = (uint32_t)(((uint64_t)f.m * (uint64_t)n) >> 32);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 extern "C" int neraf_grid_layout(const neraf_grid_desc* g, float* scales, int* resolutions, uint32_t* sizes,
                                  uint32_t* offsets) {
   GridLayout L;
