@@ -25,6 +25,10 @@ echo "SQ2 rc=$?"
 cd $R
 f=$(find gpurun_out/prof/$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -121 $f > profiles/${TAG}_${NAME}_kernel_stats.csv && echo "stats -> profiles/${TAG}_${NAME}_kernel_stats.csv"
+if [ "$MODE" != "eval" ]; then     # the same statistics over the timed (steady-state) steps alone
+  t=$(find gpurun_out/prof/$TAG -name "*kernel_trace.csv" | head -1)
+  [ -n "$t" ] && python3 tools/steady_state_stats.py $t $STEPS profiles/${TAG}_${NAME}_steady_state_kernel_stats.csv | tee profiles/${TAG}_${NAME}_steady_state_summary.txt
+fi
 tail -1 gpurun_out/prof/$TAG.log | head -c 400 > /dev/null
 grep -h '"metric"' gpurun_out/prof/$TAG.log | tail -1 > profiles/${TAG}_${NAME}_bench_under_rocprof.json
 if [ "$MODE" = "eval" ]; then PT=${TAG}_eval; else PT=$TAG; fi
