@@ -182,6 +182,27 @@ def test_split_forward_backward_vs_oracle(dev, B, C_, F_, T_):
         assert rel_l2(p.grad, sdo[name].grad) <= GRAD_REL_L2, name
 
 
+def test_shared_pose_row_equals_expanded_rows(dev):
+    """The eval branch hands forward_queries ONE (microphone, source, orientation) for the T time queries of a RIR
+    (neraf_nacf_encode_queries_ex, pose_rows = 1): the same bits as the reference's [T,3] expansions (NeRAF_model.py:676-678), with and
+    without a graph being recorded."""
+    f, _ = _make_field(1, 513, dev)
+    T_ = 60
+    b = synth.audio_batch(4, 1, 513, T_, tag="t.shared_pose")
+    aabb = T(synth.audio_aabb())
+    feat = T(synth.uniform("t.feat", (1024,), 0.0, 2.0)).to(dev)
+    tq = torch.arange(T_, device=dev)
+    mic, src, rot = (T(b[k][2]).to(dev).reshape(1, 3) for k in ("mic_pose", "source_pose", "rot"))
+    with torch.no_grad():
+        y1 = f.forward_queries(feat, tq, mic, src, rot, aabb, T_)
+        yT = f.forward_queries(feat, tq, mic.expand(T_, -1), src.expand(T_, -1), rot.expand(T_, -1), aabb, T_)
+    assert y1.shape == (T_, 1, 513) and torch.equal(y1, yT)
+    yg = f.forward_queries(feat.clone().requires_grad_(True), tq, mic, src, rot, aabb, T_)          # through the autograd node
+    assert torch.allclose(yg.detach(), y1, rtol=0, atol=2e-3)       # training-mode packing of the same weights
+    with pytest.raises(ValueError):
+        f.forward_queries(feat, tq, mic, src.expand(T_, -1), rot, aabb, T_)
+
+
 def test_split_equals_dense(dev):
     """Layer-0 split + GPU encodings == dense path on h = cat[feat, oracle encodings] (NeRAF_model.py:560)."""
     from oracle import audio as O
