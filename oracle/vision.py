@@ -28,6 +28,15 @@ from .audio import sh4_encoding
 Tensor = torch.Tensor
 PRIMES = (1, 2654435761, 805459861)
 
+# Precision-sensitivity probe (oracle/trainer.py ``OracleTrainer(probe=...)``; None = plain fp32): applied to the interpolated
+# hash encodings and to every hidden / output activation of the fused MLPs -- the places where tiny-cuda-nn's half-precision
+# FullyFusedMLP / HashGrid (and the HIP kernels) store 16-bit values.
+PROBE_ACT = None
+
+
+def _pa(t: Tensor) -> Tensor:
+    return PROBE_ACT(t) if PROBE_ACT is not None else t
+
 
 # ---------------------------------------------------------------------------
 # tiny-cuda-nn multiresolution hash grid  [TCNN-recall]
@@ -96,7 +105,7 @@ def hash_encode(x01: Tensor, table: Tensor, spec: GridSpec) -> Tensor:
             idx = (idx & 0xFFFFFFFF) % size
             acc = acc + w[:, None].to(table.dtype) * table[off + idx]
         outs.append(acc)
-    return torch.cat(outs, dim=-1)
+    return _pa(torch.cat(outs, dim=-1))
 
 
 def tcnn_mlp(x: Tensor, weights: List[Tensor]) -> Tensor:
@@ -108,6 +117,7 @@ def tcnn_mlp(x: Tensor, weights: List[Tensor]) -> Tensor:
         x = x @ w.t()
         if i + 1 < len(weights):
             x = F.relu(x)
+        x = _pa(x)
     return x
 
 

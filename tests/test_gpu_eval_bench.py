@@ -102,6 +102,13 @@ def test_measure_eval_reports_the_reference_keys(er):
     # 22 launches per frame; algorithmic bytes = samples x 512 B
     assert abs(fq["launches_per_step"] - 22) < 1e-9
     np.testing.assert_allclose(fq["work_per_step"], 700416 * 48 * 512, rtol=1e-12)
+    # every family is priced against the resource that bounds it: the proposal tables are L2-resident (bound "l2"), the main table is
+    # not (bound "hbm"); no fraction above 1; the eval roofline's headline is the HBM-priced field query
+    pd = next(f for f in fams if f["kernel"].startswith("proposal_density_kernel"))
+    assert pd["bound"] == "l2" and pd["peak"] == bench.L2_PEAK_GBS and fq["bound"] == "hbm"
+    assert all(0.0 < f["frac"] <= 1.0 for f in fams), [(f["kernel"], f["frac"]) for f in fams]
+    rf = bench.eval_roofline(fams)
+    assert rf["bound"] == "hbm" and rf["kernel"].startswith("field_query_kernel") and 0.0 < rf["frac"] <= 1.0
 
 
 def test_camera_rays_kernel_equals_the_tensor_expression():

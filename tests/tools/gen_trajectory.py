@@ -3,6 +3,8 @@
 trajectory scenario (tests/tools/trajectory_common.py), then evaluated on a held-out camera and two held-out RIRs.
 
     python tests/tools/gen_trajectory.py [--scenario g7_trajectory|g8_trajectory_pose] [--threads 8] [--probe]
+    python tests/tools/gen_trajectory.py --scenario g9_long --part main|params16|acts16|resnet_grad_bf16 --parts-dir DIR   (one run, one file)
+    python tests/tools/gen_trajectory.py --scenario g9_long --merge --parts-dir DIR                                         (parts -> fixture)
 
 Stored: per-iteration loss-dict curves, the rendered held-out image + its analytic ground truth, the predicted log-magnitude STFTs
 [T, C, F] of the held-out RIRs + their ground truth, scalar summaries.  ``--probe`` additionally trains the SAME oracle with its
@@ -26,10 +28,13 @@ import trajectory_common as TC  # noqa: E402
 from oracle.trainer import OracleTrainer  # noqa: E402
 
 
-def run(fp16_params: bool, log, cfg):
+def run(fp16_params, log, cfg):
+    """``fp16_params``: False (the fp32 oracle), True (== "params16") or the name of a probe of OracleTrainer."""
+    probe = "params16" if fp16_params is True else (fp16_params or None)
+    fp16_params = probe is not None
     P, sdn, sdr = TC.initial_weights()
     tr = OracleTrainer(P, sdn, sdr, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), TC.T(TC.synth.audio_aabb()), cfg["grid_step"], cfg["T"],
-                       cfg["start_step_audio"], cfg["R"], fp16_params=fp16_params,
+                       cfg["start_step_audio"], cfg["R"], probe=probe,
                        num_cameras=cfg["n_cam"] if cfg.get("camera_opt") else 0)
     bank = TC.rir_bank(cfg["n_rir"], cfg["tag"] + ".train")
     keys = ["rgb_loss", "interlevel_loss", "distortion_loss", "audio_sc_loss", "audio_mag_loss", "loss", "proposal_updated"]
@@ -39,7 +44,7 @@ def run(fp16_params: bool, log, cfg):
         r = tr.train_iteration(s, TC.ray_batch(s), TC.audio_batch(s, bank))
         curves[s] = [r.get(k, np.nan) for k in keys]
         if s % 10 == 0 or s == cfg["steps"] - 1:
-            log(f"[{'fp16-param probe' if fp16_params else 'fp32'}] step {s} {time.time() - t0:.0f}s " +
+            log(f"[{probe or 'fp32'}] step {s} {time.time() - t0:.0f}s " +
                 " ".join(f"{k}={r[k]:.5f}" for k in keys[:5] if k in r))
     ev = TC.synth.trajectory_eval_camera(*cfg["eval_hw"], tag=cfg["tag"])
     img = tr.render(TC.T(ev["origins"]), TC.T(ev["directions"])).reshape(*cfg["eval_hw"], 3).numpy()
@@ -63,12 +68,48 @@ def main():
     ap.add_argument("--probe", action="store_true")
     ap.add_argument("--scenario", default="g7_trajectory", choices=sorted(TC.SCENARIOS))
     ap.add_argument("--out", default=None)
+    ap.add_argument("--part", default=None, choices=["main", "params16", "acts16", "resnet_grad_bf16"],
+                    help="run ONE oracle variant and write DIR/<scenario>.<part>.npz (long scenarios: one process per variant)")
+    ap.add_argument("--parts-dir", default="/tmp/trajectory_parts")
+    ap.add_argument("--merge", action="store_true", help="assemble the fixture from the part files in --parts-dir")
+    ap.add_argument("--steps", type=int, default=None, help="override the scenario's iteration count (experiments only)")
     a = ap.parse_args()
     if a.out is None:
         a.out = os.path.join(ROOT, "tests", "golden", a.scenario + ".npz")
     torch.set_num_threads(a.threads)
     log = lambda m: print(m, flush=True)      # noqa: E731
-    cfg = TC.SCENARIOS[a.scenario]
+    cfg = dict(TC.SCENARIOS[a.scenario])
+    if a.steps is not None:
+        cfg["steps"] = a.steps
+    if a.part is not None:
+        os.makedirs(a.parts_dir, exist_ok=True)
+        r = run(False if a.part == "main" else a.part, log, cfg)
+        f = os.path.join(a.parts_dir, f"{a.scenario}.{a.part}.npz")
+        np.savez_compressed(f, **r)
+        log(f"wrote {f}")
+        return
+    if a.merge:
+        m = np.load(os.path.join(a.parts_dir, f"{a.scenario}.main.npz"))
+        out = {"steps": cfg["steps"], "R": cfg["R"], "B": cfg["B"], "start_step_audio": cfg["start_step_audio"],
+               "camera_opt": int(bool(cfg.get("camera_opt"))), "keys": m["keys"], "curves": m["curves"], "image": m["image"],
+               "stft": m["stft"], "stft_batch_stats": m["stft_batch_stats"], "gt_image": m["gt_image"],
+               "gt_stft": m["gt_stft"].astype(np.float32)}
+        probes = []
+        for name in ("params16", "acts16", "resnet_grad_bf16"):
+            f = os.path.join(a.parts_dir, f"{a.scenario}.{name}.npz")
+            if not os.path.exists(f):
+                continue
+            p = np.load(f)
+            probes.append(name)
+            pre = "probe_" if name == "params16" else f"probe_{name}_"      # "probe_*" = the fp16-parameter probe, as in G7 / G8
+            out.update({pre + "curves": p["curves"], pre + "image": p["image"], pre + "stft": p["stft"],
+                        pre + "stft_batch_stats": p["stft_batch_stats"]})
+            log(f"{name} vs fp32 oracle: image PSNR {TC.psnr(p['image'], m['image']):.2f} dB, STFT rel-L2 "
+                f"{float(np.linalg.norm(p['stft'] - m['stft']) / np.linalg.norm(m['stft'])):.4f}")
+        out["probes"] = np.array(probes)
+        np.savez_compressed(a.out, **out)
+        log(f"wrote {a.out} ({os.path.getsize(a.out) / 1e3:.0f} kB)")
+        return
     main_run = run(False, log, cfg)
     out = {"steps": cfg["steps"], "R": cfg["R"], "B": cfg["B"], "start_step_audio": cfg["start_step_audio"],
            "camera_opt": int(bool(cfg.get("camera_opt"))), "keys": main_run["keys"],
