@@ -436,7 +436,13 @@ int neraf_resnet3d_update_running_stats(neraf_ctx* ctx, const neraf_resnet3d_des
  * w_grads (HOST array, 43 device pointers shaped like the Conv3d weights, overwritten) and bn_grads (HOST
  * array, 2 per BatchNorm3d: d weight, d bias).  If n_cells > 0 the gradient w.r.t. channels [0, n_ch) of
  * the grid cells [cell_start, cell_start+n_cells) (flat x-major index, the refresh window of
- * NeRAF_model.py:306-311) is written to dgrid_cells fp32 [n_ch, n_cells]. */
+ * NeRAF_model.py:306-311) is written to dgrid_cells fp32 [n_ch, n_cells].
+ * The gradient chain is fp16 with fp32 accumulation (the reference's AMP, NeRAF_config.py:79) under per-tensor power-of-two scales
+ * that live in bwd_workspace and follow the amax each tensor's producer recorded in the previous call (delayed scaling); the first
+ * call on a workspace first repeats the chain as calibration passes until none of its tensors overflows.  neraf_resnet3d_bwd_reset forgets a workspace's calibration (call it
+ * when the buffer is (re)allocated or the weights are replaced wholesale); neraf_resnet3d_bwd_chain_state is a test aid: exponent
+ * and last recorded amax of the first n chain tensors, info2 = {tensors unsettled in the pass before the last, passes run} (HOST
+ * arrays; synchronises the stream). */
 size_t neraf_resnet3d_bwd_packed_bytes(const neraf_resnet3d_desc* d);
 size_t neraf_resnet3d_bwd_workspace_bytes(const neraf_resnet3d_desc* d);
 int neraf_resnet3d_pack_weights_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const float* const* conv_w, void* packed_t,
@@ -445,6 +451,9 @@ int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void*
                        const float* const* bn, void* workspace, void* bwd_workspace, const float* dfeat,
                        float* const* w_grads, float* const* bn_grads, size_t cell_start, int n_cells, int n_ch,
                        float* dgrid_cells, neraf_stream_t stream);
+int neraf_resnet3d_bwd_reset(neraf_ctx* ctx, void* bwd_workspace);
+int neraf_resnet3d_bwd_chain_state(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* bwd_workspace, int32_t* e_out,
+                                   float* amax_out, int n, int32_t* info2, neraf_stream_t stream);
 
 /* Test aid: one conv + BatchNorm(train) + ReLU stage, forward and backward on caller data (allocates and
  * synchronises internally; not part of the product path). */

@@ -159,6 +159,9 @@ SIGNATURES = {
     "neraf_resnet3d_bwd_packed_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),
     "neraf_resnet3d_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),
     "neraf_resnet3d_pack_weights_bwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), c_fpp, C.c_void_p, C.c_void_p]),
+    "neraf_resnet3d_bwd_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "neraf_resnet3d_bwd_chain_state": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                                 C.c_int, C.POINTER(C.c_int32), C.c_void_p]),
     "neraf_resnet3d_bwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, c_fpp, c_fpp, C.c_void_p, C.c_void_p,
                                      C.c_void_p, c_fpp, c_fpp, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "neraf_camera_rays": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
@@ -194,8 +197,15 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C neraf_amd/csrc`).  neraf_amd has no CPU / eager fallback by design.")
     lib = C.CDLL(LIB_PATH)
+    variant = "NERAF_HIP_LIB" in os.environ     # A/B measurements against an older build: entries it lacks become no-ops returning 0
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        try:
+            fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        except AttributeError:
+            if not variant:
+                raise
+            setattr(lib, name, lambda *a, **k: 0)
+            continue
         fn.restype = res
         fn.argtypes = args
     if lib.neraf_abi_version() != 1:

@@ -226,7 +226,7 @@ struct GemmParams {
   int tile_n;                        // 0 = auto; 64 forces the 128x64 tile (Cout = 64 layers)
   double alg_flops;                  // ALGORITHMIC FLOPs of the operation this GEMM implements (a convolution's
                                      // 2 dout^3 taps cin cout, also for its transposed form); 0 = 2 M N K.  Profiling only.
-  int bf16;                          // 1: every 16-bit operand/result (A, B, lmask, add16, C16, C16T) is bfloat16 (gradient chains)
+  int bf16;                          // 1: every 16-bit operand/result (A, B, lmask, add16, C16, C16T) is bfloat16 (exported for tests)
   // grouped launch (plain loader, fp32 results only): ngroups > 1 runs ngroups GEMMs of identical padded shape (Mpad, Npad, K,
   // lda, ldb) in one grid; group g takes A/B/C32/M/N/ldc32 from grp[g].  Used for the small-output weight gradients.
   int ngroups;
@@ -240,11 +240,15 @@ int launch_gemm_f16(neraf_ctx* ctx, const GemmParams& p, hipStream_t stream);
 // here and computed by TWO launches at the end of the pass (the TN GEMM over every (convolution, tile, K-split), then one
 // reducer that also writes the PyTorch layout [cout][cin_real][taps]) instead of up to three launches per convolution.
 struct WgradItem {
-  const bf16_t* dy;      // [K rows = voxels (padded)][cout] gradient w.r.t. the conv output
-  const bf16_t* x;       // [din^3][cin] bfloat16 shadow of the conv input
+  const void* dy;        // [K rows = voxels (padded)][cout] gradient w.r.t. the conv output (fp16, or bf16 with `bf16` below)
+  const void* x;         // [din^3][cin] the conv input in the same 16-bit type (fp16: the forward's own activation tensor)
   float* out;            // fp32 [cout][cin_real][taps]
   int cout, cin, cin_real, ksize, stride, pad, din, dout;
   int K;                 // voxel rows of dy (multiple of 64)
+  int alpha_idx;         // the result is multiplied by alpha_dev[alpha_idx] (1 / scale of this item's dy tensor: the fp16 chain's groups)
 };
 int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const half_t* zero_page, float* slab_ws, size_t slab_bytes,
-                         const float* alpha_dev, hipStream_t stream);
+                         const float* alpha_dev, hipStream_t stream, bool bf16 = false);
+
+constexpr int kAmaxRep = 32, kAmaxStride = 64;      // amax replicas per scale group of the fp16 gradient chain, 256 bytes apart (same-line atomics serialise)
+

@@ -858,7 +858,7 @@ int launch_wide(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
 }
 
 // ------------------------------------------------------------------------------------------------------
-// "TN" weight-gradient GEMM (bf16): C[m][n] = sum_k A[k][m] * B[row(k, n-tile)][n], 64x64 tile, K-step 64.
+// "TN" weight-gradient GEMM (fp16, or bf16 for the exported test entry): C[m][n] = sum_k A[k][m] * B[row(k, n-tile)][n], 64x64 tile, K-step 64.
 //   A = dY [voxel k][cout] , B = activation [voxel][cin] with the convolution's tap shift applied to the row index, so the
 //   operand tiles are [k][64 x 16-bit] rows exactly as they lie in HBM (no transposed copies, no im2col): LDS-DMA fills the
 //   same 4-stage ring, and both MFMA operands are read with ds_read_b64_tr_b16 (4 k-rows x 16 columns per 16-lane group,
@@ -867,11 +867,11 @@ int launch_wide(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
 // Grouped form: the geometry is taken per workgroup from a descriptor table in the kernel arguments (runtime loader type /
 // filter size), so that every convolution of the network shares one grid.
 struct WgDesc {                       // 64 bytes
-  const bf16_t* dy; const bf16_t* x; float* out;
+  const void* dy; const void* x; float* out;
   unsigned long long slab_off;        // floats, into the shared slab buffer (unused when splits == 1)
   int block_begin; int K;
   unsigned short cout, cin, cin_real, taps, din, tiles_n, splits;
-  unsigned char dl, stride, ksize, loader; signed char pad; unsigned char mh, r1, r2, r3, r4;   // mh: wide kernel, 64-row halves of the M tile (1 | 2)
+  unsigned char dl, stride, ksize, loader; signed char pad; unsigned char mh, ai, r2, r3, r4;   // mh: wide kernel, 64-row halves of the M tile (1 | 2); ai: index of the item's factor in alpha_dev
 };
 static_assert(sizeof(WgDesc) == 64, "descriptor table must fit the 4 KiB kernel-argument segment");
 constexpr int kMaxWg = 48;
@@ -888,8 +888,23 @@ __device__ __forceinline__ size_t wg_out_index(const WgDesc& d, int m, int n) { 
   return ((size_t)m * d.cin_real + c) * d.taps + tap;
 }
 
-template <int NST>
+template <bool BF> struct TrRead;
+template <> struct TrRead<true> {
+  static __device__ __forceinline__ bf16x4 rd(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+  }
+};
+template <> struct TrRead<false> {
+  typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ half4 rd(const char* p) {
+    const fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p);
+    return __builtin_bit_cast(half4, v);
+  }
+};
+
+template <int NST, bool BF>
 __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
+  using E = typename ET<BF>::s; using E4 = typename ET<BF>::v4; using E8 = typename ET<BF>::v8;
   constexpr int BM = 64, BN = 64;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -919,8 +934,8 @@ __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
     lcs[i] = (tid & 7) ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1);
   }
   const int cout = D.cout, cin = D.cin, KS = D.ksize, loader = D.loader, din = D.din, stride = D.stride, pad = D.pad;
-  const bf16_t* Ab = D.dy + bm * BM;
-  const bf16_t* Bb = D.x;
+  const E* Ab = reinterpret_cast<const E*>(D.dy) + bm * BM;
+  const E* Bb = reinterpret_cast<const E*>(D.x);
   int tap_dz = 0, tap_dy = 0, tap_dx = 0, cb = 0;
   if (loader == 1) {
     const int n0 = bn * BN;
@@ -928,7 +943,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
     tap_dz = tap / (KS * KS); tap_dy = (tap / KS) % KS; tap_dx = tap % KS;
   }
   const int dl = D.dl, dmask = (1 << dl) - 1;
-  const bf16_t* zero = reinterpret_cast<const bf16_t*>(t.zero_page);
+  const E* zero = reinterpret_cast<const E*>(t.zero_page);
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -943,7 +958,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = kt * BK + lrow[i];
-      const bf16_t* src;
+      const E* src;
       if (loader == 0) {
         src = Bb + (size_t)m * cin + bn * BN + lcs[i] * 8;
       } else {
@@ -980,7 +995,6 @@ __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
     if (s0 < nk) issue(k_begin + s0, s0);
-  typedef __attribute__((address_space(3))) bf16x4* lds_v4_t;
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const int after = nk - 1 - kt;
@@ -996,13 +1010,13 @@ __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
     char* sb = sa + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[2], fb[2];
+      E8 fa[2], fb[2];
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sa + a_off[f] + ks * 4096));
-        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sa + a_off[f] + ks * 4096 + 512));
-        const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sb + b_off[f] + ks * 4096));
-        const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sb + b_off[f] + ks * 4096 + 512));
+        const E4 a0 = TrRead<BF>::rd(sa + a_off[f] + ks * 4096);
+        const E4 a1 = TrRead<BF>::rd(sa + a_off[f] + ks * 4096 + 512);
+        const E4 b0 = TrRead<BF>::rd(sb + b_off[f] + ks * 4096);
+        const E4 b1 = TrRead<BF>::rd(sb + b_off[f] + ks * 4096 + 512);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { fa[f][e] = a0[e]; fa[f][4 + e] = a1[e]; fb[f][e] = b0[e]; fb[f][4 + e] = b1[e]; }
       }
@@ -1010,14 +1024,14 @@ __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = ET<BF>::mfma(fb[j], fa[i], acc[i][j]);
     }
     if (++stage == NST) stage = 0;
   }
   const int frow = lane & 15, fq = lane >> 4;
   const int N = D.taps * cin, Npad = tiles_n * BN;
   if (splits == 1 && D.taps == 1) {      // 1x1x1: [cout][cin] rows are contiguous; filters with taps go through the row reducer
-    const float alpha = t.alpha_dev ? *t.alpha_dev : 1.f;
+    const float alpha = t.alpha_dev ? t.alpha_dev[D.ai] : 1.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1049,8 +1063,9 @@ __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
 // transposed reads of the kernel above) and every wave owns one 64x64 block of the product -- (A half, B half) = (w >> 1, w & 1)
 // for MH = NH = 2 (cout >= 128) or (0, w) for MH = 1, NH = 4 (the 64-filter convolutions, half of the FLOPs): 32 / 40 KiB per
 // 2.1 MFLOP K-step, 16 transposed reads per 16 MFMAs instead of 16 per 8.
-template <int NST>
+template <int NST, bool BF>
 __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
+  using E = typename ET<BF>::s; using E4 = typename ET<BF>::v4; using E8 = typename ET<BF>::v8;
   constexpr int HALF = 64 * 128;
   constexpr int STAGE_BYTES = 5 * HALF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1100,10 +1115,10 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
     lcs[i] = (tid & 7) ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1);
   }
   const int cout = D.cout, cin = D.cin, KS = D.ksize, loader = D.loader, din = D.din, stride = D.stride, pad = D.pad;
-  const bf16_t* Ab = D.dy + (size_t)bm * MH * 64;
-  const bf16_t* Bb = D.x;
+  const E* Ab = reinterpret_cast<const E*>(D.dy) + (size_t)bm * MH * 64;
+  const E* Bb = reinterpret_cast<const E*>(D.x);
   const int dl = D.dl, dmask = (1 << dl) - 1;
-  const bf16_t* zero = reinterpret_cast<const bf16_t*>(t.zero_page);
+  const E* zero = reinterpret_cast<const E*>(t.zero_page);
   // per B half: filter tap and channel block of its 64 columns (loader 1), validity
   // Per B half (loader 1) or per (row, B half) chunk (loader 2: the tap is the lane's 16-byte chunk): the tap as a packed selector
   // (bit dz | bit 8+dy | bit 16+dx) and as an element offset from the row's base voxel.  A K-step then computes, per staged row, the
@@ -1148,7 +1163,6 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  typedef __attribute__((address_space(3))) bf16x4* lds_v4_t;
 
   auto body = [&](auto mh_c) {
     constexpr int MHc = decltype(mh_c)::value, NHc = MHc == 2 ? 2 : 4, NP = 2 * (MHc + NHc);   // LDS-DMA pieces per thread and stage
@@ -1176,7 +1190,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
         }
 #pragma unroll
         for (int j = 0; j < NHc; ++j) {
-          const bf16_t* src = zero;
+          const E* src = zero;
           if (h_ok[j]) {
             if (loader == 0) {
               src = Bb + (size_t)m * cin + (bnw * NHc + j) * 64 + lcs[i] * 8;
@@ -1206,13 +1220,13 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
       char* sb = smem + stage * STAGE_BYTES + (MHc + hb) * HALF;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 fa[4], fb[4];
+        E8 fa[4], fb[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sa + f_off[f] + ks * 4096));
-          const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sa + f_off[f] + ks * 4096 + 512));
-          const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sb + f_off[f] + ks * 4096));
-          const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(sb + f_off[f] + ks * 4096 + 512));
+          const E4 a0 = TrRead<BF>::rd(sa + f_off[f] + ks * 4096);
+          const E4 a1 = TrRead<BF>::rd(sa + f_off[f] + ks * 4096 + 512);
+          const E4 b0 = TrRead<BF>::rd(sb + f_off[f] + ks * 4096);
+          const E4 b1 = TrRead<BF>::rd(sb + f_off[f] + ks * 4096 + 512);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { fa[f][e] = a0[e]; fa[f][4 + e] = a1[e]; fb[f][e] = b0[e]; fb[f][4 + e] = b1[e]; }
         }
@@ -1220,7 +1234,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = ET<BF>::mfma(fb[j], fa[i], acc[i][j]);
       }
       if (++stage == NST) stage = 0;
     }
@@ -1234,7 +1248,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
   const int N = D.taps * cin, Npad = n64 * 64;
   const int m_base = (bm * MH + ha) * 64, n_base = b64 * 64;
   if (splits == 1 && D.taps == 1) {      // 1x1x1: [cout][cin] rows are contiguous; filters with taps go through the row reducer
-    const float alpha = t.alpha_dev ? *t.alpha_dev : 1.f;
+    const float alpha = t.alpha_dev ? t.alpha_dev[D.ai] : 1.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1310,7 +1324,7 @@ __global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(WgTable t, Wg
     for (int k = 0; k < 4; ++k) blk[taps == 1 ? c + k : (c + k) * pitch + tap] = v[k];
   }
   __syncthreads();
-  const float alpha = r.alpha_dev ? *r.alpha_dev : 1.f;
+  const float alpha = r.alpha_dev ? r.alpha_dev[D.ai] : 1.f;
   const int creal = (D.cin_real - ci0) < CB ? (D.cin_real - ci0) : CB;          // the stem: 7 real channels of 8
   float* dst = D.out + ((size_t)m * D.cin_real + ci0) * taps;
   for (int j = threadIdx.x; j < creal * taps; j += 256) {
@@ -1387,7 +1401,7 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p_in, hipStream_t stream) {
 }  // namespace
 
 int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const half_t* zero_page, float* slab_ws, size_t slab_bytes,
-                         const float* alpha_dev, hipStream_t stream) {
+                         const float* alpha_dev, hipStream_t stream, bool bf16) {
   if (n <= 0 || n > kMaxWg || !items || !zero_page) return neraf_fail(ctx, NERAF_EINVAL, "wgrad_grouped: bad arguments");
   static const int nst = [] { const char* e = getenv("NERAF_WGRAD_NST"); const int v = e ? atoi(e) : 3; return v < 2 ? 2 : (v > 4 ? 4 : v); }();   // 3 stages = 48 KiB: three workgroups per CU (5.42 -> 5.34 ms/step against 4 stages)
   static const int rounds = [] { const char* e = getenv("NERAF_WGRAD_ROUNDS"); return e ? atoi(e) : 8; }();
@@ -1397,11 +1411,13 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
   const int LDS_BYTES = nst * 128 * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128));
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128));
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 128));
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 5 * 8192));
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 5 * 8192));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 128));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 128));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 5 * 8192));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 5 * 8192));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 5 * 8192));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128));
     attr_set = true;
   }
   const int cus = ctx ? ctx->num_cus : 256;
@@ -1428,6 +1444,8 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
       return neraf_fail(ctx, NERAF_EINVAL, "wgrad_grouped: cout % 64, K % 64, power-of-two output edge, cin % 64 (or the 8-channel stem)");
     WgDesc& d = t.d[i];
     d.dy = it.dy; d.x = it.x; d.out = it.out; d.K = it.K;
+    if (it.alpha_idx < 0 || it.alpha_idx > 255) return neraf_fail(ctx, NERAF_EINVAL, "wgrad_grouped: alpha_idx out of range");
+    d.ai = (unsigned char)it.alpha_idx;
     d.cout = (unsigned short)it.cout; d.cin = (unsigned short)it.cin; d.cin_real = (unsigned short)it.cin_real; d.taps = (unsigned short)taps;
     d.din = (unsigned short)it.din; d.stride = (unsigned char)it.stride; d.ksize = (unsigned char)it.ksize; d.pad = (signed char)it.pad;
     d.dl = (unsigned char)(31 - __builtin_clz((unsigned)it.dout));
@@ -1458,11 +1476,15 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
   r.n = nred; r.tile_begin[nred] = red_tiles;
   {
     ProfScope prof(ctx, stream, PROF_WGRAD, flops, exec_flops);
-    if (wide && wide_nst == 2) hipLaunchKernelGGL(wgrad_wide_tn_kernel<2>, dim3(blocks), dim3(256), 2 * 5 * 8192, stream, t);
-    else if (wide) hipLaunchKernelGGL(wgrad_wide_tn_kernel<3>, dim3(blocks), dim3(256), 3 * 5 * 8192, stream, t);
-    else if (nst == 2) hipLaunchKernelGGL(wgrad_grouped_tn_kernel<2>, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
-    else if (nst == 3) hipLaunchKernelGGL(wgrad_grouped_tn_kernel<3>, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
-    else hipLaunchKernelGGL(wgrad_grouped_tn_kernel<4>, dim3(blocks), dim3(256), LDS_BYTES, stream, t);
+    if (bf16) {           // the exported bf16 test entry: one body of each form
+      if (wide) hipLaunchKernelGGL((wgrad_wide_tn_kernel<2, true>), dim3(blocks), dim3(256), 2 * 5 * 8192, stream, t);
+      else hipLaunchKernelGGL((wgrad_grouped_tn_kernel<3, true>), dim3(blocks), dim3(256), 3 * 128 * 128, stream, t);
+    }
+    else if (wide && wide_nst == 2) hipLaunchKernelGGL((wgrad_wide_tn_kernel<2, false>), dim3(blocks), dim3(256), 2 * 5 * 8192, stream, t);
+    else if (wide) hipLaunchKernelGGL((wgrad_wide_tn_kernel<3, false>), dim3(blocks), dim3(256), 3 * 5 * 8192, stream, t);
+    else if (nst == 2) hipLaunchKernelGGL((wgrad_grouped_tn_kernel<2, false>), dim3(blocks), dim3(256), LDS_BYTES, stream, t);
+    else if (nst == 3) hipLaunchKernelGGL((wgrad_grouped_tn_kernel<3, false>), dim3(blocks), dim3(256), LDS_BYTES, stream, t);
+    else hipLaunchKernelGGL((wgrad_grouped_tn_kernel<4, false>), dim3(blocks), dim3(256), LDS_BYTES, stream, t);
   }
   if (nred > 0) hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(red_tiles), dim3(256), 0, stream, t, r);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
@@ -1523,9 +1545,9 @@ extern "C" int neraf_gemm_bf16_tn(neraf_ctx* ctx, const void* A, const void* B, 
   if (!A || !B || !C32 || M <= 0 || N <= 0 || K <= 0 || (M % 64) || (N % 64) || (K % 64) || !splitk_ws || splitk_bytes < 256)
     return neraf_fail(ctx, NERAF_EINVAL, "gemm_bf16_tn: M, N, K multiples of 64; scratch required");
   WgradItem it{};
-  it.dy = (const bf16_t*)A; it.x = (const bf16_t*)B; it.out = C32;
+  it.dy = A; it.x = B; it.out = C32;
   it.cout = M; it.cin = N; it.cin_real = N; it.ksize = 1; it.stride = 1; it.pad = 0; it.din = 1; it.dout = 1; it.K = K;
   // the first 256 bytes of the scratch serve as the zero page the loaders never touch in this plain form
   return launch_wgrad_grouped(ctx, &it, 1, (const half_t*)splitk_ws, (float*)((char*)splitk_ws + 256), splitk_bytes - 256, nullptr,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, true);
 }

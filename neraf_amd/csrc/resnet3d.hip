@@ -11,32 +11,29 @@ namespace {
 
 // ---- kernels ---------------------------------------------------------------------------------------------
 // fp32 grid [7][S^3] (NeRAF_model.py:271-277) -> fp16 channels-last [S^3][8] (channel 7 = 0)
-__global__ __launch_bounds__(256) void grid_to_ndhwc8_kernel(const float* __restrict__ grid, size_t nvox, half_t* __restrict__ out,
-                                                            bf16_t* __restrict__ out_bf) {
+__global__ __launch_bounds__(256) void grid_to_ndhwc8_kernel(const float* __restrict__ grid, size_t nvox, half_t* __restrict__ out) {
   const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (v >= nvox) return;
-  half8 h; bf16x8 b;
+  half8 h;
 #pragma unroll
-  for (int c = 0; c < 7; ++c) { h[c] = (half_t)grid[c * nvox + v]; b[c] = (bf16_t)(float)h[c]; }
-  h[7] = (half_t)0.f; b[7] = (bf16_t)0.f;
+  for (int c = 0; c < 7; ++c) h[c] = (half_t)grid[c * nvox + v];
+  h[7] = (half_t)0.f;
   reinterpret_cast<half8*>(out)[v] = h;
-  if (out_bf) reinterpret_cast<bf16x8*>(out_bf)[v] = b;
 }
 
 // the same for the cells [*start, *start + n) only: the grid refresh rewrites one window of 4096 cells per step (NeRAF_model.py:395-404)
 // and the converted image in the workspace is persistent; the window's first cell travels through device memory (graph replay)
 __global__ __launch_bounds__(256) void grid_window_to_ndhwc8_kernel(const float* __restrict__ grid, size_t nvox, const unsigned long long* start,
-                                                                   int n, half_t* __restrict__ out, bf16_t* __restrict__ out_bf) {
+                                                                   int n, half_t* __restrict__ out) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
   const size_t v = (size_t)*start + t;
   if (v >= nvox) return;
-  half8 h; bf16x8 b;
+  half8 h;
 #pragma unroll
-  for (int c = 0; c < 7; ++c) { h[c] = (half_t)grid[c * nvox + v]; b[c] = (bf16_t)(float)h[c]; }
-  h[7] = (half_t)0.f; b[7] = (bf16_t)0.f;
+  for (int c = 0; c < 7; ++c) h[c] = (half_t)grid[c * nvox + v];
+  h[7] = (half_t)0.f;
   reinterpret_cast<half8*>(out)[v] = h;
-  if (out_bf) reinterpret_cast<bf16x8*>(out_bf)[v] = b;
 }
 
 __global__ void set_u64_fwd_kernel(unsigned long long* p, unsigned long long v) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = v; }
@@ -68,7 +65,7 @@ __global__ __launch_bounds__(256) void bn_update_running_all_kernel(RunTable t, 
 // arg (training): tap index (dz+1)*9 + (dy+1)*3 + (dx+1) of the FIRST maximum of each window, 255 when the maximum is not > 0 --
 // the routing table of the backward (maxpool_bwd_gather_kernel)
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnSrc s, int din, int dout, size_t m_in, half_t* __restrict__ out,
-                                                             bf16_t* __restrict__ out_bf, unsigned char* __restrict__ arg) {
+                                                             unsigned char* __restrict__ arg) {
   __shared__ float sc[64], sh[64];
   if (threadIdx.x < 64) bn_scale_shift(s, threadIdx.x, 1.f / (float)m_in, sc[threadIdx.x], sh[threadIdx.x]);
   __syncthreads();
@@ -106,12 +103,6 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(BnSrc s, int din, 
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = (half_t)best[j];
   *reinterpret_cast<half8*>(out + vox * 64 + c0) = o;
-  if (out_bf) {
-    bf16x8 ob;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ob[j] = (bf16_t)(float)o[j];
-    *reinterpret_cast<bf16x8*>(out_bf + vox * 64 + c0) = ob;
-  }
 }
 
 // AvgPool3d over all remaining voxels (NeRAF_resnet3d.py:143/:149): feat[c] = mean_rows x[row][c].  One workgroup per 64 channels:
@@ -255,14 +246,12 @@ static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
                              char* ws, float* feat, int use_batch_stats, int win_cells, hipStream_t st) {
   neraf_zero3_async(st, ws + L.zero_page, 256, ws + L.stats_begin, L.stats_bytes, feat, 1024 * sizeof(float));
   const size_t nvox = cube(A.S);
-  const bool shadow = use_batch_stats != 0;      // training forward: keep bfloat16 copies for the weight-gradient GEMMs
+  const bool training = use_batch_stats != 0;    // training forward: keep the max-pool routing for the backward
   if (win_cells > 0)      // the rest of the image is the previous call's (the caller vouches for it)
     hipLaunchKernelGGL(grid_window_to_ndhwc8_kernel, dim3((unsigned)((win_cells + 255) / 256)), dim3(256), 0, st, grid, nvox,
-                       reinterpret_cast<const unsigned long long*>(ws + L.win), win_cells, (half_t*)(ws + L.x0),
-                       shadow ? (bf16_t*)(ws + L.x0_bf) : nullptr);
+                       reinterpret_cast<const unsigned long long*>(ws + L.win), win_cells, (half_t*)(ws + L.x0));
   else
-    hipLaunchKernelGGL(grid_to_ndhwc8_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, grid, nvox, (half_t*)(ws + L.x0),
-                       shadow ? (bf16_t*)(ws + L.x0_bf) : nullptr);
+    hipLaunchKernelGGL(grid_to_ndhwc8_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, grid, nvox, (half_t*)(ws + L.x0));
   // stem: conv1 -> bn1 -> relu -> maxpool (NeRAF_resnet3d.py:185-188)
   if (int e = run_conv(ctx, st, A, L, 0, packed, ws, (const half_t*)(ws + L.x0))) return e;
   {
@@ -270,8 +259,7 @@ static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     BnSrc s = bn_src_fwd(A, L, ws, bn, 0, use_batch_stats);
     const size_t total = cube(A.pooled) * 8;
     hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, c.dout, A.pooled,
-                       cube(c.dout), (half_t*)(ws + L.act_pool), shadow ? (bf16_t*)(ws + L.act_pool_bf) : nullptr,
-                       shadow ? (unsigned char*)(ws + L.pool_arg) : nullptr);
+                       cube(c.dout), (half_t*)(ws + L.act_pool), training ? (unsigned char*)(ws + L.pool_arg) : nullptr);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
   }
   const half_t* x = (const half_t*)(ws + L.act_pool);
@@ -283,13 +271,11 @@ static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     BnApplyArgs a{};
     a.a = bn_src_fwd(A, L, ws, bn, i0, use_batch_stats);
     a.M = (int)cube(c0.dout); a.Mpad = (int)rows_pad(c0.dout); a.C = c0.cout; a.relu = 1; a.out = (half_t*)(ws + L.a1[b]);
-    a.out_bf = shadow ? (bf16_t*)(ws + L.a1_bf[b]) : nullptr;
     if (int e = run_bn_apply(ctx, st, a)) return e;
     if (int e = run_conv(ctx, st, A, L, i1, packed, ws, (const half_t*)(ws + L.a1[b]))) return e;
     BnApplyArgs a2{};
     a2.a = bn_src_fwd(A, L, ws, bn, i1, use_batch_stats);
     a2.M = (int)cube(c1.dout); a2.Mpad = (int)rows_pad(c1.dout); a2.C = c1.cout; a2.relu = 1; a2.out = (half_t*)(ws + L.a2[b]);
-    a2.out_bf = shadow ? (bf16_t*)(ws + L.a2_bf[b]) : nullptr;
     // MEASUREMENT ONLY (NERAF_SKIP_SMALL_BN=1, results are garbage): upper bound of what fusing the BatchNorm apply of a 1x1x1
     // consumer into that consumer's operand load could save -- the launch is simply dropped for the <= 4096-voxel layers
     static const int skip_small = [] { const char* e = getenv("NERAF_SKIP_SMALL_BN"); return e ? atoi(e) : 0; }();
@@ -305,7 +291,6 @@ static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
       a3.res = x;
     }
     a3.M = (int)cube(c2.dout); a3.Mpad = (int)rows_pad(c2.dout); a3.C = c2.cout; a3.relu = 1; a3.out = (half_t*)(ws + L.out[b]);
-    a3.out_bf = shadow ? (bf16_t*)(ws + L.out_bf[b]) : nullptr;
     if (int e = run_bn_apply(ctx, st, a3)) return e;
     x = (const half_t*)(ws + L.out[b]);
   }

@@ -10,18 +10,38 @@
 //            by the LDS read (ds_read_b64_tr_b16) -- no transposed copies, no im2col;
 //   BN     : two passes per layer (per-channel reductions sum dy, sum dy*xhat; then the element-wise dx), with the
 //            ReLU mask of the consumer folded into both.
-// The gradient chain (dY tensors, dgrad weights, wgrad operands) is bfloat16 -- BatchNorm backward multiplies by
-// gamma/sigma at every one of the 43 layers, which takes the magnitudes out of fp16's range in either direction --
-// with fp32 accumulation; a power-of-two scale from max|d feat| only centres the values, every fp32 output undoes it.
+// The gradient chain (dY tensors, dgrad weights, wgrad operands) is fp16 with fp32 accumulation, as the reference's AMP training
+// runs it (NeRAF_config.py:79 mixed_precision=True) -- with a power-of-two scale per SCALE GROUP instead of one GradScaler factor:
+// BatchNorm backward multiplies by gamma/sigma at every one of the 43 layers, which takes the magnitudes out of fp16's range in
+// either direction under any single factor.  A group is the output dY of one BatchNorm backward together with everything the GEMMs
+// derive from it before the next BatchNorm backward (its dgrad result, the residual sum): the GEMMs run at ratio 1 and know nothing
+// of scales; only the element-wise BatchNorm-backward kernels re-scale (an exact ratio of two powers of two folded into their
+// per-channel constant) and only they measure: each records the amax of its output AND of its input, i.e. of the GEMM results of
+// the group upstream.  Every tensor of group k is stored as value * S0 * 2^e[k]: S0 from this pass's max|d feat| (exact,
+// bwd_prologue_kernel), e[k] from the amax recorded in an EARLIER pass (delayed scaling; the prologue re-centres each group so that
+// its amax sits in [2^12, 2^13); recording passes are every 4th, neraf_resnet3d_bwd); every fp32 output is multiplied by
+// 1 / (S0 2^e[k]).  A group that overflowed (the recorded amax is the fp32 value before rounding) is re-centred exactly and the
+// pass's gradients carry inf -- the GradScaler skips that step like any other overflow.  The first passes over a workspace are
+// calibration passes (repeated until a prologue reports the previous pass clean; exponents are kept relative to the group's input
+// so that a correction carries downstream).
+// Round 4 ran this chain in bfloat16 (same MFMA rate, 8 significant bits).  Measured (profiles/r05_fp16_chain_ab.txt): the chain's
+// own rounding error -- superposition grad(a + b) vs grad(a) + grad(b) through one forward -- 1.2e-2 (median) / 3.0e-2 (worst of 129
+// parameter gradients) in bf16, 1.5e-3 / 3.4e-3 in fp16; the gate-matched oracle comparison does not move (4.2e-2 worst either way:
+// it is set by the forward's rounding differences amplified through layer3's 64-voxel BatchNorms, not by the gradient chain).
+// The bf16 shadows of the activations are gone with the bf16 chain.
 #include "resnet3d_common.h"
 #include <algorithm>
+#include <mutex>
+#include <stddef.h>
 #include <stdlib.h>
+#include <string.h>
+#include <unordered_map>
 
 namespace {
 
 // ---- packed weights for dgrad: Wt[cin][tap*cout + co] = W[co][cin][tap] ------------------------------------------
 // One launch for all convolutions; a workgroup transposes a [32 co][32 cin][taps] brick through LDS: the fp32 source is read in
-// contiguous runs of 32*taps floats, the bf16 destination written in 64-byte runs along co.
+// contiguous runs of 32*taps floats, the fp16 destination written in 64-byte runs along co.
 struct PackTTable {
   int n;
   const float* src[48];
@@ -31,7 +51,7 @@ struct PackTTable {
 };
 
 __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(PackTTable t, char* __restrict__ packed) {
-  extern __shared__ bf16_t brick[];          // [taps][32 n][34 co]
+  extern __shared__ half_t brick[];          // [taps][32 n][34 co]
   int lo = 0, hi = t.n - 1;
   const int bid = blockIdx.x;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t.tile_begin[mid] <= bid) lo = mid; else hi = mid - 1; }
@@ -46,10 +66,10 @@ __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(PackTTable t, c
     const int n_l = rem / taps, tap = rem - n_l * taps;
     float v = 0.f;
     if (n0 + n_l < cin) v = t.src[i][((size_t)(co0 + co_l) * cin + n0) * taps + rem];
-    brick[(tap * 32 + n_l) * 34 + co_l] = (bf16_t)v;
+    brick[(tap * 32 + n_l) * 34 + co_l] = (half_t)v;
   }
   __syncthreads();
-  bf16_t* dst = reinterpret_cast<bf16_t*>(packed + t.dst_off[i]);
+  half_t* dst = reinterpret_cast<half_t*>(packed + t.dst_off[i]);
   const int kc = t.kcols[i];
   for (int e = threadIdx.x; e < 32 * run; e += 256) {
     const int co_l = e & 31, rest = e >> 5;
@@ -59,7 +79,7 @@ __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(PackTTable t, c
 }
 
 int launch_pack_dgrad(neraf_ctx* ctx, const PackTTable& t, int ntiles, int max_taps, char* packed_t, hipStream_t st) {
-  const size_t lds = (size_t)max_taps * 32 * 34 * sizeof(bf16_t);
+  const size_t lds = (size_t)max_taps * 32 * 34 * sizeof(half_t);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_dgrad_weights_kernel),
@@ -71,29 +91,49 @@ int launch_pack_dgrad(neraf_ctx* ctx, const PackTTable& t, int ntiles, int max_t
   return NERAF_OK;
 }
 
+// ---- per-tensor scales of the fp16 gradient chain (see the header) ---------------------------------------------------------
+constexpr int kChainMax = 64;                  // scale groups per backward (1 + 3 per block + stem = 41): one per lane of one wave
+constexpr unsigned kChainMagic = 0x5ca1ab1eu;
+constexpr int kChainTarget = 12;               // stored amax is re-centred into [2^12, 2^13): 8x headroom below fp16's 65504
+struct ChainState {
+  unsigned magic;
+  unsigned unsettled;                          // groups that, in the last RECORDING pass before the one this prologue opened, overflowed fp16 or
+                                               // were computed from an overflowed input (0 in steady state; the calibration loop waits for it)
+  unsigned passes;                             // prologues run on this state
+  unsigned pad[61];
+  float pow2[kChainMax];                       // 2^e[t]
+  float inv[kChainMax];                        // 1 / (S0 * 2^e[t]): what an fp32 result computed from tensor t is multiplied by
+  int e[kChainMax];
+};
+struct ChainParents { unsigned char p[kChainMax]; };          // the group every group is computed from (ids in production order: p[k] < k)
+
 // ---- BatchNorm backward ----------------------------------------------------------------------------------------
 // Both passes work on [rows][64-channel] panels.  Pass 1 reduces sum(dy) and sum(dy*xhat) (registers -> LDS -> one atomic per
 // channel per workgroup into a replicated accumulator, see kStatStride); pass 2 writes dx.
 struct BnBwdArgs {
   BnSrc s;                    // x (pre-BN), finalised forward statistics, gamma
-  const bf16_t* g16; const float* g32;     // upstream gradient w.r.t. the post-activation tensor (one of them)
+  const half_t* g16; const float* g32;     // upstream gradient w.r.t. the post-activation tensor (one of them)
   const half_t* act;          // post-activation tensor for the ReLU mask (null = no mask)
   int M, Mpad, C;
   int rows_per_block;         // reduce: rows handled by one workgroup (multiple of 32)
   float* sums; int rep;       // [rep][2][cpad] (replica stride kStatStride): sum dy, sum dy*xhat
   int det;                    // reduce, deterministic mode: row block b STORES its sums into slot b of [slots][2][cpad] (no atomics)
-  bf16_t* dx;                 // apply: gradient w.r.t. the pre-BN conv output [Mpad][C]
-  bf16_t* dy_masked;          // apply (optional): g * (act > 0) for the identity residual branch
-  float* dgamma; float* dbeta; const float* inv_scale;   // apply (row-block 0 writes the un-scaled affine gradients)
+  half_t* dx;                 // apply: gradient w.r.t. the pre-BN conv output [Mpad][C]
+  half_t* dy_masked;          // apply (optional): g * (act > 0) for the identity residual branch, re-scaled into group `msc`
+  float* dgamma; float* dbeta; const float* inv_scale;   // apply (row-block 0 writes the un-scaled affine gradients): 1 / scale of g
+  // scale groups: 2^e of dx's group, of g's group, of the group dy_masked joins (null pointers: no re-scaling); amax_out / amax_in:
+  // replicated amax accumulators of dx's group and of g's group (null: this pass does not record)
+  const float* osc; const float* isc; const float* msc;
+  unsigned* amax_out; unsigned* amax_in;
 };
 
 // One thread's 8 channels of a row: the loads (bn_bwd_issue) and their conversion (bn_bwd_finish) are separate so that a kernel can
 // have the tile in flight while it still waits for the statistics it needs to use it (every dependent memory round trip of these
 // 5-7 us kernels is 1.5-2 us).
-struct BnBwdRaw { half8 x; bf16x8 g16; f32x4 g0, g1; half8 act; };
+struct BnBwdRaw { half8 x; half8 g16; f32x4 g0, g1; half8 act; };
 __device__ __forceinline__ void bn_bwd_issue(const BnBwdArgs& p, size_t off, BnBwdRaw& r) {
   r.x = *reinterpret_cast<const half8*>(p.s.x + off);
-  if (p.g16) r.g16 = *reinterpret_cast<const bf16x8*>(p.g16 + off);
+  if (p.g16) r.g16 = *reinterpret_cast<const half8*>(p.g16 + off);
   else { r.g0 = *reinterpret_cast<const f32x4*>(p.g32 + off); r.g1 = *reinterpret_cast<const f32x4*>(p.g32 + off + 4); }
   if (p.act) r.act = *reinterpret_cast<const half8*>(p.act + off);
 }
@@ -186,6 +226,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
     if (in[it]) bn_bwd_issue(p, offs[it], raw[it]);
   }
   float fm = 0.f, fv = 0.f, gam = 0.f;
+  // the chain's re-scalings of dx and of the masked copy (wave-uniform scalars, in flight with everything else)
+  const float isc = p.isc ? p.isc[0] : 1.f;
+  const float rsc = p.osc ? p.osc[0] / isc : 1.f, rmk = p.msc ? p.msc[0] / isc : 1.f;
   if (tid < 64) { bn_mean_var(p.s, c_base + tid, 0.f, fm, fv); gam = p.s.gamma[c_base + tid]; }
   {
     // the replicas of the two sums: four threads per channel take every fourth replica (a chain of rep loads otherwise)
@@ -203,15 +246,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
     const float dbeta = (part[0][0][tid] + part[0][1][tid]) + (part[0][2][tid] + part[0][3][tid]);
     const float dgamma = (part[1][0][tid] + part[1][1][tid]) + (part[1][2][tid] + part[1][3][tid]);
     mean[tid] = fm; rstd[tid] = rs;
-    k1[tid] = gam * rs; k2[tid] = dbeta * inv_m; k3[tid] = dgamma * inv_m;
+    k1[tid] = gam * rs * rsc; k2[tid] = dbeta * inv_m; k3[tid] = dgamma * inv_m;
     if (blockIdx.x == 0 && p.dgamma) { p.dgamma[c] = dgamma * p.inv_scale[0]; p.dbeta[c] = dbeta * p.inv_scale[0]; }
   }
   __syncthreads();
+  float am = 0.f, am_in = 0.f;
+  half8 o[2], om[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int ch = (it * 256 + tid) & 7;
-    const size_t off = offs[it];
-    bf16x8 o, om;
     if (in[it]) {
       float xv[8], g[8];
       bn_bwd_finish(p, raw[it], xv, g);
@@ -219,54 +262,149 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs p) {
       for (int j = 0; j < 8; ++j) {
         const int c = ch * 8 + j;
         const float xh = (xv[j] - mean[c]) * rstd[c];
-        o[j] = (bf16_t)(k1[c] * (g[j] - k2[c] - xh * k3[c]));
-        om[j] = (bf16_t)g[j];
+        const float v = k1[c] * (g[j] - k2[c] - xh * k3[c]);
+        am = fmaxf(am, fabsf(v));
+        am_in = fmaxf(am_in, fabsf(g[j]));
+        o[it][j] = (half_t)v;
+        om[it][j] = (half_t)(g[j] * rmk);
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { o[j] = (bf16_t)0.f; om[j] = (bf16_t)0.f; }
+      for (int j = 0; j < 8; ++j) { o[it][j] = (half_t)0.f; om[it][j] = (half_t)0.f; }
     }
-    *reinterpret_cast<bf16x8*>(p.dx + off) = o;
-    if (p.dy_masked) *reinterpret_cast<bf16x8*>(p.dy_masked + off) = om;
+  }
+  if (p.amax_out) {
+    // recording pass: ONE pair of atomics per workgroup, issued before the tile's stores (their round trip to the memory side
+    // overlaps the drain); replicas 256 bytes apart, because same-line atomics serialise there
+    __shared__ float wmax[2][4];
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) { am = fmaxf(am, __shfl_xor(am, o2)); am_in = fmaxf(am_in, __shfl_xor(am_in, o2)); }
+    if ((tid & 63) == 0) { wmax[0][tid >> 6] = am; wmax[1][tid >> 6] = am_in; }
+    __syncthreads();
+    if (tid < 2) {
+      const float m4 = fmaxf(fmaxf(wmax[tid][0], wmax[tid][1]), fmaxf(wmax[tid][2], wmax[tid][3]));
+      unsigned* dst = tid == 0 ? p.amax_out : p.amax_in;
+      if (dst && m4 > 0.f) atomicMax(dst + ((blockIdx.x * 3u + blockIdx.y) & (kAmaxRep - 1)) * kAmaxStride, __float_as_uint(m4));
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    *reinterpret_cast<half8*>(p.dx + offs[it]) = o[it];
+    if (p.dy_masked) *reinterpret_cast<half8*>(p.dy_masked + offs[it]) = om[it];
   }
 }
 
 // ---- pools --------------------------------------------------------------------------------------------------------
-// Backward prologue in ONE launch: the power-of-two chain scale from max |d feat| (every workgroup derives the same value from the
-// 1024 inputs; workgroup 0 publishes {S, 1/S} for the kernels that follow) and the average-pool backward
-// g[row][c] = d feat[c] * S / M.  Replaces amax + make_scale + avgpool_bwd (three dependent launches of ~4.7 us each).
+// Backward prologue in ONE launch: the power-of-two chain scale S0 from max |d feat| (every workgroup derives the same value from the
+// 1024 inputs; workgroup 0 publishes {S0, 1/S0} for the kernels that follow), the average-pool backward
+// g[row][c] = d feat[c] * S0 / M, and -- workgroup 0 -- the exponents of the chain's scale groups for THIS pass from the amax recorded
+// in the last recording pass (ChainState; group 0 is g itself: e = 0, S0 alone places it).
 __global__ __launch_bounds__(256) void bwd_prologue_kernel(const float* __restrict__ dfeat, float* __restrict__ scale, int target_log2, int M,
-                                                          int Mpad, int C, bf16_t* __restrict__ g) {
+                                                          int Mpad, int C, half_t* __restrict__ g, ChainState* __restrict__ cs,
+                                                          unsigned* __restrict__ amax, int n_groups, ChainParents par) {
   __shared__ float red[4];
+  __shared__ unsigned s_am[kChainMax];
+  __shared__ ChainParents s_par;
+  // workgroup 0 also re-centres the chain (below): everything it reads was written by earlier kernels (the amax words by atomics at
+  // the memory side: read there too, like the BatchNorm accumulators, resnet3d_common.h stat_ld) and it sits on the critical path of the
+  // whole backward, so all of it is requested up front, together with d feat -- validity is applied to the values afterwards
+  constexpr int kWords = kChainMax * kAmaxRep / 256;      // amax words per thread
+  unsigned v[kWords];
+  unsigned magic = 0u, passes_in = 0u;
+  int e_in = 0;
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < kWords; ++k) {
+      const int i = threadIdx.x + k * 256;
+      v[k] = i < n_groups * kAmaxRep ? __hip_atomic_load(amax + (size_t)i * kAmaxStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+    }
+    magic = cs->magic; passes_in = cs->passes;
+    if ((int)threadIdx.x < n_groups) e_in = cs->e[threadIdx.x];
+  }
+  float df[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) df[k] = (int)(threadIdx.x + k * 256) < C ? fabsf(dfeat[threadIdx.x + k * 256]) : 0.f;     // C <= 1024
   float m = 0.f;
-  for (int i = threadIdx.x; i < C; i += 256) { const float a = fabsf(dfeat[i]); m = (a == a && a > m) ? a : m; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m = (df[k] == df[k] && df[k] > m) ? df[k] : m;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  const float amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float S = 1.f;
-  if (amax > 0.f && amax < 3.0e38f) {
-    int e = target_log2 - (int)floorf(log2f(amax));
-    e = e > 100 ? 100 : (e < -100 ? -100 : e);
-    S = exp2f((float)e);
+  const float amx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  int es = 0;
+  if (amx > 0.f && amx < 3.0e38f) {
+    es = target_log2 - (int)floorf(log2f(amx));
+    es = es > 100 ? 100 : (es < -100 ? -100 : es);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { scale[0] = S; scale[1] = 1.f / S; }
+  const float S = exp2f((float)es);
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) { scale[0] = S; scale[1] = 1.f / S; }
+    if ((int)threadIdx.x < kChainMax) { s_par.p[threadIdx.x] = par.p[threadIdx.x]; s_am[threadIdx.x] = 0u; }
+    const bool valid = magic == kChainMagic;
+    __syncthreads();
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < kWords; ++k) {
+      const int i = threadIdx.x + k * 256;
+      if (i < n_groups * kAmaxRep && v[k]) { amax[(size_t)i * kAmaxStride] = 0u; if (valid) atomicMax(&s_am[i / kAmaxRep], v[k]); any = true; }
+    }
+    const int recorded = __syncthreads_or(any ? 1 : 0);      // the pass before this one was a recording pass
+    if (threadIdx.x < 64) {
+      // One wave, lane k = group k.  Exponents are RELATIVE to the group's input (e[k] = e[parent] + d[k]): a group whose own
+      // measurement is unusable -- it was computed from an overflowed input, or nothing was recorded -- follows its parent's
+      // correction, since a gradient tensor's magnitude is its input's times a per-layer factor.  The recorded amax is the fp32 value
+      // BEFORE the fp16 rounding, so an overflowed group is re-centred exactly in one pass.  Both recurrences run down the tree of
+      // groups (depth ~40): pointer jumping, six rounds of wave shuffles -- this wave is on the critical path of the whole backward.
+      const int lane = threadIdx.x;
+      const bool in = lane < n_groups;
+      const unsigned mx = in ? s_am[lane] : 0u;
+      const int p = (in && lane > 0) ? s_par.p[lane] : 0;
+      const int eo = (in && valid) ? e_in : 0;
+      const int eo_p = __shfl(eo, p);
+      int ok = (lane == 0 || !in) ? 1 : (mx < 0x477fe000u ? 1 : 0);      // 65504.0f: what fp16 can hold
+      int anc = p;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { ok &= __shfl(ok, anc); anc = __shfl(anc, anc); }      // finite here and in every group upstream
+      const int okp = __shfl(ok, p);
+      const bool measured = okp && mx > 0u && mx < 0x7f800000u;
+      // floor(log2(x)) of a positive finite float is its biased exponent - 127 (a subnormal amax reads as "far too small": it is)
+      int done = (lane == 0 || !in || measured) ? 1 : 0;
+      int acc = (lane == 0 || !in) ? 0 : (measured ? eo + kChainTarget - ((int)(mx >> 23) - 127) : eo - eo_p);
+      int link = done ? lane : p;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int a2 = __shfl(acc, link), d2 = __shfl(done, link), l2 = __shfl(link, link);
+        if (!done) { acc += a2; done = d2; link = l2; }
+      }
+      const int lim_lo = max(-100, -120 - es), lim_hi = min(100, 120 - es);      // S0 2^e stays a normal float
+      const int e = acc < lim_lo ? lim_lo : (acc > lim_hi ? lim_hi : acc);
+      const unsigned long long bad = __ballot(in && !ok);
+      if (in) { cs->e[lane] = e; cs->pow2[lane] = exp2f((float)e); cs->inv[lane] = exp2f((float)(-es - e)); }
+      if (lane == 0) {
+        // `unsettled` speaks about the last recording pass; it keeps its value over non-recording passes
+        if (!valid) cs->unsettled = (unsigned)n_groups;
+        else if (recorded) cs->unsettled = (unsigned)__popcll(bad);
+        cs->passes = valid ? passes_in + 1u : 1u;
+        cs->magic = kChainMagic;
+      }
+    }
+  }
   const float k = S / (float)M;
   const size_t total = (size_t)Mpad * C;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int row = (int)(idx / C), c = (int)(idx % C);
-    g[idx] = (bf16_t)(row < M ? dfeat[c] * k : 0.f);
+    g[idx] = (half_t)(row < M ? dfeat[c] * k : 0.f);
   }
 }
 
 // maxpool(3,2,1) of relu(bn(x)) backward: g[out voxel] goes to the arg-max input (first maximum), nothing if the max is <= 0.
-// Written as a GATHER over the input voxels from the forward's arg-max table: no atomics, no zero fill, bf16 out (the scatter it
+// Written as a GATHER over the input voxels from the forward's arg-max table: no atomics, no zero fill, fp16 out (the scatter it
 // replaced re-evaluated the 27 taps of every window and added fp32 atomics into a zeroed 67 MB buffer: 74 + 10 us).
 // An input coordinate i belongs to window o = i/2 through tap d = 0 when i is even, and to windows (i-1)/2 (d = +1) and
 // (i+1)/2 (d = -1) when it is odd: at most 8 windows per voxel.
 __global__ __launch_bounds__(256) void maxpool_bwd_gather_kernel(const unsigned char* __restrict__ arg, int din, int dout,
-                                                                const bf16_t* __restrict__ g, bf16_t* __restrict__ dpost, size_t rows_pad_in) {
+                                                                const half_t* __restrict__ g, half_t* __restrict__ dpost, size_t rows_pad_in) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= rows_pad_in * 8) return;
   const size_t vox = idx >> 3; const int c0 = (int)(idx & 7) * 8;
@@ -289,16 +427,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_gather_kernel(const unsigned 
           const size_t ov = ((size_t)oz[a] * dout + oy[b]) * dout + ox[c];
           const unsigned tap = (unsigned)(tz[a] * 9 + ty[b] * 3 + tx[c]);
           const unsigned long long am = *reinterpret_cast<const unsigned long long*>(arg + ov * 64 + c0);
-          const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + ov * 64 + c0);
+          const half8 gv = *reinterpret_cast<const half8*>(g + ov * 64 + c0);
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             if (((am >> (8 * j)) & 0xffu) == tap) acc[j] += (float)gv[j];
         }
   }
-  bf16x8 o;
+  half8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
-  *reinterpret_cast<bf16x8*>(dpost + vox * 64 + c0) = o;
+  for (int j = 0; j < 8; ++j) o[j] = (half_t)acc[j];      // at most 8 windows meet in a voxel: inside the group's headroom, and measured by the consumer
+  *reinterpret_cast<half8*>(dpost + vox * 64 + c0) = o;
 }
 
 __global__ void set_f32x2_kernel(float* p, float a, float b) { if (threadIdx.x == 0 && blockIdx.x == 0) { p[0] = a; p[1] = b; } }
@@ -314,7 +452,7 @@ __global__ __launch_bounds__(256) void stem_w_relayout_kernel(const float* __res
   Wt[idx] = c < 7 ? W[((size_t)co * 7 + c) * 125 + tap] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void stem_dgrid_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ Wt, int S, int dout,
+__global__ __launch_bounds__(256) void stem_dgrid_kernel(const half_t* __restrict__ dy, const float* __restrict__ Wt, int S, int dout,
                                                         const unsigned long long* __restrict__ start_dev, int n, int nch,
                                                         const float* __restrict__ inv_scale, float* __restrict__ dgrid) {
   const int lane = threadIdx.x & 63;
@@ -346,14 +484,9 @@ __global__ __launch_bounds__(256) void stem_dgrid_kernel(const bf16_t* __restric
   }
 }
 
-__global__ void f16_to_bf16_kernel(const half_t* __restrict__ a, size_t n, bf16_t* __restrict__ o) {
+__global__ void f16_to_f32_kernel(const half_t* __restrict__ a, size_t n, const float* __restrict__ mul, float* __restrict__ o) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) o[i] = (bf16_t)(float)a[i];
-}
-
-__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ a, size_t n, float* __restrict__ o) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) o[i] = (float)a[i];
+  if (i < n) o[i] = (float)a[i] * mul[0];
 }
 
 // ---- backward workspace ---------------------------------------------------------------------------------------------
@@ -361,11 +494,12 @@ struct BwdLayout {
   size_t wt[64];              // dgrad weights (in the packed-dgrad blob)
   size_t packed_total;
   size_t scale;               // fp32[4]
+  size_t chain, amax;         // ChainState; replicated amax accumulators [kChainMax][kAmaxRep] words, kAmaxStride words apart
   size_t sums[64];            // per conv/BN: [rep][2][cpad] fp32 (replica stride kStatStride); deterministic mode: [slots][2][cpad]
   size_t sums_fin[64];        // deterministic mode: the slots added in a fixed order, [2][cpad] (what bn_bwd_apply reads)
   size_t sums_begin, sums_bytes;
   size_t g[2];                // ping-pong gradient w.r.t. block outputs, fp16, largest activation
-  size_t dy[64];              // dY of every convolution [rows_pad(dout)][cout] bf16: all alive until the grouped weight-gradient launch
+  size_t dy[64];              // dY of every convolution [rows_pad(dout)][cout] fp16: all alive until the grouped weight-gradient launch
   size_t gm, da;              // masked g (identity residual), d(a1|a2) scratch
   size_t dpost;               // fp32 [din1^3][64] stem
   size_t wtmp;                // fp32 [cout][tap*cin + c] weight gradients before the layout change (k > 1 convs)
@@ -400,6 +534,8 @@ void make_bwd_layout(const Arch& A, BwdLayout* L) {
   L->packed_total = off;
   off = 0;
   L->scale = take(256);
+  L->chain = take(sizeof(ChainState));
+  L->amax = take((size_t)kChainMax * kAmaxRep * kAmaxStride * 4);
   L->sums_begin = off;
   for (int i = 0; i < A.nconv; ++i) {
     const int rep = bwd_stat_rep(A.conv[i]);
@@ -431,12 +567,18 @@ void make_bwd_layout(const Arch& A, BwdLayout* L) {
 struct Ctx {
   neraf_ctx* ctx; hipStream_t st; const Arch* A; const Layout* L; const BwdLayout* B;
   const char* packed_t; char* ws; char* bws; const float* const* bn; float* const* w_grads; float* const* bn_grads;
-  const float* inv_scale;
+  // scale group k of the fp16 chain: its 2^e, its 1 / (S0 2^e), its amax accumulator
+  const float* pow2(int t) const { return reinterpret_cast<const ChainState*>(bws + B->chain)->pow2 + t; }
+  const float* inv(int t) const { return reinterpret_cast<const ChainState*>(bws + B->chain)->inv + t; }
+  const float* inv_base() const { return reinterpret_cast<const ChainState*>(bws + B->chain)->inv; }
+  bool track = true;          // false: producers do not record amax (NERAF_CHAIN_AMAX=0, measurement only: the scales stay where they are)
+  unsigned* amax(int t) const { return track ? reinterpret_cast<unsigned*>(bws + B->amax) + (size_t)t * kAmaxRep * kAmaxStride : nullptr; }
 };
 
 // BN backward of conv ci: gradient w.r.t. the conv output, into `dx`
-int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const half_t* act, bf16_t* dx, bf16_t* dy_masked,
-                bool sums_done = false) {
+// k_in / k_out: scale groups of g and of dx; k_mask: the group dy_masked joins (the residual sum it is added into)
+int bn_backward(const Ctx& c, int ci, const half_t* g16, const float* g32, const half_t* act, half_t* dx, half_t* dy_masked,
+                int k_in, int k_out, int k_mask, bool sums_done = false) {
   const ConvSpec& cs = c.A->conv[ci];
   BnBwdArgs p{};
   p.s = bn_src_bwd(*c.A, *c.L, c.ws, c.bn, ci);
@@ -445,7 +587,9 @@ int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const
   p.rows_per_block = bwd_rows_per_block(cs);
   p.sums = (float*)(c.bws + c.B->sums[ci]); p.rep = bwd_stat_rep(cs);
   p.dx = dx; p.dy_masked = dy_masked;
-  p.dgamma = c.bn_grads[2 * ci]; p.dbeta = c.bn_grads[2 * ci + 1]; p.inv_scale = c.inv_scale;
+  p.dgamma = c.bn_grads[2 * ci]; p.dbeta = c.bn_grads[2 * ci + 1]; p.inv_scale = c.inv(k_in);
+  p.osc = c.pow2(k_out); p.isc = c.pow2(k_in); p.msc = dy_masked ? c.pow2(k_mask) : nullptr;
+  p.amax_out = c.amax(k_out); p.amax_in = g16 ? c.amax(k_in) : nullptr;
   const int nrb = (p.M + p.rows_per_block - 1) / p.rows_per_block;
   p.det = neraf_deterministic() ? 1 : 0;
   // sums_done: the dgrad GEMM that produced g16 already reduced sum g and sum g * xhat in its epilogue (fuse_bn_sums below)
@@ -462,20 +606,21 @@ int bn_backward(const Ctx& c, int ci, const bf16_t* g16, const float* g32, const
   return NERAF_OK;
 }
 
-inline WgradItem wgrad_item(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* x_in) {
+inline WgradItem wgrad_item(const Ctx& c, int ci, const half_t* dy, const half_t* x_in, int t_dy) {
   const ConvSpec& cs = c.A->conv[ci];
   WgradItem it{};
   it.dy = dy; it.x = x_in; it.out = c.w_grads[ci];
   it.cout = cs.cout; it.cin = cs.cin; it.cin_real = cs.cin_real; it.ksize = cs.k; it.stride = cs.stride; it.pad = cs.pad;
   it.din = cs.din; it.dout = cs.dout; it.K = (int)rows_pad(cs.dout);
+  it.alpha_idx = t_dy;
   return it;
 }
 
 // dW of ONE conv (the stage test entry); the network's backward collects all items and launches them together
-int conv_wgrad(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* x_in) {
-  const WgradItem it = wgrad_item(c, ci, dy, x_in);
+int conv_wgrad(const Ctx& c, int ci, const half_t* dy, const half_t* x_in, int t_dy) {
+  const WgradItem it = wgrad_item(c, ci, dy, x_in, t_dy);
   return launch_wgrad_grouped(c.ctx, &it, 1, (const half_t*)(c.ws + c.L->zero_page), (float*)(c.bws + c.B->splitk), c.B->splitk_bytes,
-                              c.inv_scale, c.st);
+                              c.inv_base(), c.st);
 }
 
 // The BatchNorm-backward reduction of the layer that CONSUMES a dgrad's result, folded into that dgrad's epilogue (or split-K
@@ -487,13 +632,12 @@ inline bool fuse_bn_sums(const ConvSpec& bn_conv) {
 }
 
 // dX [din^3][cin] = conv_transpose(dY [dout^3][cout], W) (+ add16).  bn_ci >= 0: the result is the gradient w.r.t. relu(bn_{bn_ci}(.))
-// (+ residual), `bn_act` that post-activation tensor (bf16 shadow): the epilogue masks the result with it and reduces the two
-// BatchNorm-backward sums of conv bn_ci into its accumulators.
-int conv_dgrad(const Ctx& c, int ci, const bf16_t* dy, const bf16_t* add16, bf16_t* dx, int bn_ci = -1, const bf16_t* bn_act = nullptr) {
+// (+ residual), `bn_act` that post-activation tensor: the epilogue masks the result with it and reduces the two
+// BatchNorm-backward sums of conv bn_ci into its accumulators.  The result (and add16) live in dy's scale group: ratio 1.
+int conv_dgrad(const Ctx& c, int ci, const half_t* dy, const half_t* add16, half_t* dx, int bn_ci = -1, const half_t* bn_act = nullptr) {
   const ConvSpec& cs = c.A->conv[ci];
   GemmParams g{};
   const int taps = cs.k * cs.k * cs.k;
-  g.bf16 = 1;
   g.A = (const half_t*)dy; g.lda = cs.cout;
   g.B = (const half_t*)(c.packed_t + c.B->wt[ci]); g.ldb = taps * cs.cout;
   g.M = (int)cube(cs.din); g.N = cs.cin; g.K = taps * cs.cout; g.Mpad = (int)rows_pad(cs.din);
@@ -587,22 +731,40 @@ extern "C" int neraf_resnet3d_pack_weights_bwd(neraf_ctx* ctx, const neraf_resne
 
 static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, const BwdLayout& B, const void* packed_t,
                              const float* const* conv_w, const float* const* bn, char* ws, char* bws, const float* dfeat,
-                             float* const* w_grads, float* const* bn_grads, int n_cells, int n_ch, float* dgrid_cells, hipStream_t st) {
+                             float* const* w_grads, float* const* bn_grads, int n_cells, int n_ch, float* dgrid_cells, hipStream_t st,
+                             bool track) {
   float* scale = (float*)(bws + B.scale);
   neraf_zero_async(st, bws + B.sums_begin, B.sums_bytes);
-  // d feat is spread over M voxels by the average pool; aim the per-voxel gradient at ~2^4
   const int Mlast = (int)cube(A.final_edge);
-  Ctx c{ctx, st, &A, &L, &B, (const char*)packed_t, ws, bws, bn, w_grads, bn_grads, scale + 1};
-  bf16_t* g = (bf16_t*)(bws + B.g[0]);
-  bf16_t* g_next = (bf16_t*)(bws + B.g[1]);
+  Ctx c{ctx, st, &A, &L, &B, (const char*)packed_t, ws, bws, bn, w_grads, bn_grads};
+  c.track = track;
+  half_t* g = (half_t*)(bws + B.g[0]);
+  half_t* g_next = (half_t*)(bws + B.g[1]);
+  // Scale groups, in production order (ids index ChainState: fixed by the architecture, so a replayed graph and a direct run agree).
+  // Group 0 is the prologue's g; every BatchNorm backward opens a new group for its dY, and the GEMM results computed from that dY --
+  // d a2, d a1, the residual sum g_next -- stay in it (ratio 1).  A downsample branch's dY joins the group of the block's dy0: the
+  // two dgrads are summed in place.
+  ChainParents par{};
+  int n_k = 0;
+  auto new_k = [&](int parent) { par.p[n_k] = (unsigned char)parent; return n_k++; };
+  int k_g = new_k(0);
+  const int total_k = 1 + 3 * A.nblock + 1;
+  if (total_k > kChainMax) return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_bwd: chain table too small");
   {
+    // d feat is spread over M voxels by the average pool; S0 places the per-voxel gradient's amax at 2^kChainTarget
     const int Mpad = (int)rows_pad(A.final_edge);
     const size_t n = (size_t)Mpad * 1024;
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(bwd_prologue_kernel, dim3(blocks), dim3(256), 0, st, dfeat, scale, 4 + (int)ceilf(log2f((float)Mlast)), Mlast, Mpad, 1024, g);
+    // the parents of every group, as the loop below assigns them (the prologue runs first: built here from the same rule)
+    ChainParents pp{};
+    int k = 1, kg = 0;
+    for (int b = A.nblock - 1; b >= 0; --b) { pp.p[k] = (unsigned char)kg; pp.p[k + 1] = (unsigned char)k; pp.p[k + 2] = (unsigned char)(k + 1); kg = k + 2; k += 3; }
+    pp.p[k] = (unsigned char)kg;                // stem dY
+    hipLaunchKernelGGL(bwd_prologue_kernel, dim3(blocks), dim3(256), 0, st, dfeat, scale, kChainTarget + (int)ceilf(log2f((float)Mlast)), Mlast, Mpad,
+                       1024, g, reinterpret_cast<ChainState*>(bws + B.chain), reinterpret_cast<unsigned*>(bws + B.amax), total_k, pp);
   }
-  bf16_t* gm = (bf16_t*)(bws + B.gm); bf16_t* da = (bf16_t*)(bws + B.da);
+  half_t* gm = (half_t*)(bws + B.gm); half_t* da = (half_t*)(bws + B.da);
   WgradItem items[64]; int n_items = 0;     // every weight gradient is computed by ONE grouped launch at the end
   bool g_sums_done = false;                 // the BatchNorm-backward sums of the NEXT block's bn3 were reduced by the dgrad that produced g
   for (int b = A.nblock - 1; b >= 0; --b) {
@@ -611,27 +773,27 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     const half_t* out = (const half_t*)(ws + L.out[b]);
     const half_t* a1 = (const half_t*)(ws + L.a1[b]);
     const half_t* a2 = (const half_t*)(ws + L.a2[b]);
-    const bf16_t* x_in_bf = b == 0 ? (const bf16_t*)(ws + L.act_pool_bf) : (const bf16_t*)(ws + L.out_bf[b - 1]);
-    const bf16_t* a1_bf = (const bf16_t*)(ws + L.a1_bf[b]);
-    const bf16_t* a2_bf = (const bf16_t*)(ws + L.a2_bf[b]);
-    bf16_t* dy0 = (bf16_t*)(bws + B.dy[i0]); bf16_t* dy1 = (bf16_t*)(bws + B.dy[i1]); bf16_t* dy2 = (bf16_t*)(bws + B.dy[i2]);
-    bf16_t* dyds = Bk.ds >= 0 ? (bf16_t*)(bws + B.dy[Bk.ds]) : nullptr;
-    // out = relu(bn3(c3) + residual): dy = g * (out > 0) feeds bn3 and the residual branch
-    if (int e = bn_backward(c, i2, g, nullptr, out, dy2, Bk.ds < 0 ? gm : nullptr, g_sums_done)) return e;
+    const half_t* x_in = b == 0 ? (const half_t*)(ws + L.act_pool) : (const half_t*)(ws + L.out[b - 1]);
+    half_t* dy0 = (half_t*)(bws + B.dy[i0]); half_t* dy1 = (half_t*)(bws + B.dy[i1]); half_t* dy2 = (half_t*)(bws + B.dy[i2]);
+    half_t* dyds = Bk.ds >= 0 ? (half_t*)(bws + B.dy[Bk.ds]) : nullptr;
+    const int k2 = new_k(k_g), k1 = new_k(k2), k0 = new_k(k1);       // groups of dy2 (+ d a2), dy1 (+ d a1), dy0 (+ dyds, g_next)
+    // out = relu(bn3(c3) + residual): dy = g * (out > 0) feeds bn3 and the residual branch (the masked copy joins dy0's group, where
+    // the identity residual is added)
+    if (int e = bn_backward(c, i2, g, nullptr, out, dy2, Bk.ds < 0 ? gm : nullptr, k_g, k2, k0, g_sums_done)) return e;
     g_sums_done = false;
-    items[n_items++] = wgrad_item(c, i2, dy2, a2_bf);
+    items[n_items++] = wgrad_item(c, i2, dy2, a2, k2);
     const bool f1 = fuse_bn_sums(A.conv[i1]);                                  // d a2 feeds bn2 (mask a2)
-    if (int e = conv_dgrad(c, i2, dy2, nullptr, da, f1 ? i1 : -1, f1 ? a2_bf : nullptr)) return e;                 // d a2
-    if (int e = bn_backward(c, i1, da, nullptr, a2, dy1, nullptr, f1)) return e;
-    items[n_items++] = wgrad_item(c, i1, dy1, a1_bf);
+    if (int e = conv_dgrad(c, i2, dy2, nullptr, da, f1 ? i1 : -1, f1 ? a2 : nullptr)) return e;                 // d a2
+    if (int e = bn_backward(c, i1, da, nullptr, a2, dy1, nullptr, k2, k1, -1, f1)) return e;
+    items[n_items++] = wgrad_item(c, i1, dy1, a1, k1);
     // d a1 feeds bn1 (mask a1); the stride-2 conv2 of a layer's first block runs the parity-class dgrad, which has no statistics epilogue
     const bool f0 = fuse_bn_sums(A.conv[i0]) && A.conv[i1].stride == 1;
-    if (int e = conv_dgrad(c, i1, dy1, nullptr, da, f0 ? i0 : -1, f0 ? a1_bf : nullptr)) return e;                 // d a1
-    if (int e = bn_backward(c, i0, da, nullptr, a1, dy0, nullptr, f0)) return e;
-    items[n_items++] = wgrad_item(c, i0, dy0, x_in_bf);
+    if (int e = conv_dgrad(c, i1, dy1, nullptr, da, f0 ? i0 : -1, f0 ? a1 : nullptr)) return e;                 // d a1
+    if (int e = bn_backward(c, i0, da, nullptr, a1, dy0, nullptr, k1, k0, -1, f0)) return e;
+    items[n_items++] = wgrad_item(c, i0, dy0, x_in, k0);
     if (Bk.ds >= 0) {
-      if (int e = bn_backward(c, Bk.ds, g, nullptr, out, dyds, nullptr)) return e;
-      items[n_items++] = wgrad_item(c, Bk.ds, dyds, x_in_bf);
+      if (int e = bn_backward(c, Bk.ds, g, nullptr, out, dyds, nullptr, k_g, k0, -1)) return e;
+      items[n_items++] = wgrad_item(c, Bk.ds, dyds, x_in, k0);
       // the residual branch's gradient w.r.t. x_in is ADDED IN PLACE: a strided 1x1x1 branch reaches one voxel in eight, and the
       // parity-class dgrad (ConvGeom::tclass) then skips the other seven classes' tiles altogether
       if (int e = conv_dgrad(c, i0, dy0, nullptr, g_next)) return e;
@@ -641,32 +803,56 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
       // its mask and the sums of that block's bn3 ride on this epilogue -- unless that block has a downsample branch (its second
       // BatchNorm needs its own pair of sums from the same gradient: both keep their launches)
       const bool fg = b > 0 && A.block[b - 1].ds < 0 && fuse_bn_sums(A.conv[A.block[b - 1].conv[2]]);
-      if (int e = conv_dgrad(c, i0, dy0, gm, g_next, fg ? A.block[b - 1].conv[2] : -1, fg ? (const bf16_t*)(ws + L.out_bf[b - 1]) : nullptr)) return e;
+      if (int e = conv_dgrad(c, i0, dy0, gm, g_next, fg ? A.block[b - 1].conv[2] : -1, fg ? (const half_t*)(ws + L.out[b - 1]) : nullptr)) return e;
       g_sums_done = fg;
     }
-    bf16_t* t = g; g = g_next; g_next = t;
+    half_t* t = g; g = g_next; g_next = t;
+    k_g = k0;
   }
   // stem: max-pool -> relu -> bn1 -> conv1
   {
     const ConvSpec& c0 = A.conv[0];
-    bf16_t* dpost = (bf16_t*)(bws + B.dpost);          // the fp32-sized buffer, used as bf16
+    half_t* dpost = (half_t*)(bws + B.dpost);          // the fp32-sized buffer, used as fp16
     const size_t rp = rows_pad(c0.dout);
     hipLaunchKernelGGL(maxpool_bwd_gather_kernel, dim3((unsigned)((rp * 8 + 255) / 256)), dim3(256), 0, st,
                        (const unsigned char*)(ws + L.pool_arg), c0.dout, A.pooled, g, dpost, rp);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
-    bf16_t* dy0 = (bf16_t*)(bws + B.dy[0]);
-    if (int e = bn_backward(c, 0, dpost, nullptr, nullptr, dy0, nullptr)) return e;      // relu mask already applied by the routing
-    items[n_items++] = wgrad_item(c, 0, dy0, (const bf16_t*)(ws + L.x0_bf));
+    half_t* dy0 = (half_t*)(bws + B.dy[0]);
+    const int k_s = new_k(k_g);
+    if (int e = bn_backward(c, 0, dpost, nullptr, nullptr, dy0, nullptr, k_g, k_s, -1)) return e;      // relu mask already applied by the routing
+    items[n_items++] = wgrad_item(c, 0, dy0, (const half_t*)(ws + L.x0), k_s);
     if (n_cells > 0) {
       float* Wt = (float*)(bws + B.wtmp);
       hipLaunchKernelGGL(stem_w_relayout_kernel, dim3((125 * 8 * 64 + 255) / 256), dim3(256), 0, st, conv_w[0], Wt);
       hipLaunchKernelGGL(stem_dgrid_kernel, dim3((n_cells + 3) / 4), dim3(256), 0, st, dy0, Wt, A.S, c0.dout,
-                         reinterpret_cast<const unsigned long long*>(bws + B.scale + 64), n_cells, n_ch, scale + 1, dgrid_cells);
+                         reinterpret_cast<const unsigned long long*>(bws + B.scale + 64), n_cells, n_ch, c.inv(k_s), dgrid_cells);
       NERAF_HIP_CHECK(ctx, hipGetLastError());
     }
   }
+  if (n_k != total_k) return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_bwd: scale group count mismatch");
+  (void)par;
   // all 43 weight gradients: one TN GEMM grid over every (convolution, tile, K-split) + one reducer
-  return launch_wgrad_grouped(ctx, items, n_items, (const half_t*)(ws + L.zero_page), (float*)(bws + B.splitk), B.splitk_bytes, scale + 1, st);
+  return launch_wgrad_grouped(ctx, items, n_items, (const half_t*)(ws + L.zero_page), (float*)(bws + B.splitk), B.splitk_bytes, c.inv_base(), st);
+}
+
+// Workspaces whose chain exponents have been calibrated (see the header).  neraf_resnet3d_bwd_reset forgets one.
+static std::mutex g_calib_mu;
+static std::unordered_map<const void*, unsigned> g_calibrated;      // workspace -> passes run since its calibration
+constexpr int kMaxCalibrationPasses = 48;
+
+// stage test: a valid ChainState with S0 = 1 and the given exponents for groups 0, 1, 2
+__global__ void chain_set_kernel(ChainState* cs, int e0, int e1, int e2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int e[3] = {e0, e1, e2};
+  for (int t = 0; t < 3; ++t) { cs->e[t] = e[t]; cs->pow2[t] = exp2f((float)e[t]); cs->inv[t] = exp2f((float)-e[t]); }
+  cs->magic = kChainMagic;
+}
+
+extern "C" int neraf_resnet3d_bwd_reset(neraf_ctx* ctx, void* bwd_workspace) {
+  (void)ctx;
+  std::lock_guard<std::mutex> lk(g_calib_mu);
+  g_calibrated.erase(bwd_workspace);
+  return NERAF_OK;
 }
 
 extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* packed_t, const float* const* conv_w,
@@ -684,14 +870,73 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
   // the refresh window moves every step: its start travels through device memory, outside the captured sequence
   hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long*>(bws + B.scale + 64),
                      (unsigned long long)cell_start);
+  // Producers record their amax on every kTrackPeriod-th pass only (two captured variants of the sequence): the atomics cost ~0.3 us
+  // at the tail of each of ~130 launches (+0.06 ms per step when every pass records, profiles/r05_fp16_chain_ab.txt), the magnitudes
+  // drift by far less than the 8x headroom in a handful of steps, and an overflow costs a skipped step, not a wrong one.
+  // NERAF_CHAIN_AMAX=0: never (frozen scales, measurement only); NERAF_CHAIN_AMAX_PERIOD=n: every n-th pass.
+  static const bool track_env = [] { const char* e = getenv("NERAF_CHAIN_AMAX"); return !(e && atoi(e) == 0); }();
+  static const unsigned period = [] { const char* e = getenv("NERAF_CHAIN_AMAX_PERIOD"); const int v = e ? atoi(e) : 4; return (unsigned)(v < 1 ? 1 : v); }();
+  auto run = [&](hipStream_t s2, bool track) {
+    return resnet3d_bwd_body(ctx, A, L, B, packed_t, conv_w, bn, (char*)workspace, bws, dfeat, w_grads, bn_grads, n_cells, n_ch, dgrid_cells, s2,
+                             track);
+  };
+
+  // First use of this workspace: the chain's exponents start at 0 relative to S0 (the ChainState is marked invalid) and are calibrated
+  // by running the chain on this very gradient until a prologue reports that every tensor of the pass before it was stored as finite
+  // fp16 from finite inputs (ChainState::unsettled; one device-to-host read per pass -- this happens once per workspace).  The
+  // results of the calibration passes are overwritten by the real pass below.
+  bool fresh;
+  unsigned pass_no;
+  {
+    std::lock_guard<std::mutex> lk(g_calib_mu);
+    auto it = g_calibrated.find(bwd_workspace);
+    fresh = it == g_calibrated.end();
+    if (fresh) it = g_calibrated.emplace(bwd_workspace, 0u).first;
+    pass_no = it->second++;
+  }
+  const bool track = track_env && (pass_no % period) == 0;
+  auto body = [&](hipStream_t s2) { return run(s2, track); };
+  if (fresh) {
+    NERAF_HIP_CHECK(ctx, hipMemsetAsync(bws + B.chain, 0, sizeof(ChainState), st));
+    for (int i = 0; i < kMaxCalibrationPasses; ++i) {
+      if (int e = run(st, true)) return e;
+      unsigned unsettled = 0;
+      NERAF_HIP_CHECK(ctx, hipMemcpyAsync(&unsettled, bws + B.chain + offsetof(ChainState, unsettled), 4, hipMemcpyDeviceToHost, st));
+      NERAF_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      if (i >= 1 && unsettled == 0) break;        // the pass before this one was clean, and this one ran on exponents re-centred from it
+    }
+  }
   ArgHash k;
-  k.add(0x62776431u); k.add(d->grid_size); k.add(packed_t); k.ptrs((const void* const*)conv_w, A.nconv);
+  k.add(0x62776432u); k.add(d->grid_size); k.add(packed_t); k.ptrs((const void* const*)conv_w, A.nconv);
   k.ptrs((const void* const*)bn, 4 * A.nconv); k.add(workspace); k.add(bwd_workspace); k.add(dfeat);
   k.ptrs((const void* const*)w_grads, A.nconv); k.ptrs((const void* const*)bn_grads, 2 * A.nconv);
-  k.add(n_cells); k.add(n_ch); k.add(dgrid_cells);
-  return neraf_run_graphed(ctx, st, k.h, [&](hipStream_t s2) {
-    return resnet3d_bwd_body(ctx, A, L, B, packed_t, conv_w, bn, (char*)workspace, bws, dfeat, w_grads, bn_grads, n_cells, n_ch, dgrid_cells, s2);
-  });
+  k.add(n_cells); k.add(n_ch); k.add(dgrid_cells); k.add(track);
+  return neraf_run_graphed(ctx, st, k.h, body);
+}
+
+// Test aid: the chain's state after the last pass -- exponents e[t] and the amax each tensor's producer recorded in that pass (as
+// floats; the next prologue consumes and clears them).  n = number of entries the caller's arrays hold.
+extern "C" int neraf_resnet3d_bwd_chain_state(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* bwd_workspace, int32_t* e_out,
+                                              float* amax_out, int n, int32_t* info2, neraf_stream_t stream) {
+  Arch A; BwdLayout B;
+  if (make_arch(d, &A) || !bwd_workspace || !e_out || !amax_out || n < 1 || n > kChainMax)
+    return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_bwd_chain_state: bad arguments");
+  make_bwd_layout(A, &B);
+  const char* bws = (const char*)bwd_workspace;
+  NERAF_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)stream));
+  ChainState cs;
+  NERAF_HIP_CHECK(ctx, hipMemcpy(&cs, bws + B.chain, sizeof(cs), hipMemcpyDeviceToHost));
+  std::vector<unsigned> am((size_t)n * kAmaxRep * kAmaxStride);
+  NERAF_HIP_CHECK(ctx, hipMemcpy(am.data(), bws + B.amax, am.size() * 4, hipMemcpyDeviceToHost));
+  for (int t = 0; t < n; ++t) {
+    unsigned mx = 0;
+    for (int r = 0; r < kAmaxRep; ++r) mx = std::max(mx, am[((size_t)t * kAmaxRep + r) * kAmaxStride]);
+    float f; memcpy(&f, &mx, 4);
+    e_out[t] = cs.magic == kChainMagic ? cs.e[t] : 0;
+    amax_out[t] = f;
+  }
+  if (info2) { info2[0] = (int32_t)cs.unsettled; info2[1] = (int32_t)cs.passes; }
+  return NERAF_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -745,8 +990,6 @@ extern "C" int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_r
   }
   NERAF_HIP_CHECK(ctx, hipMemcpyAsync(y_f16, yact, cube(dout) * cout * 2, hipMemcpyDeviceToDevice, st));
   // backward
-  float* scale = (float*)(bws + B.scale);
-  hipLaunchKernelGGL(set_f32x2_kernel, dim3(1), dim3(64), 0, st, scale, 1.f, 1.f);
   if (dx && cin % 64 == 0) {
     PackTTable t{};
     const int nrows = cin == 64 || cin == 8 ? 64 : round_up(cin, 128);
@@ -757,20 +1000,17 @@ extern "C" int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_r
   }
   float* wg[1] = {dw};
   float* bng[2] = {dgamma, dbeta};
-  Ctx c{ctx, st, &A, &L, &B, packed_t, ws, bws, bnp, wg, bng, scale + 1};
-  bf16_t* dy = (bf16_t*)(extra + 2 * act);
-  bf16_t* dxb = (bf16_t*)(extra + 3 * act);
-  if (int e = bn_backward(c, 0, nullptr, g, yact, dy, nullptr)) return e;
-  bf16_t* xin_bf = (bf16_t*)(extra + 4 * act);
-  {
-    const size_t n = rows_pad(din) * (size_t)cin;
-    hipLaunchKernelGGL(f16_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xin, n, xin_bf);
-  }
-  if (int e = conv_wgrad(c, 0, dy, xin_bf)) return e;
+  Ctx c{ctx, st, &A, &L, &B, packed_t, ws, bws, bnp, wg, bng};
+  // scale groups of the stage: 0 = g (fp32, unscaled), 1 = dy and its dgrad result (stored x 2^6): the re-scaling path is exercised
+  hipLaunchKernelGGL(chain_set_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<ChainState*>(bws + B.chain), 0, 6, 0);
+  half_t* dy = (half_t*)(extra + 2 * act);
+  half_t* dxb = (half_t*)(extra + 3 * act);
+  if (int e = bn_backward(c, 0, nullptr, g, yact, dy, nullptr, 0, 1, -1)) return e;
+  if (int e = conv_wgrad(c, 0, dy, xin, 1)) return e;
   if (dx && cin % 64 == 0) {
     if (int e = conv_dgrad(c, 0, dy, nullptr, dxb)) return e;
     const size_t n = cube(din) * cin;
-    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dxb, n, dx);
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dxb, n, c.inv(1), dx);
   }
   NERAF_HIP_CHECK(ctx, hipStreamSynchronize(st));
   (void)wl;

@@ -73,9 +73,6 @@ struct Layout {
   size_t act_pool;              // stem: pooled activation
   size_t pool_arg;              // stem: which of the 27 window taps held the maximum (uint8 [pooled^3][64], 255 = none > 0); training
   size_t a1[16], a2[16], out[16];   // per block post-activation tensors
-  // bfloat16 shadows of every tensor a convolution reads (written by the same passes in training mode): the weight-gradient
-  // GEMM pairs them with the bfloat16 gradient chain, and the MFMA wants both operands in one type
-  size_t x0_bf, act_pool_bf, a1_bf[16], a2_bf[16], out_bf[16];
   size_t splitk; size_t splitk_bytes;
   size_t stats_begin, stats_bytes;
   size_t total;
@@ -111,16 +108,7 @@ void make_layout(const Arch& A, Layout* L) {
   }
   L->splitk_bytes = (size_t)64 << 20;
   L->splitk = take(L->splitk_bytes);
-  L->x0_bf = take(cube(A.S) * 8 * 2);
-  L->act_pool_bf = take(rows_pad(A.pooled) * 64 * 2);
   L->pool_arg = take(cube(A.pooled) * 64);
-  for (int b = 0; b < A.nblock; ++b) {
-    const ConvSpec& c0 = A.conv[A.block[b].conv[0]]; const ConvSpec& c1 = A.conv[A.block[b].conv[1]];
-    const ConvSpec& c2 = A.conv[A.block[b].conv[2]];
-    L->a1_bf[b] = take(rows_pad(c0.dout) * c0.cout * 2);
-    L->a2_bf[b] = take(rows_pad(c1.dout) * c1.cout * 2);
-    L->out_bf[b] = take(rows_pad(c2.dout) * c2.cout * 2);
-  }
   L->total = off;
 }
 
@@ -284,7 +272,7 @@ __global__ __launch_bounds__(256) void pack_all_conv_weights_kernel(PackTable t,
 // LDS.  The fp32 source [cout][cin][taps] is read in contiguous runs of CIB*taps floats per co row (16-byte loads), converted and
 // parked in LDS in source order; the brick shape is chosen PER LAYOUT so that the destination is written in whole lines too:
 //   MODE 0  forward layout   fp16  dst[co][tap*cin + ci]     CIB = cin: a brick is COB complete destination rows (contiguous)
-//   MODE 1  dgrad layout     bf16  dst[ci][tap*cout + co]    COB = cout: every (ci, tap) run is a complete row segment of cout
+//   MODE 1  dgrad layout     fp16  dst[ci][tap*cout + co]    COB = cout: every (ci, tap) run is a complete row segment of cout
 // (the first version used [32 co][32 ci] bricks for both: 64-byte destination runs, 2 TB/s).  COB / CIB come from brick_shape().
 struct BrickTable {
   int n;
@@ -318,8 +306,8 @@ __global__ __launch_bounds__(256) void pack_bricks_kernel(BrickTable t, char* __
       unsigned short* dst = brick16 + co_l * pitch + 4 * i4;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (MODE == 0) { const half_t h = (half_t)v[k]; dst[k] = *reinterpret_cast<const unsigned short*>(&h); }
-        else { const bf16_t h = (bf16_t)v[k]; dst[k] = *reinterpret_cast<const unsigned short*>(&h); }
+        const half_t h = (half_t)v[k];
+        dst[k] = *reinterpret_cast<const unsigned short*>(&h);
       }
     };
     auto get4 = [&](int e) {
@@ -395,7 +383,6 @@ struct BnApplyArgs {
   BnSrc a; BnSrc r; const half_t* res;   // r.x != null: residual is bn_r(r.x); else res (may be null)
   int M, Mpad, C; int relu;
   half_t* out;
-  bf16_t* out_bf;       // optional bfloat16 shadow of `out`
 };
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
@@ -448,12 +435,6 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
       for (int j = 0; j < 8; ++j) o[j] = (half_t)0.f;
     }
     *reinterpret_cast<half8*>(p.out + row * p.C + c0) = o;
-    if (p.out_bf) {
-      bf16x8 ob;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ob[j] = (bf16_t)(float)o[j];
-      *reinterpret_cast<bf16x8*>(p.out_bf + row * p.C + c0) = ob;
-    }
     idx += (size_t)gridDim.x * 256;
     if (idx < total) issue(idx);
   }

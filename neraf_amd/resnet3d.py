@@ -63,6 +63,8 @@ class _ResNet3DFn(torch.autograd.Function):
         _lib.check(lib.neraf_resnet3d_pack_weights_bwd(h, C.byref(net._desc), tb["conv_w_ptrs"], packed_t.data_ptr(), st), dev)
         if net._bws is None or net._bws.device != device:
             net._bws = torch.empty(lib.neraf_resnet3d_bwd_workspace_bytes(C.byref(net._desc)), dtype=torch.uint8, device=device)
+            # the fp16 gradient chain's per-tensor scales live in this buffer: a new buffer starts with calibration passes
+            _lib.check(lib.neraf_resnet3d_bwd_reset(h, net._bws.data_ptr()), dev)
         if net._grad_bufs is None or net._grad_bufs[0]["flat"].device != device:
             sizes = [p.numel() for p in params]
             nconv = len(tb["pairs"])
