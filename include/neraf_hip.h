@@ -455,6 +455,12 @@ int neraf_resnet3d_bwd_reset(neraf_ctx* ctx, void* bwd_workspace);
 int neraf_resnet3d_bwd_chain_state(neraf_ctx* ctx, const neraf_resnet3d_desc* d, const void* bwd_workspace, int32_t* e_out,
                                    float* amax_out, int n, int32_t* info2, neraf_stream_t stream);
 
+/* Measurement aid (tools/resnet_node_roofline.py): while enabled, neraf_resnet3d_fwd / _bwd run their launches directly (no graph
+ * replay) and append one record per launch -- "<kernel-name prefix> | description", algorithmic FLOPs, bytes read, bytes written as
+ * designed (operands once, results once).  neraf_manifest_get returns the number of records (and fills record `index` if in range). */
+int neraf_manifest_enable(neraf_ctx* ctx, int on);
+int neraf_manifest_get(neraf_ctx* ctx, int index, char* name, int name_cap, double* flops, double* rbytes, double* wbytes);
+
 /* Test aid: one conv + BatchNorm(train) + ReLU stage, forward and backward on caller data (allocates and
  * synchronises internally; not part of the product path). */
 int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_real, int cout, int k, int stride, int pad, int din,

@@ -159,6 +159,8 @@ SIGNATURES = {
     "neraf_resnet3d_bwd_packed_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),
     "neraf_resnet3d_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(ResnetDesc)]),
     "neraf_resnet3d_pack_weights_bwd": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), c_fpp, C.c_void_p, C.c_void_p]),
+    "neraf_manifest_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "neraf_manifest_get": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "neraf_resnet3d_bwd_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
     "neraf_resnet3d_bwd_chain_state": (C.c_int, [C.c_void_p, C.POINTER(ResnetDesc), C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float),
                                                  C.c_int, C.POINTER(C.c_int32), C.c_void_p]),

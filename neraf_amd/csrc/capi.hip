@@ -52,6 +52,27 @@ extern "C" int neraf_graph_stats(neraf_ctx* ctx, int* captures, int* launches) {
   return ctx->graphs_enabled ? 1 : 0;
 }
 
+// Launch manifest of the ResNet3D sequences (measurement aid): while enabled, the forward / backward run un-graphed and every launch
+// appends {kernel, algorithmic FLOPs, bytes read, bytes written}; tools/resnet_node_roofline.py zips the list with a rocprofv3 trace.
+extern "C" int neraf_manifest_enable(neraf_ctx* ctx, int on) {
+  if (!ctx) return NERAF_EINVAL;
+  ctx->nodes.clear();
+  ctx->manifest = on != 0;
+  return NERAF_OK;
+}
+
+extern "C" int neraf_manifest_get(neraf_ctx* ctx, int index, char* name, int name_cap, double* flops, double* rbytes, double* wbytes) {
+  if (!ctx) return -1;
+  const int n = (int)ctx->nodes.size();
+  if (index < 0 || index >= n) return n;
+  const NodeRec& r = ctx->nodes[index];
+  if (name && name_cap > 0) { snprintf(name, (size_t)name_cap, "%s", r.name.c_str()); }
+  if (flops) *flops = r.flops;
+  if (rbytes) *rbytes = r.rbytes;
+  if (wbytes) *wbytes = r.wbytes;
+  return n;
+}
+
 extern "C" const char* neraf_last_error(neraf_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
 extern "C" int neraf_prof_enable(neraf_ctx* ctx, int on) {

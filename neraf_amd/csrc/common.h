@@ -26,6 +26,9 @@ enum { PROF_GEMM128 = 0, PROF_GEMM64 = 1, PROF_PROP_DENSITY = 2, PROF_FIELD_QUER
 struct ProfRec { hipEvent_t a, b; int kid; double work; double exec; };   // work: ALGORITHMIC FLOPs / bytes; exec: as executed (padding, zero taps)
 
 struct GraphEntry { uint64_t key; hipGraphExec_t exec; uint64_t last_use; };
+// One launch of a ResNet3D sequence as the library sees it (neraf_manifest_*, tools/resnet_node_roofline.py): algorithmic FLOPs and the
+// bytes the launch must read / write as designed (operands once, results once; split-K slabs count where they are written and read).
+struct NodeRec { std::string name; double flops, rbytes, wbytes; };
 
 struct neraf_ctx {
   int device;
@@ -40,7 +43,12 @@ struct neraf_ctx {
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
   int graph_captures = 0, graph_launches = 0;
+  bool manifest = false;               // neraf_manifest_enable: launches are recorded (and run un-graphed) instead of replayed
+  std::vector<NodeRec> nodes;
 };
+static inline void neraf_node(neraf_ctx* ctx, const char* name, double flops, double rbytes, double wbytes) {
+  if (ctx && ctx->manifest) ctx->nodes.push_back(NodeRec{name, flops, rbytes, wbytes});
+}
 
 // FNV-1a over the argument values that end up in kernel arguments: the cache key of a captured call sequence
 struct ArgHash {
@@ -84,7 +92,7 @@ static inline int neraf_fail(neraf_ctx* ctx, int code, const char* what) {
 // host cost (tools/microbench/graph_chain.hip).  Falls back to direct launches while profiling or after any failure.
 template <class Body>
 int neraf_run_graphed(neraf_ctx* ctx, hipStream_t user, uint64_t key, Body body) {
-  if (!ctx || !ctx->graphs_enabled || ctx->prof) return body(user);
+  if (!ctx || !ctx->graphs_enabled || ctx->prof || ctx->manifest) return body(user);
   const char* tr = getenv("NERAF_GRAPH_TRUNC");      // measurement only: replay just a prefix of the captured sequence
   const int trunc = tr ? atoi(tr) : -1;
   if (trunc >= 0) key = key * 1099511628211ull + (uint64_t)(trunc + 1);

@@ -1002,6 +1002,10 @@ struct FieldOwnerArgs {
   int blk_begin[MAX_LEVELS + 1];       // owner workgroups of level l: [blk_begin[l], blk_begin[l+1]) = slices x rep[l]
   unsigned char rep[MAX_LEVELS];       // coarse levels have few slices that every sample hits: rep[l] workgroups share a slice, each
                                        // takes 1/rep[l] of the samples and adds its sums to the table with (few) global atomics
+  // direct flush (dst != null): a workgroup that alone owns its slice (rep == 1) holds the slice's FINISHED sums, so it decodes them
+  // and writes (beta == 0) or adds to (beta != 0) the fp32 gradient itself -- the accumulator is never touched for those levels and
+  // field_unpack_grad_kernel skips them (it read 8 B, read + wrote 8 B of gradient and re-zeroed 8 B per table row: 60 us per step)
+  float2* dst; int beta; const float* scale;
 };
 
 // corner index of a level (dense: x + y*res + z*res^2, wrapped once; hashed: tcnn's coherent prime hash)
@@ -1129,7 +1133,24 @@ __global__ __launch_bounds__(OWN_THREADS) void field_scatter_owner_kernel(FieldO
   __syncthreads();
   const size_t e0 = (size_t)slice * NENT;
   unsigned long long* dst = a.acc + a.g.offset[l] + e0;
-  if (nrep == 1) {
+  if (nrep == 1 && a.dst) {
+    // the same decode as field_unpack_grad_kernel, operation for operation (the two paths are compared bit for bit)
+    const float m = a.lvl[16 + l] * a.scale[1];
+    float2* out = a.dst + a.g.offset[l] + e0;
+    for (unsigned i = tid; i < NENT; i += OWN_THREADS) {
+      if (e0 + i >= size) continue;
+      const long long v = (long long)own[i];
+      if (v == 0) {
+        if (!a.beta) out[i] = make_float2(0.f, 0.f);
+        continue;
+      }
+      const int lo = (int)(v & 0xffffffffll);
+      const int hi = (int)((v - (long long)lo) >> 32);
+      float2 o = make_float2((float)lo * m, (float)hi * m);
+      if (a.beta) { const float2 old = out[i]; o.x += old.x; o.y += old.y; }
+      out[i] = o;
+    }
+  } else if (nrep == 1) {
     for (unsigned i = tid; i < NENT; i += OWN_THREADS)
       if (e0 + i < size) dst[i] = own[i];
   } else {
@@ -1146,8 +1167,10 @@ __global__ __launch_bounds__(OWN_THREADS) void field_scatter_owner_kernel(FieldO
 // with a contribution only) -- the second producer of a parameter's gradient in one backward pass adds in place instead of
 // handing autograd a second tensor to sum (a 49 MB add per step for the radiance table: render batch + grid refresh)
 __global__ __launch_bounds__(256) void field_unpack_grad_kernel(GridLayout g, const float* __restrict__ lvl, const float* __restrict__ scale,
-                                                               unsigned long long* __restrict__ acc, float2* __restrict__ dst, int beta) {
+                                                               unsigned long long* __restrict__ acc, float2* __restrict__ dst, int beta,
+                                                               unsigned skip_levels = 0u) {
   const int l = blockIdx.y;
+  if ((skip_levels >> l) & 1u) return;      // flushed by its owner workgroups (FieldOwnerArgs::dst)
   const float m = lvl[16 + l] * scale[1];
   const unsigned size = g.size[l], off = g.offset[l];
   const bool inplace = reinterpret_cast<void*>(dst) == reinterpret_cast<void*>(acc);
@@ -1502,6 +1525,7 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
       sblocks = ((nruns + 63) / 64 + 3) / 4;
     }
     if (sblocks > cap) sblocks = cap;
+    unsigned direct_levels = 0u;
     {
       ProfScope prof(ctx, st, PROF_FIELD_SCATTER, (double)N * 16 * 8 * 8);   // one 8-byte update per (sample, level, corner) before merging
       if (!use_owner) hipLaunchKernelGGL(field_scatter_kernel, dim3((unsigned)sblocks, pos_run > 1 ? 16 : 1), dim3(256), 0, st, sa);
@@ -1511,6 +1535,11 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
         oa.ids = reinterpret_cast<unsigned*>(a.pos + 3 * npad);
         for (int l = 0; l <= 16; ++l) oa.blk_begin[l] = own_blk[l];
         for (int l = 0; l < 16; ++l) oa.rep[l] = own_rep[l];
+        static const int direct_on = [] { const char* e = getenv("NERAF_OWNER_DIRECT"); return e ? atoi(e) : 1; }();      // 0: A/B
+        if (acc_scratch && direct_on) {
+          oa.dst = reinterpret_cast<float2*>(table_grad); oa.beta = accumulate; oa.scale = scale;
+          for (int l = 0; l < 16; ++l) if (own_rep[l] == 1) direct_levels |= 1u << l;
+        }
         long iblocks = (npad + 255) / 256; if (iblocks > 512) iblocks = 512;
         hipLaunchKernelGGL(field_slice_ids_kernel, dim3((unsigned)iblocks, 16), dim3(256), 0, st, oa);
         hipLaunchKernelGGL(field_scatter_owner_kernel, dim3(own_blk[16]), dim3(OWN_THREADS), kOwnLds, st, oa);
@@ -1519,7 +1548,7 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
     unsigned maxsize = 0;
     for (int l = 0; l < 16; ++l) maxsize = a.g.size[l] > maxsize ? a.g.size[l] : maxsize;
     hipLaunchKernelGGL(field_unpack_grad_kernel, dim3((maxsize + 1023) / 1024, 16), dim3(256), 0, st, a.g, lvl, scale,
-                       sa.acc, reinterpret_cast<float2*>(table_grad), accumulate);
+                       sa.acc, reinterpret_cast<float2*>(table_grad), accumulate, direct_levels);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
   }
   // weight gradients: dW_l [out,in] = (1/S) dY_l [out,N] . X_l [in,N]^T   (NT GEMM, K = points, split-K)

@@ -804,6 +804,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
   }
 }
 
+// manifest records (neraf_manifest_enable) of one GEMM launch and, with split-K, of its reducer: operands once (an implicit-GEMM
+// convolution reads its source tensor once, not once per tap), results once; the K-split slabs where they are written and read
+static void gemm_manifest(neraf_ctx* ctx, const GemmParams& p, int loader, int splits, int bm, int bn, double flops, bool wide = false) {
+  const double out_elems = (double)p.M * p.N;
+  const double rA = loader == 0 ? (double)p.M * p.K * 2.0 : (double)p.conv.din * p.conv.din * p.conv.din * p.conv.cin * 2.0;
+  const double rB = (double)p.N * p.K * 2.0;
+  const double epi_r = out_elems * 2.0 * ((p.add16 ? 1 : 0) + (p.lmask ? 1 : 0) + (p.bnb_mask ? 1 : 0) + (p.bnb_x ? 1 : 0));
+  const double epi_w = out_elems * (2.0 * ((p.C16 ? 1 : 0) + (p.C16T ? 1 : 0)) + (p.C32 ? 4.0 : 0.0));
+  const double slabs = (double)splits * p.Mpad * p.Npad * 4.0;
+  char nm[96];
+  // "<rocprofv3 kernel-name prefix> | description": the tool matches the prefix against the trace
+  snprintf(nm, sizeof(nm), "%s<%d, %d | %s M=%d N=%d K=%d%s", wide ? "gemm_f16_nt_wide_kernel" : "gemm_f16_nt_pipe_kernel", bm, bn,
+           loader == 0 ? "plain" : (p.conv.tflip ? "dgrad" : "conv"), p.M, p.N, p.K, splits > 1 ? " splitK" : "");
+  if (splits > 1) {
+    neraf_node(ctx, nm, flops, rA + rB, slabs);
+    neraf_node(ctx, "splitk_reduce_kernel | K-split slabs -> result", 0.0, slabs + epi_r, epi_w);
+  } else {
+    neraf_node(ctx, nm, flops, rA + rB + epi_r, epi_w);
+  }
+}
+
 template <int BM, int BN, int NST, int LOADER, int KS, bool BF, bool TC = false>
 int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t stream) {
   using PT = PipeTile<BM, BN, NST>;
@@ -827,6 +848,7 @@ int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
   hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF, TC>), dim3(ntiles * splits * ng), dim3(256), PT::LDS_BYTES,
                      stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
+  if (ctx && ctx->manifest) gemm_manifest(ctx, p, LOADER, splits, BM, BN, flops);
   if (splits > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel<BF>, dim3(p.Npad / 32, p.Mpad / 32, ng), dim3(256), 0, stream, p, splits);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
@@ -850,6 +872,7 @@ int launch_wide(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
   ProfScope prof(ctx, stream, PROF_GEMM_WIDE, p.alg_flops > 0.0 ? p.alg_flops : 2.0 * p.M * p.N * p.K, 2.0 * p.M * p.N * p.K);
   hipLaunchKernelGGL((gemm_f16_nt_wide_kernel<BM, BN, NST, BF>), dim3(ntiles * splits), dim3(512), LDS_BYTES, stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
+  if (ctx && ctx->manifest) gemm_manifest(ctx, p, 0, splits, BM, BN, p.alg_flops > 0.0 ? p.alg_flops : 2.0 * p.M * p.N * p.K, true);
   if (splits > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel<BF>, dim3(p.Npad / 32, p.Mpad / 32, 1), dim3(256), 0, stream, p, splits);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
@@ -1488,6 +1511,17 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
   }
   if (nred > 0) hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(red_tiles), dim3(256), 0, stream, t, r);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
+  if (ctx && ctx->manifest) {
+    double rb = 0.0, wb = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const WgradItem& it = items[i];
+      const double taps = (double)it.ksize * it.ksize * it.ksize;
+      rb += (double)it.K * it.cout * 2.0 + (double)it.din * it.din * it.din * it.cin * 2.0;       // dY once, the activation once
+      wb += (double)it.cout * it.cin_real * taps * 4.0;
+    }
+    neraf_node(ctx, "wgrad_ | all 43 weight gradients, TN GEMM", flops, rb, nred > 0 ? (double)slab_off * 4.0 : wb);
+    if (nred > 0) neraf_node(ctx, "wgrad_grouped_reduce_kernel | slabs -> [cout][cin][taps]", 0.0, (double)slab_off * 4.0, wb);
+  }
   return NERAF_OK;
 }
 

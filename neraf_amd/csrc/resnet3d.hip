@@ -245,13 +245,17 @@ extern "C" int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_
 static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, const char* packed, const float* const* bn, const float* grid,
                              char* ws, float* feat, int use_batch_stats, int win_cells, hipStream_t st) {
   neraf_zero3_async(st, ws + L.zero_page, 256, ws + L.stats_begin, L.stats_bytes, feat, 1024 * sizeof(float));
+  neraf_node(ctx, "neraf_zero3_kernel | statistics accumulators", 0.0, 0.0, 256.0 + (double)L.stats_bytes + 4096.0);
   const size_t nvox = cube(A.S);
   const bool training = use_batch_stats != 0;    // training forward: keep the max-pool routing for the backward
-  if (win_cells > 0)      // the rest of the image is the previous call's (the caller vouches for it)
+  if (win_cells > 0) {    // the rest of the image is the previous call's (the caller vouches for it)
     hipLaunchKernelGGL(grid_window_to_ndhwc8_kernel, dim3((unsigned)((win_cells + 255) / 256)), dim3(256), 0, st, grid, nvox,
                        reinterpret_cast<const unsigned long long*>(ws + L.win), win_cells, (half_t*)(ws + L.x0));
-  else
+    neraf_node(ctx, "grid_window_to_ndhwc8_kernel | refresh window -> fp16 channels-last", 0.0, win_cells * 28.0, win_cells * 16.0);
+  } else {
     hipLaunchKernelGGL(grid_to_ndhwc8_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, grid, nvox, (half_t*)(ws + L.x0));
+    neraf_node(ctx, "grid_to_ndhwc8_kernel | grid -> fp16 channels-last", 0.0, (double)nvox * 28.0, (double)nvox * 16.0);
+  }
   // stem: conv1 -> bn1 -> relu -> maxpool (NeRAF_resnet3d.py:185-188)
   if (int e = run_conv(ctx, st, A, L, 0, packed, ws, (const half_t*)(ws + L.x0))) return e;
   {
@@ -261,6 +265,8 @@ static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, c.dout, A.pooled,
                        cube(c.dout), (half_t*)(ws + L.act_pool), training ? (unsigned char*)(ws + L.pool_arg) : nullptr);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
+    neraf_node(ctx, "bn_relu_maxpool_kernel | stem BatchNorm + ReLU + 3x3x3/2 max-pool", 0.0, (double)cube(c.dout) * 64 * 2.0,
+               (double)cube(A.pooled) * 64 * (training ? 3.0 : 2.0));
   }
   const half_t* x = (const half_t*)(ws + L.act_pool);
   for (int b = 0; b < A.nblock; ++b) {                                        // Bottleneck.forward, :92-113
@@ -298,6 +304,7 @@ static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     const int M = (int)cube(A.final_edge), C = 1024;
     hipLaunchKernelGGL(avgpool_kernel, dim3(C / 64), dim3(256), 0, st, x, M, C, feat);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
+    neraf_node(ctx, "avgpool_kernel | mean over the voxels", 0.0, (double)M * C * 2.0, C * 4.0);
   }
   return NERAF_OK;
 }

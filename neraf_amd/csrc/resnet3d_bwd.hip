@@ -594,6 +594,16 @@ int bn_backward(const Ctx& c, int ci, const half_t* g16, const float* g32, const
   p.det = neraf_deterministic() ? 1 : 0;
   // sums_done: the dgrad GEMM that produced g16 already reduced sum g and sum g * xhat in its epilogue (fuse_bn_sums below)
   if (!sums_done) hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nrb, p.C / 64), dim3(256), 0, c.st, p);
+  if (c.ctx && c.ctx->manifest) {
+    char nm[96];
+    const double elems = (double)p.M * p.C;
+    if (!sums_done) {
+      snprintf(nm, sizeof(nm), "bn_bwd_reduce_kernel | M=%d C=%d", p.M, p.C);
+      neraf_node(c.ctx, nm, 0.0, elems * (2.0 + (g16 ? 2.0 : 4.0) + (act ? 2.0 : 0.0)), 0.0);
+    }
+    snprintf(nm, sizeof(nm), "bn_bwd_apply_kernel | M=%d C=%d%s", p.M, p.C, dy_masked ? " + masked copy" : "");
+    neraf_node(c.ctx, nm, 0.0, elems * (2.0 + (g16 ? 2.0 : 4.0) + (act ? 2.0 : 0.0)), (double)p.Mpad * p.C * 2.0 * (dy_masked ? 2 : 1));
+  }
   static const int skip_small = [] { const char* e = getenv("NERAF_SKIP_SMALL_BN"); return e ? atoi(e) : 0; }();      // measurement only, see resnet3d.hip
   if (skip_small >= 2 && cube(cs.dout) <= 4096 && cs.k == 1) return NERAF_OK;     // BatchNorms of 1x1x1 convolutions: their dgrad consumer is a plain GEMM
   if (p.det) {     // the slots (of the reduce kernel or of the fused epilogue) added in a fixed order; the apply pass reads that
@@ -735,6 +745,7 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
                              bool track) {
   float* scale = (float*)(bws + B.scale);
   neraf_zero_async(st, bws + B.sums_begin, B.sums_bytes);
+  neraf_node(ctx, "neraf_zero_kernel | BatchNorm-backward accumulators", 0.0, 0.0, (double)B.sums_bytes);
   const int Mlast = (int)cube(A.final_edge);
   Ctx c{ctx, st, &A, &L, &B, (const char*)packed_t, ws, bws, bn, w_grads, bn_grads};
   c.track = track;
@@ -763,6 +774,7 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     pp.p[k] = (unsigned char)kg;                // stem dY
     hipLaunchKernelGGL(bwd_prologue_kernel, dim3(blocks), dim3(256), 0, st, dfeat, scale, kChainTarget + (int)ceilf(log2f((float)Mlast)), Mlast, Mpad,
                        1024, g, reinterpret_cast<ChainState*>(bws + B.chain), reinterpret_cast<unsigned*>(bws + B.amax), total_k, pp);
+    neraf_node(ctx, "bwd_prologue_kernel | S0, scale groups, average-pool backward", 0.0, 4096.0 + (double)total_k * kAmaxRep * 4.0, (double)n * 2.0);
   }
   half_t* gm = (half_t*)(bws + B.gm); half_t* da = (half_t*)(bws + B.da);
   WgradItem items[64]; int n_items = 0;     // every weight gradient is computed by ONE grouped launch at the end
@@ -817,6 +829,7 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     hipLaunchKernelGGL(maxpool_bwd_gather_kernel, dim3((unsigned)((rp * 8 + 255) / 256)), dim3(256), 0, st,
                        (const unsigned char*)(ws + L.pool_arg), c0.dout, A.pooled, g, dpost, rp);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
+    neraf_node(ctx, "maxpool_bwd_gather_kernel | max-pool routing", 0.0, (double)cube(A.pooled) * 64 * 3.0, (double)rp * 64 * 2.0);
     half_t* dy0 = (half_t*)(bws + B.dy[0]);
     const int k_s = new_k(k_g);
     if (int e = bn_backward(c, 0, dpost, nullptr, nullptr, dy0, nullptr, k_g, k_s, -1)) return e;      // relu mask already applied by the routing
@@ -827,6 +840,9 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
       hipLaunchKernelGGL(stem_dgrid_kernel, dim3((n_cells + 3) / 4), dim3(256), 0, st, dy0, Wt, A.S, c0.dout,
                          reinterpret_cast<const unsigned long long*>(bws + B.scale + 64), n_cells, n_ch, c.inv(k_s), dgrid_cells);
       NERAF_HIP_CHECK(ctx, hipGetLastError());
+      neraf_node(ctx, "stem_w_relayout_kernel | W[co][c][tap] -> Wt[tap][c][co]", 0.0, 125.0 * 7 * 64 * 4, 125.0 * 8 * 64 * 4);
+      neraf_node(ctx, "stem_dgrid_kernel | grid gradient of the refresh window", 2.0 * n_cells * (125.0 / 8.0) * 64 * n_ch, (double)n_cells * (125.0 / 8.0) * 128.0,
+                 (double)n_cells * n_ch * 4.0);
     }
   }
   if (n_k != total_k) return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_bwd: scale group count mismatch");

@@ -478,6 +478,11 @@ inline int run_bn_apply(neraf_ctx* ctx, hipStream_t st, const BnApplyArgs& a) {
   long blocks = (long)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * a.C * sizeof(float), st, a);
+  if (ctx && ctx->manifest) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "bn_apply_kernel | M=%d C=%d%s", a.M, a.C, a.r.x ? " + bn(downsample)" : (a.res ? " + residual" : ""));
+    neraf_node(ctx, nm, 0.0, (double)a.M * a.C * 2.0 * ((a.r.x || a.res) ? 2 : 1), (double)a.Mpad * a.C * 2.0);
+  }
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
 }

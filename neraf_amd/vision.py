@@ -417,6 +417,10 @@ class NerfactoField(nn.Module):
         lib = _lib.load()
         dev = _dev_index(origins)
         R, S = e_bins.shape[0], e_bins.shape[1] - 1
+        if torch.is_grad_enabled():
+            # a forward under autograd opens a new pass: pointers a FAILED backward left behind (the engine skips its end-of-pass
+            # callbacks when a node raises) must not be accumulated into by the next one
+            self._pass_ptrs = None
         tab, wfrag, emb = packed if packed is not None else self.packed()
         rgb = torch.empty((R, S, 3), dtype=torch.float32, device=origins.device)
         den = torch.empty((R, S), dtype=torch.float32, device=origins.device)
