@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void proposal_density_kernel(PropArgs a) {
 // wave per sample index" (the first coherent form, 179 -> 135 us): the rays' origins / directions are loaded once per run, the 17 bin
 // edges of a ray as one 68-byte segment (per-step loads of e_bins with lanes 4 (S + 1) bytes apart were 64 cache lines per instruction),
 // and the 16 densities of a ray leave as ONE 64-byte line through an LDS transpose (per-step stores were 64 partial lines per
-// instruction).  Measured by dropping them: stores 13 %, edge loads up to 18 % of the kernel (tools/gpu_r4_propexp.sh).
+// instruction).  Measured by dropping them: stores 13 %, edge loads up to 18 % of the kernel (profiles/r04_frame_kernel_experiments.txt).
 template <int NL>
 __global__ __launch_bounds__(256) void proposal_density_frame_kernel(PropArgs a) {
   __shared__ unsigned w0h[16][8];
