@@ -126,6 +126,11 @@ class Cameras:
         if isinstance(camera_indices, int):
             cam_single = camera_indices
         else:
+            host = camera_indices if not (isinstance(camera_indices, torch.Tensor) and camera_indices.is_cuda) else None
+            if host is not None:            # indices that live on the host are validated here (the CPU path raises IndexError too);
+                hv = torch.as_tensor(host).reshape(-1)      # device-resident ones by the kernel: out-of-range rays come back NaN
+                if hv.numel() and (int(hv.min()) < 0 or int(hv.max()) >= self.size):
+                    raise IndexError(f"camera index out of range for {self.size} cameras")
             cam_t = torch.as_tensor(camera_indices, device=dev).reshape(-1).long()
         if coords is None:
             R, width, co = self.height * self.width, self.width, None
@@ -133,6 +138,8 @@ class Cameras:
             co = coords.reshape(-1, 2).to(dev).float().contiguous()
             R, width = co.shape[0], self.width
         if cam_t is not None:
+            if cam_t.numel() not in (1, R):
+                raise ValueError(f"camera_indices must hold 1 or {R} entries, got {cam_t.numel()}")
             cam_t = cam_t.expand(R).contiguous()
         o = torch.empty((R, 3), dtype=torch.float32, device=dev)
         dd = torch.empty((R, 3), dtype=torch.float32, device=dev)

@@ -180,12 +180,21 @@ struct RayGenArgs {
   const float* coords;     // [R,2] = (row, col) in pixels, or null: pixel centres of a `width`-wide image, row-major
   int cam_single, R, width;
   float* origins; float* dirs; long long* cam_out;   // [R,3], [R,3], [R] (optional)
+  int n_cams;
 };
 
 __global__ __launch_bounds__(256) void camera_rays_kernel(RayGenArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.R) return;
   const int c = a.cam ? (int)a.cam[i] : a.cam_single;
+  if ((unsigned)c >= (unsigned)a.n_cams) {
+    // a per-ray camera index outside the camera set (the CPU path raises IndexError): no out-of-bounds read -- the ray is NaN and
+    // its camera index -1, which no consumer can mistake for a result
+    const float nan = __builtin_nanf("");
+    for (int k = 0; k < 3; ++k) { a.origins[3 * (size_t)i + k] = nan; a.dirs[3 * (size_t)i + k] = nan; }
+    if (a.cam_out) a.cam_out[i] = -1;
+    return;
+  }
   float y, x;
   if (a.coords) { y = a.coords[2 * (size_t)i]; x = a.coords[2 * (size_t)i + 1]; }
   else { y = (float)(i / a.width) + 0.5f; x = (float)(i % a.width) + 0.5f; }
@@ -263,7 +272,7 @@ extern "C" int neraf_camera_rays(neraf_ctx* ctx, const float* c2w, const float* 
   if (!c2w || !fx || !fy || !cx || !cy || n_cams <= 0 || R <= 0 || !origins || !dirs || (!coords && width <= 0) ||
       (!cam_idx && (cam_single < 0 || cam_single >= n_cams)))
     return neraf_fail(ctx, NERAF_EINVAL, "camera_rays: bad arguments");
-  RayGenArgs a{c2w, fx, fy, cx, cy, distortion, (const long long*)cam_idx, coords, cam_single, R, width, origins, dirs, (long long*)cam_out};
+  RayGenArgs a{c2w, fx, fy, cx, cy, distortion, (const long long*)cam_idx, coords, cam_single, R, width, origins, dirs, (long long*)cam_out, n_cams};
   hipLaunchKernelGGL(camera_rays_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;

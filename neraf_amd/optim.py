@@ -83,12 +83,23 @@ class FusedAdam(torch.optim.Optimizer):
         self._pending = None
         first = self._defer_to
         bt, bc = plan["sh_blk_tensor"], plan["sh_blk_chunk"]
-        if int(bt.numel()) == 0 or any(p.grad is None for p, _ in self._flat if id(p) in self._shared):
+        if int(bt.numel()) == 0:
+            return False
+        if any(p.grad is None for p, _ in self._flat if id(p) in self._shared):
+            # the counters of these tensors advanced in step(), their update cannot be applied any more: say so
+            import warnings
+            warnings.warn("FusedAdam.flush_pending: the gradients of a deferred update are gone (set to None before the later "
+                          "optimizer stepped or zero_grad ran): that update is dropped, its step counters have advanced")
             return False
         global UPDATE_EPOCH
         UPDATE_EPOCH += 1
         lib = _lib.load()
         gargs = plan.get("gargs") if plan.get("gdev") is None else None
+        if gargs is not None:
+            # the pointers recorded at step() time are stale if a .grad tensor was replaced since: rebuild them from the current ones
+            cur = tuple(e[0].grad.data_ptr() for e in self._flat if e[0].grad is not None)
+            if len(cur) == len(gargs) and cur != plan.get("gp"):
+                gargs = (C.c_void_p * len(cur))(*cur)
         _lib.check(lib.neraf_fused_adam_dual(_lib.ctx(plan["dev"]), plan["table"].data_ptr(),
                                              plan["gdev"].data_ptr() if plan.get("gdev") is not None else None, bt.data_ptr(), bc.data_ptr(),
                                              int(bt.numel()), lrs, len(self.param_groups), 0, b1, b2, float(self.param_groups[0]["eps"]),
@@ -406,7 +417,9 @@ class GradScaler(torch.amp.GradScaler):
                 dev = _dev_index(_scale)
                 # flags that belong to FusedAdam optimizers are reset by the same launch: their next check needs no clearing launch
                 owners = [o for o in getattr(self, "_fused_optimizers", {}).values() if any(o._found is f for f in founds)]
-                clear = len(owners) == len(founds)
+                # a flag with a deferred consumer still outstanding (flush_pending replays the update against it) is left standing:
+                # cleared here, a step that was skipped for non-finite gradients would be replayed as finite
+                clear = len(owners) == len(founds) and all(o._pending is None for o in owners)
                 _lib.check(_lib.load().neraf_amp_update_scale(_lib.ctx(dev), _scale.data_ptr(), _growth_tracker.data_ptr(),
                                                               _lib.ptr_array(founds), len(founds), float(self._growth_factor),
                                                               float(self._backoff_factor), int(self._growth_interval), int(clear),

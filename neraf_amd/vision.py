@@ -219,7 +219,7 @@ class HashMLPDensityField(nn.Module):
     def acc_scratch(self, device) -> torch.Tensor:
         """Persistent fixed-point accumulator of the table gradient, zero between calls (see NerfactoField.acc_scratch)."""
         a = getattr(self, "_acc_scratch", None)
-        if a is None or a.device != torch.device(device):
+        if a is None or a.device != torch.device(device) or a.numel() != self.table.shape[0]:
             a = torch.zeros(self.table.shape[0], dtype=torch.int64, device=device)
             self._acc_scratch = a
         return a
@@ -665,7 +665,12 @@ class NeRAFVisionModel(nn.Module):
         M = (1 << 64) - 1
         st = getattr(self, "_jitter_state", None)
         if st is None:
-            st = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & M
+            # the stream starts from (torch seed, data-parallel rank, training step): ranks that share the torch seed draw different
+            # jitters, and a run resumed at step k does not replay the jitters of step 0
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            st = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 + rank * 0xD1B54A32D192ED03 +
+                  int(self.step) * 0x8CB92BA72F3D8DD7) & M
         st = (st + 0x9E3779B97F4A7C15) & M
         self._jitter_state = st
         z = st

@@ -192,6 +192,23 @@ def audio_metrics(am, stft_tcf: np.ndarray, evb, i: int, seed: int = 0):
     return am.get_audio_metrics(out, batch, generator=g)
 
 
+def metric_table(am, stfts: dict, evb, gt_image=None, images: dict = None):
+    """{name: {metric: mean over the held-out RIRs}} for several sets of predicted log-magnitude STFTs [n,T,C,F] of the SAME held-out
+    RIRs (HIP run, fp32 oracle, oracle probes) through ONE evaluator (NeRAF_evaluator.py:131-190: T60 / EDT / C50 errors against ground
+    truth, seeded Griffin-Lim), plus the log-STFT rel-L2 against ground truth and -- with ``images`` -- the held-out PSNR."""
+    gt = evb["log_mag"].numpy()
+    out = {}
+    for name, st in stfts.items():
+        st = np.asarray(st)
+        ms = [audio_metrics(am, st[i], evb, i) for i in range(st.shape[0])]
+        row = {k: float(np.mean([float(m[k]) for m in ms])) for k in ms[0]}
+        row["stft_rel_l2_vs_gt"] = rel_l2(st, gt[:st.shape[0]])
+        if images is not None and name in images and gt_image is not None:
+            row["psnr_vs_gt_db"] = psnr(images[name], gt_image)
+        out[name] = row
+    return out
+
+
 def rel_l2(a, b):
     return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(np.asarray(b, np.float64)))
 
