@@ -556,43 +556,48 @@ def cpu_baseline(R, B):
 
 
 def trajectory_parity(dev):
-    """BASELINE.json's metric, second half ("PSNR & T60 err vs ref"): a short in-process training run of the HIP pipeline on the
-    trajectory scenario (tests/tools/trajectory_common.py: 100 iterations of 512 rays + 128 RIR slices, 64^3 grid) compared with
-    the CPU oracle's run from the same weights on the same batches, whose outputs are the committed fixture
-    tests/golden/g8_trajectory_pose.npz (tests/tools/gen_trajectory.py).  The same comparison is asserted by tests/test_gpu_trajectory.py."""
+    """BASELINE.json's metric, second half ("PSNR & T60 err vs ref"): an in-process training run of the HIP pipeline on the trajectory
+    scenario G9 (tests/tools/trajectory_common.py: 1000 iterations of 512 rays + 128 RIR slices on the box-room scene, 64^3 grid, audio
+    from iteration 6, the reference's optimizer groups and schedulers) next to the CPU oracle's run from the same weights on the same
+    batches, whose held-out predictions are the committed fixture tests/golden/g9_long.npz (tests/tools/gen_trajectory.py; ~2 h of
+    CPU).  1000 iterations is where the metrics mean something (T60 error ~10 % instead of ~650 % after 100) and far beyond the horizon
+    inside which two runs of this chaotic system stay tensor-comparable, so the comparison is metric against metric: held-out PSNR
+    and T60 / EDT / C50 errors against GROUND TRUTH, HIP next to the oracle, with the spread of the oracle's own precision probes
+    (fp16 parameters / fp16 storage points / bf16 encoder gradients) as the yardstick.  tests/test_gpu_trajectory.py asserts it."""
     import numpy as np
-    scenario = "g8_trajectory_pose"          # the reference's configuration: camera optimizer on, as in the timed step
+    scenario = "g9_long"
     fx = os.path.join(ROOT, "tests", "golden", scenario + ".npz")
     if not os.path.exists(fx):
         return None
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import trajectory_common as TC
     g = np.load(fx)
-    curves, img, stft, pipe, evb = TC.run_hip_trajectory(dev, cfg=TC.SCENARIOS[scenario])
-    r = TC.parity_summary(g, curves, img, stft, pipe.audio_model, evb)
-    out = {"steps": r["steps"], "psnr_db": r["psnr_hip_vs_gt_db"], "psnr_db_oracle": r["psnr_oracle_vs_gt_db"],
-           "psnr_hip_vs_oracle_db": r["psnr_hip_vs_oracle_db"],
-           "t60_err_pct": r.get("audio_T60_bs_hip"), "t60_err_pct_oracle": r.get("audio_T60_bs_oracle"),
-           "edt_err_s": r.get("audio_EDT_bs_hip"), "edt_err_s_oracle": r.get("audio_EDT_bs_oracle"),
-           "c50_err_db": r.get("audio_C50_bs_hip"), "c50_err_db_oracle": r.get("audio_C50_bs_oracle"),
-           "eval_branch": {"t60_err_pct": r.get("audio_T60_hip"), "t60_err_pct_oracle": r.get("audio_T60_oracle"),
-                           "t60_err_pct_fp16param_oracle": r.get("audio_T60_fp16param_oracle"),
-                           "stft_rel_l2_hip_vs_oracle": r["stft_rel_l2_hip_vs_oracle"],
-                           "note": "the same predictions through BatchNorm running statistics (NeRAF_model.py:680-684): ill-conditioned "
-                                   "this early in training in the reference's own arithmetic, see fp16_rounding_band.stft_rel_l2"},
-           "stft_rel_l2_hip_vs_oracle": r["stft_bs_rel_l2_hip_vs_oracle"], "stft_rel_l2_vs_gt": r["stft_bs_rel_l2_hip_vs_gt"],
-           "stft_rel_l2_vs_gt_oracle": r["stft_bs_rel_l2_oracle_vs_gt"],
-           "fixture": "tests/golden/" + scenario + ".npz",
-           "scenario": "camera optimizer SO3xR3 on (NeRAF_config.py:97); tests/test_gpu_trajectory.py also runs the scenario without it (G7)",
-           "note": "held-out camera (32x48) and 2 held-out RIRs after 100 joint training iterations from identical weights on identical "
-                   "batches: HIP pipeline (this run) vs CPU fp32 oracle (fixture); *_oracle = the oracle's own error against ground truth; the "
-                   "RIR numbers are for predictions with the encoder's BatchNorms on batch statistics (as in training), eval_branch "
-                   "repeats them through the running statistics"}
-    if "psnr_fp16param_oracle_vs_oracle_db" in r:
-        out["fp16_rounding_band"] = {"psnr_db": r["psnr_fp16param_oracle_vs_oracle_db"], "stft_rel_l2": r["stft_bs_rel_l2_fp16param_oracle_vs_oracle"],
-                                     "stft_eval_branch_rel_l2": r["stft_rel_l2_fp16param_oracle_vs_oracle"],
-                                     "note": "the same oracle trained with fp16-rounded parameters vs its fp32 run: what 16-bit rounding alone "
-                                             "does to this trajectory"}
+    cfg = TC.SCENARIOS[scenario]
+    t0 = time.perf_counter()
+    curves, img, stft, pipe, evb = TC.run_hip_trajectory(dev, cfg=cfg, fixed_scale=False)
+    train_s = time.perf_counter() - t0
+    probes = [str(p_) for p_ in g["probes"]] if "probes" in g else []
+    pre = lambda n: "probe_" if n == "params16" else f"probe_{n}_"      # noqa: E731
+    stfts = {"hip": stft["eval"], "oracle": g["stft"], **{n: g[pre(n) + "stft"] for n in probes}}
+    images = {"hip": img, "oracle": g["image"], **{n: g[pre(n) + "image"] for n in probes}}
+    m = TC.metric_table(pipe.audio_model, stfts, evb, gt_image=g["gt_image"], images=images)
+    keys = {"psnr_db": "psnr_vs_gt_db", "t60_err_pct": "audio_T60", "edt_err_s": "audio_EDT", "c50_err_db": "audio_C50",
+            "stft_rel_l2_vs_gt": "stft_rel_l2_vs_gt"}
+    out = {"steps": int(g["steps"]), "scenario": "G9: G7 scene, camera optimizer off, 1000 joint iterations, 8 held-out RIRs + 1 held-out view",
+           "fixture": "tests/golden/" + scenario + ".npz", "hip_training_seconds": round(train_s, 1)}
+    for k, mk in keys.items():
+        out[k] = m["hip"].get(mk)
+        out[k + "_oracle"] = m["oracle"].get(mk)
+        if probes:
+            out.setdefault("oracle_probe_spread", {})[k] = max(abs(m[n][mk] - m["oracle"][mk]) for n in probes)
+            out.setdefault("oracle_probes", {})[k] = {n: m[n][mk] for n in probes}
+    tail = slice(int(g["steps"]) - 50, int(g["steps"]))
+    names = [str(k_) for k_ in g["keys"]][:5]
+    out["loss_tails"] = {n: {"hip": float(np.nanmean(curves[tail, j])), "oracle": float(np.nanmean(np.asarray(g["curves"])[tail, j]))}
+                         for j, n in enumerate(names)}
+    out["note"] = ("every *_err_* is the error against ground truth through the eval branch (BatchNorm on running statistics, "
+                   "NeRAF_model.py:648-728) and the evaluator (NeRAF_evaluator.py:131-190, seeded Griffin-Lim), mean over the held-out RIRs; "
+                   "*_oracle = the fp32 CPU oracle's; oracle_probe_spread = max |probe - oracle| over the oracle's precision probes")
     return out
 
 

@@ -158,6 +158,7 @@ def run_hip_trajectory(dev, steps=None, cfg=CFG, rank: int = 0, world: int = 1, 
         _, ld = pipe.train_iteration(s, opts, scaler)
         rows.append(torch.stack([ld[k].detach().float().reshape(()) if k in ld else torch.full((), float("nan"), device=dev) for k in keys]))
     curves = torch.stack(rows).cpu().numpy().astype(np.float64)
+    pipe._trajectory_scaler = scaler            # (tools/long_trajectory.py reads the final scale: did any step overflow?)
     if fixed_scale:      # the parity fixtures: 100 iterations, far below the scaler's growth interval (long runs pass fixed_scale=False)
         assert scaler.get_scale() == 65536.0, "a GradScaler skip would shift the trajectory by one iteration"
     ev = synth.trajectory_eval_camera(*cfg["eval_hw"], tag=cfg["tag"])

@@ -26,4 +26,15 @@ for n in [int(a) for a in sys.argv[1:]] or [100, 1000, 3000]:
     ms = [TC.audio_metrics(am, stft["batch_stats"][i], evb, i) for i in range(cfg["n_rir_eval"])]
     keys = [k for k in ms[0] if any(t in k.lower() for t in ("t60", "edt", "c50"))]
     line += "; " + ", ".join(f"{k} {np.mean([float(m[k]) for m in ms]):.3f}" for k in keys)
+    # did anything overflow on the way?  the GradScaler starts at 65536, doubles every 2000 clean steps and halves on a skipped one; the
+    # ResNet3D backward's fp16 chain reports the scale groups that were not finite in its last recording pass
+    import ctypes as C
+    from neraf_amd import _lib
+    bb = am.resnet3d.backbone_net
+    e, amx, info = (C.c_int32 * 41)(), (C.c_float * 41)(), (C.c_int32 * 2)()
+    _lib.load().neraf_resnet3d_bwd_chain_state(_lib.ctx(0), C.byref(bb._desc), bb._bws.data_ptr(), e, amx, 41, info,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    expect = 65536.0 * 2.0 ** (n // 2000)
+    line += (f"; GradScaler scale {pipe._trajectory_scaler.get_scale():.0f} (no skipped step: {expect:.0f}); fp16 chain: {info[1]} passes, "
+             f"unsettled groups {info[0]}, exponents {min(e)} .. {max(e)}")
     print(line, flush=True)
