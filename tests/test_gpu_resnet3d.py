@@ -301,6 +301,59 @@ def test_resnet3d_backward_chain_scales_and_linearity():
     assert worst[1] <= 7e-3, worst
 
 
+def test_launch_manifest_accounts_for_the_encoder():
+    """neraf_manifest_* (tools/resnet_node_roofline.py): with the manifest on, one forward + backward lists every launch of the two
+    sequences with its algorithmic FLOPs and designed bytes.  The forward convolutions' FLOPs add up to SURVEY 8(d)'s 94.72 GFLOP on the
+    128^3 grid (neraf_resnet3d_forward_flops), the dgrad GEMMs to the same minus the stem's (its input gradient is a per-cell kernel),
+    the grouped weight gradient to the same again; results are unchanged by the un-graphed run."""
+    import ctypes as C
+    from neraf_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    S = 128
+    net = _model(dev, 1 / S)
+    net.train()
+    bb = net.backbone_net
+    x = T(synth.uniform(f"g1.grid{S}", (1, 7, S, S, S), 0.0, 1.0)).to(dev)
+    wsum = T(synth.uniform("g1.outw", (1024,), -1.0, 1.0)).to(dev)
+    bb.grid_window = (0, 4096, 4)
+    bb.grid_grad_sink = lambda d: None
+
+    def run():
+        for p in bb.parameters():
+            p.grad = None
+        y = net(x)
+        (y.flatten() * wsum).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach().clone(), bb.conv1.weight.grad.clone()
+
+    y0, g0 = run()
+    h = _lib.ctx(0)
+    lib.neraf_manifest_enable(h, 1)
+    try:
+        y1, g1 = run()
+        n = lib.neraf_manifest_get(h, -1, None, 0, None, None, None)
+        name, fl, rb, wb = C.create_string_buffer(160), C.c_double(), C.c_double(), C.c_double()
+        nodes = []
+        for i in range(n):
+            lib.neraf_manifest_get(h, i, name, 160, C.byref(fl), C.byref(rb), C.byref(wb))
+            nodes.append((name.value.decode(), fl.value, rb.value, wb.value))
+    finally:
+        lib.neraf_manifest_enable(h, 0)
+    bb.grid_window, bb.grid_grad_sink = None, None
+    assert 200 <= len(nodes) <= 240, len(nodes)
+    fwd_total = lib.neraf_resnet3d_forward_flops(C.byref(bb._desc))
+    conv = sum(f for nm, f, _, _ in nodes if " conv " in nm or (" plain " in nm and nm.split(" | ")[0].startswith("gemm")))
+    dgrad = sum(f for nm, f, _, _ in nodes if " dgrad " in nm)
+    wgrad = sum(f for nm, f, _, _ in nodes if nm.startswith("wgrad_ "))
+    stem = 2.0 * 64 ** 3 * 125 * 7 * 64
+    # "plain" GEMM records are the 1x1x1 convolutions of the forward AND their (plain) dgrads
+    np.testing.assert_allclose(conv + dgrad, 2 * fwd_total - stem, rtol=1e-6)
+    np.testing.assert_allclose(wgrad, fwd_total, rtol=1e-6)
+    assert all(r >= 0 and w >= 0 and (r + w) > 0 for _, _, r, w in nodes)
+    assert rel_l2(y1, y0) <= 1e-3 and rel_l2(g1, g0) <= 0.5          # same forward; gradients within the network's run-to-run chaos
+
+
 def test_resnet3d_backward_norms_vs_reference_fp32_golden(golden):
     """Whole encoder backward against the REFERENCE's own fp32 gradients (G1, 64^3 grid), as far as those can be compared: the
     randomly initialised 43-layer BatchNorm network is chaotic under fp16 rounding through its ReLU gates (the reference module

@@ -75,3 +75,49 @@ def test_fixture_head_is_reproducible_from_the_committed_oracle(golden, scenario
         assert set(tr.opt) == {"proposal_networks", "fields", "audio_fields", "camera_opt"} and float(tr.pose.abs().max()) > 0.0
     w = tr.sdn["soundfield.0.weight"]
     assert w not in tr.opt["audio_fields"].state or not tr.opt["audio_fields"].state[w]
+
+
+@pytest.mark.timeout(600)
+def test_precision_probes_perturb_one_rounding_source_each_and_leave_the_fp32_oracle_alone():
+    """OracleTrainer(probe=...) -- the yardstick runs of fixture G9: one joint iteration (audio branch on) of the fp32 oracle and of its
+    three probes from the same state.  Every probe moves the losses (it does something) by a rounding-sized amount (it does nothing
+    else), the probes' hooks are gone afterwards (the pinned arithmetic of oracle/audio.py and oracle/vision.py is untouched: a second
+    fp32 iteration reproduces the first bit for bit), and "resnet_grad_bf16" changes no FORWARD quantity at all."""
+    import trajectory_common as TC
+    from oracle import audio as O, vision as V
+    from oracle.trainer import OracleTrainer
+    cfg = TC.SCENARIOS["g9_long"]
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    bank = TC.rir_bank(cfg["n_rir"], cfg["tag"] + ".train")
+    step = cfg["start_step_audio"] + 1
+
+    def one(probe):
+        P, sdn, sdr = TC.initial_weights()
+        tr = OracleTrainer(P, sdn, sdr, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), TC.T(TC.synth.audio_aabb()), cfg["grid_step"], cfg["T"],
+                           cfg["start_step_audio"], cfg["R"], probe=probe)
+        r = tr.train_iteration(step, TC.ray_batch(step), TC.audio_batch(step, bank))
+        # Adam's first moment after one step = 0.1 x the gradient: the observable of a backward-only probe (the first update itself is
+        # lr x sign(g) whatever the magnitudes)
+        return r, tr.opt["audio_fields"].state[tr.sdr["conv1.weight"]]["exp_avg"].detach().clone(), tr.P["field.table"].detach().clone()
+
+    base, w0, t0 = one(None)
+    again, w0b, t0b = one(None)
+    same = lambda a, b: all(abs(a[k] - b[k]) <= 1e-5 * abs(b[k]) + 1e-12 for k in b)      # noqa: E731
+    assert same(again, base)
+    rel = lambda a, b: float((a - b).norm() / b.norm())      # noqa: E731
+    assert rel(w0b, w0) <= 1e-4
+    torch.testing.assert_close(t0b, t0, rtol=1e-3, atol=2e-6)
+    assert V.PROBE_ACT is None and O.PROBE["act"] is None and O.PROBE["grad"] is None
+    for probe in ("params16", "acts16", "resnet_grad_bf16"):
+        r, w, t = one(probe)
+        assert V.PROBE_ACT is None and O.PROBE["act"] is None and O.PROBE["grad"] is None, probe
+        if probe == "resnet_grad_bf16":
+            assert same(r, base), probe                                           # a backward-only perturbation: same forward, same losses
+        else:
+            assert any(r[k] != base[k] for k in ("rgb_loss", "audio_mag_loss")), probe
+            for k in ("rgb_loss", "audio_mag_loss", "audio_sc_loss"):
+                assert abs(r[k] - base[k]) <= 2e-2 * abs(base[k]), (probe, k, r[k], base[k])
+        # the gradient of the encoder's first convolution: close, and different where the probe touches the encoder's own arithmetic
+        # (bf16 gradients: 8 significant bits through 43 layers; fp16 storage points can flip ReLU gates: larger)
+        dw = rel(w, w0)
+        assert dw <= 0.8 and (probe == "params16" or dw > 1e-3), (probe, dw)
