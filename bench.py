@@ -39,7 +39,7 @@ L2_PEAK_GBS = 34500.0       # same guide, "L2 (per XCD)": 4 MiB per XCD, ~34.5 T
 # their gathered bytes are priced against the aggregate L2 rate, not against HBM (round 4 printed frac 1.04 of 8 TB/s for them); the
 # 24 MB main table is served from the Infinity Cache / HBM and stays priced against HBM.
 BYTE_FAMILY_BOUND = {2: "l2", 5: "l2", 3: "hbm", 6: "hbm", 7: "hbm"}
-DTYPE = "f16 (bf16 gradient chain in the ResNet3D backward)"
+DTYPE = "f16"      # every 16-bit tensor of the step is fp16 (the ResNet3D backward's gradient chain too since round 5: per-group power-of-two scales)
 PRIME_STEPS = 8             # untimed set-up steps before the --warmup steps (see main)
 CLOCK_STEPS = 120           # further untimed steps (~0.5 s) in the full run only: five consecutive 30-step windows of a fresh process read
                             # 4.40 / 4.48 / 4.40 / 4.32 / 4.29 ms -- the first ~100 steps run before clocks and caches settle

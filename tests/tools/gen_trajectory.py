@@ -68,7 +68,8 @@ def main():
     ap.add_argument("--probe", action="store_true")
     ap.add_argument("--scenario", default="g7_trajectory", choices=sorted(TC.SCENARIOS))
     ap.add_argument("--out", default=None)
-    ap.add_argument("--part", default=None, choices=["main", "params16", "acts16", "resnet_grad_bf16"],
+    ap.add_argument("--part-name", default=None, help="file name of the part (default: --part); e.g. 'order' for a second fp32 run on another thread count")
+    ap.add_argument("--part", default=None, choices=["main", "params16", "acts16", "resnet_grad_bf16", "all16"],
                     help="run ONE oracle variant and write DIR/<scenario>.<part>.npz (long scenarios: one process per variant)")
     ap.add_argument("--parts-dir", default="/tmp/trajectory_parts")
     ap.add_argument("--merge", action="store_true", help="assemble the fixture from the part files in --parts-dir")
@@ -84,7 +85,7 @@ def main():
     if a.part is not None:
         os.makedirs(a.parts_dir, exist_ok=True)
         r = run(False if a.part == "main" else a.part, log, cfg)
-        f = os.path.join(a.parts_dir, f"{a.scenario}.{a.part}.npz")
+        f = os.path.join(a.parts_dir, f"{a.scenario}.{a.part_name or a.part}.npz")
         np.savez_compressed(f, **r)
         log(f"wrote {f}")
         return
@@ -95,7 +96,7 @@ def main():
                "stft": m["stft"], "stft_batch_stats": m["stft_batch_stats"], "gt_image": m["gt_image"],
                "gt_stft": m["gt_stft"].astype(np.float32)}
         probes = []
-        for name in ("params16", "acts16", "resnet_grad_bf16"):
+        for name in ("params16", "acts16", "resnet_grad_bf16", "all16", "order"):
             f = os.path.join(a.parts_dir, f"{a.scenario}.{name}.npz")
             if not os.path.exists(f):
                 continue
