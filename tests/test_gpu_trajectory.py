@@ -30,8 +30,8 @@ Tolerances (stated here, checked below -- the numbers in the code ARE these; obs
   * the same through the eval branch proper (BatchNorm on running statistics, NeRAF_model.py:680-684): this early in training
     that path is ill-conditioned in the reference's own arithmetic -- 43 exponential averages with a ~10-iteration memory over
     weights that move every iteration drive the NAcF towards its tanh rails: the two fp32-oracle variants above differ by 0.20 /
-    0.015 rel-L2 there -- so its bound is that band: rel-L2(HIP, oracle) <= 2 x rel-L2(fp16-parameter oracle, oracle) of the
-    scenario's fixture (0.40 for G7, 0.28 for G8; observed 0.007-0.04 in round 4's four runs, 0.02-0.29 in round 3's);
+    0.015 rel-L2 there -- so its bound comes from that band: rel-L2(HIP, oracle) <= 0.30 (G7) / 0.21 (G8) = 1.5 x rel-L2(fp16-parameter
+    oracle, oracle) of the scenario's fixture (observed 0.06-0.18 in round 5's four runs, 0.007-0.04 in round 4's, 0.02-0.29 in round 3's);
   * loss curves: every loss-dict term, averaged over the last 20 iterations, within 15 % of the oracle's (+ 1e-6 absolute; observed
     <= 3 % except the interlevel term, 9-11 %: a histogram bound on ~1e-3 of weight mass).
 
@@ -59,6 +59,9 @@ pytestmark = pytest.mark.gpu
 # 0.23 dB from the fp32 one on the held-out view (35.0 dB between their images); the bound is 1 dB there.
 TOL = {"g7_trajectory": (33.0, 0.3), "g8_trajectory_pose": (32.0, 1.0)}
 T60_REL = 0.15
+# eval branch (running-statistics BatchNorm) after 100 iterations: 1.5 x what the fixture's fp16-parameter oracle probe moves it by
+# (0.2018 for G7, 0.1409 for G8), as numbers (round 4 asserted "<= 2 x band").  Observed: round 4 0.007-0.04, round 5 0.06-0.18.
+EVAL_BRANCH_REL_L2 = {"g7_trajectory": 0.30, "g8_trajectory_pose": 0.21}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _RUNS = {}
 
@@ -104,8 +107,7 @@ def _check_against_oracle(g, run, scenario, t60_rel=T60_REL):
     # eval branch (running-statistics BatchNorm, NeRAF_model.py:680-684): ill-conditioned this early in training in the reference's
     # own arithmetic -- the SAME oracle with fp16-rounded parameters moves its predictions by 0.20 rel-L2 (the band) -- so the bound is
     # the band: the HIP run may be at most twice as far from the fp32 oracle as that
-    band = r.get("stft_rel_l2_fp16param_oracle_vs_oracle")
-    assert np.isfinite(r["stft_rel_l2_hip_vs_oracle"]) and r["stft_rel_l2_hip_vs_oracle"] <= (2.0 * band if band else 1.0)
+    assert np.isfinite(r["stft_rel_l2_hip_vs_oracle"]) and r["stft_rel_l2_hip_vs_oracle"] <= EVAL_BRANCH_REL_L2[scenario]
     for k in ("rgb_loss", "interlevel_loss", "distortion_loss", "audio_sc_loss", "audio_mag_loss"):
         a, b = r[f"{k}_tail_hip"], r[f"{k}_tail_oracle"]
         assert abs(a - b) <= 0.15 * abs(b) + 1e-6, (k, a, b)
