@@ -1310,8 +1310,10 @@ static int proposal_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, cons
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   a.w_part = (scratch && scratch_bytes >= (size_t)blocks * 272 * sizeof(float)) ? (float*)scratch : nullptr;
-  // packed two-pass table gradient when the scratch holds it (neraf_proposal_backward_scratch_bytes) -- NERAF_PROP_PACKED=0: fp32 atomics
-  static const int packed_on = [] { const char* e = getenv("NERAF_PROP_PACKED"); return e ? atoi(e) : 1; }();
+  // packed two-pass table gradient when the scratch holds it (neraf_proposal_backward_scratch_bytes); without the scratch: fp32 atomics
+  // from the MLP-backward kernel (the NERAF_PROP_PACKED=0 toggle of rounds 2-4 is gone: with the persistent accumulator every caller
+  // passes since round 4 it could only fail)
+  constexpr int packed_on = 1;
   const long npad = (n + 63) / 64 * 64;
   float* lvl = nullptr;
   if (packed_on && a.w_part && scratch_bytes >= neraf_proposal_backward_scratch_bytes(R, S, a.g.n_levels)) {

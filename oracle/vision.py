@@ -32,10 +32,33 @@ PRIMES = (1, 2654435761, 805459861)
 # hash encodings and to every hidden / output activation of the fused MLPs -- the places where tiny-cuda-nn's half-precision
 # FullyFusedMLP / HashGrid (and the HIP kernels) store 16-bit values.
 PROBE_ACT = None
+# Second probe: the GRADIENT arriving at the interpolated hash encodings rounded the way an fp16 backward chain stores it -- scaled by
+# a power of two that puts the tensor's amax at 2^12, rounded to fp16 (values below 2^-24 of that flush to ZERO), un-scaled.  With
+# Adam at eps = 1e-15 this is not a rounding-sized effect: a table row that only ever receives gradients below the flush threshold
+# takes full lr-sized steps in fp32 and none at all in fp16 (tiny-cuda-nn's half-precision backward and the HIP engine alike).
+PROBE_ENC_GRAD = None
 
 
 def _pa(t: Tensor) -> Tensor:
     return PROBE_ACT(t) if PROBE_ACT is not None else t
+
+
+class _EncGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return PROBE_ENC_GRAD(g) if PROBE_ENC_GRAD is not None else g
+
+
+def fp16_scaled_round(g: Tensor) -> Tensor:
+    amax = float(g.abs().max())
+    if not (amax > 0.0 and math.isfinite(amax)):
+        return g
+    s = 2.0 ** (12 - math.floor(math.log2(amax)))
+    return (g * s).half().float() / s
 
 
 # ---------------------------------------------------------------------------
@@ -105,7 +128,8 @@ def hash_encode(x01: Tensor, table: Tensor, spec: GridSpec) -> Tensor:
             idx = (idx & 0xFFFFFFFF) % size
             acc = acc + w[:, None].to(table.dtype) * table[off + idx]
         outs.append(acc)
-    return _pa(torch.cat(outs, dim=-1))
+    enc = _pa(torch.cat(outs, dim=-1))
+    return _EncGrad.apply(enc) if PROBE_ENC_GRAD is not None else enc
 
 
 def tcnn_mlp(x: Tensor, weights: List[Tensor]) -> Tensor:

@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--scenario", default="g7_trajectory", choices=sorted(TC.SCENARIOS))
     ap.add_argument("--out", default=None)
     ap.add_argument("--part-name", default=None, help="file name of the part (default: --part); e.g. 'order' for a second fp32 run on another thread count")
-    ap.add_argument("--part", default=None, choices=["main", "params16", "acts16", "resnet_grad_bf16", "all16"],
+    ap.add_argument("--part", default=None, choices=["main", "params16", "acts16", "resnet_grad_bf16", "all16", "enc_grad16", "all16+enc_grad16"],
                     help="run ONE oracle variant and write DIR/<scenario>.<part>.npz (long scenarios: one process per variant)")
     ap.add_argument("--parts-dir", default="/tmp/trajectory_parts")
     ap.add_argument("--merge", action="store_true", help="assemble the fixture from the part files in --parts-dir")

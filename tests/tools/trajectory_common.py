@@ -150,7 +150,9 @@ def run_hip_trajectory(dev, steps=None, cfg=CFG, rank: int = 0, world: int = 1, 
                          start_step_audio=cfg["start_step_audio"], world_size=world, local_rank=rank)
     if world > 1:
         pipe.attach_gradient_reducer()
-    opts, scaler = pipe.make_optimizers(init_scale=65536.0, optimizers_config=Cfg.default_optimizers(cfg["start_step_audio"]),
+    import os
+    init_scale = float(os.environ.get("NERAF_TRAJ_INIT_SCALE", "65536"))       # (tests/tools/g7_hip_toggles.py varies it: an experiment)
+    opts, scaler = pipe.make_optimizers(init_scale=init_scale, optimizers_config=Cfg.default_optimizers(cfg["start_step_audio"]),
                                         with_schedulers=True)
     keys = ["rgb_loss", "interlevel_loss", "distortion_loss", "audio_sc_loss", "audio_mag_loss"]
     rows = []
@@ -160,7 +162,7 @@ def run_hip_trajectory(dev, steps=None, cfg=CFG, rank: int = 0, world: int = 1, 
     curves = torch.stack(rows).cpu().numpy().astype(np.float64)
     pipe._trajectory_scaler = scaler            # (tools/long_trajectory.py reads the final scale: did any step overflow?)
     if fixed_scale:      # the parity fixtures: 100 iterations, far below the scaler's growth interval (long runs pass fixed_scale=False)
-        assert scaler.get_scale() == 65536.0, "a GradScaler skip would shift the trajectory by one iteration"
+        assert scaler.get_scale() == init_scale, "a GradScaler skip would shift the trajectory by one iteration"
     ev = synth.trajectory_eval_camera(*cfg["eval_hw"], tag=cfg["tag"])
     img = vm.get_outputs_for_camera_ray_bundle(RayBundle(T(ev["origins"]).to(dev), T(ev["directions"]).to(dev), None))["rgb"]
     img = img.reshape(*cfg["eval_hw"], 3).cpu().numpy()
