@@ -67,6 +67,10 @@ class _NacfSplitFn(torch.autograd.Function):
         # optional hand-off: the producer of `feat` names the buffer it wants d loss / d feat in (ResNet3D.dfeat_buffer)
         gb = getattr(feat, "_neraf_grad_buffer", None)
         ctx.dfeat_out = gb if (gb is not None and gb.shape == feat.shape and gb.dtype == feat.dtype and gb.device == feat.device) else None
+        if ctx.dfeat_out is not None:
+            # ONE consumer per forward may write its gradient into the producer's buffer: a second NAcF call on the same feature would
+            # overwrite the first one's gradient before autograd sums them -- it gets a tensor of its own
+            feat._neraf_grad_buffer = None
         ctx.save_for_backward(feat, ws, out, packed, *params)
         return out
 
@@ -195,6 +199,8 @@ class NeRAFAudioSoundField(nn.Module):
         dev = _dev_index(mic_pose)
         B = int(time_query.shape[0])
         gb = getattr(feat, "_neraf_grad_buffer", None)
+        if gb is not None:
+            feat._neraf_grad_buffer = None    # one consumer per forward (see _NacfSplitFn.forward): a second call gets its own tensor
         feat = feat.reshape(-1).float().contiguous()
         if gb is not None:                    # the view made above is a new tensor object: carry the producer's hand-off along
             feat._neraf_grad_buffer = gb

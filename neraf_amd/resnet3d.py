@@ -272,12 +272,17 @@ class ResNet3D(nn.Module):
         if self._ws is None or self._ws.device != x.device:
             self._ws = torch.empty(lib.neraf_resnet3d_workspace_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
         if self._feat_buf is None or self._feat_buf[0].device != x.device:
-            self._feat_buf = [torch.empty(1024, dtype=torch.float32, device=x.device) for _ in range(2)]
+            self._feat_buf = [torch.empty(1024, dtype=torch.float32, device=x.device) for _ in range(3)]
             self._feat_turn = 0
-        # two output buffers alternate (two captured forward graphs): the feature handed out is not copied, and stays intact while
-        # the next forward writes the other buffer
-        self._feat_turn ^= 1
-        feat_buf = self._feat_buf[self._feat_turn]
+        # two output buffers alternate between TRAINING forwards (two captured forward graphs): the feature handed out is not copied,
+        # and stays intact while the next forward writes the other buffer -- contract: at most one training feature is awaiting its
+        # backward when the forward after next runs (the training loop's shape).  Eval-mode forwards write a third buffer of their own,
+        # so an evaluation between a training forward and its backward cannot touch the saved feature
+        if self.training:
+            self._feat_turn ^= 1
+            feat_buf = self._feat_buf[self._feat_turn]
+        else:
+            feat_buf = self._feat_buf[2]
         key = (grid.data_ptr(), self._ws.data_ptr(), bool(self.training))
         win = (0, 0)
         if (grid_state is not None and _GRID_WINDOW and getattr(self, "_x0_state", None) == (key, grid_state[1], grid_state[4])
