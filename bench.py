@@ -591,6 +591,17 @@ def trajectory_parity(dev):
         if probes:
             out.setdefault("oracle_probe_spread", {})[k] = max(abs(m[n][mk] - m["oracle"][mk]) for n in probes)
             out.setdefault("oracle_probes", {})[k] = {n: m[n][mk] for n in probes}
+    # the test's gates (tests/test_gpu_trajectory.py G9_*): not WORSE than the oracle by more than 1.5 x the probes' spread, and not further
+    # than 3 x the spread from it in either direction
+    if probes:
+        gates = {}
+        for k in ("psnr_db", "t60_err_pct", "edt_err_s", "c50_err_db"):
+            d_ = out[k] - out[k + "_oracle"]
+            worse = -d_ if k == "psnr_db" else d_
+            sp = out["oracle_probe_spread"][k]
+            gates[k] = {"worse_than_oracle_by": worse, "gate_one_sided": 1.5 * sp, "gate_two_sided": 3.0 * sp,
+                        "inside": bool(worse <= 1.5 * sp and abs(d_) <= 3.0 * sp)}
+        out["gates"] = gates
     tail = slice(int(g["steps"]) - 50, int(g["steps"]))
     names = [str(k_) for k_ in g["keys"]][:5]
     out["loss_tails"] = {n: {"hip": float(np.nanmean(curves[tail, j])), "oracle": float(np.nanmean(np.asarray(g["curves"])[tail, j]))}
