@@ -638,7 +638,8 @@ int conv_wgrad(const Ctx& c, int ci, const half_t* dy, const half_t* x_in, int t
 // NERAF_BN_FUSE_SUMS=0 restores the separate launches.
 inline bool fuse_bn_sums(const ConvSpec& bn_conv) {
   static const int on = [] { const char* e = getenv("NERAF_BN_FUSE_SUMS"); return e ? atoi(e) : 1; }();
-  return on && cube(bn_conv.dout) <= 4096 && (bn_conv.cout % 64) == 0;
+  static const long max_vox = [] { const char* e = getenv("NERAF_BN_FUSE_MAX_VOX"); return e ? atol(e) : 4096l; }();      // A/B knob
+  return on && (long)cube(bn_conv.dout) <= max_vox && (bn_conv.cout % 64) == 0;
 }
 
 // dX [din^3][cin] = conv_transpose(dY [dout^3][cout], W) (+ add16).  bn_ci >= 0: the result is the gradient w.r.t. relu(bn_{bn_ci}(.))

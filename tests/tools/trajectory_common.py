@@ -25,7 +25,10 @@ CFG = dict(R=512, B=128, steps=100, start_step_audio=5, grid_step=1 / 64, n_cam=
 #                           16-bit-perturbed runs of this chaotic system stay tensor-comparable, and far enough for the METRICS of
 #                           BASELINE.json ("PSNR & T60 err vs ref") to mean something (T60 error ~10 % instead of ~650 %): compared
 #                           metric by metric against the spread of the oracle's own precision probes.
-SCENARIOS = {"g7_trajectory": dict(CFG), "g8_trajectory_pose": dict(CFG, camera_opt=True), "g9_long": dict(CFG, steps=1000, n_rir_eval=8)}
+#   "g10_long_pose"      -- the same 1000 iterations with the camera optimizer SO3xR3 ON: the reference's configuration (NeRAF_config.py:97),
+#                           what bench.py times; 4 held-out RIRs (fixture size).
+SCENARIOS = {"g7_trajectory": dict(CFG), "g8_trajectory_pose": dict(CFG, camera_opt=True), "g9_long": dict(CFG, steps=1000, n_rir_eval=8),
+             "g10_long_pose": dict(CFG, steps=1000, n_rir_eval=4, camera_opt=True)}
 
 
 def T(a):
