@@ -91,7 +91,15 @@ class GradientReducer:
     parameters received no gradient this step (the proposal networks between their update steps) send nothing -- the schedule
     is the same on every rank."""
 
-    def __init__(self, groups: List[List[torch.nn.Parameter]], group=None, direct_bytes: int = 1 << 20, overlap: bool = True):
+    def __init__(self, groups: List[List[torch.nn.Parameter]], group=None, direct_bytes: int = 1 << 20, overlap: bool = True,
+                 compress_bytes: Optional[int] = None):
+        """``compress_bytes`` (default off; ``NERAF_DP_COMPRESS_MB`` in the pipeline): gradient tensors of at least that many bytes
+        travel as bfloat16 -- the 49 MB radiance hash-table gradient is the one collective of the step the backward cannot hide
+        (it is produced last), and half the bytes are half the exposed time on the per-link-bound xGMI rings.  bfloat16 keeps
+        fp32's range (the gradients are GradScaler-scaled); the reduced values are rounded to 8 significant bits ONCE per rank on the
+        way in and once on the way out, identically on every rank (an all-reduce returns the same bits everywhere), so replicas stay
+        bit-identical.  Exactness is given up for those tensors only: off by default, unmeasured on hardware (no multi-GPU box)."""
+        self.compress_bytes = compress_bytes
         self.groups = [list(g) for g in groups]
         self.pg = group
         self.world = dist.get_world_size(group)
@@ -131,7 +139,11 @@ class GradientReducer:
         for flat, _members in runs:
             self._pending.append((dist.all_reduce(flat, op=op, group=self.pg, async_op=True), None if self._avg else flat, []))
         for g in rest:
-            if g.is_contiguous() and g.numel() * g.element_size() >= self.direct_bytes:
+            nbytes = g.numel() * g.element_size()
+            if self.compress_bytes is not None and g.dtype == torch.float32 and g.is_contiguous() and nbytes >= self.compress_bytes:
+                g16 = g.to(torch.bfloat16)                   # the collective moves half the bytes; finish() widens the result back into g
+                self._pending.append((dist.all_reduce(g16, op=op, group=self.pg, async_op=True), None if self._avg else g16, [(g, g16)]))
+            elif g.is_contiguous() and nbytes >= self.direct_bytes:
                 self._pending.append((dist.all_reduce(g, op=op, group=self.pg, async_op=True), None if self._avg else g, []))
             else:
                 small.append(g)

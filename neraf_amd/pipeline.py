@@ -351,7 +351,9 @@ class NeRAFPipeline(nn.Module):
                   list(self.model.camera_optimizer.parameters()) if hasattr(self.model, "camera_optimizer") else []]
         groups = [g for g in groups if g]
         import os
-        self._reducer = GradientReducer(groups, group=group, overlap=os.environ.get("NERAF_DP_OVERLAP", "1") != "0")
+        cmb = os.environ.get("NERAF_DP_COMPRESS_MB")      # e.g. 8: tensors >= 8 MB (the hash-table gradients) are all-reduced in bfloat16
+        self._reducer = GradientReducer(groups, group=group, overlap=os.environ.get("NERAF_DP_OVERLAP", "1") != "0",
+                                        compress_bytes=int(float(cmb) * (1 << 20)) if cmb else None)
         if self.audio_model.use_grid:
             # the ResNet3D backward assigns its parameters' gradients itself (no per-parameter autograd hooks fire): it tells the
             # reducer when they are final

@@ -118,6 +118,48 @@ def test_world2_gloo_loss_and_gradients():
     assert res[0][9] == (0, 32) and res[1][9] == (32, 64)
 
 
+def _compress_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(3)
+        big = torch.nn.Parameter(torch.zeros(300, 400))            # 480 kB: above the compression threshold below
+        small = torch.nn.Parameter(torch.zeros(17))
+        red = parallel.GradientReducer([[big, small]], direct_bytes=1 << 30, compress_bytes=100_000)
+        g_big = [torch.from_numpy(synth.normal(f"dp.cmp.big{r}", (300, 400))) * 65536.0 for r in range(world)]     # GradScaler-sized values
+        g_small = [torch.from_numpy(synth.normal(f"dp.cmp.small{r}", (17,))) for r in range(world)]
+        big.grad, small.grad = g_big[rank].clone(), g_small[rank].clone()
+        red.finish()
+        red.close()
+        q.put((rank, big.grad.numpy(), small.grad.numpy(), (sum(g_big) / world).numpy(), (sum(g_small) / world).numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_compressed_allreduce_keeps_replicas_identical():
+    """GradientReducer(compress_bytes=...): tensors above the threshold are all-reduced as bfloat16 (half the bytes of the one
+    collective the backward cannot hide: the radiance hash-table gradient).  Both ranks end with the SAME bits (replicas stay
+    identical), within bfloat16's 8 significant bits of the fp32 average; tensors below the threshold are averaged exactly."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_compress_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, s0, ref_b, ref_s), (_, b1, s1, _, _) = res
+    assert np.array_equal(b0, b1) and np.array_equal(s0, s1)
+    np.testing.assert_allclose(s0, ref_s, rtol=1e-6, atol=1e-7)
+    # three bfloat16 roundings (each rank's input, the result): element-wise within 2^-7 of the inputs' magnitudes, 5e-3 in norm
+    mag = sum(np.abs(synth.normal(f"dp.cmp.big{r}", (300, 400))) * 65536.0 for r in range(world)) / world
+    assert (np.abs(b0 - ref_b) <= 2.0 ** -7 * mag + 1e-6).all()
+    assert float(np.linalg.norm(b0 - ref_b) / np.linalg.norm(ref_b)) <= 5e-3
+
+
 def _gather_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
