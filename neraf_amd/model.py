@@ -89,6 +89,9 @@ class _RefreshFn(torch.autograd.Function):
         _lib.check(lib.neraf_grid_refresh_vals(_lib.ctx(dev), rgb.data_ptr(), den.data_ptr(), n, nd, 1, delta, vals.data_ptr(),
                                                grid.data_ptr() if grid is not None else None, nvox, int(start), _stream_ptr()), dev)   # :352-357, :386
         ctx.field, ctx.nd, ctx.delta, ctx.packed, ctx.dev, ctx.saved = field, nd, delta, packed, dev, saved
+        # the caller switches the scene contraction off for the duration of THIS call only (NeRAF_model.py:302, :407): the backward
+        # runs after it has been switched back on and must map positions as the forward did
+        ctx.contract = field.spatial_distortion is not None
         ctx.save_for_backward(oris, dd, z, cam, den)
         return vals
 
@@ -104,7 +107,8 @@ class _RefreshFn(torch.autograd.Function):
         _lib.check(lib.neraf_grid_refresh_vals_bwd(_lib.ctx(ctx.dev), dvals.data_ptr(), den.data_ptr(), n, nd, 1, delta,
                                                    d_rgb.data_ptr(), d_den.data_ptr(), _stream_ptr()), ctx.dev)
         grads = ctx.field.backward_query(ctx.packed, oris, dd, z, cam, den, d_rgb, d_den, pos_run=nd, saved=ctx.saved,
-                                         in_autograd=all(ctx.needs_input_grad[8:15]))          # cell-major: nd rays per position
+                                         in_autograd=all(ctx.needs_input_grad[8:15]),          # cell-major: nd rays per position
+                                         contract=ctx.contract)
         return (None, None, None, None, None, None, None, None, *grads)
 
 

