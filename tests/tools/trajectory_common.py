@@ -162,7 +162,7 @@ def run_hip_trajectory(dev, steps=None, cfg=CFG, rank: int = 0, world: int = 1, 
     for s in range(steps):
         _, ld = pipe.train_iteration(s, opts, scaler)
         rows.append(torch.stack([ld[k].detach().float().reshape(()) if k in ld else torch.full((), float("nan"), device=dev) for k in keys]))
-    curves = torch.stack(rows).cpu().numpy().astype(np.float64)
+    curves = torch.stack(rows).cpu().numpy().astype(np.float64) if rows else np.zeros((0, len(keys)))
     pipe._trajectory_scaler = scaler            # (tools/long_trajectory.py reads the final scale: did any step overflow?)
     if fixed_scale:      # the parity fixtures: 100 iterations, far below the scaler's growth interval (long runs pass fixed_scale=False)
         assert scaler.get_scale() == init_scale, "a GradScaler skip would shift the trajectory by one iteration"
