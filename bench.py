@@ -442,12 +442,12 @@ def _median(xs):
 
 
 def cpu_baseline(R, B):
-    """The CPU oracle (torch fp32; audio half pinned to the reference on G1-G5, radiance half unpinned) timed on this host: ONE
-    complete step at the FULL batch -- every stage the GPU step contains, at its full size, forward + backward + torch Adam -- timed
-    stage by stage, once each, after a warm-up of the same code path at 1/64 of the batch (thread-pool start-up, first-touch
+    """The CPU oracle (torch fp32; audio half pinned to the reference on G1-G5, radiance half unpinned) timed on this host: TWO
+    complete steps at the FULL batch (mean) -- every stage the GPU step contains, at its full size, forward + backward + torch Adam --
+    timed stage by stage after a warm-up of the same code path at 1/64 of the batch (thread-pool start-up, first-touch
     allocations; the per-step-constant ResNet3D forward + backward has no smaller size and is run twice, second run timed).  No
-    extrapolation.  A full step is ~17 s on 64 threads, so SURVEY 8(d)'s 3 warm-up + >= 10 timed steps (~4 minutes) do not fit the
-    ~20 s of host time a default run may spend here; `sample` says exactly what was timed.  Forward-only figures come from a
+    extrapolation.  A full step is ~9-17 s on 64 threads, so SURVEY 8(d)'s 3 warm-up + >= 10 timed steps (~4 minutes) do not fit the
+    ~20-30 s of host time a default run may spend here; `sample` says exactly what was timed.  Forward-only figures come from a
     second, no-grad pass of the same stages."""
     import torch
     from neraf_amd import synth
@@ -528,14 +528,18 @@ def cpu_baseline(R, B):
                     opt_a.step()
         return run
 
-    t = {}
+    t, spread = {}, {}
     for name, make, n_full in (("vision", vision, R), ("refresh", refresh, R), ("audio", audio, B)):
         if name == "audio":      # the NAcF stage consumes the feature: the ResNet3D comes first, as in the step
             resnet(True)()                                           # warm-up (first-touch of 87 M activation elements + autograd graph)
-            t["resnet3d_train"] = once(resnet(True))
+            both = [once(resnet(True)) for _ in range(2)]
+            spread["resnet3d"] = [round(v_, 3) for v_ in both]
+            t["resnet3d_train"] = sum(both) / 2
             t["resnet3d_fwd"] = once(resnet(False))
         make(max(n_full // 64, 8), True)()                           # warm-up of this stage's code path
-        t[name + "_train"] = once(make(n_full, True))
+        both = [once(make(n_full, True)) for _ in range(2)]          # the training form twice: two complete steps, mean reported
+        spread[name] = [round(v_, 3) for v_ in both]
+        t[name + "_train"] = sum(both) / 2
         t[name + "_fwd"] = once(make(n_full, False))
     step_train = t["vision_train"] + t["refresh_train"] + t["resnet3d_train"] + t["audio_train"]
     step_fwd = t["vision_fwd"] + t["refresh_fwd"] + t["resnet3d_fwd"] + t["audio_fwd"]
@@ -545,8 +549,9 @@ def cpu_baseline(R, B):
             "bins_per_s_train": bins / (t["resnet3d_train"] + t["audio_train"]), "bins_per_s_fwd": bins / (t["resnet3d_fwd"] + t["audio_fwd"]),
             "field_samples_per_s_fwd": (R + bins) / step_fwd,
             "stage_seconds_full_step": {k: round(v_, 3) for k, v_ in t.items()},
+            "train_stage_seconds_each_of_the_two_steps": spread,
             "extrapolated": False,
-            "sample": ("ONE full-batch step, every stage timed once at its full size after a warm-up of the same code path at 1/64 of the "
+            "sample": ("TWO full-batch training steps (mean), every stage timed at its full size after a warm-up of the same code path at 1/64 of the "
                        "batch (ResNet3D: run twice, second timed): radiance step at %d rays (sampler, 2 proposal nets, field, composite, "
                        "3 losses, backward, torch Adam lr 1e-2), grid refresh at %d cells x 18 directions (forward + backward with a unit "
                        "upstream gradient), ResNet3D forward + backward on the full 7x128^3 grid, NAcF + STFT loss at %d slices (forward + "
