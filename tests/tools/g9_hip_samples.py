@@ -3,7 +3,7 @@
 one deterministic run, each in a fresh process, through the same evaluator as tests/test_gpu_trajectory.py -- next to the oracle and
 its probes.  The spread between the HIP runs is the chaos of the system itself, seen from the engine's side.
 
-    python tests/tools/g9_hip_samples.py [N=3]
+    python tests/tools/g9_hip_samples.py [N=3] [scenario = g9_long | g10_long_pose]
 """
 import os, subprocess, sys, tempfile
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
@@ -14,14 +14,15 @@ from neraf_amd import synth
 from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-g = np.load(os.path.join(ROOT, "tests", "golden", "g9_long.npz"))
-cfg = TC.SCENARIOS["g9_long"]
+SC = sys.argv[2] if len(sys.argv) > 2 else "g9_long"
+g = np.load(os.path.join(ROOT, "tests", "golden", SC + ".npz"))
+cfg = TC.SCENARIOS[SC]
 runs = {}
 tmp = tempfile.mkdtemp()
 for name, det in [("hip deterministic", "1")] + [(f"hip default #{i + 1}", "0") for i in range(n)]:
     out = os.path.join(tmp, name.replace(" ", "_").replace("#", "") + ".npz")
     env = dict(os.environ, NERAF_DETERMINISTIC=det, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "trajectory_worker.py"), "g9_long", out], env=env, cwd=ROOT, check=True,
+    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "trajectory_worker.py"), SC, out], env=env, cwd=ROOT, check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     runs[name] = dict(np.load(out))
 dev = torch.device("cuda:0")

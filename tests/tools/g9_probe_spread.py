@@ -4,7 +4,7 @@ ground truth of the fp32 oracle's and of its precision probes' held-out predicti
 package's evaluator (seeded Griffin-Lim on the GPU), and the spread max |probe - oracle| per metric.  Needs the GPU (the evaluator),
 not the HIP training pipeline: run it BEFORE the first HIP run of the scenario and write the spread into the test.
 
-    python tests/tools/g9_probe_spread.py
+    python tests/tools/g9_probe_spread.py [scenario = g9_long | g10_long_pose]
 """
 import os, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
@@ -14,8 +14,9 @@ import trajectory_common as TC
 from neraf_amd import synth
 from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
 
-g = np.load(os.path.join(ROOT, "tests", "golden", "g9_long.npz"))
-cfg = TC.SCENARIOS["g9_long"]
+SC = sys.argv[1] if len(sys.argv) > 1 else "g9_long"
+g = np.load(os.path.join(ROOT, "tests", "golden", SC + ".npz"))
+cfg = TC.SCENARIOS[SC]
 dev = torch.device("cuda:0")
 am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 64), TC.T(synth.audio_aabb())).to(dev)
 evb = TC.rir_bank(cfg["n_rir_eval"], cfg["tag"] + ".eval")
