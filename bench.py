@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed windows of exactly --steps steps each, back to back (the headline value is the MEDIAN window; all of "
                          "them, min and max are reported)")
-    ap.add_argument("--no-parity", action="store_true", help="skip the short trajectory-parity run (tests/golden/g7_trajectory.npz)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-process trajectory-parity runs (fixtures tests/golden/g9_long.npz, g10_long_pose.npz)")
     ap.add_argument("--plain", action="store_true",
                     help="priming + warm-up + timed steps only (no second regime, no instrumented replay, no CPU baseline): the form that "
                          "runs under rocprofv3, so that its per-kernel totals divide by exactly PRIME_STEPS + warmup + steps")
@@ -560,7 +560,7 @@ def cpu_baseline(R, B):
                        "would take ~4 minutes") % (R, R, B, step_train, step_fwd, ncores)}
 
 
-def trajectory_parity(dev):
+def trajectory_parity(dev, scenario="g9_long", floor_spread=None):
     """BASELINE.json's metric, second half ("PSNR & T60 err vs ref"): an in-process training run of the HIP pipeline on the trajectory
     scenario G9 (tests/tools/trajectory_common.py: 1000 iterations of 512 rays + 128 RIR slices on the box-room scene, 64^3 grid, audio
     from iteration 6, the reference's optimizer groups and schedulers) next to the CPU oracle's run from the same weights on the same
@@ -570,7 +570,6 @@ def trajectory_parity(dev):
     and T60 / EDT / C50 errors against GROUND TRUTH, HIP next to the oracle, with the spread of the oracle's own precision probes
     (fp16 parameters / fp16 storage points / bf16 encoder gradients) as the yardstick.  tests/test_gpu_trajectory.py asserts it."""
     import numpy as np
-    scenario = "g9_long"
     fx = os.path.join(ROOT, "tests", "golden", scenario + ".npz")
     if not os.path.exists(fx):
         return None
@@ -588,7 +587,9 @@ def trajectory_parity(dev):
     m = TC.metric_table(pipe.audio_model, stfts, evb, gt_image=g["gt_image"], images=images)
     keys = {"psnr_db": "psnr_vs_gt_db", "t60_err_pct": "audio_T60", "edt_err_s": "audio_EDT", "c50_err_db": "audio_C50",
             "stft_rel_l2_vs_gt": "stft_rel_l2_vs_gt"}
-    out = {"steps": int(g["steps"]), "scenario": "G9: G7 scene, camera optimizer off, 1000 joint iterations, 8 held-out RIRs + 1 held-out view",
+    what = ("G9: G7 scene, camera optimizer off, 1000 joint iterations, 8 held-out RIRs + 1 held-out view" if scenario == "g9_long" else
+            "G10: G7 scene, camera optimizer SO3xR3 ON (the reference's configuration), 1000 joint iterations, 4 held-out RIRs + 1 held-out view")
+    out = {"steps": int(g["steps"]), "scenario": what,
            "fixture": "tests/golden/" + scenario + ".npz", "hip_training_seconds": round(train_s, 1)}
     for k, mk in keys.items():
         out[k] = m["hip"].get(mk)
@@ -604,6 +605,8 @@ def trajectory_parity(dev):
             d_ = out[k] - out[k + "_oracle"]
             worse = -d_ if k == "psnr_db" else d_
             sp = out["oracle_probe_spread"][k]
+            if floor_spread is not None:          # G10: the larger of G9's five-probe spread and its own two-probe spread
+                sp = max(sp, floor_spread[k])
             gates[k] = {"worse_than_oracle_by": worse, "gate_one_sided": 1.5 * sp, "gate_two_sided": 3.0 * sp,
                         "inside": bool(worse <= 1.5 * sp and abs(d_) <= 3.0 * sp)}
         out["gates"] = gates
@@ -613,7 +616,13 @@ def trajectory_parity(dev):
                          for j, n in enumerate(names)}
     out["note"] = ("every *_err_* is the error against ground truth through the eval branch (BatchNorm on running statistics, "
                    "NeRAF_model.py:648-728) and the evaluator (NeRAF_evaluator.py:131-190, seeded Griffin-Lim), mean over the held-out RIRs; "
-                   "*_oracle = the fp32 CPU oracle's; oracle_probe_spread = max |probe - oracle| over the oracle's precision probes")
+                   "*_oracle = the fp32 CPU oracle's; oracle_probe_spread = max |probe - oracle| over the oracle's precision probes; this is "
+                   "ONE default-mode run (fp32 atomics: another run lands elsewhere inside the family) -- the gated run of "
+                   "tests/test_gpu_trajectory.py is the deterministic one")
+    if scenario != "g9_long":
+        out["note"] += ("; four held-out RIRs only: four default-mode HIP runs of this scenario read EDT errors of 0.0150-0.0245 s and T60 "
+                        "errors of 9.9-15.8 %, the oracle's own summation-order probe moves its T60 error from 20.0 to 9.9 % "
+                        "(profiles/r05_g10_long_pose.txt)")
     return out
 
 
@@ -982,8 +991,14 @@ def main():
         if not a.no_parity and world == 1:
             try:
                 out["parity"] = trajectory_parity(dev)
+                # the same comparison in the reference's configuration (camera optimizer on): with four held-out RIRs the oracle's own
+                # summation-order probe moves its T60 error by 10 points -- PSNR / EDT / C50 are the informative columns there
+                p10 = trajectory_parity(dev, "g10_long_pose", floor_spread=(out["parity"] or {}).get("oracle_probe_spread"))
+                if p10 is not None:
+                    out["parity_camera_optimizer_on"] = p10
             except Exception as e:                      # a measurement aid must not take the bench line down
-                out["parity"] = {"error": repr(e)}
+                out.setdefault("parity", {"error": repr(e)})
+                out["parity_error"] = repr(e)
         if not a.no_cpu_baseline and world == 1:      # the host baseline is reported by the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(a.rays, a.slices)
         print(json.dumps(out))
