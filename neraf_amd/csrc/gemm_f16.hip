@@ -1389,8 +1389,12 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p_in, hipStream_t stream) {
   const int ntiles = (p.Mpad / bm) * (p.Npad / bn) * ng;
   // split-K: only with scratch, when the grid under-fills the chip and every slice keeps >= 4 K-steps
   int splits = 1;
+  // implicit-GEMM convolutions on >= 64 tiles (the 4096-voxel layers) are split to TWO workgroups per CU: a lone 4-wave workgroup has
+  // nothing to hide its LDS-DMA waits behind (16.1 -> 13.3 us per 27-tap convolution; on 32 tiles -- 512 voxels -- the extra slabs
+  // cost the reducer what the GEMM gains: profiles/r05_splitk_oversubscription_ab.txt).  NERAF_SPLIT_OVERSUB=1 restores one per CU.
+  static const int kOversub = [] { const char* e = getenv("NERAF_SPLIT_OVERSUB"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
   if (p.splitk_ws && ntiles * 2 <= cus && nk >= kSplitMinK) {
-    splits = cus / ntiles;
+    splits = ((LOADER != 0 && ntiles >= 64) ? kOversub : 1) * cus / ntiles;
     if (splits > nk / 4) splits = nk / 4;
     if (splits > 128) splits = 128;
     while (splits >= 2 && (size_t)splits * ng * p.Mpad * p.Npad * 4 > p.splitk_ws_bytes) splits >>= 1;

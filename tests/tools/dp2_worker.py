@@ -54,6 +54,14 @@ def main():
     res["scale"] = js.scaler.get_scale()
 
     # ---- averaged data-parallel gradient of the audio loss == single-process gradient on the concatenated batch
+    # The pipeline's GradientReducer is DETACHED first: its post-accumulate hooks are still armed on these parameters, and a backward
+    # outside train_iteration would make it launch asynchronous in-place all-reduces (SUM on gloo) that nobody finishes -- racing
+    # with the manual all-reduce below.  That race, not GPU sharing, was the intermittent failure of this check (one run in eight:
+    # the 24 MB layer-0 weight gradient arrived already summed over the ranks on one or both of them: norm exactly 2 x, rel 0.51 /
+    # 1.0; round 5, tools/dp2_flake_probe.py: 8 bad rank-results in 30 runs before, none after).
+    if js.pipe._reducer is not None:
+        js.pipe._reducer.finish()
+        js.pipe._reducer.close()
     C_, F_, T_ = 1, 513, 60
     B = 192
     full = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in synth.audio_batch(B, C_, F_, T_, tag="dp2.audio").items()}
