@@ -110,6 +110,10 @@ class GradientReducer:
         self._launched = [False] * len(self.groups)
         self._pending = []       # (work handle, tensor to divide or None, [(grad, source slice)] to copy back)
         self._hooks = []
+        # the hooks act only while armed: a training loop that owns the reducer (NeRAFPipeline.train_iteration) arms it for its own
+        # backward pass and disarms it after finish(), so that a backward OUTSIDE the loop (an evaluation of gradients, a test) does
+        # not launch asynchronous in-place collectives that nobody waits for.  Stand-alone use: armed from construction.
+        self.armed = True
         if overlap:
             for gi, params in enumerate(self.groups):
                 for p in params:
@@ -117,6 +121,8 @@ class GradientReducer:
 
     def _make_hook(self, gi: int):
         def hook(_param):
+            if not self.armed:
+                return
             self._count[gi] += 1
             if self._count[gi] == len(self.groups[gi]) and not self._launched[gi]:
                 self._launch(gi)
@@ -125,7 +131,7 @@ class GradientReducer:
     def notify_group(self, gi: int):
         """For engines that assign a group's gradients themselves instead of routing them through autograd (the ResNet3D
         backward): the group's gradients are final, launch its collectives now."""
-        if not self._launched[gi]:
+        if self.armed and not self._launched[gi]:
             self._launch(gi)
 
     def _launch(self, gi: int):

@@ -344,7 +344,9 @@ class NeRAFPipeline(nn.Module):
         return (opts if with_schedulers else opts.steppers), scaler
 
     def attach_gradient_reducer(self, group=None):
-        """Data parallel: average gradients over the ranks, overlapped with the backward pass (neraf_amd/parallel.py)."""
+        """Data parallel: average gradients over the ranks, overlapped with the backward pass (neraf_amd/parallel.py).  The reducer's
+        hooks are ARMED by ``train_iteration`` for its own backward pass only; a caller that drives ``get_train_loss_dict`` + backward
+        itself sets ``reducer.armed = True`` before the backward and calls ``reducer.finish()`` after it."""
         from .parallel import GradientReducer
         groups = [list(self.audio_model.field.parameters()), list(self.audio_model.resnet3d.parameters()) if self.audio_model.use_grid else [],
                   list(self.model.field.parameters()), [p for pn in self.model.proposal_networks for p in pn.parameters()],
@@ -362,6 +364,7 @@ class NeRAFPipeline(nn.Module):
             gi = next(i for i, g in enumerate(groups) if any(p is first for p in g))
             red = self._reducer
             net.grads_ready_hook = lambda: red.notify_group(gi)
+        self._reducer.armed = False             # armed by train_iteration for its own backward pass
         return self._reducer
 
     def train_iteration(self, step: int, optimizers, scaler) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
@@ -375,9 +378,12 @@ class NeRAFPipeline(nn.Module):
         _, loss_dict, _ = self.get_train_loss_dict(step)
         # Trainer.train_iteration: loss = reduce(add, loss_dict.values()); grad_scaler.scale(loss).backward() -- as one node
         scaled, loss = _ScaledLossSum.apply(scaler, *loss_dict.values())
+        if self._reducer is not None:
+            self._reducer.armed = True          # its hooks act during THIS backward only (see GradientReducer.armed)
         scaled.backward(gradient=_unit_scalar(scaled.device) if scaled.is_cuda else None)
         if self._reducer is not None:
             self._reducer.finish()
+            self._reducer.armed = False
         for o in optimizers:
             scaler.step(o)
         scaler.update()

@@ -160,6 +160,46 @@ def test_world2_compressed_allreduce_keeps_replicas_identical():
     assert float(np.linalg.norm(b0 - ref_b) / np.linalg.norm(ref_b)) <= 5e-3
 
 
+def _armed_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = torch.nn.Parameter(torch.ones(600, 500))                    # 1.2 MB: all-reduced in place (direct_bytes = 1 MB)
+        red = parallel.GradientReducer([[w]])
+        red.armed = False
+        (w * float(rank + 1)).sum().backward()                          # a backward outside the training loop: nothing may be launched
+        disarmed = (len(red._pending), red._count[0], float(w.grad[0, 0]))
+        w.grad = None
+        red.armed = True
+        (w * float(rank + 1)).sum().backward()                          # the loop's own backward: the hook launches the collective
+        launched = len(red._pending)
+        red.finish()
+        red.close()
+        q.put((rank, disarmed, launched, float(w.grad[0, 0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_reducer_hooks_act_only_while_armed():
+    """GradientReducer.armed: a backward pass outside the training loop (gradient inspection, a test) must not make the hooks launch
+    asynchronous in-place all-reduces that nobody waits for -- NeRAFPipeline arms the reducer for train_iteration's own backward only.
+    (Round 5: exactly that, in tests/tools/dp2_worker.py, was the intermittent failure of the two-rank gradient check.)"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_armed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, disarmed, launched, avg in res:
+        assert disarmed == (0, 0, float(rank + 1))                      # no collective, no count, the LOCAL gradient untouched
+        assert launched == 1 and avg == 1.5                             # armed: one collective, the average of 1 and 2
+
+
 def _gather_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
