@@ -12,9 +12,12 @@ NeRAF_config.py:57,87); ``config.workload`` states exactly which stages are insi
 ``--scaling weak`` (default): every rank owns --rays / --slices of its own; ``--scaling strong``: --rays / --slices are the GLOBAL
 batch, split contiguously over the ranks.  Gradients and STFT-loss sums are all-reduced over RCCL.
 
-Rank 0 prints ONE JSON line: whole-job field-samples/s (and rays/s, bins/s), ``roofline`` for the kernel family with the largest
-share of the step (HIP-event durations recorded inside the library over an instrumented replay of the same steps; every family
-with its own fraction of the gfx950 peak), and ``cpu_baseline`` (the CPU oracle on this host, bounded sample of the same workload).
+Rank 0 prints ONE COMPACT JSON line (< 6 KB, asserted: ``compact_line``): whole-job field-samples/s (and rays/s, bins/s),
+``roofline`` for the kernel family with the largest share of the step (HIP-event durations recorded inside the library over an
+instrumented replay of the same steps), ``cpu_baseline`` (the CPU oracle on this host, bounded sample of the same workload),
+``eval_render`` and ``parity`` in short.  The FULL record (every kernel family, every window, the notes) goes to the file the
+line names under ``detail`` (gpurun_out/bench_detail_*.json) -- round 5 printed it all on stdout, 22.7 KB, and the driver could
+not read the line.
 """
 import argparse
 import ctypes as C
@@ -39,6 +42,11 @@ L2_PEAK_GBS = 34500.0       # same guide, "L2 (per XCD)": 4 MiB per XCD, ~34.5 T
 # their gathered bytes are priced against the aggregate L2 rate, not against HBM (round 4 printed frac 1.04 of 8 TB/s for them); the
 # 24 MB main table is served from the Infinity Cache / HBM and stays priced against HBM.
 BYTE_FAMILY_BOUND = {2: "l2", 5: "l2", 3: "hbm", 6: "hbm", 7: "hbm"}
+LINE_LIMIT = 6144           # bytes of the one stdout line (the driver reads a bounded tail of stdout)
+# The committed profiles the line cites, by NAME (round 5 took sorted(glob)[-1]: a stale file could silently become the evidence).
+# Updated by hand when tools/gpu_profile.sh / tools/gpu_pmc.sh produce a new set for a new build.
+PROFILE_REFS = {"train_stats": "r05_f_joint_step_kernel_stats.csv", "train_pmc": "r05_f_pmc_traffic.json",
+                "eval_stats": "r05_d_eval_kernel_stats.csv", "eval_pmc": "r05_d_eval_pmc_traffic.json"}
 DTYPE = "f16"      # every 16-bit tensor of the step is fp16 (the ResNet3D backward's gradient chain too since round 5: per-group power-of-two scales)
 PRIME_STEPS = 8             # untimed set-up steps before the --warmup steps (see main)
 CLOCK_STEPS = 120           # further untimed steps (~0.5 s) in the full run only: five consecutive 30-step windows of a fresh process read
@@ -60,7 +68,11 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed windows of exactly --steps steps each, back to back (the headline value is the MEDIAN window; all of "
                          "them, min and max are reported)")
-    ap.add_argument("--no-parity", action="store_true", help="skip the in-process trajectory-parity runs (fixtures tests/golden/g9_long.npz, g10_long_pose.npz)")
+    ap.add_argument("--parity", choices=("off", "g9", "all"), default="g9",
+                    help="in-process trajectory-parity run(s) after the timed region: g9 (default; one 1000-iteration HIP training on fixture "
+                         "tests/golden/g9_long.npz, ~16 s), all (+ g10_long_pose: camera optimizer on), off")
+    ap.add_argument("--no-parity", action="store_true", help="same as --parity off")
+    ap.add_argument("--detail", default=None, help="where the full record goes (default gpurun_out/bench_detail_<mode>_n<N>.json)")
     ap.add_argument("--plain", action="store_true",
                     help="priming + warm-up + timed steps only (no second regime, no instrumented replay, no CPU baseline): the form that "
                          "runs under rocprofv3, so that its per-kernel totals divide by exactly PRIME_STEPS + warmup + steps")
@@ -75,6 +87,118 @@ def parse():
                     help="audio head shape: raf = 1 x 513 bins, T = 60 (BASELINE configs[1..2], the default and the metric's config); "
                          "soundspaces = 2 x 257 bins, T = 101 (configs[3]: globally 32768 rays + 6464 slices, i.e. per GPU 4096 + 808)")
     return ap.parse_args()
+
+
+# ---- the stdout line ------------------------------------------------------------------------------------------------------------
+def _sig(x, n=6):
+    """Floats to n significant digits (bytes of the line), containers recursively; everything else as is."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us", "launches_per_step",
+              "whole_step_mfma_frac", "rocprof_reference", "above_peak")
+
+
+def _compact_roofline(r, n_families=6):
+    if not isinstance(r, dict):
+        return r
+    out = _pick(r, _ROOF_KEYS)
+    if "kernel" in out:
+        out["kernel"] = _short(out["kernel"], 96)
+    fams = sorted(r.get("all_kernel_families") or [], key=lambda k: -k.get("ms_per_step", 0.0))[:n_families]
+    if fams:      # the largest families of the step, each with its own fraction of its own peak (all of them: the detail file)
+        out["families"] = [{"k": _short(k["kernel"], 56), "ms": k["ms_per_step"], "bound": k["bound"], "frac": k["frac"]} for k in fams]
+    return out
+
+
+def compact_line(full: dict, detail: str = None, limit: int = LINE_LIMIT) -> str:
+    """The ONE stdout line, built from the full record: the contract's keys, ``roofline`` / ``cpu_baseline`` / ``eval_render`` /
+    ``parity`` reduced to their figures, ``detail`` = the file holding the full record.  Always shorter than ``limit`` bytes
+    (optional parts are dropped in a fixed order if it is not; the contract's keys never are) -- asserted here and by
+    tests/test_bench_line.py on canned records."""
+    top = ("metric", "mode", "plain", "value", "unit", "n_gpus", "ranks_seen", "backend", "steps", "warmup", "ms_per_step", "ms_per_step_min",
+           "ms_per_step_max", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "rays_per_s", "bins_per_s", "fps", "fps_audio",
+           "ms_per_frame", "us_per_rir", "priming_steps", "steps_executed_in_process", "rirs_per_step")
+    out = _pick(full, top)
+    cfg = full.get("config") or {}
+    out["config"] = {"workload": _short(cfg.get("workload", ""), 200),
+                     **_pick(cfg, ("rays_per_gpu", "slices_per_gpu", "global_rays", "global_slices", "rays_per_frame", "rirs_per_step",
+                                   "bins_per_rir", "parallelism", "distinct_resident_batches"))}
+    if "roofline" in full:
+        out["roofline"] = _compact_roofline(full["roofline"])
+    if isinstance(full.get("cpu_baseline"), dict):
+        cb = full["cpu_baseline"]
+        out["cpu_baseline"] = {**_pick(cb, ("value", "unit", "cores", "kind")), "sample": _short(cb.get("sample_short") or cb.get("sample", ""), 240)}
+    ev = full.get("eval_render")
+    if isinstance(ev, dict):
+        e = _pick(ev, ("ms_per_step", "value", "ms_per_frame", "rays_per_s", "bins_per_s", "us_per_rir", "rirs_per_step", "error"))
+        if isinstance(ev.get("roofline"), dict):
+            e["roofline"] = _pick(ev["roofline"], ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "above_peak"))
+        if isinstance(ev.get("cpu_baseline"), dict):
+            e["cpu_baseline"] = _pick(ev["cpu_baseline"], ("value", "unit", "cores", "kind"))
+        out["eval_render"] = e
+    par = full.get("parity")
+    if isinstance(par, dict):
+        out["parity"] = _pick(par, ("fixture", "steps", "psnr_db", "psnr_db_oracle", "t60_err_pct", "t60_err_pct_oracle", "edt_err_s",
+                                    "edt_err_s_oracle", "c50_err_db", "c50_err_db_oracle", "inside", "outside", "mode", "rule", "error"))
+    if "hip_graphs" in full:
+        out["hip_graphs"] = _pick(full["hip_graphs"], ("enabled", "captures", "launches"))
+    out["detail"] = detail
+    out = _sig(out)
+    # never longer than `limit`: optional parts go first, in this order
+    for drop in (None, ("roofline", "families"), ("eval_render", "cpu_baseline"), ("hip_graphs",), ("cpu_baseline", "sample"),
+                 ("eval_render", "roofline"), ("parity",), ("eval_render",)):
+        if drop is not None:
+            d = out
+            for k in drop[:-1]:
+                d = d.get(k) if isinstance(d, dict) else None
+            if isinstance(d, dict):
+                d.pop(drop[-1], None)
+        line = json.dumps(out, separators=(",", ":"))
+        if len(line.encode()) < limit:
+            break
+    assert len(line.encode()) < limit, len(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step"):
+        assert k in out, k
+    return line
+
+
+def emit(full: dict, a, mode: str, world: int):
+    """Write the full record to the detail file, print the compact line (the LAST thing on stdout)."""
+    path = a.detail or os.path.join(ROOT, "gpurun_out", f"bench_detail_{mode}_n{world}.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f)
+        shown = os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT + os.sep) else path
+    except OSError as e:             # a read-only tree must not cost the line
+        import tempfile
+        path = os.path.join(tempfile.gettempdir(), f"bench_detail_{mode}_n{world}.json")
+        try:
+            with open(path, "w") as f:
+                json.dump(full, f)
+            shown = path
+        except OSError:
+            shown = None
+    sys.stdout.flush()
+    print(compact_line(full, shown), flush=True)
 
 
 def _spawn_ranks(a):
@@ -297,6 +421,8 @@ def eval_cpu_baseline(n_rays=4096):
     return {"value": (n + bins) / (frame_s + t_rir), "unit": "field-samples/s", "cores": ncores, "kind": "port",
             "rays_per_s": len(idx) / t_rays, "bins_per_s_cached_feature": bins / t_rir, "bins_per_s_resnet_per_rir": bins / (t_rir + t_resnet),
             "seconds": {"rays_sample": round(t_rays, 3), "resnet3d_eval_fwd": round(t_resnet, 3), "one_rir": round(t_rir, 4)},
+            "sample_short": "%d rays strided over one 684x1024 frame (time scaled to the frame) + 1 RIR with cached scene feature; torch-CPU fp32 "
+                            "oracle, %d threads" % (len(idx), ncores),
             "sample": ("%d rays strided over one 684x1024 frame through the oracle's eval-mode nerfacto forward (1 warm-up at 64 rays + 1 timed), "
                        "one RIR = %d time queries through prologue + NAcF (1 warm-up + 1 timed) with the scene feature given, the ResNet3D eval "
                        "forward on 7x128^3 once; value = (frame rays + one RIR's bins) / (rays time scaled to the %d-ray frame + one RIR, cached "
@@ -394,16 +520,9 @@ def measure_eval(er, steps, warmup, rirs, lib, h, local, sync, full=True):
 def eval_roofline(fams, dataset="raf", world=1):
     """``roofline`` object of the eval render from the instrumented families: the committed counter traffic / rocprofv3 averages
     attached, the family with the largest share of the eval step as the headline (the frame form of the field query)."""
-    import csv
-    import glob
-    pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_eval_pmc_traffic.json")))
-    pmc = json.load(open(pmc_files[-1]))["families"] if pmc_files and dataset == "raf" and world == 1 else {}
-    ref = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_eval_kernel_stats.csv")))
-    ref_rows = {}
-    if ref:
-        with open(ref[-1]) as f:
-            for r in csv.DictReader(f):
-                ref_rows[r["Name"]] = (int(r["Calls"]), float(r["TotalDurationNs"]))
+    pmc_file = os.path.join(ROOT, "profiles", PROFILE_REFS["eval_pmc"])
+    pmc = json.load(open(pmc_file))["families"] if os.path.exists(pmc_file) and dataset == "raf" and world == 1 else {}
+    ref_name, ref_rows = _rocprof_reference("eval_stats")
     for k in fams:
         t = pmc.get(k["kernel"])
         k["traffic"] = t["hbm_bytes_per_launch"] if t else None
@@ -414,7 +533,10 @@ def eval_roofline(fams, dataset="raf", world=1):
         tot = sum(t_ for n_, (_, t_) in ref_rows.items() if rx.search(n_))
         if calls:
             k["rocprof_avg_us"] = tot / calls / 1e3
-        assert k["frac"] <= 1.0, f"family {k['kernel']} priced above its {k['bound']} peak: wrong bound"
+        # HIP-event timing noise around a few-microsecond launch can read above a guide figure (round 4: 1.04 of the aggregate L2 rate);
+        # flagged here, asserted only in tests/test_gpu_eval_bench.py (an exception here would cost the whole line)
+        if k["frac"] > 1.0:
+            k["above_peak"] = True
     if not fams:
         return None
     byte_fams = [k for k in fams if k["bound"] == "hbm"] or fams
@@ -427,8 +549,8 @@ def eval_roofline(fams, dataset="raf", world=1):
             "algorithmic_work_per_launch": dom["work_per_launch"],
             "selection": "the HBM-priced family with the largest share of the eval step among the instrumented families",
             "durations": "HIP events on the launch stream, as recorded",
-            "traffic_source": os.path.basename(pmc_files[-1]) if pmc and dom.get("traffic") is not None else None,
-            "rocprof_reference": os.path.basename(ref[-1]) if ref else None,
+            "traffic_source": PROFILE_REFS["eval_pmc"] if pmc and dom.get("traffic") is not None else None,
+            "rocprof_reference": ref_name, "above_peak": any(k.get("above_peak") for k in fams),
             "field_query_inference": fq,
             "algorithmic_bytes": "proposal density: samples x 5 levels x 8 corners x 4 B = 160 B/sample (352 samples/ray), tables L2-resident: "
                                  "priced against the aggregate L2 rate; field query: samples x 16 x 8 x 4 B = 512 B/sample (48 samples/ray), "
@@ -551,6 +673,8 @@ def cpu_baseline(R, B):
             "stage_seconds_full_step": {k: round(v_, 3) for k, v_ in t.items()},
             "train_stage_seconds_each_of_the_two_steps": spread,
             "extrapolated": False,
+            "sample_short": ("2 full training steps (mean) of the torch-CPU fp32 oracle at the full batch (%d rays + %d slices; radiance, grid refresh, "
+                             "ResNet3D, NAcF, backward, Adam), %.1f s each, %d threads; no extrapolation") % (R, B, step_train, ncores),
             "sample": ("TWO full-batch training steps (mean), every stage timed at its full size after a warm-up of the same code path at 1/64 of the "
                        "batch (ResNet3D: run twice, second timed): radiance step at %d rays (sampler, 2 proposal nets, field, composite, "
                        "3 losses, backward, torch Adam lr 1e-2), grid refresh at %d cells x 18 directions (forward + backward with a unit "
@@ -560,15 +684,16 @@ def cpu_baseline(R, B):
                        "would take ~4 minutes") % (R, R, B, step_train, step_fwd, ncores)}
 
 
-def trajectory_parity(dev, scenario="g9_long", floor_spread=None):
+def trajectory_parity(dev, scenario="g9_long", floor_family=None):
     """BASELINE.json's metric, second half ("PSNR & T60 err vs ref"): an in-process training run of the HIP pipeline on the trajectory
     scenario G9 (tests/tools/trajectory_common.py: 1000 iterations of 512 rays + 128 RIR slices on the box-room scene, 64^3 grid, audio
-    from iteration 6, the reference's optimizer groups and schedulers) next to the CPU oracle's run from the same weights on the same
+    from iteration 6, the reference's optimizer groups and schedulers) next to the CPU oracle's runs from the same weights on the same
     batches, whose held-out predictions are the committed fixture tests/golden/g9_long.npz (tests/tools/gen_trajectory.py; ~2 h of
-    CPU).  1000 iterations is where the metrics mean something (T60 error ~10 % instead of ~650 % after 100) and far beyond the horizon
-    inside which two runs of this chaotic system stay tensor-comparable, so the comparison is metric against metric: held-out PSNR
-    and T60 / EDT / C50 errors against GROUND TRUTH, HIP next to the oracle, with the spread of the oracle's own precision probes
-    (fp16 parameters / fp16 storage points / bf16 encoder gradients) as the yardstick.  tests/test_gpu_trajectory.py asserts it."""
+    CPU each).  1000 iterations is where the metrics mean something (T60 error ~10 % instead of ~650 % after 100) and far beyond the
+    horizon inside which two runs of this chaotic system stay tensor-comparable, so the comparison is metric against metric: held-out
+    PSNR and T60 / EDT / C50 errors against GROUND TRUTH, HIP next to the oracle family (the fp32 oracle and its precision / summation-
+    order probes) through the frozen rule trajectory_common.GATE_RULE.  tests/test_gpu_trajectory.py asserts the same on the
+    deterministic run and on the median of three default-mode runs; this is ONE default-mode run, reported."""
     import numpy as np
     fx = os.path.join(ROOT, "tests", "golden", scenario + ".npz")
     if not os.path.exists(fx):
@@ -576,7 +701,7 @@ def trajectory_parity(dev, scenario="g9_long", floor_spread=None):
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import trajectory_common as TC
     g = np.load(fx)
-    cfg = TC.SCENARIOS[scenario]
+    cfg = dict(TC.SCENARIOS[scenario], n_rir_eval=int(g["stft"].shape[0]))
     t0 = time.perf_counter()
     curves, img, stft, pipe, evb = TC.run_hip_trajectory(dev, cfg=cfg, fixed_scale=False)
     train_s = time.perf_counter() - t0
@@ -587,58 +712,42 @@ def trajectory_parity(dev, scenario="g9_long", floor_spread=None):
     m = TC.metric_table(pipe.audio_model, stfts, evb, gt_image=g["gt_image"], images=images)
     keys = {"psnr_db": "psnr_vs_gt_db", "t60_err_pct": "audio_T60", "edt_err_s": "audio_EDT", "c50_err_db": "audio_C50",
             "stft_rel_l2_vs_gt": "stft_rel_l2_vs_gt"}
-    what = ("G9: G7 scene, camera optimizer off, 1000 joint iterations, 8 held-out RIRs + 1 held-out view" if scenario == "g9_long" else
-            "G10: G7 scene, camera optimizer SO3xR3 ON (the reference's configuration), 1000 joint iterations, 4 held-out RIRs + 1 held-out view")
-    out = {"steps": int(g["steps"]), "scenario": what,
-           "fixture": "tests/golden/" + scenario + ".npz", "hip_training_seconds": round(train_s, 1)}
+    out = {"steps": int(g["steps"]), "scenario": scenario, "held_out_rirs": int(g["stft"].shape[0]), "camera_optimizer": bool(cfg.get("camera_opt")),
+           "fixture": "tests/golden/" + scenario + ".npz", "hip_training_seconds": round(train_s, 1), "mode": "default (fp32 atomics), one run"}
     for k, mk in keys.items():
         out[k] = m["hip"].get(mk)
         out[k + "_oracle"] = m["oracle"].get(mk)
-        if probes:
-            out.setdefault("oracle_probe_spread", {})[k] = max(abs(m[n][mk] - m["oracle"][mk]) for n in probes)
-            out.setdefault("oracle_probes", {})[k] = {n: m[n][mk] for n in probes}
-    # the test's gates (tests/test_gpu_trajectory.py G9_*): not WORSE than the oracle by more than 1.5 x the probes' spread, and not further
-    # than 3 x the spread from it in either direction
-    if probes:
-        gates = {}
-        for k in ("psnr_db", "t60_err_pct", "edt_err_s", "c50_err_db"):
-            d_ = out[k] - out[k + "_oracle"]
-            worse = -d_ if k == "psnr_db" else d_
-            sp = out["oracle_probe_spread"][k]
-            if floor_spread is not None:          # G10: the larger of G9's five-probe spread and its own two-probe spread
-                sp = max(sp, floor_spread[k])
-            gates[k] = {"worse_than_oracle_by": worse, "gate_one_sided": 1.5 * sp, "gate_two_sided": 3.0 * sp,
-                        "inside": bool(worse <= 1.5 * sp and abs(d_) <= 3.0 * sp)}
-        out["gates"] = gates
+    family = ["oracle"] + probes
+    out["oracle_family"] = {mk: [m[n][mk] for n in family] for mk in TC.GATE_METRICS}
+    out["oracle_family_names"] = family
+    out["gates"] = TC.gate_table(m, family, floor_family=floor_family)
+    out["inside"] = all(v["inside"] for v in out["gates"].values())
+    # which metric left its gate and on which side ("better": an error against ground truth LOWER than the gate's better-side bound)
+    short = {"psnr_vs_gt_db": "psnr_db", "audio_T60": "t60_err_pct", "audio_EDT": "edt_err_s", "audio_C50": "c50_err_db"}
+    out["outside"] = {short[k]: ("better" if (v["hip"] > v["high"]) == TC.GATE_METRICS[k] else "worse") for k, v in out["gates"].items() if not v["inside"]}
+    out["rule"] = TC.GATE_RULE
     tail = slice(int(g["steps"]) - 50, int(g["steps"]))
     names = [str(k_) for k_ in g["keys"]][:5]
     out["loss_tails"] = {n: {"hip": float(np.nanmean(curves[tail, j])), "oracle": float(np.nanmean(np.asarray(g["curves"])[tail, j]))}
                          for j, n in enumerate(names)}
     out["note"] = ("every *_err_* is the error against ground truth through the eval branch (BatchNorm on running statistics, "
                    "NeRAF_model.py:648-728) and the evaluator (NeRAF_evaluator.py:131-190, seeded Griffin-Lim), mean over the held-out RIRs; "
-                   "*_oracle = the fp32 CPU oracle's; oracle_probe_spread = max |probe - oracle| over the oracle's precision probes; this is "
-                   "ONE default-mode run (fp32 atomics: another run lands elsewhere inside the family) -- the gated run of "
-                   "tests/test_gpu_trajectory.py is the deterministic one")
-    if scenario != "g9_long":
-        out["note"] += ("; four held-out RIRs only: four default-mode HIP runs of this scenario read EDT errors of 0.0150-0.0245 s and T60 "
-                        "errors of 9.9-15.8 %, the oracle's own summation-order probe moves its T60 error from 20.0 to 9.9 % "
-                        "(profiles/r05_g10_long_pose.txt)")
+                   "*_oracle = the fp32 CPU oracle's; oracle_family = the fp32 oracle and its probes, in oracle_family_names order")
     return out
 
 
-def _rocprof_reference():
-    """Average kernel durations from the newest committed rocprofv3 --kernel-trace --stats summary of this command (profiles/), so
-    that the HIP-event durations in ``roofline`` can be cross-checked without re-running the profiler."""
+def _rocprof_reference(which="train_stats"):
+    """Average kernel durations from the committed rocprofv3 --kernel-trace --stats summary of this command that PROFILE_REFS names
+    (profiles/), so that the HIP-event durations in ``roofline`` can be cross-checked without re-running the profiler."""
     import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_joint_step_kernel_stats.csv")))
-    if not files:
+    f_ = os.path.join(ROOT, "profiles", PROFILE_REFS[which])
+    if not os.path.exists(f_):
         return None, {}
     rows = {}
-    with open(files[-1]) as f:
+    with open(f_) as f:
         for r in csv.DictReader(f):
             rows[r["Name"]] = (int(r["Calls"]), float(r["TotalDurationNs"]))
-    return os.path.basename(files[-1]), rows
+    return PROFILE_REFS[which], rows
 
 
 def _family_regex(pattern: str):
@@ -702,13 +811,15 @@ def run_eval_mode(a, dev, rank, local, world):
     if rank != 0:
         return
     out = {"metric": "field-samples/sec (rays + RIR STFT bins), eval render", "mode": "eval",
-           "value": m["value"], "unit": "field-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "value": m["value"], "unit": "field-samples/s", "n_gpus": world, "ranks_seen": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
            "data": "synthetic",
            "rays_per_s": m["rays_per_s"] * world, "fps": m["fps"] * world, "bins_per_s": m["bins_per_s"] * world,
            "fps_audio": m["fps_audio"] * world, "ms_per_frame": m["ms_per_frame"], "us_per_rir": m["us_per_rir"],
            "batched_rirs": m["batched_rirs"],
-           "config": {"workload": ("BASELINE configs[4] (full eval render) per GPU, no grad: a step = one 684x1024 RAF frame (700,416 rays) through "
+           "config": {"workload": "BASELINE configs[4] (full eval render) per GPU, no grad: a step = one 684x1024 RAF frame (22 chunks of 32768 rays) + "
+                                  "%d RIRs through the audio eval branch, scene feature cached" % a.rirs,
+                      "workload_detail": ("BASELINE configs[4] (full eval render) per GPU, no grad: a step = one 684x1024 RAF frame (700,416 rays) through "
                                    "NeRAFVisionModel.get_outputs_for_camera(camera, None, eval=True) -- OPENCV camera -> rays -> %d chunks of 32,768 "
                                    "(sampler, 2 proposal nets, 2 PDF resamplings, fused field query with the mean appearance embedding, "
                                    "composite) -> [H,W,.] images, rgb clipped -- plus %d RIRs through NeRAFAudioModel.get_outputs_for_camera(None, "
@@ -724,7 +835,7 @@ def run_eval_mode(a, dev, rank, local, world):
         out["roofline"] = eval_roofline(fams, a.dataset, world)
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = eval_cpu_baseline()
-    print(json.dumps(out))
+    emit(out, a, "eval", world)
 
 
 def main():
@@ -753,6 +864,9 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)   # RCCL
+        ranks_seen, backend = dist.get_world_size(), dist.get_backend()
+    else:
+        ranks_seen, backend = 1, None
     from neraf_amd import _lib
     from neraf_amd.parallel import shard_range
 
@@ -817,7 +931,11 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "field-samples/sec (rays + RIR STFT bins)", "value": (R_global + B_global * C_ * F_) * a.steps / elapsed,
                               "unit": "field-samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "priming_steps": PRIME_STEPS,
-                              "ms_per_step": elapsed / a.steps * 1e3, "scaling": a.scaling, "plain": True,
+                              "ms_per_step": elapsed / a.steps * 1e3, "scaling": a.scaling, "plain": True, "ranks_seen": ranks_seen,
+                              "backend": backend, "dtype": DTYPE, "data": "synthetic", "higher_is_better": True,
+                              "rays_per_s": R_global * a.steps / elapsed, "bins_per_s": B_global * C_ * F_ * a.steps / elapsed,
+                              "config": {"rays_per_gpu": R_local, "slices_per_gpu": B_local, "global_rays": R_global,
+                                         "global_slices": B_global, "parallelism": f"dp{world}", "dataset": a.dataset},
                               "steps_executed_in_process": PRIME_STEPS + a.warmup + a.steps}))
         if world > 1:
             import torch.distributed as dist
@@ -898,10 +1016,9 @@ def main():
         samples = (R_global + bins) * a.steps
         # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 cannot wrap itself from inside):
         # tools/gpu_pmc.sh -> profiles/*_pmc_traffic.json (FETCH_SIZE doubled as the gfx950 guide prescribes, + WRITE_SIZE)
-        import glob
-        pmc_files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")) if "_eval_" not in os.path.basename(f))
+        pmc_file = os.path.join(ROOT, "profiles", PROFILE_REFS["train_pmc"])
         default_shape = a.rays == 4096 and a.slices == 2048 and a.dataset == "raf" and world == 1
-        pmc = json.load(open(pmc_files[-1]))["families"] if pmc_files and default_shape else {}
+        pmc = json.load(open(pmc_file))["families"] if os.path.exists(pmc_file) and default_shape else {}
         for k in fams:
             t = pmc.get(k["kernel"])
             k["traffic"] = t["hbm_bytes_per_launch"] if t else None
@@ -915,6 +1032,7 @@ def main():
             "value": samples / elapsed,
             "unit": "field-samples/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen, "backend": backend,
             "steps": a.steps,
             "warmup": a.warmup,
             "priming_steps": PRIME_STEPS + CLOCK_STEPS,
@@ -944,7 +1062,10 @@ def main():
                                     "note": "data parallel: the ResNet3D forward + backward runs on every rank (the grid and its weights are "
                                             "replicated); rays, RIR slices and the grid-refresh cells are sharded"},
             "config": {
-                "workload": (("RAF FurnishedRoom joint step (BASELINE configs[2] shape: %d rays + %d RIR slices x 513 bins per GPU): " if a.dataset == "raf"
+                "workload": (("RAF FurnishedRoom joint training step (BASELINE configs[2]): %d rays + %d RIR slices x 513 bins per GPU" if a.dataset == "raf"
+                              else "SoundSpaces joint training step (BASELINE configs[3] head): %d rays + %d RIR slices x 2 x 257 bins per GPU")
+                             % (R_local, B_local)) + "; radiance + grid refresh + ResNet3D + NAcF + STFT loss, backward, GradScaler + fused Adam; batches resident",
+                "workload_detail": (("RAF FurnishedRoom joint step (BASELINE configs[2] shape: %d rays + %d RIR slices x 513 bins per GPU): " if a.dataset == "raf"
                               else "SoundSpaces joint step (BASELINE configs[3] head shape: %d rays + %d RIR slices x 2 x 257 bins per GPU): ") +
                              "radiance forward (camera-pose deltas, sampler, 2 proposal nets, 2 PDF resamplings, fused field query, composite) + rgb/"
                              "interlevel/distortion losses -> grid refresh (%d cells x 18 dirs%s) -> ResNet3D forward on the 7x128^3 "
@@ -965,7 +1086,7 @@ def main():
         if dom:
             out["roofline"] = {"bound": dom["bound"], "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": dom["peak"],
                                "unit": dom["unit"], "frac": dom["frac"], "traffic": dom["traffic"],
-                               "traffic_source": os.path.basename(pmc_files[-1]) if pmc and dom["traffic"] is not None else None,
+                               "traffic_source": PROFILE_REFS["train_pmc"] if pmc and dom["traffic"] is not None else None,
                                "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches_per_step"],
                                "algorithmic_work_per_launch": dom["work_per_launch"],
                                "selection": "family with the largest share of the step (ms_per_step) among the instrumented families",
@@ -988,20 +1109,19 @@ def main():
                              "launches": g_launch.value}
         if eval_line is not None:
             out["eval_render"] = eval_line
-        if not a.no_parity and world == 1:
+        parity = "off" if a.no_parity else a.parity
+        if parity != "off" and world == 1:
             try:
                 out["parity"] = trajectory_parity(dev)
-                # the same comparison in the reference's configuration (camera optimizer on): with four held-out RIRs the oracle's own
-                # summation-order probe moves its T60 error by 10 points -- PSNR / EDT / C50 are the informative columns there
-                p10 = trajectory_parity(dev, "g10_long_pose", floor_spread=(out["parity"] or {}).get("oracle_probe_spread"))
-                if p10 is not None:
-                    out["parity_camera_optimizer_on"] = p10
+                if parity == "all":     # the same comparison in the reference's configuration (camera optimizer on); detail file only
+                    p10 = trajectory_parity(dev, "g10_long_pose", floor_family=(out["parity"] or {}).get("oracle_family"))
+                    if p10 is not None:
+                        out["parity_camera_optimizer_on"] = p10
             except Exception as e:                      # a measurement aid must not take the bench line down
                 out.setdefault("parity", {"error": repr(e)})
-                out["parity_error"] = repr(e)
         if not a.no_cpu_baseline and world == 1:      # the host baseline is reported by the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(a.rays, a.slices)
-        print(json.dumps(out))
+        emit(out, a, "train", world)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -33,7 +33,8 @@ enum {
   NERAF_OK = 0,
   NERAF_EINVAL = -1, /* bad argument / unsupported shape */
   NERAF_EHIP = -2,   /* a HIP runtime call failed */
-  NERAF_ENOGPU = -3  /* no gfx950 device */
+  NERAF_ENOGPU = -3, /* no gfx950 device */
+  NERAF_ESTATE = -4  /* a numerical state the call depends on could not be established (fp16 gradient-chain calibration) */
 };
 
 #define NERAF_ABI_VERSION 1

@@ -21,7 +21,9 @@
 // bwd_prologue_kernel), e[k] from the amax recorded in an EARLIER pass (delayed scaling; the prologue re-centres each group so that
 // its amax sits in [2^12, 2^13); recording passes are every 4th, neraf_resnet3d_bwd); every fp32 output is multiplied by
 // 1 / (S0 2^e[k]).  A group that overflowed (the recorded amax is the fp32 value before rounding) is re-centred exactly and the
-// pass's gradients carry inf -- the GradScaler skips that step like any other overflow.  The first passes over a workspace are
+// pass's gradients carry inf -- the GradScaler skips that step like any other overflow; a group whose GEMM results overflowed while
+// its producer's output did not is read back as inf by its consumer and steps down by 2^6 per recording pass until it can be
+// measured (bwd_prologue_kernel "blind").  The first passes over a workspace are
 // calibration passes (repeated until a prologue reports the previous pass clean; exponents are kept relative to the group's input
 // so that a correction carries downstream).
 // Round 4 ran this chain in bfloat16 (same MFMA rate, 8 significant bits).  Measured (profiles/r05_fp16_chain_ab.txt): the chain's
@@ -95,12 +97,14 @@ int launch_pack_dgrad(neraf_ctx* ctx, const PackTTable& t, int ntiles, int max_t
 constexpr int kChainMax = 64;                  // scale groups per backward (1 + 3 per block + stem = 41): one per lane of one wave
 constexpr unsigned kChainMagic = 0x5ca1ab1eu;
 constexpr int kChainTarget = 12;               // stored amax is re-centred into [2^12, 2^13): 8x headroom below fp16's 65504
+constexpr int kChainOverflowStep = 6;          // a group whose recorded amax is not finite (see bwd_prologue_kernel) steps down by 2^6 per recording pass
 struct ChainState {
   unsigned magic;
   unsigned unsettled;                          // groups that, in the last RECORDING pass before the one this prologue opened, overflowed fp16 or
                                                // were computed from an overflowed input (0 in steady state; the calibration loop waits for it)
   unsigned passes;                             // prologues run on this state
-  unsigned pad[61];
+  unsigned dfeat_bad;                          // this pass's d feat holds inf / NaN (an overflow upstream: the GradScaler will skip the step)
+  unsigned pad[60];
   float pow2[kChainMax];                       // 2^e[t]
   float inv[kChainMax];                        // 1 / (S0 * 2^e[t]): what an fp32 result computed from tensor t is multiplied by
   int e[kChainMax];
@@ -325,8 +329,9 @@ __global__ __launch_bounds__(256) void bwd_prologue_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < 4; ++k) df[k] = (int)(threadIdx.x + k * 256) < C ? fabsf(dfeat[threadIdx.x + k * 256]) : 0.f;     // C <= 1024
   float m = 0.f;
+  int nan_seen = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) m = (df[k] == df[k] && df[k] > m) ? df[k] : m;
+  for (int k = 0; k < 4; ++k) { m = (df[k] == df[k] && df[k] > m) ? df[k] : m; nan_seen |= df[k] != df[k]; }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -339,6 +344,7 @@ __global__ __launch_bounds__(256) void bwd_prologue_kernel(const float* __restri
   }
   const float S = exp2f((float)es);
   if (blockIdx.x == 0) {
+    const int dfeat_bad = __syncthreads_or(nan_seen) || !(amx < 3.0e38f);
     if (threadIdx.x == 0) { scale[0] = S; scale[1] = 1.f / S; }
     if ((int)threadIdx.x < kChainMax) { s_par.p[threadIdx.x] = par.p[threadIdx.x]; s_am[threadIdx.x] = 0u; }
     const bool valid = magic == kChainMagic;
@@ -368,9 +374,16 @@ __global__ __launch_bounds__(256) void bwd_prologue_kernel(const float* __restri
       for (int r = 0; r < 6; ++r) { ok &= __shfl(ok, anc); anc = __shfl(anc, anc); }      // finite here and in every group upstream
       const int okp = __shfl(ok, p);
       const bool measured = okp && mx > 0u && mx < 0x7f800000u;
+      // A group's word merges what its producer recorded (fp32, before rounding: always finite) with what its consumer read back
+      // (the fp16 GEMM results derived from it, AFTER rounding): when those overflowed although the producer's output did not, the
+      // word reads inf / NaN and says nothing about the magnitude.  Following the parent then would keep the exponent for good if the
+      // parent is settled (every later pass inf, the GradScaler skipping every step): such a group steps DOWN by a fixed 2^6 -- an
+      // overflow of up to 2^6 x 8 (the headroom) lands inside fp16's range, where the next recording pass measures it exactly; a
+      // larger jump takes another step.  It counts as unsettled until a recording pass finds it finite.
+      const bool blind = okp && in && lane > 0 && mx >= 0x7f800000u;
       // floor(log2(x)) of a positive finite float is its biased exponent - 127 (a subnormal amax reads as "far too small": it is)
-      int done = (lane == 0 || !in || measured) ? 1 : 0;
-      int acc = (lane == 0 || !in) ? 0 : (measured ? eo + kChainTarget - ((int)(mx >> 23) - 127) : eo - eo_p);
+      int done = (lane == 0 || !in || measured || blind) ? 1 : 0;
+      int acc = (lane == 0 || !in) ? 0 : (measured ? eo + kChainTarget - ((int)(mx >> 23) - 127) : (blind ? eo - kChainOverflowStep : eo - eo_p));
       int link = done ? lane : p;
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
@@ -386,6 +399,7 @@ __global__ __launch_bounds__(256) void bwd_prologue_kernel(const float* __restri
         if (!valid) cs->unsettled = (unsigned)n_groups;
         else if (recorded) cs->unsettled = (unsigned)__popcll(bad);
         cs->passes = valid ? passes_in + 1u : 1u;
+        cs->dfeat_bad = dfeat_bad ? 1u : 0u;
         cs->magic = kChainMagic;
       }
     }
@@ -914,13 +928,34 @@ extern "C" int neraf_resnet3d_bwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
   const bool track = track_env && (pass_no % period) == 0;
   auto body = [&](hipStream_t s2) { return run(s2, track); };
   if (fresh) {
+    // calibration passes are set-up work: they stay out of the per-kernel event statistics (neraf_prof_enable)
+    struct ProfPause { neraf_ctx* c; bool was; ProfPause(neraf_ctx* c_) : c(c_), was(c_ && c_->prof) { if (c) c->prof = false; }
+                       ~ProfPause() { if (c) c->prof = was; } } pause(ctx);
+    auto forget = [&] { std::lock_guard<std::mutex> lk(g_calib_mu); g_calibrated.erase(bwd_workspace); };
     NERAF_HIP_CHECK(ctx, hipMemsetAsync(bws + B.chain, 0, sizeof(ChainState), st));
-    for (int i = 0; i < kMaxCalibrationPasses; ++i) {
-      if (int e = run(st, true)) return e;
-      unsigned unsettled = 0;
-      NERAF_HIP_CHECK(ctx, hipMemcpyAsync(&unsettled, bws + B.chain + offsetof(ChainState, unsettled), 4, hipMemcpyDeviceToHost, st));
-      NERAF_HIP_CHECK(ctx, hipStreamSynchronize(st));
-      if (i >= 1 && unsettled == 0) break;        // the pass before this one was clean, and this one ran on exponents re-centred from it
+    bool settled = false, postponed = false;
+    unsigned unsettled = 0;
+    for (int i = 0; i < kMaxCalibrationPasses && !settled && !postponed; ++i) {
+      if (int e = run(st, true)) { forget(); return e; }
+      struct { unsigned unsettled, passes, dfeat_bad; } rd = {0u, 0u, 0u};
+      static_assert(offsetof(ChainState, dfeat_bad) == offsetof(ChainState, unsettled) + 8, "read as one block");
+      hipError_t he = hipMemcpyAsync(&rd, bws + B.chain + offsetof(ChainState, unsettled), sizeof(rd), hipMemcpyDeviceToHost, st);
+      if (he == hipSuccess) he = hipStreamSynchronize(st);
+      if (he != hipSuccess) { forget(); NERAF_HIP_CHECK(ctx, he); }
+      unsettled = rd.unsettled;
+      // an overflowed d feat (the GradScaler's first steps) has no magnitude to calibrate on: this step's gradients are inf whatever
+      // the exponents, the optimizer will skip it, and the next backward calibrates
+      postponed = rd.dfeat_bad != 0;
+      settled = i >= 1 && unsettled == 0;         // the pass before this one was clean, and this one ran on exponents re-centred from it
+    }
+    if (postponed) forget();
+    else if (!settled) {
+      // never silently: the real pass would run on uncalibrated exponents and every later step would carry inf gradients
+      forget();
+      char msg[200];
+      snprintf(msg, sizeof(msg), "resnet3d_bwd: the fp16 gradient chain did not calibrate in %d passes (%u scale groups still overflow): "
+               "non-finite activations or weights?", kMaxCalibrationPasses, unsettled);
+      return neraf_fail(ctx, NERAF_ESTATE, msg);
     }
   }
   ArgHash k;

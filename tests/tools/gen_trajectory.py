@@ -57,6 +57,10 @@ def run(fp16_params, log, cfg):
     log(f"  held-out PSNR vs ground truth {TC.psnr(img, ev['image']):.2f} dB; STFT rel-L2 vs ground truth "
         f"{float(np.linalg.norm(stft - evb['log_mag'].numpy()) / np.linalg.norm(evb['log_mag'].numpy())):.4f}")
     extra = {"pose": tr.pose.detach().numpy().copy()} if cfg.get("camera_opt") else {}
+    if cfg.get("save_state"):      # the trained oracle (not committed): more held-out RIRs / views can be evaluated later without re-training
+        torch.save({"P": {k: v.detach() for k, v in tr.P.items()}, "sdn": {k: v.detach() for k, v in tr.sdn.items()},
+                    "sdr": {k: v.detach() for k, v in tr.sdr.items()}, "grid": tr.grid, "cursor": tr.cursor,
+                    "pose": tr.pose.detach() if cfg.get("camera_opt") else None}, cfg["save_state"])
     return {**extra, "curves": curves, "image": img.astype(np.float32), "stft": stft.astype(np.float32), "stft_batch_stats": stft_bs.astype(np.float32),
             "keys": np.array(keys),
             "gt_image": ev["image"], "gt_stft": evb["log_mag"].numpy()}
@@ -74,6 +78,7 @@ def main():
     ap.add_argument("--parts-dir", default="/tmp/trajectory_parts")
     ap.add_argument("--merge", action="store_true", help="assemble the fixture from the part files in --parts-dir")
     ap.add_argument("--steps", type=int, default=None, help="override the scenario's iteration count (experiments only)")
+    ap.add_argument("--save-state", action="store_true", help="--part runs: also write DIR/<scenario>.<part>.state.pt (the trained oracle)")
     a = ap.parse_args()
     if a.out is None:
         a.out = os.path.join(ROOT, "tests", "golden", a.scenario + ".npz")
@@ -84,6 +89,8 @@ def main():
         cfg["steps"] = a.steps
     if a.part is not None:
         os.makedirs(a.parts_dir, exist_ok=True)
+        if a.save_state:
+            cfg["save_state"] = os.path.join(a.parts_dir, f"{a.scenario}.{a.part_name or a.part}.state.pt")
         r = run(False if a.part == "main" else a.part, log, cfg)
         f = os.path.join(a.parts_dir, f"{a.scenario}.{a.part_name or a.part}.npz")
         np.savez_compressed(f, **r)

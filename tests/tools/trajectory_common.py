@@ -26,9 +26,10 @@ CFG = dict(R=512, B=128, steps=100, start_step_audio=5, grid_step=1 / 64, n_cam=
 #                           BASELINE.json ("PSNR & T60 err vs ref") to mean something (T60 error ~10 % instead of ~650 %): compared
 #                           metric by metric against the spread of the oracle's own precision probes.
 #   "g10_long_pose"      -- the same 1000 iterations with the camera optimizer SO3xR3 ON: the reference's configuration (NeRAF_config.py:97),
-#                           what bench.py times; 4 held-out RIRs (fixture size).
+#                           what bench.py times; 16 held-out RIRs (round 6: with round 5's four, the oracle's own summation-order
+#                           probe moved its T60 error from 20.0 to 9.9 % -- the gate carried no information).
 SCENARIOS = {"g7_trajectory": dict(CFG), "g8_trajectory_pose": dict(CFG, camera_opt=True), "g9_long": dict(CFG, steps=1000, n_rir_eval=8),
-             "g10_long_pose": dict(CFG, steps=1000, n_rir_eval=4, camera_opt=True)}
+             "g10_long_pose": dict(CFG, steps=1000, n_rir_eval=16, camera_opt=True)}
 
 
 def T(a):
@@ -212,6 +213,37 @@ def metric_table(am, stfts: dict, evb, gt_image=None, images: dict = None):
         if images is not None and name in images and gt_image is not None:
             row["psnr_vs_gt_db"] = psnr(images[name], gt_image)
         out[name] = row
+    return out
+
+
+# ---- the metric-level parity rule (G9 / G10 and the default-mode runs) -----------------------------------------------------------
+# FROZEN 2026-10-04, round 6, BEFORE any HIP run of this round was looked at; not to be edited after a result (history of the earlier,
+# re-derived gates: tests/test_gpu_trajectory.py).  Per metric (every one an error against GROUND TRUTH, or the held-out PSNR):
+#   family  = the fixture's oracle runs of the scenario: the fp32 oracle and each of its probes (G9: six runs, G10: three);
+#   spread  = max(family) - min(family); for G10 at least G9's spread of the same metric (three runs under-sample the range);
+#   PASS    = the HIP figure lies inside [min(family), max(family)], widened by 0.5 x spread on the WORSE side (lower PSNR, higher error)
+#             and by 2 x spread on the BETTER side.  The better side is wide on purpose: an error against ground truth lower than any
+#             oracle run's is not a parity failure; that bound only catches a broken evaluation (e.g. scoring training data).
+GATE_WORSE, GATE_BETTER = 0.5, 2.0
+GATE_RULE = "HIP inside oracle-family [min,max] widened 0.5 x spread on the worse side, 2 x on the better side (frozen 2026-10-04)"
+GATE_METRICS = {"psnr_vs_gt_db": True, "audio_T60": False, "audio_EDT": False, "audio_C50": False}      # metric -> higher is better
+
+
+def family_gate(hip: float, family, higher_is_better: bool, floor_spread: float = 0.0) -> dict:
+    lo, hi = float(min(family)), float(max(family))
+    s = max(hi - lo, float(floor_spread))
+    low = lo - (GATE_WORSE if higher_is_better else GATE_BETTER) * s
+    high = hi + (GATE_BETTER if higher_is_better else GATE_WORSE) * s
+    return {"hip": float(hip), "family_min": lo, "family_max": hi, "spread": s, "low": low, "high": high, "inside": bool(low <= hip <= high)}
+
+
+def gate_table(m: dict, family_names, hip_name: str = "hip", floor_family: dict = None) -> dict:
+    """{metric: family_gate(...)} from a ``metric_table`` result; ``floor_family`` = {metric: [values]} of G9's family (for G10)."""
+    out = {}
+    for k, hib in GATE_METRICS.items():
+        fam = [m[n][k] for n in family_names]
+        floor = (max(floor_family[k]) - min(floor_family[k])) if floor_family else 0.0
+        out[k] = family_gate(m[hip_name][k], fam, hib, floor)
     return out
 
 

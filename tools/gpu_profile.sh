@@ -5,10 +5,13 @@
 #   3. --pmc SQ matrix-pipe / wait counters, --pmc SQ LDS + TCC -> profiles/<tag>_pmc_sq_by_kernel.csv
 # Counter passes use --kernel-trace only (no runtime / sys tracing next to --pmc); the program after `--` is python3 itself.
 #   tools/gpu_profile.sh <tag> eval   profiles `bench.py --mode eval --plain` instead (BASELINE configs[4]) -> profiles/<tag>_eval_*
+#   BENCH_ARGS="--dataset soundspaces --rays 32768 --slices 6464 --rotate 4" tools/gpu_profile.sh r06_cfg3_global   profiles another shape
+#   (profiles/<tag>_* as above; tools/pmc_summary.py prices the families by the same per-launch work the library's profiler reports)
 TAG=${1:-r02_x}
 MODE=${2:-train}
 R=$GRAFT_REPO_ROOT
-if [ "$MODE" = "eval" ]; then MARGS="--mode eval"; STEPS=10; WARM=2; PSTEPS=2; PWARM=1; NAME=eval; else MARGS=""; STEPS=40; WARM=3; PSTEPS=4; PWARM=2; NAME=joint_step; fi
+if [ "$MODE" = "eval" ]; then MARGS="--mode eval"; STEPS=10; WARM=2; PSTEPS=2; PWARM=1; NAME=eval; else MARGS=""; STEPS=${STEPS:-40}; WARM=3; PSTEPS=4; PWARM=2; NAME=joint_step; fi
+MARGS="$MARGS $BENCH_ARGS"
 mkdir -p $R/gpurun_out/prof $R/gpurun_out/pmc $R/profiles
 export TMPDIR=/tmp
 cd /tmp
