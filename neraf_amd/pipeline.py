@@ -348,15 +348,28 @@ class NeRAFPipeline(nn.Module):
         hooks are ARMED by ``train_iteration`` for its own backward pass only; a caller that drives ``get_train_loss_dict`` + backward
         itself sets ``reducer.armed = True`` before the backward and calls ``reducer.finish()`` after it."""
         from .parallel import GradientReducer
-        groups = [list(self.audio_model.field.parameters()), list(self.audio_model.resnet3d.parameters()) if self.audio_model.use_grid else [],
+        import os
+        # The scene encoder's gradients.  Every rank holds the same grid and the same weights and the encoder's backward is linear in
+        # d feat, so averaging those 1024 floats (4 KiB) over the ranks BEFORE the backward gives every rank the already-averaged
+        # weight gradients and takes the encoder's 17 M parameters (68 MB) off the wire (SURVEY 8e (2)).  That is exact -- and keeps the
+        # replicas bit-identical -- iff the encoder's forward and backward are bit-identical on every rank: true under
+        # NERAF_DETERMINISTIC=1 (every order-dependent sum of the step is formed in a fixed order, csrc/common.h), where it is the
+        # default; with fp32-atomic BatchNorm sums (the default mode) the replicas would drift, and the encoder's gradients are
+        # all-reduced like everything else.  NERAF_DP_DFEAT=0 / 1 forces either.
+        mode = os.environ.get("NERAF_DP_DFEAT", "auto")
+        dfeat = self.audio_model.use_grid and (mode == "1" or (mode == "auto" and os.environ.get("NERAF_DETERMINISTIC") == "1"))
+        self.dp_dfeat_allreduce = bool(dfeat)
+        groups = [list(self.audio_model.field.parameters()),
+                  list(self.audio_model.resnet3d.parameters()) if (self.audio_model.use_grid and not dfeat) else [],
                   list(self.model.field.parameters()), [p for pn in self.model.proposal_networks for p in pn.parameters()],
                   list(self.model.camera_optimizer.parameters()) if hasattr(self.model, "camera_optimizer") else []]
         groups = [g for g in groups if g]
-        import os
         cmb = os.environ.get("NERAF_DP_COMPRESS_MB")      # e.g. 8: tensors >= 8 MB (the hash-table gradients) are all-reduced in bfloat16
         self._reducer = GradientReducer(groups, group=group, overlap=os.environ.get("NERAF_DP_OVERLAP", "1") != "0",
                                         compress_bytes=int(float(cmb) * (1 << 20)) if cmb else None)
-        if self.audio_model.use_grid:
+        if dfeat:
+            self.audio_model.resnet3d.backbone_net.dp_group = group if group is not None else True
+        elif self.audio_model.use_grid:
             # the ResNet3D backward assigns its parameters' gradients itself (no per-parameter autograd hooks fire): it tells the
             # reducer when they are final
             net = self.audio_model.resnet3d.backbone_net

@@ -89,11 +89,12 @@ class _ResNet3DFn(torch.autograd.Function):
         if dfeat.data_ptr() != net._dfeat_buf.data_ptr():      # the consumer wrote its gradient straight into the buffer: see dfeat_buffer
             net._dfeat_buf.copy_(dfeat.reshape(-1))
         if net.dp_group is not None:
-            # data parallel, OPT-IN: every rank holds the same grid and weights and the backward is linear in d feat, so
+            # data parallel: every rank holds the same grid and weights and the backward is linear in d feat, so
             # averaging these 1024 floats (4 KiB) replaces the all-reduce of 17 M ResNet3D gradients (68 MB).  Exact only if the
-            # forward is bit-identical on every rank; the BatchNorm statistics are accumulated with fp32 atomics (last-bit order
-            # dependence, amplified by the chaotic encoder), so replicas drift unless the weights are re-synchronised -- the
-            # default path all-reduces the gradients instead (GradientReducer)
+            # forward is bit-identical on every rank: NeRAFPipeline.attach_gradient_reducer switches this on under
+            # NERAF_DETERMINISTIC=1 (fixed-order sums) and leaves it off in the default mode, where the BatchNorm statistics are
+            # accumulated with fp32 atomics (last-bit order dependence, amplified by the chaotic encoder) and the gradients are
+            # all-reduced instead (GradientReducer); NERAF_DP_DFEAT=0 / 1 forces either
             import torch.distributed as dist
             grp = None if net.dp_group is True else net.dp_group
             if dist.get_backend(grp) == "nccl":

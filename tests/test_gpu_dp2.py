@@ -30,13 +30,42 @@ def test_two_ranks_one_gpu_replicas_stay_bit_identical(tmp_path):
     shared_gpu.attempts_for_shared_gpu(lambda i: _run_two_ranks(tmp_path, i))
 
 
-def _run_two_ranks(tmp_path, attempt):
+def test_deterministic_mode_reduces_d_feat_instead_of_the_encoder_gradients(tmp_path):
+    """SURVEY 8e (2), VERDICT round 5 item 4: under NERAF_DETERMINISTIC=1 the encoder's forward and backward are bit-identical on
+    every rank, so the data-parallel step all-reduces d feat (4 KiB) before the ResNet3D backward and keeps the encoder's 17 M
+    gradients (68 MB) off the wire -- by default (NeRAFPipeline.attach_gradient_reducer).  Two ranks on the one GPU, gloo, 5 steps:
+      * the reducer's groups no longer hold the encoder, d feat mode is on;
+      * the replicas stay BIT-IDENTICAL (parameters incl. the encoder's, grid, GradScaler state);
+      * the encoder gradients of the first iteration equal the ones the all-reduce path (NERAF_DP_DFEAT=0, same deterministic
+        mode) produces, to the fp16 chain's rounding (<= 5e-3 rel-L2 on the sampled entries, norms within 2e-3)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    a, b = _run_two_ranks(tmp_path, "dfeat", check=False, extra_env={"NERAF_DETERMINISTIC": "1"})
+    c, d_ = _run_two_ranks(tmp_path, "allreduce", check=False, extra_env={"NERAF_DETERMINISTIC": "1", "NERAF_DP_DFEAT": "0"})
+    assert a["dfeat_allreduce"] and b["dfeat_allreduce"] and not c["dfeat_allreduce"]
+    assert c["reducer_numel"] - a["reducer_numel"] == a["encoder_numel"] > 17_000_000
+    for x, y in ((a, b), (c, d_)):
+        assert x["init"] == y["init"]
+        diff = [k for k in x["per_param"] if x["per_param"][k] != y["per_param"][k]]
+        assert not diff, f"replicas diverged in {len(diff)} tensors, e.g. {diff[:5]}"
+        assert x["grid"] == y["grid"] and x["scale"] == y["scale"]
+    for k, v in a["encoder_grads_step1"].items():
+        assert v == b["encoder_grads_step1"][k]                                  # identical on both ranks, bit for bit
+        u, w = np.array(v), np.array(c["encoder_grads_step1"][k])
+        rel = float(np.linalg.norm(u - w) / np.linalg.norm(w))
+        print(f"d-feat path vs gradient all-reduce, {k}: rel-L2 of 64 entries {rel:.2e}")
+        assert rel <= 5e-3, (k, rel)
+    for k, v in a["encoder_grad_norms_step1"].items():
+        np.testing.assert_allclose(v, c["encoder_grad_norms_step1"][k], rtol=2e-3)
+    np.testing.assert_allclose(a["losses"][0], c["losses"][0], rtol=1e-6)         # same forward, same data
+
+
+def _run_two_ranks(tmp_path, attempt, check=True, extra_env=None):
     import shared_gpu
     port = _free_port()
     procs, outs = [], []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", NERAF_WORKER_DEVICE=str(shared_gpu.rank_device(r)))
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", NERAF_WORKER_DEVICE=str(shared_gpu.rank_device(r)), **(extra_env or {}))
         out = str(tmp_path / f"attempt{attempt}_rank{r}.json")
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "dp2_worker.py"), out], env=env, cwd=ROOT,
@@ -53,8 +82,11 @@ def _run_two_ranks(tmp_path, attempt):
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-4000:]
     a, b = (json.load(open(o)) for o in outs)
-    assert a["init"] == b["init"]
     assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
+    if not check:
+        return a, b
+    assert a["init"] == b["init"]
+    assert not a["dfeat_allreduce"]               # default mode (fp32-atomic BatchNorm sums): the encoder's gradients are all-reduced
     diff = [k for k in a["per_param"] if a["per_param"][k] != b["per_param"][k]]
     assert not diff, f"replicas diverged in {len(diff)} tensors, e.g. {diff[:5]}"
     assert a["params"] == b["params"] and a["grid"] == b["grid"] and a["scale"] == b["scale"]

@@ -185,11 +185,15 @@ def test_trunc_exp_backward_clamps_at_plus_and_minus_15_like_the_oracle(vm):
 
 
 # ---- configs[2] / configs[3]: the joint step at full size ---------------------------------------------------------------------
-@pytest.mark.parametrize("dataset,B,C_,F_,T_", [("raf", 2048, 1, 513, 60), ("soundspaces", 808, 2, 257, 101)])
-def test_joint_step_full_size_vs_oracle(dataset, B, C_, F_, T_):
+@pytest.mark.parametrize("dataset,R,B,C_,F_,T_", [("raf", 4096, 2048, 1, 513, 60), ("soundspaces", 4096, 808, 2, 257, 101),
+                                                   ("soundspaces", 32768, 6464, 2, 257, 101)])
+def test_joint_step_full_size_vs_oracle(dataset, R, B, C_, F_, T_):
     """One NeRAFPipeline.get_train_loss_dict + backward at the benchmark's shapes (the bench's own JointStep object): configs[2]
-    = 4096 rays + 2048 RAF slices, configs[3] per-GPU = 4096 rays + 808 SoundSpaces slices (2 x 257 head, T = 101), 128^3 grid.
-      * rendered colours of every 16th ray == oracle render of those rays with the same jitters;
+    = 4096 rays + 2048 RAF slices, configs[3] per-GPU = 4096 rays + 808 SoundSpaces slices (2 x 257 head, T = 101), 128^3 grid, and
+    configs[3] at its GLOBAL size in one process -- 32768 rays + 64 RIRs x T = 6464 slices (NeRAF_config.py:43-47, :87), the batch
+    the reference's single process trains on: 12.6 M proposal + 1.57 M field samples, a 32768-cell refresh window, M = 6464 NAcF rows.
+      * rendered colours of every 16th (global size: 128th) ray == oracle render of those rays with the same jitters; render
+        invariants on ALL rays (colours and accumulation in [0, 1], finite positive depth);
       * the audio outputs of ALL slices == oracle NAcF on the feature the HIP ResNet3D produced; both audio losses == oracle;
       * NAcF parameter gradients (incl. layer 0's feature half and both heads) == oracle autograd on the full slice batch;
       * every parameter of both models receives a finite gradient; the rgb loss equals the mean over the HIP colours."""
@@ -204,11 +208,11 @@ def test_joint_step_full_size_vs_oracle(dataset, B, C_, F_, T_):
     torch.manual_seed(0)
     bench.C_, bench.F_, bench.T_ = C_, F_, T_
     try:
-        js = bench.JointStep(dev, 4096, B, 1, dataset=dataset)
+        js = bench.JointStep(dev, R, B, 1, dataset=dataset, rotate=1)
     finally:
         bench.C_, bench.F_, bench.T_ = 1, 513, 60
     vm_, am, pipe = js.vm, js.am, js.pipe
-    rb = synth.ray_batch(4096, tag="bench.rays.r0")
+    rb = synth.ray_batch(R, tag="bench.rays.r0")
     jit = [T(j).to(dev) for j in rb["jitters"]]
     vm_.forward = lambda bundle: NeRAFVisionModel.get_outputs(vm_, bundle, jitters=jit)
     cap = {}
@@ -235,11 +239,16 @@ def test_joint_step_full_size_vs_oracle(dataset, B, C_, F_, T_):
     # -- radiance: strided rays against the oracle
     spec = V.NerfactoSpec()
     P16 = _vision_P(vm_)
-    sel = torch.arange(0, 4096, 16)
+    sel = torch.arange(0, R, 16 * (R // 4096))
     ref = V.nerfacto_forward(T(rb["origins"])[sel], T(rb["directions"])[sel], T(rb["camera_indices"])[sel], P16, spec, step=step,
                              training=True, jitters=[T(j)[sel] for j in rb["jitters"]])
     assert float((outs["rgb"][sel.to(dev)].cpu() - ref["rgb"]).abs().max()) <= 5e-3
     np.testing.assert_allclose(float(ld["rgb_loss"]), float(((outs["rgb"] - js.gt["image"]) ** 2).mean()), rtol=1e-4)
+    assert tuple(outs["rgb"].shape) == (R, 3) and bool(torch.isfinite(outs["rgb"]).all())
+    assert float(outs["rgb"].min()) >= 0.0 and float(outs["rgb"].max()) <= 1.0
+    acc = outs["accumulation"]
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-3
+    assert bool(torch.isfinite(outs["depth"]).all()) and float(outs["depth"].min()) > 0.0
     # -- audio: all slices, oracle NAcF on the HIP feature
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in am.field.state_dict().items()}
     bc = {k: v.cpu() for k, v in js.batch.items()}

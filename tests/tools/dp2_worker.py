@@ -24,6 +24,12 @@ def digest(tensors):
     return h.hexdigest()
 
 
+def getattr_path(obj, path):
+    for part in path.split("."):
+        obj = obj[int(part)] if part.isdigit() else getattr(obj, part)
+    return obj
+
+
 def main():
     out_path = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -41,11 +47,21 @@ def main():
     params = [p for _, p in list(js.vm.named_parameters()) + list(js.am.named_parameters())]
     res["init"] = digest(params)
     losses = []
-    for _ in range(5):
+    net = js.am.resnet3d.backbone_net
+    res["dfeat_allreduce"] = bool(js.pipe.dp_dfeat_allreduce)
+    res["reducer_numel"] = int(sum(p.numel() for g in js.pipe._reducer.groups for p in g))
+    res["encoder_numel"] = int(sum(p.numel() for p in net.parameters()))
+    for it in range(5):
         js.i += 1
         loss, ld = js.pipe.train_iteration(js.i, js.optimizers, js.scaler)
         losses.append(float(loss))
         assert js.am._dp_world() is not None
+        if it == 0:       # the encoder's (rank-averaged, GradScaler-scaled: same scale in every mode) gradients of the first iteration
+            sc = 1.0
+            res["encoder_grads_step1"] = {k: (getattr_path(net, k).grad.double().flatten()[:64] / sc).cpu().tolist()
+                                          for k in ("conv1.weight", "layer2.1.conv2.weight", "layer3.5.conv3.weight", "layer3.5.bn3.weight")}
+            res["encoder_grad_norms_step1"] = {k: float(getattr_path(net, k).grad.double().norm() / sc)
+                                               for k in ("conv1.weight", "layer2.1.conv2.weight", "layer3.5.conv3.weight")}
     torch.cuda.synchronize()
     res["losses"] = losses
     res["params"] = digest(params)
