@@ -357,12 +357,33 @@ def test_chain_recovers_from_a_magnitude_jump_its_consumer_read_back_as_inf():
     assert recovered_at is not None and recovered_at <= 2 * period + 1, history
     e1, _ = chain_info()
     assert (e1 != e0).any()
-    # the recovered gradients are the gradients: a fresh workspace (calibrated on the modified network) gives the same
+    print("exponents calibrated before the jump:", e0.tolist())
+    print("exponents after the recovery:        ", e1.tolist())
+    # the recovered gradients are the gradients: a fresh calibration gives the same -- through ONE forward (two training forwards of
+    # this network differ in their ReLU gates: fp32-atomic BatchNorm sums, and the modified BatchNorm's successor now normalises a
+    # variance of the order of its eps), i.e. the same activations and gates for both backward passes
+    def grads_of(y, retain):
+        for p in bb.parameters():
+            p.grad = None
+        (y.flatten() * w).sum().backward(retain_graph=retain)
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in bb.named_parameters()}
+    y = net(x)
+    g = grads_of(y, True)
+    assert chain_info()[1][0] == 0
     _lib.check(lib.neraf_resnet3d_bwd_reset(_lib.ctx(0), C.c_void_p(bb._bws.data_ptr())))
-    g_ref = one_pass()
-    worst = max(rel_l2(g[k], g_ref[k]) for k in g if k != "bn1.bias")
-    print(f"recovered vs freshly calibrated: worst rel-L2 {worst:.2e}")
-    assert worst <= 1e-2, worst
+    g_ref = grads_of(y, False)
+    errs = sorted(((rel_l2(g[k], g_ref[k]), k) for k in g if k != "bn1.bias"), reverse=True)
+    print("recovered vs freshly calibrated, worst five:", [(k, f"{v:.2e}") for v, k in errs[:5]], "median", f"{errs[len(errs) // 2][0]:.2e}")
+    e2, _ = chain_info()
+    print("exponents of the fresh calibration:  ", e2.tolist())
+    if os.environ.get("NERAF_TEST_VERBOSE"):
+        for v, k in sorted(errs, key=lambda t: t[1]):
+            print(f"   {k:36s} {v:.3e}  |g| {float(g[k].double().norm()):.4e} |ref| {float(g_ref[k].double().norm()):.4e}")
+    worst = errs[0][0]
+    # observed 8.6e-3 (the re-centred group sits one octave from where a fresh calibration puts it: one bit of an 11-bit mantissa in
+    # the one weight gradient that is formed from it), median 1.5e-5
+    assert worst <= 2e-2, errs[:5]
 
 
 def test_backward_on_an_overflowed_upstream_gradient_postpones_calibration():
