@@ -78,7 +78,10 @@ struct WsLayout {
 
 WsLayout make_ws_layout(const neraf_nacf_desc* d, const Dims& D, int B, int training) {
   WsLayout L{};
-  L.Mpad = round_up(B, 128);
+  // rows padded to the tile height the GEMM dispatcher can use (csrc/gemm_f16.hip dispatch_tile: 128-row tiles need Mpad % 128, the
+  // wide 256-row bodies Mpad % 256): NERAF_NACF_MALIGN (measurement knob)
+  static const int kAlign = [] { const char* e = getenv("NERAF_NACF_MALIGN"); const int v = e ? atoi(e) : 128; return (v == 256 || v == 512) ? v : 128; }();
+  L.Mpad = round_up(B, kAlign);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += round_up_sz(bytes, 256); return o; };
   const size_t M = L.Mpad;

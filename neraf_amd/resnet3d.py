@@ -272,26 +272,39 @@ class ResNet3D(nn.Module):
         packed = self._packed
         if self._ws is None or self._ws.device != x.device:
             self._ws = torch.empty(lib.neraf_resnet3d_workspace_bytes(C.byref(self._desc)), dtype=torch.uint8, device=x.device)
+        # Eval-mode forwards run in a workspace of their own (allocated at the first one): the training workspace holds the activations,
+        # pool arguments and BatchNorm statistics a pending training backward reads, and an evaluation between a training forward and
+        # its backward (a viewer frame, an eval hook) must not overwrite them (the third feature buffer alone protected
+        # 4 KB of output, not the saved activations).  ~0.4 GB at 128^3, of 288.
+        if self.training:
+            ws = self._ws
+        else:
+            if getattr(self, "_ws_eval", None) is None or self._ws_eval.device != x.device:
+                self._ws_eval = torch.empty(self._ws.numel(), dtype=torch.uint8, device=x.device)
+            ws = self._ws_eval
         if self._feat_buf is None or self._feat_buf[0].device != x.device:
             self._feat_buf = [torch.empty(1024, dtype=torch.float32, device=x.device) for _ in range(3)]
             self._feat_turn = 0
         # two output buffers alternate between TRAINING forwards (two captured forward graphs): the feature handed out is not copied,
         # and stays intact while the next forward writes the other buffer -- contract: at most one training feature is awaiting its
-        # backward when the forward after next runs (the training loop's shape).  Eval-mode forwards write a third buffer of their own,
-        # so an evaluation between a training forward and its backward cannot touch the saved feature
+        # backward when the forward after next runs (the training loop's shape).  Eval-mode forwards write a third buffer of their own
+        # (and their own workspace, above)
         if self.training:
             self._feat_turn ^= 1
             feat_buf = self._feat_buf[self._feat_turn]
         else:
             feat_buf = self._feat_buf[2]
-        key = (grid.data_ptr(), self._ws.data_ptr(), bool(self.training))
+        # the fp16 channels-last image of the grid lives in the workspace: each workspace remembers which grid generation it holds
+        key = (grid.data_ptr(), ws.data_ptr(), bool(self.training))
+        if not isinstance(getattr(self, "_x0_states", None), dict):
+            self._x0_states = {}
         win = (0, 0)
-        if (grid_state is not None and _GRID_WINDOW and getattr(self, "_x0_state", None) == (key, grid_state[1], grid_state[4])
+        if (grid_state is not None and _GRID_WINDOW and self._x0_states.get(bool(self.training)) == (key, grid_state[1], grid_state[4])
                 and grid_state[0] == grid_state[1] + 1 and x._version == grid_state[5] and 0 < grid_state[3] <= S ** 3 - grid_state[2]):
             win = (int(grid_state[2]), int(grid_state[3]))
         _lib.check(lib.neraf_resnet3d_fwd(h, C.byref(self._desc), packed.data_ptr(), tb["bn_ptrs"], grid.data_ptr(),
-                                          self._ws.data_ptr(), feat_buf.data_ptr(), int(self.training), win[0], win[1], st), dev)
-        self._x0_state = (key, grid_state[0], x._version) if grid_state is not None else None
+                                          ws.data_ptr(), feat_buf.data_ptr(), int(self.training), win[0], win[1], st), dev)
+        self._x0_states[bool(self.training)] = (key, grid_state[0], x._version) if grid_state is not None else None
         feat = feat_buf
         if self.training:
             mom = pairs[0][1].momentum if pairs[0][1].momentum is not None else 0.1
