@@ -64,7 +64,11 @@ def test_state_changes_between_forward_and_backward_do_not_reach_the_gradients(t
 def test_pipeline_driven_nodes_equal_the_hand_driven_nodes(tmp_path_factory):
     r = _run(tmp_path_factory)
     lp, lh, keys = r["_losses"]
-    assert np.array_equal(lp, lh), dict(zip(keys, zip(lp, lh)))         # same forward: the windowed grid conversion == the full one
+    for k, x, y in zip(keys, lp, lh):
+        if k.startswith("audio_"):      # same forward: the windowed grid conversion == the full one, bit for bit through encoder + NAcF
+            assert x == y, (k, x, y)
+        else:                           # the radiance loss VALUES are summed with fp32 atomics in either mode (their gradients are not)
+            np.testing.assert_allclose(x, y, rtol=1e-5, err_msg=k)
     a, b = r["pipeline"], r["by_hand"]
     diff = _differing(a, b)
     loose = [k for k in diff if k.startswith("vision.field.module.") and k.rsplit(".", 1)[-1] in FIELD_MATRICES]
