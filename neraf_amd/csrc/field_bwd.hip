@@ -996,8 +996,6 @@ struct FieldOwnerArgs {
   GridLayout g;
   const float* pos; long npad; long N;
   const unsigned* d_enc;
-  const float2* d_red; long npad_r; int run;   // run > 1 (the grid refresh): N = runs of `run` rays sharing one position, element n = run n: its
-                                       // gradient is d_red[l][n] (fp32 sums over the run, field_runsum_kernel), its position sample n * run's
   unsigned* ids;                       // [16][npad]: bit s set = some corner of the sample falls into slice s of that level
   const float* lvl;
   unsigned long long* acc;
@@ -1023,17 +1021,10 @@ __global__ __launch_bounds__(256) void field_slice_ids_kernel(FieldOwnerArgs a) 
   const float scale = a.g.scale[l];
   const int res = a.g.res[l]; const unsigned size = a.g.size[l]; const int hashed = a.g.hashed[l];
   const unsigned nsl_mask = (size >> OWN_SLICE_LOG2) - 1u;     // hashed levels only
-  const long n_ids = a.run > 1 ? a.npad_r : a.npad;      // (the owners mask entries >= N themselves: words beyond n_ids may be stale)
-  for (long n = (long)blockIdx.x * 256 + threadIdx.x; n < n_ids; n += (long)gridDim.x * 256) {
+  for (long n = (long)blockIdx.x * 256 + threadIdx.x; n < a.npad; n += (long)gridDim.x * 256) {
     unsigned word = 0u;
-    bool live = false;
-    if (n < a.N) {
-      if (a.run > 1) { const float2 gr = a.d_red[(long)l * a.npad_r + n]; live = gr.x != 0.f || gr.y != 0.f; }
-      else live = a.d_enc[(long)l * a.npad + n] != 0u;
-    }
-    if (live) {
-      const long pn = a.run > 1 ? n * a.run : n;
-      const float py = fmaf(scale, a.pos[a.npad + pn], 0.5f), pz = fmaf(scale, a.pos[2 * a.npad + pn], 0.5f);
+    if (n < a.N && a.d_enc[(long)l * a.npad + n] != 0u) {
+      const float py = fmaf(scale, a.pos[a.npad + n], 0.5f), pz = fmaf(scale, a.pos[2 * a.npad + n], 0.5f);
       const unsigned iy = (unsigned)(int)floorf(py), iz = (unsigned)(int)floorf(pz);
       if (hashed) {
 #pragma unroll
@@ -1042,7 +1033,7 @@ __global__ __launch_bounds__(256) void field_slice_ids_kernel(FieldOwnerArgs a) 
           word |= 1u << ((t >> OWN_SLICE_LOG2) & nsl_mask);
         }
       } else {
-        const unsigned ix = (unsigned)(int)floorf(fmaf(scale, a.pos[pn], 0.5f));
+        const unsigned ix = (unsigned)(int)floorf(fmaf(scale, a.pos[n], 0.5f));
 #pragma unroll
         for (int c = 0; c < 8; ++c)
           word |= 1u << (corner_index(ix + (c & 1), iy + ((c >> 1) & 1), iz + ((c >> 2) & 1), res, size, 0) >> OWN_SLICE_LOG2);
@@ -1078,18 +1069,10 @@ __global__ __launch_bounds__(OWN_THREADS) void field_scatter_owner_kernel(FieldO
   auto expand = [&](unsigned head, int cnt) {
     if (lane < cnt) {
       const long n = (long)queue[(head + lane) & (OWN_QUEUE - 1)];
-      float g0, g1;
-      long pn = n;
-      if (a.run > 1) {              // the product F * sum of field_scatter_kernel's run form, operation for operation
-        const float2 gr = a.d_red[(long)l * a.npad_r + n];
-        g0 = gr.x * F; g1 = gr.y * F;
-        pn = n * a.run;
-      } else {
-        const unsigned raw = genc[n];
-        const half2v gh = *reinterpret_cast<const half2v*>(&raw);
-        g0 = (float)gh[0] * F; g1 = (float)gh[1] * F;
-      }
-      const float x = xs[pn], y = ys[pn], z = zs[pn];
+      const unsigned raw = genc[n];
+      const float x = xs[n], y = ys[n], z = zs[n];
+      const half2v gh = *reinterpret_cast<const half2v*>(&raw);
+      const float g0 = (float)gh[0] * F, g1 = (float)gh[1] * F;
       const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
       const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
       const float wx = px - flx, wy = py - fly, wz = pz - flz;
@@ -1133,7 +1116,7 @@ __global__ __launch_bounds__(OWN_THREADS) void field_scatter_owner_kernel(FieldO
     const unsigned wv[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool has = ((wv[j] >> slice) & 1u) && base + lane * 4 + j < a.N;
+      const bool has = (wv[j] >> slice) & 1u;
       const unsigned long long b = __ballot(has);
       if (b == 0ull) continue;
       if (has) {
@@ -1467,11 +1450,7 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
   constexpr int kOwnLds = (1 << OWN_SLICE_LOG2) * 8 + (OWN_THREADS / 64) * OWN_QUEUE * 4;
   const char* own_e = getenv("NERAF_FIELD_OWNER_SCATTER");      // read per call: the parity test flips it between two runs
   const int own_env = own_e ? atoi(own_e) : 1;
-  // pos_run > 1 (the grid refresh: runs of 18 rays per cell): the owners work on the RUN sums -- N / pos_run elements; with global atomics
-  // the refresh's scatter was 67 us at 4096 cells and 365 us at configs[3]'s 32768 (profiles/r06_cfg3_global_*)
-  static const int own_runs = [] { const char* e = getenv("NERAF_FIELD_OWNER_RUNS"); return e ? atoi(e) : 1; }();      // 0: A/B
-  bool use_owner = own_env && ((pos_run == 1 && (N >= 131072 || own_env == 2)) || (pos_run > 1 && own_runs && (N / pos_run >= 2048 || own_env == 2))) &&
-                   N < (1l << 30);   // own_env 2 = also for small batches (tests)
+  bool use_owner = own_env && pos_run == 1 && (N >= 131072 || own_env == 2) && N < (1l << 30);   // 2 = also for small batches (tests)
   int own_blk[MAX_LEVELS + 1] = {0};
   unsigned char own_rep[MAX_LEVELS] = {0};
   for (int l = 0; l < 16 && use_owner; ++l) {
@@ -1554,8 +1533,7 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
       if (!use_owner) hipLaunchKernelGGL(field_scatter_kernel, dim3((unsigned)sblocks, pos_run > 1 ? 16 : 1), dim3(256), 0, st, sa);
       else {
         FieldOwnerArgs oa{};
-        oa.g = a.g; oa.pos = a.pos; oa.npad = npad; oa.N = pos_run > 1 ? N / pos_run : N; oa.d_enc = a.d_enc; oa.lvl = lvl; oa.acc = sa.acc;
-        oa.d_red = sa.d_red; oa.npad_r = sa.npad_r; oa.run = pos_run;
+        oa.g = a.g; oa.pos = a.pos; oa.npad = npad; oa.N = N; oa.d_enc = a.d_enc; oa.lvl = lvl; oa.acc = sa.acc;
         oa.ids = reinterpret_cast<unsigned*>(a.pos + 3 * npad);
         for (int l = 0; l <= 16; ++l) oa.blk_begin[l] = own_blk[l];
         for (int l = 0; l < 16; ++l) oa.rep[l] = own_rep[l];
@@ -1564,7 +1542,7 @@ static int field_backward_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const v
           oa.dst = reinterpret_cast<float2*>(table_grad); oa.beta = accumulate; oa.scale = scale;
           for (int l = 0; l < 16; ++l) if (own_rep[l] == 1) direct_levels |= 1u << l;
         }
-        long iblocks = ((pos_run > 1 ? sa.npad_r : npad) + 255) / 256; if (iblocks > 512) iblocks = 512;
+        long iblocks = (npad + 255) / 256; if (iblocks > 512) iblocks = 512;
         hipLaunchKernelGGL(field_slice_ids_kernel, dim3((unsigned)iblocks, 16), dim3(256), 0, st, oa);
         hipLaunchKernelGGL(field_scatter_owner_kernel, dim3(own_blk[16]), dim3(OWN_THREADS), kOwnLds, st, oa);
       }

@@ -74,45 +74,6 @@ def test_owner_scatter_equals_atomic_scatter_bit_for_bit(vm, monkeypatch):
         np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=1e-4, atol=1e-7)
 
 
-@pytest.mark.parametrize("n_cells", [4096, 32768, 300])
-def test_refresh_owner_scatter_equals_atomic_scatter_bit_for_bit(vm, monkeypatch, n_cells):
-    """The grid refresh's backward (runs of 18 rays sharing a cell centre, their encoding gradients summed per run first) through the
-    LDS-owner scatter (round 6: 67 -> us at 4096 cells, 365 -> us at configs[3]'s 32768-cell window) against the global-atomic path:
-    identical bits in the table gradient -- the same fixed-point integers are added.  300 cells: below the size at which the owners
-    are chosen by default, forced with NERAF_FIELD_OWNER_SCATTER=2."""
-    m, dev = vm
-    f = m.field.module
-    nd = 18
-    g = torch.Generator(device=dev).manual_seed(2)
-    # cell centres of a 128^3 grid window, in the radiance field's box, positions NOT contracted (the refresh switches that off)
-    ax = torch.arange(0.5 / 128, 1, 1 / 128, device=dev)
-    cells = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).view(-1, 3)[777 * 128:777 * 128 + n_cells]
-    ori = (cells * 2.0 - 1.0).repeat_interleave(nd, dim=0).contiguous()                    # cell-major: the nd rays of a cell adjacent
-    dirs = torch.nn.functional.normalize(torch.randn((nd, 3), generator=g, device=dev), dim=-1).repeat(n_cells, 1).contiguous()
-    z = torch.zeros((n_cells * nd, 2), device=dev)
-    cam = torch.zeros(n_cells * nd, dtype=torch.int32, device=dev)
-    old = f.spatial_distortion
-    f.spatial_distortion = None
-    try:
-        packed = f.packed(with_average=False)
-        rgb, den = f.query(ori, dirs, z, cam, packed=packed)
-        d_rgb = ((torch.rand(rgb.shape, generator=g, device=dev) - 0.5) * 1e-3).contiguous()
-        d_den = ((torch.rand(den.shape, generator=g, device=dev) - 0.5) * 1e-5).contiguous()
-        monkeypatch.setenv("NERAF_FIELD_OWNER_SCATTER", "0")
-        a = f.backward_query(packed, ori, dirs, z, cam, den, d_rgb, d_den, pos_run=nd, contract=False)
-        monkeypatch.setenv("NERAF_FIELD_OWNER_SCATTER", "2" if n_cells < 2048 else "1")
-        b = f.backward_query(packed, ori, dirs, z, cam, den, d_rgb, d_den, pos_run=nd, contract=False)
-        # second producer of a pass: adds into the first one's tensors in place (the render batch after the refresh)
-        c = f.backward_query(packed, ori, dirs, z, cam, den, d_rgb, d_den, pos_run=nd, contract=False, accumulate_into=[t.clone() for t in a])
-    finally:
-        f.spatial_distortion = old
-    assert float(a[0].abs().max()) > 0 and bool(torch.isfinite(a[0]).all())
-    assert torch.equal(a[0], b[0])
-    assert torch.equal(c[0], a[0] + a[0])
-    for x, y in zip(a[1:6], b[1:6]):
-        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=1e-4, atol=1e-7)
-
-
 def test_full_size_render_invariants(vm):
     from neraf_amd.vision import RayBundle
     m, dev = vm
