@@ -253,6 +253,19 @@ int neraf_pdf_resample_ex(neraf_ctx* ctx, const float* density, const float* s_b
                           int R, int S, float anneal, const float* jitter, uint64_t jitter_seed, int n_new, float near, float far,
                           float* weights, float* s_new, float* e_new, neraf_stream_t stream);
 
+/* ... and the expected-depth clip range of the composite that follows folded into the sampler (nerfstudio's DepthRenderer clips the
+ * expected depth to [steps.min(), steps.max()] of the batch [NS-recall]; NerfactoModel.get_outputs, reached from NeRAF_model.py:65-68):
+ * minmax_scratch holds 64 REPLICAS of the pair {bits(min), bits(max)}, 256 bytes apart (ray r updates replica r & 63: atomics on one
+ * line serialise in its L2 channel), i.e. 16384 bytes, followed by up to 60 further words.  minmax_mode 1 -- the launch also SEEDS the
+ * replicas = {bits(+FLT_MAX), 0} and zeroes the words behind them (bytes 16384..scratch_bytes: the loss node's four fp32 sums,
+ * neraf_render_loss); minmax_mode 2 -- the launch also ACCUMULATES {min, max} of 0.5 (e_new[0] + e_new[1]) and 0.5 (e_new[n_new-1] +
+ * e_new[n_new]) over its rays (n_new <= 63); 0 = neraf_pdf_resample_ex.  The two sampler stages of a render call it with 1 then 2;
+ * neraf_composite_mm reduces the replicas.  scratch_bytes: 16384..16624, a multiple of 4. */
+int neraf_pdf_resample_mm(neraf_ctx* ctx, const float* density, const float* s_bins, const float* e_bins, int64_t bins_row_stride,
+                          int R, int S, float anneal, const float* jitter, uint64_t jitter_seed, int n_new, float near, float far,
+                          float* weights, float* s_new, float* e_new, void* minmax_scratch, size_t scratch_bytes, int minmax_mode,
+                          neraf_stream_t stream);
+
 /* Fused nerfacto field query: position map (mode 0: L-inf scene contraction, mode 1: AABB
  * normalisation with aabb_host[6]) -> 16-level hash grid -> base MLP -> density; SH(dir) +
  * appearance embedding -> colour MLP -> sigmoid.  wfrag_f16: 24 MFMA weight fragments (24 KB)
@@ -278,6 +291,11 @@ int neraf_field_query_train(neraf_ctx* ctx, const neraf_grid_desc* g, const void
 int neraf_composite(neraf_ctx* ctx, const float* density, const float* rgb, const float* e_bins, int R, int S,
                     int training, float* weights, float* rgb_out, float* depth, float* expected, float* acc,
                     void* scratch, size_t scratch_bytes, neraf_stream_t stream);
+/* The same as ONE launch: `minmax` = the 64 replicated {min, max} step pairs the sampler left (neraf_pdf_resample_mm modes 1 and 2) -- no seeding
+ * launch and no reduction launch in front of the composite (an eval frame is 22 chunks: 44 launches, 0.39 ms of 11.15). */
+int neraf_composite_mm(neraf_ctx* ctx, const float* density, const float* rgb, const float* e_bins, int R, int S,
+                       int training, float* weights, float* rgb_out, float* depth, float* expected, float* acc,
+                       const void* minmax, neraf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Radiance half, training: losses (V4) and backward.  These replace autograd through nerfstudio's

@@ -99,6 +99,11 @@ SIGNATURES = {
     "neraf_pdf_resample_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float,
                                         C.c_void_p, C.c_uint64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "neraf_pdf_resample_mm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float,
+                                        C.c_void_p, C.c_uint64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "neraf_composite_mm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "neraf_pdf_resample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                      C.c_void_p, C.c_uint64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),

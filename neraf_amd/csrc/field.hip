@@ -217,6 +217,11 @@ struct PdfArgs {
   float* weights; float* s_new; float* e_new;
   unsigned long long jitter_seed;   // jitter == null and seed != 0: the per-ray jitter is drawn in the kernel (jitter_u01)
   size_t bins_stride;               // floats between the input bin rows of consecutive rays: S + 1, or 0 (every ray shares row 0)
+  // {min, max} over the batch of the NEW samples' first / last mid-points (the expected-depth clip range of the composite that
+  // follows, DepthRenderer "expected" [NS-recall]) folded into the sampler: mm_mode 1 = this launch SEEDS mm[0..1] (and zeroes
+  // mm_zero further words: the loss node's sums), 2 = this launch ACCUMULATES its rays' range (n_new + 1 <= 64).  Round 5 spent two
+  // launches per composite on this (minmax_seed + steps_minmax: 22 x 17.7 us of an 11.15 ms frame).
+  unsigned* mm; int mm_mode; int mm_zero;
 };
 
 constexpr int PDF_MAX_S = 256;
@@ -290,6 +295,7 @@ __global__ __launch_bounds__(256) void pdf_resample_kernel(PdfArgs a) {
   // --- inverse-CDF sampling of n_new+1 bin edges
   const int nb = a.n_new + 1;
   const float sn = spacing_fn(a.near), sf = spacing_fn(a.far);
+  float e_first = 0.f;
   for (int j = lane; j < nb; j += 64) {
     float u = (float)j * ((1.f - 1.f / (float)nb) / (float)(nb - 1));    // linspace(0, 1-1/nb, nb)
     if (j == nb - 1) u = 1.f - 1.f / (float)nb;
@@ -303,9 +309,30 @@ __global__ __launch_bounds__(256) void pdf_resample_kernel(PdfArgs a) {
     if (!(t == t)) t = 0.f;                      // nan_to_num(nan=0); +-inf are absorbed by the clip
     t = fminf(fmaxf(t, 0.f), 1.f);
     const float b = b0 + t * (b1 - b0);
+    const float ev = spacing_inv(b * sf + (1.f - b) * sn);
+    e_first = ev;                                 // (nb <= 64 when the range is asked for: lane j holds edge j)
     if (active) {
       a.s_new[(size_t)ray * nb + j] = b;
-      a.e_new[(size_t)ray * nb + j] = spacing_inv(b * sf + (1.f - b) * sn);
+      a.e_new[(size_t)ray * nb + j] = ev;
+    }
+  }
+  if (a.mm_mode == 1) {
+    // 64 replicas of the pair, 256 bytes apart; the loss node's sums (mm_zero words) behind them
+    if (blockIdx.x == 0) {
+      if (threadIdx.x < 64) { a.mm[threadIdx.x * 64] = 0x7f7fffffu; a.mm[threadIdx.x * 64 + 1] = 0u; }
+      else if ((int)threadIdx.x < 64 + a.mm_zero) a.mm[64 * 64 + (threadIdx.x - 64)] = 0u;
+    }
+  } else if (a.mm_mode == 2) {
+    // the mid-points steps_minmax_kernel forms, from the values just stored: 0.5 (e[0] + e[1]) and 0.5 (e[nb-2] + e[nb-1]).
+    // One atomic pair per ray into replica (ray & 63): 32768 rays = 512 pairs per replica, each replica its own line (one line for
+    // all of them serialised the launch: 8192 workgroups x 3.6 ns).  Positive floats order like their bit patterns.
+    const float e_next = __shfl_down(e_first, 1);
+    const float mid = 0.5f * (e_first + e_next);
+    const float lo = __shfl(mid, 0), hi = __shfl(mid, nb - 2);
+    if (lane == 0) {
+      unsigned* slot = a.mm + (size_t)(ray & 63) * 64;
+      atomicMin(slot, __float_as_uint(lo));
+      atomicMax(slot + 1, __float_as_uint(hi));
     }
   }
 }
@@ -529,7 +556,9 @@ struct CompArgs {
   int R, S, training;
   float* weights; float* rgb_out; float* depth; float* expected; float* acc;
   const unsigned* minmax;        // {bits(min step), bits(max step)} over the whole batch (expected-depth clip range)
+  int mm_replicas;               // 1, or MM_REPLICAS partial pairs MM_STRIDE words apart (neraf_pdf_resample_mm): reduced by every wave
 };
+constexpr int MM_REPLICAS = 64, MM_STRIDE = 64;      // 64 pairs, 256 bytes apart: same-line atomics serialise in their L2 channel
 
 // global min / max of the sample mid-points (positive floats order like their bit patterns)
 // seeds the {min, max} pair of steps_minmax_kernel on the device (a host-side 8-byte copy would come from pageable memory:
@@ -583,6 +612,14 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
   const unsigned long long ge = __ballot(on && cum >= 0.5f);
   const int mi = ge ? (int)__ffsll((long long)ge) - 1 : S - 1;
   const float med = __shfl(step, mi);
+  unsigned mm_lo = 0u, mm_hi = 0u;
+  if (a.expected) {
+    if (a.mm_replicas > 1) {       // lane r reads replica r (its own line, L1-resident after the CU's first wave); min / max of unsigned bit patterns
+      mm_lo = a.minmax[lane * MM_STRIDE]; mm_hi = a.minmax[lane * MM_STRIDE + 1];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { mm_lo = min(mm_lo, (unsigned)__shfl_xor((int)mm_lo, o)); mm_hi = max(mm_hi, (unsigned)__shfl_xor((int)mm_hi, o)); }
+    } else { mm_lo = a.minmax[0]; mm_hi = a.minmax[1]; }
+  }
   if (lane == 0) {
     float cr = sr + lr * (1.f - sw), cg = sg + lg * (1.f - sw), cb = sb + lb * (1.f - sw);
     if (!a.training) { cr = fminf(fmaxf(cr, 0.f), 1.f); cg = fminf(fmaxf(cg, 0.f), 1.f); cb = fminf(fmaxf(cb, 0.f), 1.f); }
@@ -591,7 +628,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompArgs a) {
     a.rgb_out[ray * 3 + 1] = fminf(fmaxf(cg, 0.f), 1.f);
     a.rgb_out[ray * 3 + 2] = fminf(fmaxf(cb, 0.f), 1.f);
     if (a.depth) a.depth[ray] = med;
-    if (a.expected) a.expected[ray] = fminf(fmaxf(sd / (sw + 1e-10f), __uint_as_float(a.minmax[0])), __uint_as_float(a.minmax[1]));
+    if (a.expected) a.expected[ray] = fminf(fmaxf(sd / (sw + 1e-10f), __uint_as_float(mm_lo)), __uint_as_float(mm_hi));
     if (a.acc) a.acc[ray] = sw;
   }
 }
@@ -814,7 +851,23 @@ extern "C" int neraf_pdf_resample_ex(neraf_ctx* ctx, const float* density, const
   if (R <= 0 || S <= 0 || S > PDF_MAX_S || n_new <= 0 || !density || !s_bins || !e_bins || !s_new || !e_new)
     return neraf_fail(ctx, NERAF_EINVAL, "pdf_resample: bad arguments (S <= 256)");
   if (bins_row_stride != 0 && bins_row_stride != (int64_t)S + 1) return neraf_fail(ctx, NERAF_EINVAL, "pdf_resample: bins_row_stride is S + 1 or 0");
-  PdfArgs a{density, s_bins, e_bins, R, S, anneal, jitter, n_new, near, far, weights, s_new, e_new, (unsigned long long)jitter_seed, (size_t)bins_row_stride};
+  return neraf_pdf_resample_mm(ctx, density, s_bins, e_bins, bins_row_stride, R, S, anneal, jitter, jitter_seed, n_new, near, far, weights, s_new, e_new,
+                               nullptr, 0, 0, stream);
+}
+
+extern "C" int neraf_pdf_resample_mm(neraf_ctx* ctx, const float* density, const float* s_bins, const float* e_bins, int64_t bins_row_stride,
+                                     int R, int S, float anneal, const float* jitter, uint64_t jitter_seed, int n_new, float near, float far,
+                                     float* weights, float* s_new, float* e_new, void* minmax_scratch, size_t scratch_bytes, int minmax_mode,
+                                     neraf_stream_t stream) {
+  if (R <= 0 || S <= 0 || S > PDF_MAX_S || n_new <= 0 || !density || !s_bins || !e_bins || !s_new || !e_new)
+    return neraf_fail(ctx, NERAF_EINVAL, "pdf_resample: bad arguments (S <= 256)");
+  if (bins_row_stride != 0 && bins_row_stride != (int64_t)S + 1) return neraf_fail(ctx, NERAF_EINVAL, "pdf_resample: bins_row_stride is S + 1 or 0");
+  constexpr size_t kMmBytes = (size_t)MM_REPLICAS * MM_STRIDE * 4;
+  if (minmax_mode < 0 || minmax_mode > 2 || (minmax_mode && (!minmax_scratch || scratch_bytes < kMmBytes || scratch_bytes > kMmBytes + 4 * 60 || (scratch_bytes & 3))) ||
+      (minmax_mode == 2 && (n_new + 1 > 64 || n_new < 2)))
+    return neraf_fail(ctx, NERAF_EINVAL, "pdf_resample_mm: mode 0 / 1 (seed) / 2 (accumulate, 2 <= n_new <= 63), 16384..16624 scratch bytes");
+  PdfArgs a{density, s_bins, e_bins, R, S, anneal, jitter, n_new, near, far, weights, s_new, e_new, (unsigned long long)jitter_seed, (size_t)bins_row_stride,
+            (unsigned*)minmax_scratch, minmax_mode, minmax_mode == 1 ? (int)((scratch_bytes - kMmBytes) / 4) : 0};
   hipLaunchKernelGGL(pdf_resample_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;
@@ -878,6 +931,17 @@ static int field_query_impl(neraf_ctx* ctx, const neraf_grid_desc* g, const void
   return NERAF_OK;
 }
 
+extern "C" int neraf_composite_mm(neraf_ctx* ctx, const float* density, const float* rgb, const float* e_bins, int R, int S,
+                                  int training, float* weights, float* rgb_out, float* depth, float* expected, float* acc,
+                                  const void* minmax, neraf_stream_t stream) {
+  if (R <= 0 || S <= 0 || S > 64 || !density || !rgb || !e_bins || !rgb_out || (expected && !minmax))
+    return neraf_fail(ctx, NERAF_EINVAL, "composite_mm: bad arguments (S <= 64; the {min, max} pair of neraf_pdf_resample_mm for expected depth)");
+  CompArgs a{density, rgb, e_bins, R, S, training, weights, rgb_out, depth, expected, acc, (const unsigned*)minmax, MM_REPLICAS};
+  hipLaunchKernelGGL(composite_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  NERAF_HIP_CHECK(ctx, hipGetLastError());
+  return NERAF_OK;
+}
+
 extern "C" int neraf_composite(neraf_ctx* ctx, const float* density, const float* rgb, const float* e_bins, int R, int S,
                                int training, float* weights, float* rgb_out, float* depth, float* expected, float* acc,
                                void* scratch, size_t scratch_bytes, neraf_stream_t stream) {
@@ -889,7 +953,7 @@ extern "C" int neraf_composite(neraf_ctx* ctx, const float* density, const float
     hipLaunchKernelGGL(minmax_seed_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mm, (int)((scratch_bytes - 8) / 4));
     hipLaunchKernelGGL(steps_minmax_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, e_bins, R, S, mm);
   }
-  CompArgs a{density, rgb, e_bins, R, S, training, weights, rgb_out, depth, expected, acc, mm};
+  CompArgs a{density, rgb, e_bins, R, S, training, weights, rgb_out, depth, expected, acc, mm, 1};
   hipLaunchKernelGGL(composite_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   return NERAF_OK;

@@ -471,6 +471,9 @@ class RGBRenderer:
         return comp + rgb[..., -1, :] * (1.0 - acc)
 
 
+_MINMAX_FOLD = __import__("os").environ.get("NERAF_MINMAX_FOLD", "1") != "0"
+
+
 class _VisionLossFn(torch.autograd.Function):
     """{rgb_loss, interlevel_loss, distortion_loss} as one autograd node over the radiance parameters."""
 
@@ -743,6 +746,11 @@ class NeRAFVisionModel(nn.Module):
         prop_updated = self._proposal_updated() if self.training else False
         weights_list, samples_list = [], []
         s_prev, e_prev = s0, e0
+        # {min step, max step} of the expected-depth clip, formed by the two sampler launches themselves (first: seeds the pair and
+        # zeroes the loss node's four sums behind it; second: accumulates its rays' range) -- the composite is then ONE launch
+        fold = _MINMAX_FOLD
+        n_mm = 64 * 64 if fold else 2           # folded: 64 replicas of the pair, 256 bytes apart (include/neraf_hip.h, neraf_pdf_resample_mm)
+        scratch = torch.empty(n_mm + (4 if self.training else 0), dtype=torch.float32, device=o.device)
         if self.training:
             self._refresh_packs()
         prop_packed = [pn.packed() for pn in self.proposal_networks]
@@ -754,10 +762,10 @@ class NeRAFVisionModel(nn.Module):
             # the proposal levels' rendering weights only feed the interlevel loss: a whole-frame render (_out given) does not ask for them
             w = torch.empty((R, S_cur), **f32) if _out is None else None
             s_n, e_n = torch.empty((R, S_next + 1), **f32), torch.empty((R, S_next + 1), **f32)
-            _lib.check(lib.neraf_pdf_resample_ex(h, dens.data_ptr(), s_prev.data_ptr(), e_prev.data_ptr(),
+            _lib.check(lib.neraf_pdf_resample_mm(h, dens.data_ptr(), s_prev.data_ptr(), e_prev.data_ptr(),
                                                  0 if (e_prev.shape[0] == 1 and R > 1) else S_cur + 1, R, S_cur, anneal,
                                                  jp[i + 1], seeds[i + 1], S_next, near, far, w.data_ptr() if w is not None else None,
-                                                 s_n.data_ptr(), e_n.data_ptr(), st), dev)
+                                                 s_n.data_ptr(), e_n.data_ptr(), scratch.data_ptr(), scratch.numel() * 4, (i + 1) if fold else 0, st), dev)
             weights_list.append(w)
             samples_list.append(RaySamples(None, ray_bundle.camera_indices, s_prev, e_prev))
             s_prev, e_prev = s_n, e_n
@@ -777,11 +785,14 @@ class NeRAFVisionModel(nn.Module):
         else:
             rgb, depth = torch.empty((R, 3), **f32), torch.empty((R, 1), **f32)
             expd, acc = torch.empty((R, 1), **f32), torch.empty((R, 1), **f32)
-        # {min step, max step} of the expected-depth clip + (training) the loss node's four sums, zeroed by the seeding launch
-        scratch = torch.empty(6 if self.training else 2, dtype=torch.float32, device=o.device)
-        _lib.check(lib.neraf_composite(h, dens.data_ptr(), rgb_s.data_ptr(), e_prev.data_ptr(), R, S2, int(self.training),
-                                       w.data_ptr(), rgb.data_ptr(), depth.data_ptr(), expd.data_ptr(), acc.data_ptr(),
-                                       scratch.data_ptr(), scratch.numel() * 4, st), dev)
+        if fold:
+            _lib.check(lib.neraf_composite_mm(h, dens.data_ptr(), rgb_s.data_ptr(), e_prev.data_ptr(), R, S2, int(self.training),
+                                              w.data_ptr(), rgb.data_ptr(), depth.data_ptr(), expd.data_ptr(), acc.data_ptr(),
+                                              scratch.data_ptr(), st), dev)
+        else:       # round 5's form (A/B: NERAF_MINMAX_FOLD=0): the composite's own seeding + reduction launches
+            _lib.check(lib.neraf_composite(h, dens.data_ptr(), rgb_s.data_ptr(), e_prev.data_ptr(), R, S2, int(self.training),
+                                           w.data_ptr(), rgb.data_ptr(), depth.data_ptr(), expd.data_ptr(), acc.data_ptr(),
+                                           scratch.data_ptr(), scratch.numel() * 4, st), dev)
         weights_list.append(w)
         samples_list.append(RaySamples(None, ray_bundle.camera_indices, s_prev, e_prev))
         out = {"rgb": rgb, "accumulation": acc, "depth": depth, "expected_depth": expd}
@@ -791,7 +802,7 @@ class NeRAFVisionModel(nn.Module):
             # everything the fused loss/backward node needs (same packed fp16 parameter copies as the forward used)
             out["_state"] = dict(o=o, d=d, ray_o=ray_o, ray_d=ray_d, cam=cam32, samples=samples_list, prop_dens=prop_dens,
                                  prop_packed=prop_packed, field_packed=field_packed, field_saved=saved, rgb_s=rgb_s, dens=dens, w_fine=w,
-                                 prop_updated=prop_updated, loss_sums=scratch[2:6], contract=field.spatial_distortion is not None)
+                                 prop_updated=prop_updated, loss_sums=scratch[n_mm:n_mm + 4], contract=field.spatial_distortion is not None)
         out["rgb_samples"], out["density"] = rgb_s, dens
         return out
 

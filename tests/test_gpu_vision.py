@@ -227,6 +227,57 @@ def test_weights_at_surface_densities(dev, setup):
             assert float(acc.max()) <= 1.0 + 1e-5 and bool(torch.isfinite(rgb).all())
 
 
+@pytest.mark.parametrize("R", [5, 4096, 32768])
+def test_sampler_folded_depth_range_equals_the_standalone_reduction(dev, R):
+    """Round 6: the {min, max} step pair that clips the expected depth (DepthRenderer "expected" [NS-recall]) is formed by the sampler
+    launches (neraf_pdf_resample_mm: mode 1 seeds + zeroes the loss sums, mode 2 accumulates the new samples' range) instead of two
+    launches in front of every composite.  Same bits as the stand-alone reduction (neraf_composite's own seed + minmax launches): the
+    pair itself, the words behind it zeroed, and the composite's five outputs through neraf_composite_mm vs neraf_composite."""
+    from neraf_amd import _lib
+    lib = _lib.load()
+    h = _lib.ctx(0)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    S0, S1 = 96, 48
+    g = torch.Generator(device=dev).manual_seed(R)
+    s0, e0 = torch.empty((R, S0 + 1), device=dev), torch.empty((R, S0 + 1), device=dev)
+    _lib.check(lib.neraf_sample_uniform(h, R, S0, 0.05, 1000.0, None, 12345, s0.data_ptr(), e0.data_ptr(), st), 0)
+    dens0 = (torch.rand((R, S0), generator=g, device=dev) ** 6 * 50.0).contiguous()
+    NM = 64 * 64                                                      # 64 replicas of the pair, 256 bytes apart
+    scratch = torch.full((NM + 4,), 7.0, device=dev)                  # garbage: the seeding launch owns the initial state
+    s1, e1 = torch.empty((R, S1 + 1), device=dev), torch.empty((R, S1 + 1), device=dev)
+    _lib.check(lib.neraf_pdf_resample_mm(h, dens0.data_ptr(), s0.data_ptr(), e0.data_ptr(), S0 + 1, R, S0, 1.0, None, 999, S1, 0.05, 1000.0,
+                                         None, s1.data_ptr(), e1.data_ptr(), scratch.data_ptr(), (NM + 4) * 4, 1, st), 0)
+    seeded = scratch.view(torch.int32).cpu()
+    assert seeded[0:NM:64].tolist() == [0x7F7FFFFF] * 64 and seeded[1:NM:64].tolist() == [0] * 64 and seeded[NM:].tolist() == [0] * 4
+    _lib.check(lib.neraf_pdf_resample_mm(h, dens0.data_ptr(), s0.data_ptr(), e0.data_ptr(), S0 + 1, R, S0, 1.0, None, 999, S1, 0.05, 1000.0,
+                                         None, s1.data_ptr(), e1.data_ptr(), scratch.data_ptr(), (NM + 4) * 4, 2, st), 0)
+    mid = 0.5 * (e1[:, :-1] + e1[:, 1:])
+    lo_f, hi_f = scratch[0:NM:64].min(), scratch[1:NM:64].max()
+    assert float(lo_f) == float(mid[:, 0].min()) and float(hi_f) == float(mid[:, -1].max())
+    assert scratch[NM:].cpu().tolist() == [0.0] * 4
+    dens = (torch.rand((R, S1), generator=g, device=dev) ** 8 * 3.0).contiguous()      # many rays with almost no mass: the clip acts
+    dens[::3] = 0.0
+    rgb_s = torch.rand((R, S1, 3), generator=g, device=dev).contiguous()
+    outs = []
+    for form in ("mm", "standalone"):
+        w = torch.empty((R, S1), device=dev)
+        rgb, depth = torch.empty((R, 3), device=dev), torch.empty((R, 1), device=dev)
+        expd, acc = torch.empty((R, 1), device=dev), torch.empty((R, 1), device=dev)
+        if form == "mm":
+            _lib.check(lib.neraf_composite_mm(h, dens.data_ptr(), rgb_s.data_ptr(), e1.data_ptr(), R, S1, 0, w.data_ptr(), rgb.data_ptr(),
+                                              depth.data_ptr(), expd.data_ptr(), acc.data_ptr(), scratch.data_ptr(), st), 0)
+        else:
+            own = torch.empty(2, dtype=torch.int32, device=dev)
+            _lib.check(lib.neraf_composite(h, dens.data_ptr(), rgb_s.data_ptr(), e1.data_ptr(), R, S1, 0, w.data_ptr(), rgb.data_ptr(),
+                                           depth.data_ptr(), expd.data_ptr(), acc.data_ptr(), own.data_ptr(), 8, st), 0)
+            assert own.cpu().tolist() == torch.stack([lo_f, hi_f]).view(torch.int32).cpu().tolist()
+        outs.append((w, rgb, depth, expd, acc))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    lo, hi = float(lo_f), float(hi_f)
+    assert float(outs[0][3].min()) >= lo and float(outs[0][3].max()) <= hi and float((outs[0][3] == lo).sum()) >= R // 3
+
+
 @pytest.mark.parametrize("mode,training", [("contract", True), ("contract", False), ("aabb", True)])
 def test_field_query(dev, setup, mode, training):
     m, P16, spec, V = setup
