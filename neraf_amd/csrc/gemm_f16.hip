@@ -1232,7 +1232,9 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
       const int after = nk - 1 - kt;
-      if (NST >= 3 && after >= 1) wait_vmcnt<NP>();
+      // stage kt must have landed; up to NST - 2 younger stages stay in flight across the barrier (and NST - 1 during the MFMAs)
+      if (NST >= 4 && after >= 2) wait_vmcnt<2 * NP>();
+      else if (NST >= 3 && after >= 1) wait_vmcnt<NP>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       if (kt + NST - 1 < nk) {
@@ -1262,7 +1264,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
       if (++stage == NST) stage = 0;
     }
   };
-  static_assert(NST == 2 || NST == 3, "ring depths the waits are written for");
+  static_assert(NST == 2 || NST == 3 || NST == 4, "ring depths the waits are written for");
   if (MH == 2) body(std::integral_constant<int, 2>{}); else body(std::integral_constant<int, 1>{});
 
   const int b64 = bnw * NH + hb;
@@ -1433,7 +1435,7 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
   static const int nst = [] { const char* e = getenv("NERAF_WGRAD_NST"); const int v = e ? atoi(e) : 3; return v < 2 ? 2 : (v > 4 ? 4 : v); }();   // 3 stages = 48 KiB: three workgroups per CU (5.42 -> 5.34 ms/step against 4 stages)
   static const int rounds = [] { const char* e = getenv("NERAF_WGRAD_ROUNDS"); return e ? atoi(e) : 8; }();
   static const int wide = [] { const char* e = getenv("NERAF_WGRAD_WIDE"); return e ? atoi(e) : 1; }();        // 0: 64x64 tiles only
-  static const int wide_nst = [] { const char* e = getenv("NERAF_WGRAD_WIDE_NST"); return (e && atoi(e) == 3) ? 3 : 2; }();
+  static const int wide_nst = [] { const char* e = getenv("NERAF_WGRAD_WIDE_NST"); const int v = e ? atoi(e) : 2; return (v == 3 || v == 4) ? v : 2; }();
   static const int wide_rounds = [] { const char* e = getenv("NERAF_WGRAD_WIDE_ROUNDS"); return e ? atoi(e) : 4; }();
   const int LDS_BYTES = nst * 128 * 128;
   static bool attr_set = false;
@@ -1443,6 +1445,7 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 128));
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 5 * 8192));
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 5 * 8192));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 5 * 8192));
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 5 * 8192));
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128));
     attr_set = true;
@@ -1508,6 +1511,7 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
       else hipLaunchKernelGGL((wgrad_grouped_tn_kernel<3, true>), dim3(blocks), dim3(256), 3 * 128 * 128, stream, t);
     }
     else if (wide && wide_nst == 2) hipLaunchKernelGGL((wgrad_wide_tn_kernel<2, false>), dim3(blocks), dim3(256), 2 * 5 * 8192, stream, t);
+    else if (wide && wide_nst == 4) hipLaunchKernelGGL((wgrad_wide_tn_kernel<4, false>), dim3(blocks), dim3(256), 4 * 5 * 8192, stream, t);
     else if (wide) hipLaunchKernelGGL((wgrad_wide_tn_kernel<3, false>), dim3(blocks), dim3(256), 3 * 5 * 8192, stream, t);
     else if (nst == 2) hipLaunchKernelGGL((wgrad_grouped_tn_kernel<2, false>), dim3(blocks), dim3(256), LDS_BYTES, stream, t);
     else if (nst == 3) hipLaunchKernelGGL((wgrad_grouped_tn_kernel<3, false>), dim3(blocks), dim3(256), LDS_BYTES, stream, t);
