@@ -6,11 +6,19 @@ import torch
 from neraf_amd import _lib
 lib = _lib.load(); h = _lib.ctx(0)
 dev = torch.device("cuda:0")
+import sys
+if len(sys.argv) > 1 and sys.argv[1] == "m6464":
+    shapes_override = [(6464, 5096, 192, 1), (6464, 2048, 5120, 1), (6464, 1024, 2048, 1), (6464, 1024, 1024, 1), (6464, 512, 1024, 1),
+                       (6464, 5096, 2048, 1), (5096, 2048, 6464, 4), (2048, 1024, 6464, 4), (8192, 8192, 8192, 1)]
+else:
+    shapes_override = None
 shapes = [  # (M, N, K, outputs)  outputs: 1=C16, 2=C16T, 4=C32
     (2048, 5096, 192, 3), (2048, 2048, 5120, 3), (2048, 1024, 2048, 3), (2048, 1024, 1024, 3), (2048, 512, 1024, 3),
     (2048, 513, 512, 4), (2048, 5096, 2048, 3), (2048, 5096, 2048, 4), (1024, 2048, 2048, 4), (5096, 163, 2048, 4),
     (4096, 4096, 4096, 1),
 ]
+if shapes_override:
+    shapes = shapes_override
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 print("variant", os.environ.get("NERAF_GEMM_VARIANT", "default"))
 for M, N, K, o in shapes:
