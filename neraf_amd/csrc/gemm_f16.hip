@@ -1086,8 +1086,14 @@ __global__ __launch_bounds__(256) void wgrad_grouped_tn_kernel(WgTable t) {
 // transposed reads of the kernel above) and every wave owns one 64x64 block of the product -- (A half, B half) = (w >> 1, w & 1)
 // for MH = NH = 2 (cout >= 128) or (0, w) for MH = 1, NH = 4 (the 64-filter convolutions, half of the FLOPs): 32 / 40 KiB per
 // 2.1 MFLOP K-step, 16 transposed reads per 16 MFMAs instead of 16 per 8.
-template <int NST, bool BF>
-__global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
+// NW = 8 (round 6): the SAME tile and LDS footprint on twice the waves -- the wave pair (w, w + 4) owns one 64x64 block of the product and
+// splits every K-step's two 32-deep halves between them (each wave: 8 + 8 transposed reads, 16 MFMAs per K-step instead of 32 + 32), the
+// 512 threads stage a row each instead of two, and the pair's accumulators are added through LDS before the epilogue.  Why: the kernel is
+// bound by how many waves a SIMD has to interleave (profiles/r06_wgrad_nst_ab.txt: 412 us at one wave per SIMD, 264 at two, whatever
+// the ring depth), and the LDS admits no third 4-wave workgroup; two 8-wave workgroups give every SIMD four waves.
+template <int NST, bool BF, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void wgrad_wide_tn_kernel(WgTable t) {
+  constexpr int NI = NW == 4 ? 2 : 1;               // staged rows per thread: rows i * 32 + (tid >> 3)
   using E = typename ET<BF>::s; using E4 = typename ET<BF>::v4; using E8 = typename ET<BF>::v8;
   constexpr int HALF = 64 * 128;
   constexpr int STAGE_BYTES = 5 * HALF;
@@ -1112,7 +1118,8 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
   const int gi = wg_find(t, lb);
   const WgDesc& D = t.d[gi];
   const int MH = D.mh, NH = MH == 2 ? 2 : 4;
-  const int ha = MH == 2 ? (wave >> 1) : 0, hb = MH == 2 ? (wave & 1) : wave;
+  const int pw = wave & 3, kh = wave >> 2;          // the 64x64 block this wave works on; NW == 8: which half of each K-step it multiplies
+  const int ha = MH == 2 ? (pw >> 1) : 0, hb = MH == 2 ? (pw & 1) : pw;
   int bid = lb - D.block_begin;
   const int splits = D.splits, n64 = D.tiles_n, tiles_m = D.cout / (64 * MH);
   int split, bm, bnw;
@@ -1130,9 +1137,9 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
   const int k_end = (k_begin + per) < nk_total ? (k_begin + per) : nk_total;
   const int nk = k_end > k_begin ? k_end - k_begin : 0;
 
-  int lrow[2], lcs[2];
+  int lrow[NI], lcs[NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int row = i * 32 + (tid >> 3);
     lrow[i] = row;
     lcs[i] = (tid & 7) ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1);
@@ -1149,18 +1156,18 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
   // -- this loop runs one wave per SIMD, and the generic bounds tests + 64-bit address products cost more than its 32 MFMAs.
   int h_cb[4];
   bool h_ok[4];
-  unsigned h_sel[2][4];
-  int h_toff[2][4];
+  unsigned h_sel[NI][4];
+  int h_toff[NI][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int b64 = bnw * NH + j;
     h_ok[j] = j < NH && b64 < n64;
     h_cb[j] = 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { h_sel[i][j] = 0u; h_toff[i][j] = 0; }
+    for (int i = 0; i < NI; ++i) { h_sel[i][j] = 0u; h_toff[i][j] = 0; }
     if (loader != 0 && h_ok[j]) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NI; ++i) {
         int tap;
         if (loader == 1) { const int n0 = b64 * 64; tap = n0 / cin; h_cb[j] = n0 - tap * cin; }
         else tap = b64 * 8 + lcs[i];
@@ -1188,11 +1195,11 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto body = [&](auto mh_c) {
-    constexpr int MHc = decltype(mh_c)::value, NHc = MHc == 2 ? 2 : 4, NP = 2 * (MHc + NHc);   // LDS-DMA pieces per thread and stage
+    constexpr int MHc = decltype(mh_c)::value, NHc = MHc == 2 ? 2 : 4, NP = NI * (MHc + NHc);   // LDS-DMA pieces per thread and stage
     auto issue = [&](int kt, int stage) {
-      char* base = smem + stage * STAGE_BYTES + wave * 1024;
+      char* base = smem + stage * STAGE_BYTES + wave * 1024;       // (eight waves: waves 4-7 write what i == 1 writes for four)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NI; ++i) {
         const int m = kt * BK + lrow[i];
 #pragma unroll
         for (int h = 0; h < MHc; ++h)
@@ -1244,7 +1251,8 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
       char* sa = smem + stage * STAGE_BYTES + ha * HALF;
       char* sb = smem + stage * STAGE_BYTES + (MHc + hb) * HALF;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks0 = 0; ks0 < (NW == 8 ? 1 : 2); ++ks0) {
+        const int ks = NW == 8 ? kh : ks0;
         E8 fa[4], fb[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
@@ -1268,8 +1276,28 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
   if (MH == 2) body(std::integral_constant<int, 2>{}); else body(std::integral_constant<int, 1>{});
 
   const int b64 = bnw * NH + hb;
-  if (b64 >= n64) return;
   const int frow = lane & 15, fq = lane >> 4;
+  if constexpr (NW == 8) {
+    // the pair's two partial products: wave kh == 1 parks its accumulators in the (now idle) staging ring, wave kh == 0 adds them
+    constexpr int PR_LD = 68;
+    __syncthreads();                                 // every wave is done with the staging ring
+    float* pr = reinterpret_cast<float*>(smem) + pw * (64 * PR_LD);
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(pr + (i * 16 + frow) * PR_LD + j * 16 + fq * 4) = acc[i][j];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] += *reinterpret_cast<const f32x4*>(pr + (i * 16 + frow) * PR_LD + j * 16 + fq * 4);
+  }
+  if (b64 >= n64) return;
   const int N = D.taps * cin, Npad = n64 * 64;
   const int m_base = (bm * MH + ha) * 64, n_base = b64 * 64;
   if (splits == 1 && D.taps == 1) {      // 1x1x1: [cout][cin] rows are contiguous; filters with taps go through the row reducer
@@ -1293,7 +1321,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_tn_kernel(WgTable t) {
   float* slab = t.slab + D.slab_off + (size_t)split * cout * Npad;
   constexpr int IM_LD = 68;
   __syncthreads();                                   // every wave is done with the staging ring
-  float* im = reinterpret_cast<float*>(smem) + wave * (64 * IM_LD);
+  float* im = reinterpret_cast<float*>(smem) + pw * (64 * IM_LD);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1437,6 +1465,7 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
   static const int wide = [] { const char* e = getenv("NERAF_WGRAD_WIDE"); return e ? atoi(e) : 1; }();        // 0: 64x64 tiles only
   static const int wide_nst = [] { const char* e = getenv("NERAF_WGRAD_WIDE_NST"); const int v = e ? atoi(e) : 2; return (v == 3 || v == 4) ? v : 2; }();
   static const int wide_rounds = [] { const char* e = getenv("NERAF_WGRAD_WIDE_ROUNDS"); return e ? atoi(e) : 4; }();
+  static const int wide_waves = [] { const char* e = getenv("NERAF_WGRAD_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();   // 4: round 5's form (A/B): 264 vs 226 us
   const int LDS_BYTES = nst * 128 * 128;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1446,6 +1475,7 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 5 * 8192));
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 5 * 8192));
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 5 * 8192));
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<2, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 5 * 8192));
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_tn_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 5 * 8192));
     NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_grouped_tn_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 128 * 128));
     attr_set = true;
@@ -1510,6 +1540,7 @@ int launch_wgrad_grouped(neraf_ctx* ctx, const WgradItem* items, int n, const ha
       if (wide) hipLaunchKernelGGL((wgrad_wide_tn_kernel<2, true>), dim3(blocks), dim3(256), 2 * 5 * 8192, stream, t);
       else hipLaunchKernelGGL((wgrad_grouped_tn_kernel<3, true>), dim3(blocks), dim3(256), 3 * 128 * 128, stream, t);
     }
+    else if (wide && wide_nst == 2 && wide_waves == 8) hipLaunchKernelGGL((wgrad_wide_tn_kernel<2, false, 8>), dim3(blocks), dim3(512), 2 * 5 * 8192, stream, t);
     else if (wide && wide_nst == 2) hipLaunchKernelGGL((wgrad_wide_tn_kernel<2, false>), dim3(blocks), dim3(256), 2 * 5 * 8192, stream, t);
     else if (wide && wide_nst == 4) hipLaunchKernelGGL((wgrad_wide_tn_kernel<4, false>), dim3(blocks), dim3(256), 4 * 5 * 8192, stream, t);
     else if (wide) hipLaunchKernelGGL((wgrad_wide_tn_kernel<3, false>), dim3(blocks), dim3(256), 3 * 5 * 8192, stream, t);
