@@ -93,12 +93,13 @@ class GradientReducer:
 
     def __init__(self, groups: List[List[torch.nn.Parameter]], group=None, direct_bytes: int = 1 << 20, overlap: bool = True,
                  compress_bytes: Optional[int] = None):
-        """``compress_bytes`` (default off; ``NERAF_DP_COMPRESS_MB`` in the pipeline): gradient tensors of at least that many bytes
-        travel as bfloat16 -- the 49 MB radiance hash-table gradient is the one collective of the step the backward cannot hide
-        (it is produced last), and half the bytes are half the exposed time on the per-link-bound xGMI rings.  bfloat16 keeps
-        fp32's range (the gradients are GradScaler-scaled); the reduced values are rounded to 8 significant bits ONCE per rank on the
-        way in and once on the way out, identically on every rank (an all-reduce returns the same bits everywhere), so replicas stay
-        bit-identical.  Exactness is given up for those tensors only: off by default, unmeasured on hardware (no multi-GPU box)."""
+        """``compress_bytes`` (default off, EXPERIMENTAL; ``NERAF_DP_COMPRESS_MB`` in the pipeline): gradient tensors of at least that many
+        bytes travel as bfloat16 -- the 49 MB radiance hash-table gradient is the one collective of the step the backward cannot hide
+        (it is produced last), and half the bytes are half the exposed time on the per-link-bound xGMI rings.  bfloat16 keeps fp32's
+        range (the gradients are GradScaler-scaled).  Precision: every rank rounds its contribution to 8 significant bits on the way
+        in, and a ring all-reduce on a bfloat16 tensor ACCUMULATES in bfloat16 -- world - 1 further roundings, so the error of the
+        average grows with the world size.  Replicas stay bit-identical (an all-reduce returns the same bits on every
+        rank).  Tested on gloo at world 2 only, unmeasured on RCCL at any world size: not for production runs until it is."""
         self.compress_bytes = compress_bytes
         self.groups = [list(g) for g in groups]
         self.pg = group
