@@ -103,7 +103,7 @@ def main():
                "stft": m["stft"], "stft_batch_stats": m["stft_batch_stats"], "gt_image": m["gt_image"],
                "gt_stft": m["gt_stft"].astype(np.float32)}
         probes = []
-        for name in ("params16", "acts16", "resnet_grad_bf16", "all16", "order"):
+        for name in ("params16", "acts16", "resnet_grad_bf16", "all16", "order", "order2"):      # order / order2: the fp32 oracle on other thread counts
             f = os.path.join(a.parts_dir, f"{a.scenario}.{name}.npz")
             if not os.path.exists(f):
                 continue
