@@ -375,21 +375,22 @@ def test_long_trajectory_metric_parity(golden, tmp_path_factory, scenario):
         assert a - b <= 0.15 * abs(b) + 1e-6 and abs(a - b) <= 0.45 * abs(b) + 1e-6, (k, a, b)
 
 
-def test_default_mode_long_trajectory_median_of_three(golden, tmp_path_factory):
-    """The mode that is benchmarked and shipped (fp32 atomics), gated: THREE default-mode runs of G9 (1000
-    iterations each, ~16 s), the MEDIAN of each metric through the same frozen rule as the deterministic run.  Every run is printed."""
+@pytest.mark.parametrize("scenario", ["g9_long", "g10_long_pose"])
+def test_default_mode_long_trajectory_median_of_three(golden, tmp_path_factory, scenario):
+    """The mode that is benchmarked and shipped (fp32 atomics), gated: THREE default-mode runs of the scenario
+    (1000 iterations each, ~16 s), the MEDIAN of each metric through the same frozen rule as the deterministic run.  Every run is
+    printed.  G10 (camera optimizer on: the configuration bench.py times) was added to this test on 2026-10-04 before its first run."""
     import trajectory_common as TC
-    scenario = "g9_long"
     if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", scenario + ".npz")):
-        pytest.skip("fixture tests/golden/g9_long.npz not generated")
+        pytest.skip(f"fixture tests/golden/{scenario}.npz not generated")
     g = golden(scenario)
     runs = {f"hip{t}": _run_worker(scenario, tmp_path_factory, "0", t) for t in ("a", "b", "c")}
     assert all(int(r["deterministic"]) == 0 for r in runs.values())
     m, family = _long_metric_table(g, runs, scenario)
     med = {k: float(np.median([m[n][k] for n in runs])) for k in TC.GATE_METRICS}
     m["median"] = med
-    gates = TC.gate_table(m, family, hip_name="median")
-    print("g9_long default mode, median of three through the frozen rule:", {k: {kk: round(vv, 5) if isinstance(vv, float) else vv for kk, vv in v.items()} for k, v in gates.items()})
+    gates = TC.gate_table(m, family, hip_name="median", floor_family=_floor_family(scenario))
+    print(f"{scenario} default mode, median of three through the frozen rule:", {k: {kk: round(vv, 5) if isinstance(vv, float) else vv for kk, vv in v.items()} for k, v in gates.items()})
     failed = {k: v for k, v in gates.items() if not v["inside"]}
     assert not failed, failed
 
