@@ -105,7 +105,7 @@ def main():
         if cfg["steps"] > 100 and m["stft"].shape[0] > 8:      # 16 held-out RIRs: the batch-statistics diagnostic is not part of the long fixture
             del out["stft_batch_stats"]
         probes = []
-        for name in ("params16", "acts16", "resnet_grad_bf16", "all16", "order", "order2", "order3", "order4"):      # order*: the fp32 oracle on other thread counts
+        for name in ("params16", "acts16", "resnet_grad_bf16", "all16", "order", "order2"):      # order / order2: the fp32 oracle on other thread counts
             f = os.path.join(a.parts_dir, f"{a.scenario}.{name}.npz")
             if not os.path.exists(f):
                 continue
