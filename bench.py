@@ -707,7 +707,7 @@ def trajectory_parity(dev, scenario="g9_long", floor_family=None):
     train_s = time.perf_counter() - t0
     probes = [str(p_) for p_ in g["probes"]] if "probes" in g else []
     pre = lambda n: "probe_" if n == "params16" else f"probe_{n}_"      # noqa: E731
-    stfts = {"hip": stft["eval"], "oracle": g["stft"], **{n: g[pre(n) + "stft"] for n in probes}}
+    stfts = {"hip": stft["eval"], "oracle": g["stft"], **{n: np.asarray(g[pre(n) + "stft"], np.float32) for n in probes}}
     images = {"hip": img, "oracle": g["image"], **{n: g[pre(n) + "image"] for n in probes}}
     m = TC.metric_table(pipe.audio_model, stfts, evb, gt_image=g["gt_image"], images=images)
     keys = {"psnr_db": "psnr_vs_gt_db", "t60_err_pct": "audio_T60", "edt_err_s": "audio_EDT", "c50_err_db": "audio_C50",

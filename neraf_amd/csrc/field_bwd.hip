@@ -1083,11 +1083,21 @@ __global__ __launch_bounds__(OWN_THREADS) void field_scatter_owner_kernel(FieldO
         if (v != 0) atomicAdd(&own[idx & (NENT - 1u)], (unsigned long long)v);
       };
       if (hashed) {
+        // which of the sample's four (cy, cz) pairs fall into this slice: 1.09 of them on average (a queued sample has at least one).
+        // The lanes pop their pairs round by round, so the two LDS atomics of the first round run with every hit lane active and a
+        // second round only for the lanes that have a second pair -- as four predicated pairs the same updates took EIGHT atomic
+        // instructions at a quarter of the lanes each, and the owner's expansion is priced by atomic instructions issued (round 6).
+        unsigned m4 = 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+          const unsigned t = ((iy + (k & 1)) * HASH_P1) ^ ((iz + (k >> 1)) * HASH_P2);
+          if (((t >> OWN_SLICE_LOG2) & nsl_mask) == slice) m4 |= 1u << k;
+        }
+        while (m4) {
+          const int k = __builtin_ctz(m4);
+          m4 &= m4 - 1u;
           const int kb = k & 1, kc = k >> 1;
           const unsigned t = ((iy + kb) * HASH_P1) ^ ((iz + kc) * HASH_P2);
-          if (((t >> OWN_SLICE_LOG2) & nsl_mask) != slice) continue;
           const float wyv = kb ? wy : 1.f - wy, wzv = kc ? wz : 1.f - wz;
 #pragma unroll
           for (int ka = 0; ka < 2; ++ka)

@@ -323,7 +323,7 @@ def _long_metric_table(g, runs, scenario):
     evb = TC.rir_bank(n_eval, cfg["tag"] + ".eval")
     probes = [str(p) for p in g["probes"]]
     pre = lambda n: "probe_" if n == "params16" else f"probe_{n}_"      # noqa: E731
-    stfts = {**{k: r["stft_eval"] for k, r in runs.items()}, "oracle": g["stft"], **{n: g[pre(n) + "stft"] for n in probes}}
+    stfts = {**{k: r["stft_eval"] for k, r in runs.items()}, "oracle": g["stft"], **{n: np.asarray(g[pre(n) + "stft"], np.float32) for n in probes}}
     images = {**{k: r["image"] for k, r in runs.items()}, "oracle": g["image"], **{n: g[pre(n) + "image"] for n in probes}}
     for k, r in runs.items():
         assert r["stft_eval"].shape[0] == n_eval, (k, r["stft_eval"].shape, n_eval)

@@ -30,7 +30,7 @@ am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 64), TC.
 evb = TC.rir_bank(cfg["n_rir_eval"], cfg["tag"] + ".eval")
 probes = [str(p) for p in g["probes"]]
 pre = lambda k: "probe_" if k == "params16" else f"probe_{k}_"
-stfts = {**{k: v["stft_eval"] for k, v in runs.items()}, "oracle": g["stft"], **{k: g[pre(k) + "stft"] for k in probes}}
+stfts = {**{k: v["stft_eval"] for k, v in runs.items()}, "oracle": g["stft"], **{k: np.asarray(g[pre(k) + "stft"], np.float32) for k in probes}}
 images = {**{k: v["image"] for k, v in runs.items()}, "oracle": g["image"], **{k: g[pre(k) + "image"] for k in probes}}
 m = TC.metric_table(am, stfts, evb, gt_image=g["gt_image"], images=images)
 for name, row in m.items():

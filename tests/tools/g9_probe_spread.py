@@ -22,7 +22,7 @@ am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 64), TC.
 evb = TC.rir_bank(cfg["n_rir_eval"], cfg["tag"] + ".eval")
 probes = [str(p) for p in g["probes"]]
 pre = lambda n: "probe_" if n == "params16" else f"probe_{n}_"
-stfts = {"oracle": g["stft"], **{n: g[pre(n) + "stft"] for n in probes}}
+stfts = {"oracle": g["stft"], **{n: np.asarray(g[pre(n) + "stft"], np.float32) for n in probes}}
 images = {"oracle": g["image"], **{n: g[pre(n) + "image"] for n in probes}}
 m = TC.metric_table(am, stfts, evb, gt_image=g["gt_image"], images=images)
 for name, row in m.items():
