@@ -715,7 +715,9 @@ class NeRAFVisionModel(nn.Module):
         neighbouring RAYS, not neighbouring samples of a ray, into a wavefront (same results, fewer cache lines per instruction).
         ``_out``: preallocated rgb / depth / expected_depth / accumulation rows to write into (the chunked frame render)."""
         lib = _lib.load()
-        cam32 = ray_bundle.camera_indices_i32()
+        # eval renders use the mean appearance embedding: the per-ray camera indices are not read (their int32 conversion was one torch
+        # launch per 32768-ray chunk: 22 x 5 us of a frame)
+        cam32 = ray_bundle.camera_indices_i32() if self.training else None
         if self.training:
             ray_bundle = self.camera_optimizer.apply_to_raybundle(ray_bundle)     # NerfactoModel.get_outputs [NS-recall]
         ray_o, ray_d = ray_bundle.origins, ray_bundle.directions      # carry the camera optimizer's graph when it is on
