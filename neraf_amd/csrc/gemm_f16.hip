@@ -302,17 +302,25 @@ struct PipeTile {
 };
 
 // LOADER: 0 plain GEMM, 1 conv tap-per-K-step (cin % 64 == 0), 2 conv tap-per-chunk (cin == 8).  KS = filter size.
-template <int BM, int BN, int NST, int LOADER, int KS, bool BF, bool TC = false>
-__global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int splits) {
+// NW = 8 (round 6): the same tile, ring and epilogue on twice the waves -- wave pair (w, w + 4) owns one wave tile and splits every K-step's
+// two 32-deep halves (half the fragment reads and MFMAs per wave and K-step), the 512 threads stage half the chunks each, and the pair's
+// accumulators are added through the (idle) ring before the unchanged 4-wave epilogue.  For the K-loops that run one or two waves per
+// SIMD behind a long per-K-step issue chain (the implicit-GEMM convolutions), as for wgrad_wide_tn_kernel (profiles/r06_wgrad_waves_ab.txt).
+template <int BM, int BN, int NST, int LOADER, int KS, bool BF, bool TC = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_f16_nt_pipe_kernel(GemmParams p, int splits) {
   using T = Tile<BM, BN>;
   using E8 = typename ET<BF>::v8;
   constexpr int WM = T::WM, WN = T::WN, FM = T::FM, FN = T::FN;
-  constexpr int LOADS = T::A_CH + T::B_CH;
+  constexpr int KH = NW / 4, NTH = NW * 64;
+  static_assert((NW == 4 || NW == 8) && T::A_CH % KH == 0 && T::B_CH % KH == 0, "4 waves, or 8 with whole chunks per thread");
+  constexpr int A_CH = T::A_CH / KH, B_CH = T::B_CH / KH;      // 16-byte chunks a thread stages per K-step
+  constexpr int LOADS = A_CH + B_CH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave8 & 3, kh = wave8 >> 2;      // wave tile; NW == 8: which half of each K-step this wave multiplies
   const int wm = wave >> 1, wn = wave & 1;
 
   // ---- XCD-aware tile mapping (bijective for any tile count) + split-K slice
@@ -361,18 +369,18 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
   const int nk = k_end > k_begin ? k_end - k_begin : 0;
 
   const half_t* Bg = Bg0 + (size_t)bn * BN * p.ldb;
-  const half_t* b_src[T::B_CH];
+  const half_t* b_src[B_CH];
 #pragma unroll
-  for (int i = 0; i < T::B_CH; ++i) {
-    const int c = i * 256 + tid, row = c >> 3, lc = (c & 7) ^ (row & 7);
+  for (int i = 0; i < B_CH; ++i) {
+    const int c = i * NTH + tid, row = c >> 3, lc = (c & 7) ^ (row & 7);
     b_src[i] = Bg + (size_t)row * p.ldb + lc * 8;
   }
   // A side: plain rows, or output-voxel coordinates for the convolution loaders
-  const half_t* a_src[T::A_CH];
-  int az[T::A_CH], ay[T::A_CH], ax[T::A_CH], alc[T::A_CH];
+  const half_t* a_src[A_CH];
+  int az[A_CH], ay[A_CH], ax[A_CH], alc[A_CH];
 #pragma unroll
-  for (int i = 0; i < T::A_CH; ++i) {
-    const int c = i * 256 + tid, row = c >> 3, lc = (c & 7) ^ (row & 7);
+  for (int i = 0; i < A_CH; ++i) {
+    const int c = i * NTH + tid, row = c >> 3, lc = (c & 7) ^ (row & 7);
     alc[i] = lc;
     az[i] = ay[i] = ax[i] = 0;
     a_src[i] = nullptr;
@@ -393,8 +401,8 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
   // per-axis validity mask (bit a of byte 0 / 1 / 2: tap offset a along z / y / x stays inside the source grid), and the K-step keeps
   // scalar tap counters: a chunk's source is one AND, one compare, one add and two selects.
   const bool fastc = LOADER == 1 && (tclass || p.conv.tstride != 2) && nk_total > 0;
-  int c_off[T::A_CH];
-  unsigned c_msk[T::A_CH];
+  int c_off[A_CH];
+  unsigned c_msk[A_CH];
   int jz = 0, jy = 0, jx = 0, jcb = 0;                    // tap counters / channel block of the NEXT K-step to issue (uniform)
   const int lim_y = tclass ? cy : KS, lim_x = tclass ? cx : KS;
   const int tsgn = (LOADER == 1 && p.conv.tflip) ? -1 : 1;
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
     jcb = k_begin - t * cpb;
     jx = t % lim_x; t /= lim_x; jy = t % lim_y; jz = t / lim_y;
 #pragma unroll
-    for (int i = 0; i < T::A_CH; ++i) {
+    for (int i = 0; i < A_CH; ++i) {
       int bz = az[i], by = ay[i], bx = ax[i];
       if (tclass) { bz = (bz - t0z) >> 1; by = (by - t0y) >> 1; bx = (bx - t0x) >> 1; }   // tap t0 + 2j reaches source voxel b - j
       unsigned m = 0;
@@ -422,13 +430,13 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
   auto issue = [&](int kt, int stage) {
-    char* sa = smem + stage * T::STAGE_BYTES + wave * 1024;   // wave-uniform base; HW adds lane*16
+    char* sa = smem + stage * T::STAGE_BYTES + wave8 * 1024;   // wave-uniform base; HW adds lane*16
     char* sb = sa + BM * 128;
     int kb = kt;                                               // K-step of the B panel (differs from kt for parity-class tiles)
     if (LOADER == 0) {
 #pragma unroll
-      for (int i = 0; i < T::A_CH; ++i)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + (size_t)kt * BK), (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
+      for (int i = 0; i < A_CH; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + (size_t)kt * BK), (lds_ptr_t)(sa + i * (NW * 1024)), 16, 0, 0);
     } else if (LOADER == 1 && fastc) {
       const int cpb = p.conv.cin >> 6, din = p.conv.din;
       const unsigned sel = (1u << jz) | (1u << (8 + jy)) | (1u << (16 + jx));
@@ -436,9 +444,9 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
       const int rz = tclass ? t0z + 2 * jz : jz, ry = tclass ? t0y + 2 * jy : jy, rx = tclass ? t0x + 2 * jx : jx;
       kb = ((rz * KS + ry) * KS + rx) * cpb + jcb;
 #pragma unroll
-      for (int i = 0; i < T::A_CH; ++i) {
+      for (int i = 0; i < A_CH; ++i) {
         const half_t* src = (c_msk[i] & sel) == sel ? p.A + (c_off[i] + toff) : p.conv.zero_page;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sa + i * (NW * 1024)), 16, 0, 0);
       }
       if (++jcb == cpb) { jcb = 0; if (++jx == lim_x) { jx = 0; if (++jy == lim_y) { jy = 0; ++jz; } } }
     } else if (LOADER == 1) {
@@ -455,29 +463,29 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
       const int sdz = p.conv.tflip ? -dz : dz, sdy = p.conv.tflip ? -dy : dy, sdx = p.conv.tflip ? -dx : dx;
       const bool half_grid = p.conv.tstride == 2;
 #pragma unroll
-      for (int i = 0; i < T::A_CH; ++i) {
+      for (int i = 0; i < A_CH; ++i) {
         int iz = az[i] + sdz, iy = ay[i] + sdy, ix = ax[i] + sdx;
         bool ok = true;
         if (half_grid) { ok = ((iz | iy | ix) & 1) == 0; iz >>= 1; iy >>= 1; ix >>= 1; }   // negatives stay negative -> rejected below
         ok = ok && (unsigned)iz < (unsigned)din && (unsigned)iy < (unsigned)din && (unsigned)ix < (unsigned)din;
         const half_t* src = ok ? p.A + ((size_t)(iz * din + iy) * din + ix) * p.conv.cin + cb * 64 + alc[i] * 8 : p.conv.zero_page;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sa + i * (NW * 1024)), 16, 0, 0);
       }
     } else {
       const int din = p.conv.din;
 #pragma unroll
-      for (int i = 0; i < T::A_CH; ++i) {
+      for (int i = 0; i < A_CH; ++i) {
         const int tap = kt * 8 + alc[i];
         const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
         const int iz = az[i] + dz, iy = ay[i] + dy, ix = ax[i] + dx;
         const bool ok = tap < KS * KS * KS && (unsigned)iz < (unsigned)din && (unsigned)iy < (unsigned)din && (unsigned)ix < (unsigned)din;
         const half_t* src = ok ? p.A + ((size_t)(iz * din + iy) * din + ix) * 8 : p.conv.zero_page;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sa + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(sa + i * (NW * 1024)), 16, 0, 0);
       }
     }
 #pragma unroll
-    for (int i = 0; i < T::B_CH; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[i] + (size_t)kb * BK), (lds_ptr_t)(sb + i * 4096), 16, 0, 0);
+    for (int i = 0; i < B_CH; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(b_src[i] + (size_t)kb * BK), (lds_ptr_t)(sb + i * (NW * 1024)), 16, 0, 0);
   };
 
   const int frow = lane & 15, fq = lane >> 4;
@@ -511,7 +519,8 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
     const char* sa = smem + stage * T::STAGE_BYTES;
     const char* sb = sa + BM * 128;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks0 = 0; ks0 < 2 / KH; ++ks0) {
+      const int ks = NW == 8 ? kh : ks0;
       E8 xa[FM], wb[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i)
@@ -529,6 +538,23 @@ __global__ __launch_bounds__(256) void gemm_f16_nt_pipe_kernel(GemmParams p, int
     if (++stage == NST) stage = 0;
   }
   __syncthreads();
+  if constexpr (NW == 8) {
+    // the pair's two partial products: wave kh == 1 parks its accumulators in the idle ring, wave kh == 0 adds them (fixed order)
+    f32x4* pr = reinterpret_cast<f32x4*>(smem) + wave * (FM * FN * 64);
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) pr[(i * FN + j) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] += pr[(i * FN + j) * 64 + lane];
+    __syncthreads();                 // (the four remaining waves) before the epilogue re-uses the ring
+  }
 
   if (splits > 1) {
     // raw fp32 partial slab [split][Mpad][Npad]; finished by splitk_reduce_kernel
@@ -825,12 +851,12 @@ static void gemm_manifest(neraf_ctx* ctx, const GemmParams& p, int loader, int s
   }
 }
 
-template <int BM, int BN, int NST, int LOADER, int KS, bool BF, bool TC = false>
+template <int BM, int BN, int NST, int LOADER, int KS, bool BF, bool TC = false, int NW = 4>
 int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t stream) {
   using PT = PipeTile<BM, BN, NST>;
   static bool attr_set = false;
   if (!attr_set) {
-    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF, TC>),
+    NERAF_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF, TC, NW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, PT::LDS_BYTES));
     attr_set = true;
   }
@@ -845,7 +871,7 @@ int launch_pipe(neraf_ctx* ctx, const GemmParams& p, int splits, hipStream_t str
                       : LOADER == 1 ? (BM * BN == 128 * 128 ? PROF_CONV128 : (BM == 128 ? PROF_CONV12864 : (BF ? PROF_CONV64_BF16 : PROF_CONV)))
                                     : (BM * BN == 128 * 128 ? PROF_GEMM128 : (BM == 128 ? PROF_GEMM12864 : (BF ? PROF_GEMM64_BF16 : PROF_GEMM64)));
   ProfScope prof(ctx, stream, kid, flops, exec_flops);
-  hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF, TC>), dim3(ntiles * splits * ng), dim3(256), PT::LDS_BYTES,
+  hipLaunchKernelGGL((gemm_f16_nt_pipe_kernel<BM, BN, NST, LOADER, KS, BF, TC, NW>), dim3(ntiles * splits * ng), dim3(NW * 64), PT::LDS_BYTES,
                      stream, p, splits);
   NERAF_HIP_CHECK(ctx, hipGetLastError());
   if (ctx && ctx->manifest) gemm_manifest(ctx, p, LOADER, splits, BM, BN, flops);
@@ -1391,6 +1417,9 @@ __global__ __launch_bounds__(256) void wgrad_grouped_reduce_kernel(WgTable t, Wg
 static const int kWide = [] { const char* e = getenv("NERAF_GEMM_WIDE"); return e ? atoi(e) : 1; }();
 static const int kSplitMinK = [] { const char* e = getenv("NERAF_SPLIT_MIN_K"); return e ? atoi(e) : 32; }();
 
+// NERAF_CONV_WAVES=8: the implicit-GEMM convolutions' 64x64 tiles on 8 waves per workgroup (gemm_f16_nt_pipe_kernel NW)
+static bool conv_waves8() { static const bool v = [] { const char* e = getenv("NERAF_CONV_WAVES"); return e && atoi(e) == 8; }(); return v; }
+
 template <int LOADER, int KS, bool BF>
 int dispatch_tile(neraf_ctx* ctx, const GemmParams& p_in, hipStream_t stream) {
   GemmParams p = p_in;
@@ -1403,6 +1432,7 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p_in, hipStream_t stream) {
       p.Mpad == p.conv.dout * p.conv.dout * p.conv.dout && (p.Mpad % 512) == 0 && (p.Npad % 64) == 0 && !p.lmask && !p.C16T && !p.C32 &&
       !p.colsum && !p.colsumsq) {
     p.conv.tclass = 1;
+    if constexpr (LOADER == 1) { if (conv_waves8()) return launch_pipe<64, 64, 4, LOADER, KS, BF, true, 8>(ctx, p, 1, stream); }
     return launch_pipe<64, 64, 4, LOADER, KS, BF, LOADER == 1>(ctx, p, 1, stream);
   }
   const int nk = p.K / BK;
@@ -1452,6 +1482,7 @@ int dispatch_tile(neraf_ctx* ctx, const GemmParams& p_in, hipStream_t stream) {
   }
   if (bm == 128 && bn == 128) return launch_pipe<128, 128, 2, LOADER, KS, BF>(ctx, p, splits, stream);
   if (bm == 128 && bn == 64) return launch_pipe<128, 64, 3, LOADER, KS, BF>(ctx, p, splits, stream);
+  if constexpr (LOADER == 1) { if (conv_waves8()) return launch_pipe<64, 64, 4, LOADER, KS, BF, false, 8>(ctx, p, splits, stream); }
   return launch_pipe<64, 64, 4, LOADER, KS, BF>(ctx, p, splits, stream);
 }
 
