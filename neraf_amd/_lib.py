@@ -253,13 +253,16 @@ _HOST_F32 = {}
 
 def host_f32(t):
     """ctypes float array with the values of a small device tensor (AABBs).  Cached per (storage, version): a ``.cpu()`` per
-    call is a stream synchronisation, which drains the launch queue five times per training step."""
+    call is a stream synchronisation, which drains the launch queue five times per training step.  The entry HOLDS the tensor's
+    storage: a freed AABB's address is reissued by the caching allocator to the next small tensor (another model's AABB, version 0
+    again), and a key of a dead tensor would then answer with the old values (round 6: test order made the RAF model pick up the
+    previous test's box -- outputs 7% off).  At most 65 small storages stay alive."""
     key = (t.data_ptr(), t._version, t.numel())
     hit = _HOST_F32.get(key)
     if hit is None:
         vals = [float(v) for v in t.detach().reshape(-1).cpu().tolist()]
-        hit = (C.c_float * len(vals))(*vals)
+        hit = ((C.c_float * len(vals))(*vals), t.untyped_storage())
         if len(_HOST_F32) > 64:
             _HOST_F32.clear()
         _HOST_F32[key] = hit
-    return hit
+    return hit[0]

@@ -85,3 +85,22 @@ def test_amp_update_scale_matches_torch():
     z = [torch.zeros(1, device=dev)]
     _lib.check(lib.neraf_amp_update_scale(h, big.data_ptr(), trk.data_ptr(), _lib.ptr_array(z), 1, 2.0, 0.5, 3, 0, _st()), 0)
     assert float(big) == pytest.approx(3.0e38) and int(trk) == 0
+
+
+def test_host_f32_cache_survives_address_reuse():
+    """_lib.host_f32 caches the host copy of an AABB per (address, version, numel).  The caching allocator hands a freed small
+    tensor's address to the next one of the same size (version 0 again): the cache entry pins the storage, so a later model's box
+    can never alias a dead one's key (round 6: in suite order the RAF model read the previous test's AABB)."""
+    dev = torch.device("cuda:0")
+    seen = set()
+    for i in range(8):
+        t = torch.full((2, 3), float(i + 1), device=dev)
+        vals = list(_lib.host_f32(t))
+        assert vals == [float(i + 1)] * 6, (i, vals)
+        assert t.data_ptr() not in seen           # pinned: every live-keyed address is still owned by its entry
+        seen.add(t.data_ptr())
+        del t
+    u = torch.zeros(6, device=dev)
+    assert list(_lib.host_f32(u)) == [0.0] * 6
+    u.add_(2.0)                                    # an in-place edit bumps the version: re-read
+    assert list(_lib.host_f32(u)) == [2.0] * 6
