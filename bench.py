@@ -45,8 +45,8 @@ BYTE_FAMILY_BOUND = {2: "l2", 5: "l2", 3: "hbm", 6: "hbm", 7: "hbm"}
 LINE_LIMIT = 6144           # bytes of the one stdout line (the driver reads a bounded tail of stdout)
 # The committed profiles the line cites, by NAME (round 5 took sorted(glob)[-1]: a stale file could silently become the evidence).
 # Updated by hand when tools/gpu_profile.sh / tools/gpu_pmc.sh produce a new set for a new build.
-PROFILE_REFS = {"train_stats": "r06_c_joint_step_kernel_stats.csv", "train_pmc": "r06_c_pmc_traffic.json",
-                "eval_stats": "r06_c_eval_kernel_stats.csv", "eval_pmc": "r06_c_eval_pmc_traffic.json"}
+PROFILE_REFS = {"train_stats": "r06_d_joint_step_kernel_stats.csv", "train_pmc": "r06_d_pmc_traffic.json",
+                "eval_stats": "r06_d_eval_kernel_stats.csv", "eval_pmc": "r06_d_eval_pmc_traffic.json"}
 DTYPE = "f16"      # every 16-bit tensor of the step is fp16 (the ResNet3D backward's gradient chain too since round 5: per-group power-of-two scales)
 PRIME_STEPS = 8             # untimed set-up steps before the --warmup steps (see main)
 CLOCK_STEPS = 120           # further untimed steps (~0.5 s) in the full run only: five consecutive 30-step windows of a fresh process read
