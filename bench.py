@@ -693,7 +693,7 @@ def trajectory_parity(dev, scenario="g9_long", floor_family=None):
     horizon inside which two runs of this chaotic system stay tensor-comparable, so the comparison is metric against metric: held-out
     PSNR and T60 / EDT / C50 errors against GROUND TRUTH, HIP next to the oracle family (the fp32 oracle and its precision / summation-
     order probes) through the frozen rule trajectory_common.GATE_RULE.  tests/test_gpu_trajectory.py asserts the same on the
-    deterministic run and on the median of three default-mode runs; this is ONE default-mode run, reported."""
+    deterministic run and on the median of five default-mode runs; this is ONE default-mode run, reported."""
     import numpy as np
     fx = os.path.join(ROOT, "tests", "golden", scenario + ".npz")
     if not os.path.exists(fx):
