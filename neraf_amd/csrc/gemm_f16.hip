@@ -923,7 +923,7 @@ struct WgDesc {                       // 64 bytes
   unsigned char dl, stride, ksize, loader; signed char pad; unsigned char mh, ai, r2, r3, r4;   // mh: wide kernel, 64-row halves of the M tile (1 | 2); ai: index of the item's factor in alpha_dev
 };
 static_assert(sizeof(WgDesc) == 64, "descriptor table must fit the 4 KiB kernel-argument segment");
-constexpr int kMaxWg = 48;
+constexpr int kMaxWg = 56;      // 43 weight gradients at N_features = 1024, 53 with layer4; 56 x 64 B + header < 4 KiB of kernel arguments
 struct WgTable { int n; int total_blocks; const half_t* zero_page; const float* alpha_dev; float* slab; int order; WgDesc d[kMaxWg]; };
 
 __device__ __forceinline__ int wg_find(const WgTable& t, int bid) {

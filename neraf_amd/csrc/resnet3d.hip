@@ -1,5 +1,5 @@
-// ResNet3D scene encoder (NeRAF_resnet3d.py:116-201; 'resnet50' truncated after layer3, N_features = 1024):
-// voxel grid fp32 [7,S,S,S] -> 1024-vector.  Forward (train-mode batch statistics or eval-mode running
+// ResNet3D scene encoder (NeRAF_resnet3d.py:116-201; 'resnet50' truncated after layer3, N_features = 1024 -- or with layer4, 2048):
+// voxel grid fp32 [7,S,S,S] -> N_features-vector.  Forward (train-mode batch statistics or eval-mode running
 // statistics).  Activations are channels-last fp16 [D*H*W, C]; every Conv3d is the implicit-GEMM form of
 // gemm_f16.hip (1x1x1 convs are plain GEMMs), whose epilogue also accumulates the per-channel sum and sum of
 // squares that BatchNorm3d needs (batch = 1: statistics over the voxels, NeRAF_resnet3d.py:82-87 / SURVEY A4),
@@ -40,12 +40,12 @@ __global__ void set_u64_fwd_kernel(unsigned long long* p, unsigned long long v) 
 
 struct RunTable {
   int n;
-  int begin[49];                     // prefix of channel counts
-  unsigned long long stat_off[48];   // finalised mean / biased variance [2][cpad]
-  int cpad[48];
-  float unbias[48];
-  float* rmean[48]; float* rvar[48];
-  long long* nbt[48];                // num_batches_tracked of each BatchNorm (or null): += 1 in the same launch
+  int begin[kMaxConv + 1];                     // prefix of channel counts
+  unsigned long long stat_off[kMaxConv];   // finalised mean / biased variance [2][cpad]
+  int cpad[kMaxConv];
+  float unbias[kMaxConv];
+  float* rmean[kMaxConv]; float* rvar[kMaxConv];
+  long long* nbt[kMaxConv];                // num_batches_tracked of each BatchNorm (or null): += 1 in the same launch
 };
 
 __global__ __launch_bounds__(256) void bn_update_running_all_kernel(RunTable t, const char* __restrict__ ws, float mom) {
@@ -244,7 +244,7 @@ extern "C" int neraf_resnet3d_pack_weights(neraf_ctx* ctx, const neraf_resnet3d_
 
 static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, const char* packed, const float* const* bn, const float* grid,
                              char* ws, float* feat, int use_batch_stats, int win_cells, hipStream_t st) {
-  neraf_zero3_async(st, ws + L.zero_page, 256, ws + L.stats_begin, L.stats_bytes, feat, 1024 * sizeof(float));
+  neraf_zero3_async(st, ws + L.zero_page, 256, ws + L.stats_begin, L.stats_bytes, feat, (size_t)A.n_features * sizeof(float));
   neraf_node(ctx, "neraf_zero3_kernel | statistics accumulators", 0.0, 0.0, 256.0 + (double)L.stats_bytes + 4096.0);
   const size_t nvox = cube(A.S);
   const bool training = use_batch_stats != 0;    // training forward: keep the max-pool routing for the backward
@@ -301,7 +301,7 @@ static int resnet3d_fwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     x = (const half_t*)(ws + L.out[b]);
   }
   {
-    const int M = (int)cube(A.final_edge), C = 1024;
+    const int M = (int)cube(A.final_edge), C = A.n_features;
     hipLaunchKernelGGL(avgpool_kernel, dim3(C / 64), dim3(256), 0, st, x, M, C, feat);
     NERAF_HIP_CHECK(ctx, hipGetLastError());
     neraf_node(ctx, "avgpool_kernel | mean over the voxels", 0.0, (double)M * C * 2.0, C * 4.0);
@@ -315,7 +315,7 @@ extern "C" int neraf_resnet3d_fwd(neraf_ctx* ctx, const neraf_resnet3d_desc* d, 
   Arch A; Layout L;
   if (make_arch(d, &A) || !packed_ || !bn || !grid || !workspace || !feat || win_cells < 0 ||
       (win_cells > 0 && win_start + (size_t)win_cells > cube(d->grid_size)))
-    return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_fwd: bad arguments (grid_size 64|128, in_channels 7, n_features 1024, window inside the grid)");
+    return neraf_fail(ctx, NERAF_EINVAL, "resnet3d_fwd: bad arguments (grid_size 64|128|256, in_channels 7, n_features 1024|2048, window inside the grid)");
   make_layout(A, &L);
   if (win_cells > 0)      // the window moves every step: its first cell travels through device memory, outside the captured sequence
     hipLaunchKernelGGL(set_u64_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,

@@ -46,10 +46,10 @@ namespace {
 // contiguous runs of 32*taps floats, the fp16 destination written in 64-byte runs along co.
 struct PackTTable {
   int n;
-  const float* src[48];
-  int tile_begin[49];                // prefix of (cout/32)*(nrows/32) bricks
-  unsigned long long dst_off[48];
-  int cout[48], cin[48], taps[48], kcols[48], nrows[48];
+  const float* src[kMaxConv];
+  int tile_begin[kMaxConv + 1];                // prefix of (cout/32)*(nrows/32) bricks
+  unsigned long long dst_off[kMaxConv];
+  int cout[kMaxConv], cin[kMaxConv], taps[kMaxConv], kcols[kMaxConv], nrows[kMaxConv];
 };
 
 __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(PackTTable t, char* __restrict__ packed) {
@@ -325,13 +325,13 @@ __global__ __launch_bounds__(256) void bwd_prologue_kernel(const float* __restri
     magic = cs->magic; passes_in = cs->passes;
     if ((int)threadIdx.x < n_groups) e_in = cs->e[threadIdx.x];
   }
-  float df[4];
+  float df[8];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) df[k] = (int)(threadIdx.x + k * 256) < C ? fabsf(dfeat[threadIdx.x + k * 256]) : 0.f;     // C <= 1024
+  for (int k = 0; k < 8; ++k) df[k] = (int)(threadIdx.x + k * 256) < C ? fabsf(dfeat[threadIdx.x + k * 256]) : 0.f;     // C <= 2048
   float m = 0.f;
   int nan_seen = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { m = (df[k] == df[k] && df[k] > m) ? df[k] : m; nan_seen |= df[k] != df[k]; }
+  for (int k = 0; k < 8; ++k) { m = (df[k] == df[k] && df[k] > m) ? df[k] : m; nan_seen |= df[k] != df[k]; }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -779,7 +779,7 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
   {
     // d feat is spread over M voxels by the average pool; S0 places the per-voxel gradient's amax at 2^kChainTarget
     const int Mpad = (int)rows_pad(A.final_edge);
-    const size_t n = (size_t)Mpad * 1024;
+    const size_t n = (size_t)Mpad * A.n_features;
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     // the parents of every group, as the loop below assigns them (the prologue runs first: built here from the same rule)
@@ -788,7 +788,7 @@ static int resnet3d_bwd_body(neraf_ctx* ctx, const Arch& A, const Layout& L, con
     for (int b = A.nblock - 1; b >= 0; --b) { pp.p[k] = (unsigned char)kg; pp.p[k + 1] = (unsigned char)k; pp.p[k + 2] = (unsigned char)(k + 1); kg = k + 2; k += 3; }
     pp.p[k] = (unsigned char)kg;                // stem dY
     hipLaunchKernelGGL(bwd_prologue_kernel, dim3(blocks), dim3(256), 0, st, dfeat, scale, kChainTarget + (int)ceilf(log2f((float)Mlast)), Mlast, Mpad,
-                       1024, g, reinterpret_cast<ChainState*>(bws + B.chain), reinterpret_cast<unsigned*>(bws + B.amax), total_k, pp);
+                       A.n_features, g, reinterpret_cast<ChainState*>(bws + B.chain), reinterpret_cast<unsigned*>(bws + B.amax), total_k, pp);
     neraf_node(ctx, "bwd_prologue_kernel | S0, scale groups, average-pool backward", 0.0, 4096.0 + (double)total_k * kAmaxRep * 4.0, (double)n * 2.0);
   }
   half_t* gm = (half_t*)(bws + B.gm); half_t* da = (half_t*)(bws + B.da);
@@ -1004,7 +1004,7 @@ extern "C" int neraf_debug_conv_bn_relu_stage(neraf_ctx* ctx, int cin, int cin_r
                                               void* y_f16, float* dx, float* dw, float* dgamma, float* dbeta, neraf_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   Arch A{};
-  A.S = din; A.nconv = 1; A.nblock = 0; A.pooled = din; A.final_edge = din;
+  A.S = din; A.nconv = 1; A.nblock = 0; A.pooled = din; A.final_edge = din; A.n_features = 1024;
   const int dout = (din + 2 * pad - k) / stride + 1;
   A.conv[0] = ConvSpec{cin, cout, k, stride, pad, din, dout, cin_real};
   Layout L{}; BwdLayout B{};

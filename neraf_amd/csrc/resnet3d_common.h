@@ -4,6 +4,7 @@
 
 namespace {
 
+constexpr int kMaxConv = 56;      // 43 conv / BatchNorm pairs at N_features = 1024, 53 with layer4 (tables in kernel arguments)
 struct ConvSpec { int cin, cout, k, stride, pad, din, dout; int cin_real; };   // cin_real < cin only for the stem (7 of 8)
 struct BlockSpec { int conv[3]; int ds; int planes; };   // indices into the conv list (state-dict order); ds = -1 if none
 
@@ -14,18 +15,24 @@ struct Arch {
   int nblock;
   BlockSpec block[16];
   int pooled;                  // edge after the stem max-pool
-  int final_edge;              // edge of layer3's output
+  int final_edge;              // edge of the last layer's output (layer3; layer4 when N_features = 2048)
+  int n_features;              // 1024 (layers 1-3) | 2048 (+ layer4), NeRAF_resnet3d.py:128-131
 };
 
 int make_arch(const neraf_resnet3d_desc* d, Arch* A) {
-  if (!d || d->in_channels != 7 || d->n_features != 1024 || (d->grid_size != 128 && d->grid_size != 64)) return NERAF_EINVAL;
+  // N_features 1024 | 2048 (NeRAF_resnet3d.py:128), grid 64^3 | 128^3 | 256^3 (grid_step 1/64 | 1/128 | 1/256, :138-156: the average pool
+  // spans the last layer's whole output in every combination)
+  if (!d || d->in_channels != 7 || (d->n_features != 1024 && d->n_features != 2048) ||
+      (d->grid_size != 128 && d->grid_size != 64 && d->grid_size != 256)) return NERAF_EINVAL;
   A->S = d->grid_size;
+  A->n_features = d->n_features;
   int n = 0;
   A->conv[n++] = ConvSpec{8, 64, 5, 2, 2, A->S, A->S / 2, 7};             // stem: 7 (padded to 8) -> 64, NeRAF_resnet3d.py:120
   A->pooled = A->S / 4;                                                  // MaxPool3d(3, 2, 1), :123
   int edge = A->pooled, in_planes = 64, nb = 0;
-  const int planes_l[3] = {64, 128, 256}, blocks_l[3] = {3, 4, 6}, stride_l[3] = {1, 2, 2};   // :124-126, resnet50 :237
-  for (int li = 0; li < 3; ++li) {
+  const int planes_l[4] = {64, 128, 256, 512}, blocks_l[4] = {3, 4, 6, 3}, stride_l[4] = {1, 2, 2, 2};   // :124-126, :131, resnet50 :237
+  const int n_layers = d->n_features == 2048 ? 4 : 3;
+  for (int li = 0; li < n_layers; ++li) {
     for (int b = 0; b < blocks_l[li]; ++b) {
       const int s = b == 0 ? stride_l[li] : 1, p = planes_l[li];
       BlockSpec B{};
@@ -244,13 +251,13 @@ inline BnSrc bn_src_bwd(const Arch& A, const Layout& L, const char* ws, const fl
 }
 
 
-// one launch for all 43 convolutions: table of per-conv descriptors in the kernel arguments
+// one launch for all convolutions (43 | 53): table of per-conv descriptors in the kernel arguments
 struct PackTable {
   int n;
-  const float* src[48];
-  unsigned long long begin[49];      // prefix of packed element counts
-  unsigned long long dst_off[48];    // byte offset of the conv's packed matrix
-  int cout[48], cin_real[48], cin[48], taps[48], kpad[48];
+  const float* src[kMaxConv];
+  unsigned long long begin[kMaxConv + 1];      // prefix of packed element counts
+  unsigned long long dst_off[kMaxConv];    // byte offset of the conv's packed matrix
+  int cout[kMaxConv], cin_real[kMaxConv], cin[kMaxConv], taps[kMaxConv], kpad[kMaxConv];
 };
 
 __global__ __launch_bounds__(256) void pack_all_conv_weights_kernel(PackTable t, char* __restrict__ packed) {
@@ -276,10 +283,10 @@ __global__ __launch_bounds__(256) void pack_all_conv_weights_kernel(PackTable t,
 // (the first version used [32 co][32 ci] bricks for both: 64-byte destination runs, 2 TB/s).  COB / CIB come from brick_shape().
 struct BrickTable {
   int n;
-  const float* src[48];
-  int tile_begin[49];                // prefix of (cout/COB)*(cin/CIB) bricks
-  unsigned long long dst_off[48];
-  int cout[48], cin[48], taps[48], cib[48], cob[48];
+  const float* src[kMaxConv];
+  int tile_begin[kMaxConv + 1];                // prefix of (cout/COB)*(cin/CIB) bricks
+  unsigned long long dst_off[kMaxConv];
+  int cout[kMaxConv], cin[kMaxConv], taps[kMaxConv], cib[kMaxConv], cob[kMaxConv];
 };
 
 template <int MODE>

@@ -151,23 +151,31 @@ class _Bottleneck(nn.Module):
 
 
 class ResNet3D(nn.Module):
-    """'resnet50' layout truncated after layer3 (N_features = 1024), NeRAF_resnet3d.py:116-165."""
+    """'resnet50' layout truncated after layer3 (N_features = 1024) or with layer4 (N_features = 2048), on a 64^3, 128^3 or 256^3
+    grid (grid_step 1/64 | 1/128 | 1/256) -- every combination the reference's constructor accepts (NeRAF_resnet3d.py:116-165: the
+    average pool spans the last layer's whole output in each of them)."""
 
     def __init__(self, in_channels: int = 7, layers=(3, 4, 6), grid_step: float = 1 / 128, N_features: int = 1024):
         super().__init__()
-        if N_features != 1024 or in_channels != 7 or tuple(layers) != (3, 4, 6):
-            raise NotImplementedError("the HIP scene encoder implements the configuration NeRAF uses: "
-                                      "in_channels=7, resnet50[3,4,6], N_features=1024 (NeRAF_model.py:185)")
+        if N_features not in (1024, 2048):
+            raise ValueError("N_features should be 1024 or 2048")                      # NeRAF_resnet3d.py:128
+        layers = tuple(layers)
+        if N_features == 2048 and layers == (3, 4, 6):
+            layers = (3, 4, 6, 3)                                                      # resnet50's layer4, :131 / :237
+        if in_channels != 7 or layers != ((3, 4, 6) if N_features == 1024 else (3, 4, 6, 3)):
+            raise NotImplementedError("the HIP scene encoder implements the configurations NeRAF uses: "
+                                      "in_channels=7, resnet50 [3,4,6(,3)], N_features 1024 | 2048 (NeRAF_model.py:185)")
         if grid_step >= 1 / 64 - 1 / 512:
             self.grid_size = 64
         elif grid_step >= 1 / 128 - 1 / 512:
             self.grid_size = 128
         else:
-            raise NotImplementedError("grid_step 1/256 is not supported by the HIP scene encoder yet")
+            self.grid_size = 256                                                       # :150-156
+        self.n_layers = len(layers)
         self.conv1 = nn.Conv3d(in_channels, 64, kernel_size=5, stride=2, padding=2, bias=False)
         self.bn1 = nn.BatchNorm3d(64)
         in_planes = 64
-        for li, (planes, nblocks, stride) in enumerate(zip((64, 128, 256), layers, (1, 2, 2)), start=1):
+        for li, (planes, nblocks, stride) in enumerate(zip((64, 128, 256, 512), layers, (1, 2, 2, 2)), start=1):
             blocks = []
             for b in range(nblocks):
                 s = stride if b == 0 else 1
@@ -199,12 +207,12 @@ class ResNet3D(nn.Module):
         hipGraph).  A consumer of the feature that is handed this buffer (``feature._neraf_grad_buffer``, set by ``forward``) may write
         its gradient w.r.t. the feature directly into it and return it as that gradient: the backward then skips its 4 KB copy."""
         if self._dfeat_buf is None or self._dfeat_buf.device != torch.device(device):
-            self._dfeat_buf = torch.empty(1024, dtype=torch.float32, device=device)
+            self._dfeat_buf = torch.empty(self.N_features, dtype=torch.float32, device=device)
         return self._dfeat_buf
 
     def conv_bn_pairs(self):
         pairs = [(self.conv1, self.bn1)]
-        for li in (1, 2, 3):
+        for li in range(1, self.n_layers + 1):
             for blk in getattr(self, f"layer{li}"):
                 pairs += blk.conv_bn_pairs()
         return pairs
@@ -232,7 +240,7 @@ class ResNet3D(nn.Module):
         return c
 
     def forward(self, x: torch.Tensor, window=None, window_vals: torch.Tensor = None, grid_state=None) -> torch.Tensor:
-        """x fp32 [1,7,S,S,S] -> [1,1024,1,1,1] (NeRAF_resnet3d.py:184-198).  ``window`` = (cell_start, n_cells, n_ch) and
+        """x fp32 [1,7,S,S,S] -> [1,N_features,1,1,1] (NeRAF_resnet3d.py:184-198).  ``window`` = (cell_start, n_cells, n_ch) and
         ``window_vals`` [n_ch, n_cells] (requires_grad) describe the grid cells refreshed this step, whose gradient is
         returned to ``window_vals`` by the backward.
 
@@ -283,7 +291,7 @@ class ResNet3D(nn.Module):
                 self._ws_eval = torch.empty(self._ws.numel(), dtype=torch.uint8, device=x.device)
             ws = self._ws_eval
         if self._feat_buf is None or self._feat_buf[0].device != x.device:
-            self._feat_buf = [torch.empty(1024, dtype=torch.float32, device=x.device) for _ in range(3)]
+            self._feat_buf = [torch.empty(self.N_features, dtype=torch.float32, device=x.device) for _ in range(3)]
             self._feat_turn = 0
         # two output buffers alternate between TRAINING forwards (two captured forward graphs): the feature handed out is not copied,
         # and stays intact while the next forward writes the other buffer -- contract: at most one training feature is awaiting its
@@ -320,10 +328,10 @@ class ResNet3D(nn.Module):
             if self._anchor is None or self._anchor.device != x.device:
                 self._anchor = torch.zeros(1, dtype=torch.float32, device=x.device, requires_grad=True)
             feat = _ResNet3DFn.apply(self, feat, window, self.grid_grad_sink, window_vals, self._anchor)    # the buffer itself, see there
-            out = feat.reshape(1, 1024, 1, 1, 1)
+            out = feat.reshape(1, self.N_features, 1, 1, 1)
             out._neraf_grad_buffer = self.dfeat_buffer(x.device)
             return out
-        return feat.clone().reshape(1, 1024, 1, 1, 1)      # inference: callers cache this (never the persistent buffer)
+        return feat.clone().reshape(1, self.N_features, 1, 1, 1)      # inference: callers cache this (never the persistent buffer)
 
 
 class ResNet3D_helper(nn.Module):
@@ -334,7 +342,7 @@ class ResNet3D_helper(nn.Module):
         super().__init__()
         if backbone != "resnet50" or pretrained:
             raise NotImplementedError("only backbone='resnet50', pretrained=False (what NeRAF instantiates, NeRAF_model.py:185)")
-        self.backbone_net = ResNet3D(in_channels, (3, 4, 6), grid_step if grid_step is not None else 1 / 128, N_features)
+        self.backbone_net = ResNet3D(in_channels, (3, 4, 6), grid_step if grid_step is not None else 1 / 128, N_features if N_features is not None else 1024)
 
     def forward(self, x, window=None, window_vals=None, grid_state=None):
         return self.backbone_net(x, window, window_vals, grid_state)

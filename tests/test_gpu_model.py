@@ -140,6 +140,66 @@ def test_get_outputs_loss_and_eval_branch(models):
     am.train()
 
 
+def test_audio_model_with_layer4_features():
+    """NeRAFAudioModelConfig(N_features=2048) (NeRAF_model.py:92, :181-189): the encoder keeps resnet50's layer4, the NAcF's first
+    layer takes 2048 + 163 inputs.  State-dict keys as the reference's; eval-mode outputs (running statistics: no small-batch
+    amplification) against oracle ResNet3D -> oracle NAcF; train-mode outputs against the oracle NAcF on the feature the HIP encoder
+    produced; loss + backward reach every parameter, layer4's and the 2211-column first layer's included."""
+    from oracle import audio as O
+    from neraf_amd.model import NeRAFAudioModel, NeRAFAudioModelConfig
+    dev = torch.device("cuda:0")
+    am = NeRAFAudioModel(NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 64, N_features=2048), T(synth.audio_aabb()))
+    assert am.field.in_size == 2048 + 163 and am.resnet3d.backbone_net.N_features == 2048
+    sdn = {k: T(v) for k, v in synth.nacf_state_dict(2211, 512, 1, 513).items()}
+    sdr = {k: T(v) for k, v in synth.resnet3d_state_dict(7, layers=(3, 4, 6, 3)).items()}
+    am.field.load_state_dict(sdn)
+    am.resnet3d.backbone_net.load_state_dict(sdr, strict=True)
+    keys = set(am.state_dict().keys())
+    for k in ("resnet3d.backbone_net.layer4.0.downsample.1.running_var", "resnet3d.backbone_net.layer4.2.conv3.weight"):
+        assert k in keys, k
+    assert tuple(am.state_dict()["field.soundfield.0.weight"].shape) == (5096, 2211)
+    am = am.to(dev)
+    with torch.no_grad():
+        am.grid.copy_(T(synth.uniform("t.model.grid2048", (7, 64, 64, 64), 0.0, 1.0)))
+    am.mark_grid_written()
+    B = 192
+    b = {k: T(v) for k, v in synth.audio_batch(B, 1, 513, 60, tag="t.model2048").items()}
+    bd = {k: v.to(dev) for k, v in b.items()}
+    # eval mode: the whole chain against the oracle
+    am.eval()
+    with torch.no_grad():
+        ye = am.get_outputs(bd)
+        feat_o = O.resnet3d_forward(am.grid.cpu().unsqueeze(0), sdr, train=False, layers=(3, 4, 6, 3)).flatten()
+        yo = O.audio_get_outputs(b, feat_o, sdn, T(synth.audio_aabb()), 60)
+    assert ye.shape == (B, 1, 513)
+    rel = float((ye.cpu() - yo).norm() / yo.norm())
+    print(f"N_features = 2048, eval chain vs oracle: rel-L2 {rel:.2e}")
+    assert rel <= 5e-3, rel
+    # train mode: NAcF on the HIP encoder's own feature; loss; backward
+    am.train()
+    cap = {}
+    orig = am.scene_feature
+    am.scene_feature = lambda: cap.setdefault("f", orig())
+    y = am.get_outputs(bd)
+    am.scene_feature = orig
+    with torch.no_grad():
+        yo2 = O.audio_get_outputs(b, cap["f"].detach().flatten().cpu(), sdn, T(synth.audio_aabb()), 60)
+    rel2 = float((y.detach().cpu() - yo2).norm() / yo2.norm())
+    assert rel2 <= 5e-3, rel2
+    ld = am.get_loss_dict(y, bd)
+    lo = O.audio_loss_dict(yo2, b["data"])
+    np.testing.assert_allclose(ld["audio_sc_loss"].item(), lo["audio_sc_loss"].item(), rtol=1e-2)
+    (ld["audio_sc_loss"] + ld["audio_mag_loss"]).backward()
+    torch.cuda.synchronize()
+    n = 0
+    for name, p_ in am.named_parameters():
+        assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), name
+        n += 1
+    assert n == 159 + 12                      # 53 conv + 53 x 2 BatchNorm affine + 6 Linear x 2
+    assert float(am.resnet3d.backbone_net.layer4[2].conv3.weight.grad.abs().max()) > 0
+    assert float(am.field.soundfield[0].weight.grad[:, :2048].abs().max()) > 0
+
+
 def test_refresh_gradient_edge_vs_oracle(models):
     """The autograd edge from the refreshed grid cells into the radiance field (NeRAF_model.py:395-400): for a random
     upstream d loss / d grid[0:4, window], gradients of the field parameters against autograd through the oracle's refresh

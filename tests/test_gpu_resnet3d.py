@@ -21,10 +21,14 @@ def T(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-def _model(dev, grid_step):
+def _layers(N):
+    return (3, 4, 6, 3) if N == 2048 else (3, 4, 6)
+
+
+def _model(dev, grid_step, N=1024):
     from neraf_amd.resnet3d import ResNet3D_helper
-    net = ResNet3D_helper(in_channels=7, backbone="resnet50", pretrained=False, grid_step=grid_step, N_features=1024)
-    sd = {k: T(v) for k, v in synth.resnet3d_state_dict(7).items()}
+    net = ResNet3D_helper(in_channels=7, backbone="resnet50", pretrained=False, grid_step=grid_step, N_features=N)
+    sd = {k: T(v) for k, v in synth.resnet3d_state_dict(7, layers=_layers(N)).items()}
     net.backbone_net.load_state_dict(sd, strict=True)      # identical keys to the reference module
     for m in net.modules():
         if isinstance(m, torch.nn.BatchNorm3d):
@@ -51,6 +55,95 @@ def test_resnet3d_forward_vs_reference_golden(golden, S, tag):
     with torch.no_grad():
         ye = net(x)
     assert rel_l2(ye, T(g["out_eval"])) <= 1e-2
+
+
+@pytest.mark.parametrize("S,N", [(64, 2048), (128, 2048), (256, 1024)])
+def test_resnet3d_variants_forward_vs_reference_golden(golden, S, N):
+    """The other configurations the reference's constructor accepts (NeRAF_resnet3d.py:128-156): N_features = 2048 (resnet50's
+    layer4: 3 more bottlenecks, 512 -> 2048 channels at S/32, average pool over that edge) on the 64^3 and 128^3 grids, and
+    grid_step = 1/256 (7 x 256^3 voxels: 8 x the encoder's work, 0.76 TFLOP forward).  Fixtures g1_resnet3d_<S>_<N>.npz are the
+    reference module's own outputs (tests/tools/gen_golden.py g1v); same tolerance as G1: feature within 1e-2 relative L2 in train
+    and eval mode, every stage statistic within 1e-2."""
+    dev = torch.device("cuda:0")
+    g = golden(f"g1_resnet3d_{S}_{N}")
+    net = _model(dev, 1 / S, N)
+    bb = net.backbone_net
+    x = T(synth.uniform(f"g1.grid{S}", (1, 7, S, S, S), 0.0, 1.0)).to(dev)
+    net.train()
+    with torch.no_grad():
+        y = net(x)
+    assert y.shape == (1, N, 1, 1, 1)
+    r = rel_l2(y, T(g["out_train"]))
+    # stage statistics from the workspace: block outputs (post-activation, channels-last fp16)
+    nb = np.cumsum(_layers(N))
+    for li, b_last in enumerate(nb, start=1):
+        t = _ws_tensor(bb, 2, int(b_last) - 1, torch.float16).double()
+        st = np.array([t.mean().item(), t.abs().mean().item(), t.pow(2).mean().sqrt().item()])
+        np.testing.assert_allclose(st, g[f"stage_layer{li}"], rtol=1e-2, err_msg=f"layer{li}")
+    last = _ws_tensor(bb, 2, int(nb[-1]) - 1, torch.float16)
+    e = round(last.shape[0] ** (1 / 3))
+    slab = last.reshape(e, e, e, -1)[1, 1, :, :16].T.float().cpu().numpy()          # [16 channels][x] at z = 1, y = 1
+    rs = float(np.linalg.norm(slab - g["last_slab"]) / np.linalg.norm(g["last_slab"]))
+    net.eval()
+    with torch.no_grad():
+        ye = net(x)
+    re_ = rel_l2(ye, T(g["out_eval"]))
+    print(f"ResNet3D S={S} N_features={N}: feature rel-L2 vs the reference train {r:.2e} eval {re_:.2e}; last-layer slab (element level) {rs:.2e}")
+    # eval mode (running statistics) is where the kernels are compared without amplification: 3e-4 in every configuration.  In train
+    # mode layer4's BatchNorms normalise over 64 voxels (128^3 grid) or EIGHT (64^3): what fp16 storage alone does to the feature
+    # there is the yardstick -- the oracle with the engine's rounding points emulated against the all-fp32 oracle, same gates,
+    # measured in test_resnet3d_backward_gate_matched: 2.7e-3 (N = 1024, 128^3), 2.1e-2 (2048, 128^3), 6.7e-2 (2048, 64^3).  HIP against
+    # the fp32 reference: 6e-4 / 1.3e-2 / 5.0e-2 -- inside that yardstick each time; tolerances 1e-2 / 3e-2 / 1e-1.
+    tol = {(256, 1024): 1e-2, (128, 2048): 3e-2, (64, 2048): 1e-1}[(S, N)]
+    assert r <= tol and re_ <= 2e-3
+    assert rs <= (0.3 if N == 2048 else 0.1)        # element level at the last layer (not a mean over voxels): layout bugs read ~1.4
+
+
+@pytest.mark.parametrize("S,N", [(128, 2048), (256, 1024)])
+def test_resnet3d_variants_backward_norms_vs_reference_golden(golden, S, N):
+    """Backward of the variants against the REFERENCE's fp32 gradients, in the form that survives the gate flips of a chaotic
+    BatchNorm network (see test_resnet3d_backward_norms_vs_reference_fp32_golden): every parameter gradient finite, gradient norms
+    within 10 % (d gamma of the stem: 20 %), the grid gradient's rms within 10 % (single entries of an ungated comparison are chaos: the
+    sampled grid-gradient entries of the 256^3 run correlate -0.3 ... 0.0 with the fp32 reference's while the gate-matched test
+    below agrees on all 16.7 M cells to 2e-2).  Element-wise parity: test_resnet3d_backward_gate_matched[128-2048] / [256-1024]."""
+    dev = torch.device("cuda:0")
+    g = golden(f"g1_resnet3d_{S}_{N}")
+    net = _model(dev, 1 / S, N)
+    net.train()
+    bb = net.backbone_net
+    x = T(synth.uniform(f"g1.grid{S}", (1, 7, S, S, S), 0.0, 1.0)).to(dev)
+    wsum = T(synth.uniform("g1.outw" if N == 1024 else f"g1.outw{N}", (N,), -1.0, 1.0)).to(dev)
+    got = {}
+    n_win = min(S ** 3, 1 << 21)                     # the grid gradient of the first 2 M cells (the whole grid at 128^3)
+    bb.grid_window = (0, n_win, 7)
+    bb.grid_grad_sink = lambda d: got.__setitem__("dx", d.clone())
+    y = net(x)
+    assert rel_l2(y, T(g["out_train"])) <= (3e-2 if N == 2048 else 1e-2)
+    (y.flatten() * wsum).sum().backward()
+    bb.grid_window, bb.grid_grad_sink = None, None
+    n_params = 0
+    for p_ in bb.parameters():
+        assert p_.grad is not None and bool(torch.isfinite(p_.grad).all())
+        n_params += 1
+    assert n_params == (129 if N == 1024 else 159)
+
+    def norm_ratio(a, b):
+        return float(a.double().cpu().norm() / T(b).double().norm())
+    lastl = getattr(bb, f"layer{bb.n_layers}")
+    ratios = {"dw conv1": norm_ratio(bb.conv1.weight.grad, g["dw_conv1"]),
+              "dgamma bn1": norm_ratio(bb.bn1.weight.grad, g["dgamma_bn1"]),
+              "dgamma last.0.downsample": norm_ratio(lastl[0].downsample[1].weight.grad, g["dgamma_last_0_ds"])}
+    rms = lambda t: t.double().pow(2).mean().sqrt().item()
+    ratios["dw layer1.0.conv2 rms"] = rms(bb.layer1[0].conv2.weight.grad) / g["dw_l1_0_conv2_stats"][2]
+    ratios["dw last.-1.conv3 rms"] = rms(lastl[-1].conv3.weight.grad) / g["dw_last_conv3_stats"][2]
+    ratios["dw last.0.conv2 rms"] = rms(lastl[0].conv2.weight.grad) / g["dw_last_0_conv2_stats"][2]
+    dx = got["dx"].reshape(7, -1).cpu()
+    if n_win == S ** 3:
+        ratios["d grid rms"] = rms(dx) / g["dx_stats"][2]
+    print(f"ResNet3D S={S} N_features={N} backward / reference fp32:", {k: round(v, 3) for k, v in ratios.items()})
+    for k, v in ratios.items():
+        lo, hi = (0.8, 1.2) if k == "dgamma bn1" else (0.9, 1.1)
+        assert lo <= v <= hi, (k, v)
 
 
 def test_resnet3d_running_stats_update():
@@ -146,7 +239,7 @@ def _hip_gates(bb):
     """ReLU gates and max-pool routing the HIP forward used, in oracle.audio.resnet3d_forward_gated's format."""
     gates = {"pool_arg": _ws_tensor(bb, 4, 0, torch.uint8).cpu()}
     b = 0
-    for li, nblocks in zip((1, 2, 3), (3, 4, 6)):
+    for li, nblocks in zip((1, 2, 3, 4), _layers(bb.N_features)):
         for k in range(nblocks):
             for kind, name in ((0, "a1"), (1, "a2"), (2, "out")):
                 t = _ws_tensor(bb, kind, b, torch.float16)
@@ -156,8 +249,8 @@ def _hip_gates(bb):
     return gates
 
 
-@pytest.mark.parametrize("S", [64, 128])
-def test_resnet3d_backward_gate_matched(S):
+@pytest.mark.parametrize("S,N", [(64, 1024), (128, 1024), (64, 2048), (128, 2048), (256, 1024)])
+def test_resnet3d_backward_gate_matched(S, N):
     """A4 backward, tight: EVERY one of the 129 parameter gradients and the full grid gradient of the HIP encoder against autograd
     through the pinned oracle with the network's discrete decisions (ReLU gates, max-pool routing) fixed to the ones the HIP
     forward took -- oracle.audio.resnet3d_forward_gated, which with its own gates is bit-identical to the G1-pinned
@@ -172,11 +265,12 @@ def test_resnet3d_backward_gate_matched(S):
     rounding error is pinned by test_resnet3d_backward_chain_scales_and_linearity (superposition, <= 7e-3)."""
     from oracle import audio as O
     dev = torch.device("cuda:0")
-    net = _model(dev, 1 / S)
+    net = _model(dev, 1 / S, N)
     net.train()
     bb = net.backbone_net
+    layers = _layers(N)
     x = T(synth.uniform(f"g1.grid{S}", (1, 7, S, S, S), 0.0, 1.0))
-    wsum = T(synth.uniform("g1.outw", (1024,), -1.0, 1.0))
+    wsum = T(synth.uniform("g1.outw" if N == 1024 else f"g1.outw{N}", (N,), -1.0, 1.0))
     got = {}
     bb.grid_window = (0, S ** 3, 7)
     bb.grid_grad_sink = lambda d: got.__setitem__("dx", d.clone())
@@ -185,13 +279,13 @@ def test_resnet3d_backward_gate_matched(S):
     bb.grid_window, bb.grid_grad_sink = None, None
     torch.cuda.synchronize()
     gates = _hip_gates(bb)
-    sd = {k: T(v) for k, v in synth.resnet3d_state_dict(7).items()}
+    sd = {k: T(v) for k, v in synth.resnet3d_state_dict(7, layers=layers).items()}
     params = dict(bb.named_parameters())
 
     def oracle_grads(fp16_storage):
         sdg = {k: (v.clone().requires_grad_(True) if k.endswith("weight") or k.endswith("bias") else v) for k, v in sd.items()}
         xg = x.clone().requires_grad_(True)
-        yo = O.resnet3d_forward_gated(xg, sdg, gates, fp16_storage=fp16_storage)
+        yo = O.resnet3d_forward_gated(xg, sdg, gates, layers=layers, fp16_storage=fp16_storage)
         (yo.flatten() * wsum).sum().backward()
         return yo.detach(), xg.grad[0], {k: v.grad for k, v in sdg.items() if v.requires_grad}
 
@@ -211,24 +305,39 @@ def test_resnet3d_backward_gate_matched(S):
 
     # (1) the parity target: the engine's rounding points emulated in the oracle's FORWARD, exact fp32 autograd backward
     yo, dxo, go = oracle_grads(True)
-    assert len(go) == 129
-    assert rel_l2(y, yo) <= 2e-3
+    assert len(go) == (129 if N == 1024 else 159)
+    ry = rel_l2(y, yo)
+    print(f"gate-matched S={S} N={N}: feature rel-L2 vs fp16-storage oracle {ry:.3e}")
     errs = compare(yo, dxo, go)
     if os.environ.get("NERAF_TEST_VERBOSE"):
         for k, v in errs.items():
             print(f"  {k:40s} {v:.3e}")
     worst = max(errs.items(), key=lambda kv: kv[1])
-    print(f"gate-matched backward S={S} vs fp16-storage oracle: worst {worst[0]} rel-L2 {worst[1]:.3e}; conv1.weight {errs['conv1.weight']:.3e}; "
+    print(f"gate-matched backward S={S} N={N} vs fp16-storage oracle: worst {worst[0]} rel-L2 {worst[1]:.3e}; conv1.weight {errs['conv1.weight']:.3e}; "
           f"d grid {errs['d grid']:.3e}; median {float(np.median(list(errs.values()))):.3e}")
-    assert worst[1] <= 5e-2, worst
     # (2) against the all-fp32 forward with the same gates the distance is the fp16 FORWARD's share (measured on CPU with an
     # exact backward on both sides: 6e-2 ... 1.2e-1, oracle/audio.py resnet3d_forward_gated): bounded, not the parity claim
     yo32, dxo32, go32 = oracle_grads(False)
-    assert rel_l2(y, yo32) <= 1e-2
     errs32 = compare(yo32, dxo32, go32)
     worst32 = max(errs32.items(), key=lambda kv: kv[1])
-    print(f"  vs all-fp32 gated oracle: worst {worst32[0]} {worst32[1]:.3e}")
-    assert worst32[1] <= 0.2, worst32
+    sens_y = rel_l2(yo, yo32)            # what the engine's rounding points alone do to the feature in THIS configuration
+    print(f"  vs all-fp32 gated oracle: worst {worst32[0]} {worst32[1]:.3e}; feature {rel_l2(y, yo32):.3e}; oracle-16 vs oracle-32 feature {sens_y:.3e}")
+    if N == 1024:
+        assert ry <= 2e-3
+        assert worst[1] <= 5e-2, worst
+        assert rel_l2(y, yo32) <= 1e-2
+        assert worst32[1] <= 0.2, worst32
+    else:
+        # layer4 (round 6): its BatchNorms normalise over 64 voxels on the 128^3 grid and over EIGHT on the 64^3 grid, and amplify every
+        # rounding difference accordingly -- the configuration's own sensitivity is measured right here (fp16-storage oracle vs all-fp32
+        # oracle, same gates: feature 2.1e-2 / 6.7e-2 against 2.7e-3 at N = 1024; gradients 0.32 / 0.71 against 0.11).  Across all five
+        # configurations the engine's distance to the fp16-storage oracle is one third of that sensitivity (0.33 ... 0.36; 0.46 where
+        # 0.71 saturates towards sqrt 2): the bound is HALF of it for the 64-voxel case.  The eight-voxel configuration is reported
+        # and bounded by 0.6 of its sensitivity only: a network whose gradients move by 70 % under fp16 storage has no element-wise
+        # parity to assert in either implementation (the reference trains under fp16 autocast too, NeRAF_config.py:79).
+        frac = 0.5 if S >= 128 else 0.6
+        assert ry <= frac * sens_y, (ry, sens_y)
+        assert worst[1] <= frac * worst32[1], (worst, worst32)
 
 
 def _backward_from_one_forward(bb, net, x, upstreams, after_first=None):

@@ -97,6 +97,56 @@ def test_g1_resnet3d_128_forward(golden):
         np.testing.assert_allclose(stats(st[k]), g["stage_" + k], rtol=1e-4)
 
 
+def _run_resnet_variant(S, N, need_grad):
+    layers = (3, 4, 6, 3) if N == 2048 else (3, 4, 6)
+    sd = {k: T(v) for k, v in synth.resnet3d_state_dict(7, layers=layers).items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(need_grad)
+    x = T(synth.uniform(f"g1.grid{S}", (1, 7, S, S, S), 0.0, 1.0)).requires_grad_(need_grad)
+    return sd, x, layers
+
+
+def test_g1_resnet3d_64_2048(golden):
+    """N_features = 2048 (layer4, NeRAF_resnet3d.py:131 / :193-195) on the 64^3 grid: forward, stages, backward and eval mode of the
+    restatement against the reference module's own outputs (tests/tools/gen_golden.py g1v)."""
+    g = golden("g1_resnet3d_64_2048")
+    sd, x, layers = _run_resnet_variant(64, 2048, True)
+    wsum = T(synth.uniform("g1.outw2048", (2048,), -1.0, 1.0))
+    y, st = O.resnet3d_forward(x, sd, train=True, layers=layers, return_stages=True)
+    assert y.shape == (1, 2048, 1, 1, 1)
+    np.testing.assert_allclose(y.detach().flatten().numpy(), g["out_train"], rtol=2e-4, atol=2e-5)
+    for k in ("conv1", "maxpool", "layer1", "layer2", "layer3", "layer4"):
+        np.testing.assert_allclose(stats(st[k]), g["stage_" + k], rtol=1e-4)
+    np.testing.assert_allclose(st["layer4"][0, :16, 1, 1, :].detach().numpy(), g["last_slab"], rtol=2e-4, atol=2e-5)
+    (y.flatten() * wsum).sum().backward()
+    p = g["probe_idx"]
+    np.testing.assert_allclose(x.grad[0, p[:, 0], p[:, 1], p[:, 2], p[:, 3]].numpy(), g["dx_probe"], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(stats(x.grad), g["dx_stats"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(sd["conv1.weight"].grad.numpy(), g["dw_conv1"], rtol=2e-3, atol=1e-3)
+    np.testing.assert_allclose(stats(sd["layer4.2.conv3.weight"].grad), g["dw_last_conv3_stats"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(sd["layer4.2.conv3.weight"].grad[:8, :8, 0, 0, 0].numpy(), g["dw_last_conv3_slab"], rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(stats(sd["layer4.0.conv2.weight"].grad), g["dw_last_0_conv2_stats"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(sd["layer4.0.downsample.1.weight"].grad.numpy(), g["dgamma_last_0_ds"], rtol=2e-3, atol=1e-3)
+    with torch.no_grad():
+        ye = O.resnet3d_forward(x, sd, train=False, layers=layers)
+    np.testing.assert_allclose(ye.flatten().numpy(), g["out_eval"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("S,N", [(128, 2048), (256, 1024)])
+def test_g1_resnet3d_variants_forward(golden, S, N):
+    """Layer4 at the BASELINE grid and the 7 x 256^3 grid (grid_step 1/256, average pool 16, NeRAF_resnet3d.py:150-156): forward
+    only (the 256^3 pass is 0.76 TFLOP of CPU convolutions)."""
+    g = golden(f"g1_resnet3d_{S}_{N}")
+    sd, x, layers = _run_resnet_variant(S, N, False)
+    with torch.no_grad():
+        y, st = O.resnet3d_forward(x, sd, train=True, layers=layers, return_stages=True)
+    assert y.shape == (1, N, 1, 1, 1)
+    np.testing.assert_allclose(y.flatten().numpy(), g["out_train"], rtol=2e-4, atol=2e-5)
+    for k in ["conv1", "maxpool", "layer1", "layer2", "layer3"] + (["layer4"] if N == 2048 else []):
+        np.testing.assert_allclose(stats(st[k]), g["stage_" + k], rtol=1e-4)
+
+
 def _drive_refresh(gs, bs, steps, start=0):
     grid = O.reset_grid(gs)
     coords = O.coordinates_to_render(gs)

@@ -162,6 +162,66 @@ def g1_resnet3d(r3):
         print(tag, "out_train", stats(y), "dx", out["dx_stats"])
 
 
+def g1v_resnet3d_variants(r3, which=None):
+    """The other configurations the reference's constructor accepts (NeRAF_resnet3d.py:128-156): N_features = 2048 (layer4) on the
+    64^3 and 128^3 grids, and grid_step = 1/256 (7 x 256^3) with N_features = 1024.  Same content as G1, with the last layer's
+    stages; fixtures g1_resnet3d_<S>_<N>.npz."""
+    torch.manual_seed(0)
+    for S, N in ((64, 2048), (128, 2048), (256, 1024)):
+        tag = f"g1_resnet3d_{S}_{N}"
+        if which and tag not in which:
+            continue
+        layers = (3, 4, 6, 3) if N == 2048 else (3, 4, 6)
+        sd_np = synth.resnet3d_state_dict(7, layers=layers)
+        net = r3.ResNet3D_helper(in_channels=7, backbone="resnet50", pretrained=False, grid_step=1 / S, N_features=N)
+        net.backbone_net.load_state_dict({k: t(v) for k, v in sd_np.items()}, strict=True)
+        x = t(synth.uniform(f"g1.grid{S}", (1, 7, S, S, S), 0.0, 1.0)).requires_grad_(True)
+        wsum = t(synth.uniform(f"g1.outw{N}", (N,), -1.0, 1.0))
+        out = {}
+        net.train()
+        stage = {}
+        bb = net.backbone_net
+        names = ["layer1", "layer2", "layer3"] + (["layer4"] if N == 2048 else [])
+        hooks = [bb.relu.register_forward_hook(lambda m, i, o: stage.__setitem__("conv1", o.detach().clone())),
+                 bb.maxpool.register_forward_hook(lambda m, i, o: stage.__setitem__("maxpool", o.detach().clone()))]
+        for nm in names:
+            hooks.append(getattr(bb, nm).register_forward_hook(lambda m, i, o, nm=nm: stage.__setitem__(nm, o.detach().clone())))
+        for m in bb.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.momentum = 0.0
+        y = net(x)
+        for h in hooks:
+            h.remove()
+        assert tuple(y.shape) == (1, N, 1, 1, 1), y.shape
+        (y.flatten() * wsum).sum().backward()
+        out["out_train"] = y.detach().flatten().numpy()
+        for k, v in stage.items():
+            out["stage_" + k] = stats(v)
+        last = names[-1]
+        out["conv1_slab"] = stage["conv1"][0, :8, 3, 5, :16].numpy()
+        out["last_slab"] = stage[last][0, :16, 1, 1, :].numpy()
+        gx = x.grad.detach()
+        probes = synth.integers("g1.probes", (64, 4), 0, 10 ** 9)
+        probes = np.stack([probes[:, 0] % 7, probes[:, 1] % S, probes[:, 2] % S, probes[:, 3] % S], 1)
+        out["probe_idx"] = probes
+        out["dx_probe"] = gx[0, probes[:, 0], probes[:, 1], probes[:, 2], probes[:, 3]].numpy()
+        out["dx_stats"] = stats(gx)
+        out["dw_conv1"] = bb.conv1.weight.grad.detach().numpy()
+        out["dw_l1_0_conv2_stats"] = stats(bb.layer1[0].conv2.weight.grad)
+        lastl = getattr(bb, last)
+        out["dw_last_conv3_stats"] = stats(lastl[-1].conv3.weight.grad)
+        out["dw_last_conv3_slab"] = lastl[-1].conv3.weight.grad[:8, :8, 0, 0, 0].detach().numpy()
+        out["dw_last_0_conv2_stats"] = stats(lastl[0].conv2.weight.grad)
+        out["dgamma_bn1"] = bb.bn1.weight.grad.detach().numpy()
+        out["dbeta_bn1"] = bb.bn1.bias.grad.detach().numpy()
+        out["dgamma_last_0_ds"] = lastl[0].downsample[1].weight.grad.detach().numpy()
+        net.eval()
+        with torch.no_grad():
+            out["out_eval"] = net(x).flatten().numpy()
+        np.savez_compressed(os.path.join(OUT, tag + ".npz"), **out)
+        print(tag, "out_train", stats(y), "dx", out["dx_stats"], flush=True)
+
+
 def g2_nacf(nf):
     """NeRAFAudioSoundField(1187,512,sound_rez,N_frequencies) -- NeRAF_field.py:37-65."""
     for C, Fq, tag in ((1, 513, "g2_nacf_raf"), (2, 257, "g2_nacf_ss")):
@@ -392,3 +452,6 @@ if __name__ == "__main__":
         g6_dataparsers()
     if "g1" in which:
         g1_resnet3d(r3)
+    if any(w.startswith("g1v") for w in which):        # "g1v" = all three, "g1v:g1_resnet3d_64_2048" = one
+        sel = [w.split(":", 1)[1] for w in which if w.startswith("g1v:")]
+        g1v_resnet3d_variants(r3, sel or None)
