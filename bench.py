@@ -83,6 +83,10 @@ def parse():
     ap.add_argument("--rotate", type=int, default=16,
                     help="train mode: number of DISTINCT resident ray / slice batches the steps cycle through (1 = the same batch every step)")
     ap.add_argument("--no-eval-line", action="store_true", help="train mode: skip the short eval-render measurement (key eval_render)")
+    ap.add_argument("--grid", type=int, choices=(64, 128, 256), default=128,
+                    help="voxel-grid edge of the scene encoder (grid_step = 1/edge; the reference's and the metric's configuration: 128)")
+    ap.add_argument("--n-features", type=int, choices=(1024, 2048), default=1024,
+                    help="scene-feature size: 1024, or 2048 = resnet50 with layer4 (NeRAF_resnet3d.py:128-131); the metric's configuration: 1024")
     ap.add_argument("--dataset", choices=("raf", "soundspaces"), default="raf",
                     help="audio head shape: raf = 1 x 513 bins, T = 60 (BASELINE configs[1..2], the default and the metric's config); "
                          "soundspaces = 2 x 257 bins, T = 101 (configs[3]: globally 32768 rays + 6464 slices, i.e. per GPU 4096 + 808)")
@@ -141,6 +145,8 @@ def compact_line(full: dict, detail: str = None, limit: int = LINE_LIMIT) -> str
     out["config"] = {"workload": _short(cfg.get("workload", ""), 200),
                      **_pick(cfg, ("rays_per_gpu", "slices_per_gpu", "global_rays", "global_slices", "rays_per_frame", "rirs_per_step",
                                    "bins_per_rir", "parallelism", "distinct_resident_batches"))}
+    if (cfg.get("encoder_grid", 128), cfg.get("encoder_features", 1024)) != (128, 1024):
+        out["config"].update(_pick(cfg, ("encoder_grid", "encoder_features")))
     if "roofline" in full:
         out["roofline"] = _compact_roofline(full["roofline"])
     if isinstance(full.get("cpu_baseline"), dict):
@@ -236,7 +242,7 @@ class JointStep:
 
     ``R`` / ``B`` are THIS rank's rays / slices; ``tag_rank`` selects which synthetic shard it holds."""
 
-    def __init__(self, dev, R, B, world, dataset="raf", start_step=20000, camera_opt=True, rotate=16):
+    def __init__(self, dev, R, B, world, dataset="raf", start_step=20000, camera_opt=True, rotate=16, grid=128, n_features=1024):
         import torch
         from neraf_amd import synth
         from neraf_amd.config import NeRAFVisionModelConfig, CameraOptimizerConfig, SceneBox
@@ -253,11 +259,14 @@ class JointStep:
             g = torch.Generator(device="cpu").manual_seed(0)
             for p in [self.vm.field.module.table] + [pn.table for pn in self.vm.proposal_networks]:
                 p.copy_((torch.rand(p.shape, generator=g) - 0.5).to(dev))
-        cfg = (NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / 128) if dataset == "raf" else
-               NeRAFAudioModelConfig(dataset="SoundSpaces", grid_step=1 / 128, max_len=T_, N_freq_stft=F_))
+        # grid / n_features: the reference's defaults (NeRAF_config.py:102-103: 1/128, 1024) are the benchmark's; the other values its
+        # constructor accepts (256^3 grid, layer4 -> 2048 features) are measurable with --grid / --n-features
+        cfg = (NeRAFAudioModelConfig(dataset="RAF", grid_step=1 / grid, N_features=n_features) if dataset == "raf" else
+               NeRAFAudioModelConfig(dataset="SoundSpaces", grid_step=1 / grid, N_features=n_features, max_len=T_, N_freq_stft=F_))
         self.am = NeRAFAudioModel(cfg, T(synth.audio_aabb()), process_group=True if world > 1 else None)
-        self.am.field.load_state_dict({k: T(v) for k, v in synth.nacf_state_dict(1187, 512, C_, F_).items()})
-        self.am.resnet3d.backbone_net.load_state_dict({k: T(v) for k, v in synth.resnet3d_state_dict(7).items()})
+        self.am.field.load_state_dict({k: T(v) for k, v in synth.nacf_state_dict(n_features + 163, 512, C_, F_).items()})
+        self.am.resnet3d.backbone_net.load_state_dict(
+            {k: T(v) for k, v in synth.resnet3d_state_dict(7, layers=(3, 4, 6, 3) if n_features == 2048 else (3, 4, 6)).items()})
         self.am.to(dev)
         self.vm.train(); self.am.train()
         # `rotate` DISTINCT resident batches, cycled step by step: the reference draws a fresh ray batch and fresh slices every step
@@ -888,7 +897,7 @@ def main():
             import torch.distributed as dist
             dist.destroy_process_group()
         return
-    st = JointStep(dev, R_local, B_local, world, dataset=a.dataset, rotate=a.rotate)
+    st = JointStep(dev, R_local, B_local, world, dataset=a.dataset, rotate=a.rotate, grid=a.grid, n_features=a.n_features)
     # Setup, before the W warm-up steps: the first steps of a run build the optimizer launch plans (the step with the first
     # proposal-network update builds a second one), capture the ResNet3D hipGraphs and grow the allocator pools --
     # tools/step_trace.py shows them as 10-400 ms steps -- and a full Python garbage collection over the module graph costs
@@ -970,7 +979,7 @@ def main():
     torch.cuda.synchronize()
     net = st.am.resnet3d
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    w1024 = torch.ones(1024, device=dev)
+    w1024 = torch.ones(a.n_features, device=dev)
     for it in range(6):
         if it == 1:
             ev0.record()
@@ -979,6 +988,11 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     resnet_ms = ev0.elapsed_time(ev1) / 5
+    # SURVEY 8(d) figures for THIS encoder configuration (the module constants at the default 128^3 / 1024)
+    _fl = _lib.load().neraf_resnet3d_forward_flops
+    _fl.restype = C.c_double
+    resnet_fwd_gflop = RESNET_FWD_GFLOP if (a.grid, a.n_features) == (128, 1024) else _fl(C.byref(net.backbone_net._desc)) / 1e9
+    nacf_flop_slice = NACF_DENSE_FLOP_PER_SLICE_FWD + 2 * (a.n_features - 1024) * 5096
 
     # ---- instrumented replay (not timed): per-kernel-family HIP-event durations, as recorded (no overhead subtraction: an event
     # pair around a few-microsecond kernel reads ~3 us more than rocprofv3's kernel duration, so small kernels are UNDER-stated)
@@ -1067,7 +1081,8 @@ def main():
             "config": {
                 "workload": (("RAF FurnishedRoom joint training step (BASELINE configs[2]): %d rays + %d RIR slices x 513 bins per GPU" if a.dataset == "raf"
                               else "SoundSpaces joint training step (BASELINE configs[3] head): %d rays + %d RIR slices x 2 x 257 bins per GPU")
-                             % (R_local, B_local)) + "; radiance + grid refresh + ResNet3D + NAcF + STFT loss, backward, GradScaler + fused Adam; batches resident",
+                             % (R_local, B_local)) + "; radiance + grid refresh + ResNet3D + NAcF + STFT loss, backward, GradScaler + fused Adam; batches resident"
+                            + ("" if (a.grid, a.n_features) == (128, 1024) else f"; NON-DEFAULT encoder: {a.grid}^3 grid, {a.n_features} features"),
                 "workload_detail": (("RAF FurnishedRoom joint step (BASELINE configs[2] shape: %d rays + %d RIR slices x 513 bins per GPU): " if a.dataset == "raf"
                               else "SoundSpaces joint step (BASELINE configs[3] head shape: %d rays + %d RIR slices x 2 x 257 bins per GPU): ") +
                              "radiance forward (camera-pose deltas, sampler, 2 proposal nets, 2 PDF resamplings, fused field query, composite) + rgb/"
@@ -1082,7 +1097,7 @@ def main():
                              % (R_local, B_local, 4096, ", sharded over the ranks" if world > 1 else "", "RCCL all-reduce -> " if world > 1 else "",
                                 a.rotate),
                 "rays_per_gpu": R_local, "slices_per_gpu": B_local, "global_rays": R_global, "global_slices": B_global,
-                "parallelism": f"dp{world}", "distinct_resident_batches": a.rotate,
+                "parallelism": f"dp{world}", "distinct_resident_batches": a.rotate, "encoder_grid": a.grid, "encoder_features": a.n_features,
                 "repeat_windows_ms_per_step": {"n": len(repeat_ms), "median": _median(repeat_ms), "min": min(repeat_ms), "max": max(repeat_ms)},
             },
         }
@@ -1095,8 +1110,8 @@ def main():
                                "selection": "family with the largest share of the step (ms_per_step) among the instrumented families",
                                "durations": "HIP events on the launch stream, as recorded (no overhead subtraction)",
                                "rocprof_reference": ref_name,
-                               "dense_equiv_gflop_per_step": {"nacf_fwd_bwd": 3 * NACF_DENSE_FLOP_PER_SLICE_FWD * B_local / 1e9,
-                                                              "resnet3d_fwd_bwd": 3 * RESNET_FWD_GFLOP},
+                               "dense_equiv_gflop_per_step": {"nacf_fwd_bwd": 3 * nacf_flop_slice * B_local / 1e9,
+                                                              "resnet3d_fwd_bwd": 3 * resnet_fwd_gflop},
                                "instrumented_gflop_per_step": {
                                    "algorithmic": sum(k["work_per_step"] for k in fams if k["bound"] == "mfma") / 1e9,
                                    "executed": sum(k["executed_per_launch"] * k["launches_per_step"] for k in fams if k["bound"] == "mfma") / 1e9,
@@ -1104,7 +1119,7 @@ def main():
                                            "gradient is a per-cell kernel, not a GEMM) + the NAcF GEMMs as executed (layer-0 split: the "
                                            "1024 shared inputs are a GEMV, so less than the dense-equivalent 3 x 40.84 MFLOP/slice) + the "
                                            "radiance field's weight-gradient GEMMs"},
-                               "whole_step_mfma_frac": ((3 * NACF_DENSE_FLOP_PER_SLICE_FWD * B_local / 1e9 + 3 * RESNET_FWD_GFLOP) / 1e3)
+                               "whole_step_mfma_frac": ((3 * nacf_flop_slice * B_local / 1e9 + 3 * resnet_fwd_gflop) / 1e3)
                                                        / (ms_step * 1e-3) / MFMA_PEAK_TFLOPS,
                                "all_kernel_families": fams}
         g_cap, g_launch = C.c_int(), C.c_int()

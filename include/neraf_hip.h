@@ -417,20 +417,20 @@ int neraf_refresh_origins(neraf_ctx* ctx, const float* coords, int n, int ndirs,
 /* ------------------------------------------------------------------------------------
  * ResNet3D scene encoder (ResNet3D_helper / ResNet3D.forward, NeRAF_resnet3d.py:116-201,266-285;
  * backbone 'resnet50' truncated after layer3, N_features = 1024; called at NeRAF_model.py:554-558
- * and :680-684): voxel grid fp32 [7,S,S,S] (S = 128 for grid_step 1/128, 64 for 1/64) -> feat fp32
- * [1024].  conv_w: HOST array of the Conv3d weights (device pointers) in state-dict order (conv1,
+ * and :680-684): voxel grid fp32 [7,S,S,S] (S = 128 for grid_step 1/128, 64 for 1/64, 256 for 1/256) -> feat fp32
+ * [n_features] (1024: layers 1-3; 2048: + resnet50's layer4, NeRAF_resnet3d.py:128-131, 53 convolutions).  conv_w: HOST array of the Conv3d weights (device pointers) in state-dict order (conv1,
  * then per Bottleneck conv1, conv2, conv3, [downsample.0]); bn: HOST array of 4 device pointers per
  * BatchNorm3d in the same order {weight, bias, running_mean, running_var}.  use_batch_stats = 1 is
  * nn.Module.train() behaviour (statistics over the voxels of the single sample), 0 uses the running
  * statistics.
  * ---------------------------------------------------------------------------------- */
 typedef struct neraf_resnet3d_desc {
-  int grid_size;   /* 128 or 64 */
+  int grid_size;   /* 64, 128 or 256 */
   int in_channels; /* 7: rgb, alpha, xyz (NeRAF_model.py:185) */
-  int n_features;  /* 1024 */
+  int n_features;  /* 1024 or 2048 */
 } neraf_resnet3d_desc;
 
-int neraf_resnet3d_num_convs(const neraf_resnet3d_desc* d); /* 43 */
+int neraf_resnet3d_num_convs(const neraf_resnet3d_desc* d); /* 43 (1024 features) | 53 (2048) */
 size_t neraf_resnet3d_packed_bytes(const neraf_resnet3d_desc* d);
 size_t neraf_resnet3d_workspace_bytes(const neraf_resnet3d_desc* d);
 /* Algorithmic forward FLOPs of the encoder: sum over its 43 convolutions of 2 dout^3 taps cin cout with the real channel
