@@ -382,8 +382,8 @@ def test_long_trajectory_metric_parity(golden, tmp_path_factory, scenario):
 
 @pytest.mark.parametrize("scenario", ["g9_long", "g10_long_pose"])
 def test_default_mode_long_trajectory_median(golden, tmp_path_factory, scenario):
-    """The mode that is benchmarked and shipped (fp32 atomics), gated: FIVE default-mode runs of the scenario
-    (1000 iterations each, ~16 s), the MEDIAN of each metric through the same frozen rule as the deterministic run.  Every run is
+    """The mode that is benchmarked and shipped (fp32 atomics), gated: FIVE (G10) / THREE (G9) default-mode
+    runs of the scenario (1000 iterations each, ~16 s), the MEDIAN of each metric through the same frozen rule as the deterministic run.  Every run is
     printed.  G10 (camera optimizer on: the configuration bench.py times) was added to this test on 2026-10-04 before its first run.
     Three runs until the distribution was measured (profiles/r06_g10_hip_default_distribution.txt: 24 default-mode G10 runs, every
     metric's mean inside the oracle family's own range, T60 sd 0.95 points, 2 of 24 single runs above the T60 gate): the median of
@@ -393,13 +393,15 @@ def test_default_mode_long_trajectory_median(golden, tmp_path_factory, scenario)
     if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", scenario + ".npz")):
         pytest.skip(f"fixture tests/golden/{scenario}.npz not generated")
     g = golden(scenario)
-    runs = {f"hip{t}": _run_worker(scenario, tmp_path_factory, "0", t) for t in ("a", "b", "c", "d", "e")}
+    # sample size by the measured single-run exceedance: G10 2 of 24 runs outside -> five; G9 none of 28 -> three
+    tags = ("a", "b", "c", "d", "e") if scenario == "g10_long_pose" else ("a", "b", "c")
+    runs = {f"hip{t}": _run_worker(scenario, tmp_path_factory, "0", t) for t in tags}
     assert all(int(r["deterministic"]) == 0 for r in runs.values())
     m, family = _long_metric_table(g, runs, scenario)
     med = {k: float(np.median([m[n][k] for n in runs])) for k in TC.GATE_METRICS}
     m["median"] = med
     gates = TC.gate_table(m, family, hip_name="median", floor_family=_floor_family(scenario))
-    print(f"{scenario} default mode, median of five through the frozen rule:", {k: {kk: round(vv, 5) if isinstance(vv, float) else vv for kk, vv in v.items()} for k, v in gates.items()})
+    print(f"{scenario} default mode, median of {len(runs)} through the frozen rule:", {k: {kk: round(vv, 5) if isinstance(vv, float) else vv for kk, vv in v.items()} for k, v in gates.items()})
     failed = {k: v for k, v in gates.items() if not v["inside"]}
     assert not failed, failed
 
