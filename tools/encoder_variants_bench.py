@@ -15,11 +15,14 @@ from neraf_amd import _lib, synth
 from neraf_amd.resnet3d import ResNet3D_helper
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+only = tuple(int(v) for v in sys.argv[2].split("x")) if len(sys.argv) > 2 else None      # e.g. 256x1024: that configuration alone (under rocprofv3)
 dev = torch.device("cuda:0")
 lib = _lib.load()
 lib.neraf_resnet3d_forward_flops.restype = C.c_double
 print(f"{'grid':>6s} {'N_feat':>6s} {'convs':>5s} {'fwd GFLOP':>10s} {'fwd ms':>8s} {'fwd+bwd ms':>10s} {'TFLOP/s':>8s} {'of 2.5 PF':>9s} {'workspaces GB':>13s}")
 for S, N in ((64, 1024), (64, 2048), (128, 1024), (128, 2048), (256, 1024), (256, 2048)):
+    if only and (S, N) != only:
+        continue
     layers = (3, 4, 6, 3) if N == 2048 else (3, 4, 6)
     net = ResNet3D_helper(in_channels=7, backbone="resnet50", pretrained=False, grid_step=1 / S, N_features=N)
     net.backbone_net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.resnet3d_state_dict(7, layers=layers).items()})
