@@ -891,6 +891,8 @@ def main():
     else:
         R_local, B_local = a.rays, a.slices
         R_global, B_global = a.rays * world, a.slices * world
+    if a.mode == "eval" and (a.grid, a.n_features) != (128, 1024):
+        raise SystemExit("--grid / --n-features select the training step's encoder; the eval-render line is measured on the metric's configuration (128^3, 1024)")
     if a.mode == "eval":
         run_eval_mode(a, dev, rank, local, world)
         if world > 1:
