@@ -178,7 +178,14 @@ class GriffinLim(nn.Module):
         self.hop_length = hop_length or self.win_length // 2
         self.power, self.n_iter, self.momentum, self.rand_init = power, n_iter, momentum, rand_init
 
-    def forward(self, specgram: torch.Tensor, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    def initial_phase(self, shape, device, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """The uniform [0, 1) draw ``forward`` makes for a spectrogram of ``shape`` (flattened to [-1, F, T]) -- exposed so that a caller
+        batching several spectrograms into ONE reconstruction can draw them in the order separate calls would have."""
+        shape = (int(np.prod(shape[:-2])) if len(shape) > 2 else 1, shape[-2], shape[-1])
+        device = torch.device(device)
+        return torch.rand(shape, generator=generator, device=device if generator is None or generator.device == device else "cpu").to(device)
+
+    def forward(self, specgram: torch.Tensor, generator: Optional[torch.Generator] = None, init_phase: Optional[torch.Tensor] = None) -> torch.Tensor:
         shp = specgram.shape
         mag = specgram.reshape(-1, shp[-2], shp[-1]).float()
         if self.power != 1.0:
@@ -186,8 +193,7 @@ class GriffinLim(nn.Module):
         win = torch.hann_window(self.win_length, periodic=True, dtype=torch.float32, device=mag.device)
         length = (shp[-1] - 1) * self.hop_length
         if self.rand_init:
-            ang = torch.rand(mag.shape, generator=generator, device=mag.device if generator is None or generator.device == mag.device
-                             else "cpu").to(mag.device)
+            ang = init_phase.reshape(mag.shape).to(mag.device) if init_phase is not None else self.initial_phase(mag.shape, mag.device, generator)
             angles = torch.polar(torch.ones_like(mag), 2 * np.pi * ang)
         else:
             angles = torch.ones_like(mag, dtype=torch.complex64)

@@ -63,6 +63,28 @@ class NeRAFAudioModelConfig(InstantiateConfig):
             self._target = NeRAFAudioModel
 
 
+class _few_host_threads:
+    """The metric chain's host side is dozens of torch CPU operations on 30 k-element tensors (exp, log, a 61-frame STFT, L1 means):
+    on a 128-thread host every one of them wakes the whole intra-op pool -- measured 94 ms per RIR with 128 threads, 17.6 ms with 8,
+    16.4 ms with 1 (tools/eval_metrics_threads_probe.py), i.e. 80 % of ``get_average_eval_image_metrics``' time per RIR was thread
+    wake-ups.  Caps the pool at 8 threads for the duration of the block and restores it.  Element-wise results are unchanged; the
+    room-acoustic metrics (T60 / EDT / C50) are numpy on the Griffin-Lim waveform and do not depend on it at all."""
+
+    def __init__(self, cap: int = 8):
+        self.cap = cap
+
+    def __enter__(self):
+        self.prev = torch.get_num_threads()
+        if self.prev > self.cap:
+            torch.set_num_threads(self.cap)
+        return self
+
+    def __exit__(self, *exc):
+        if torch.get_num_threads() != self.prev:
+            torch.set_num_threads(self.prev)
+        return False
+
+
 class _RefreshFn(torch.autograd.Function):
     """vals [4, n] = (mean_dirs rgb, alpha) of the refreshed cells as a function of the radiance-field parameters
     (NeRAF_model.py:339-357, :386).  Forward = fused field query in AABB mode; backward = fused field backward."""
@@ -440,7 +462,7 @@ class NeRAFAudioModel(nn.Module):
         """The metric half of get_image_metrics_and_images (:738-761): magnitude STFTs -> Griffin-Lim waveforms (on the model's
         device) -> T60 / EDT / C50 (and RAF's spectral error) against the ground-truth waveform.  batch: 'data' [C,F,T] log-magnitude,
         'waveform' [C, n]; the image half is in ``get_image_metrics_and_images``."""
-        with torch.no_grad():
+        with torch.no_grad(), _few_host_threads():
             stft = outputs["raw_output"].permute(1, 2, 0).detach().cpu()               # [C, F, T]
             data = batch["data"].detach().cpu()
             mag_prd = torch.clip(torch.exp(stft) - 1e-3, 0.0, 10000.0)
@@ -451,6 +473,32 @@ class NeRAFAudioModel(nn.Module):
             wav_istft_prd = self.istft_transform(mag_prd.to(dev), generator=generator).cpu().numpy()
             return self.evaluator.get_full_metrics(mag_prd.numpy(), mag_gt.numpy(), wav_gt, wav_istft_prd, wav_istft_gt,
                                                    stft.numpy(), data.numpy())
+
+    def get_audio_metrics_block(self, raws: torch.Tensor, batches, generator=None):
+        """``get_audio_metrics`` for N RIRs at once (the eval loop's blocks, NeRAFPipeline.get_average_eval_image_metrics): raws
+        [N,T,C,F] log-magnitudes, batches = the N eval items.  The 2 N Griffin-Lim reconstructions (ground truth and prediction of
+        every item: 32 iterations of an inverse + forward STFT each) run as ONE batched reconstruction instead of 2 N launches
+        sequences of 61-frame transforms; the random initial phases are drawn item by item in the order the separate calls draw them
+        (gt_0, prd_0, gt_1, ...), so a seeded generator gives the per-item results.  Returns the N metric dicts."""
+        with torch.no_grad(), _few_host_threads():
+            n = int(raws.shape[0])
+            stft = raws.permute(0, 2, 3, 1).detach().cpu()                                # [N, C, F, T]
+            data = torch.stack([b["data"].detach().cpu() for b in batches])            # [N, C, F, T]
+            mag_prd = torch.clip(torch.exp(stft) - 1e-3, 0.0, 10000.0)
+            mag_gt = torch.clip(torch.exp(data) - 1e-3, 0.0, 10000.0)
+            dev = self.aabb.device
+            gl = self.istft_transform
+            phases = []
+            for k in range(n):
+                phases.append(gl.initial_phase(mag_gt[k].shape, dev, generator))
+                phases.append(gl.initial_phase(mag_prd[k].shape, dev, generator))
+            mags = torch.stack([mag_gt, mag_prd], dim=1).reshape(2 * n, *mag_gt.shape[1:]).to(dev)      # gt_0, prd_0, gt_1, ...
+            wav = gl(mags, init_phase=torch.cat(phases, 0)).cpu().numpy()               # [2 N, C, L]
+            out = []
+            for k, b in enumerate(batches):
+                out.append(self.evaluator.get_full_metrics(mag_prd[k].numpy(), mag_gt[k].numpy(), b["waveform"].detach().cpu().numpy(),
+                                                           wav[2 * k + 1], wav[2 * k], stft[k].numpy(), data[k].numpy()))
+            return out
 
     def get_image_metrics_and_images(self, outputs: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], generator=None):
         """NeRAF_model.py:738-803 as its callers use it (NeRAF_pipeline.py:278, :364): (metrics_dict, images_dict).  The metric

@@ -276,11 +276,14 @@ class NeRAFPipeline(nn.Module):
                         raws = self.audio_model.get_outputs_for_rirs(*(torch.stack([it[k].to(dev).reshape(3) for it in items])
                                                                        for k in ("mic_pose", "source_pose", "rot")))
                         torch.cuda.synchronize() if torch.cuda.is_available() else None
-                        share = (time() - t_blk) / len(ids)            # this item's share of the block's field call
+                        # the block's 2 x len(ids) Griffin-Lim reconstructions + metric chains (:364) as one batched reconstruction
+                        block_metrics = self.audio_model.get_audio_metrics_block(raws, items)
+                        torch.cuda.synchronize() if torch.cuda.is_available() else None
+                        share = (time() - t_blk) / len(ids)            # this item's share of the block's field call + metric chain
                         for k, (i, batch) in enumerate(zip(ids, items)):
                             t0 = time()
                             outputs = self.audio_model.eval_outputs_from_raw(raws[k], batch)               # :362
-                            metrics_dict = self.audio_model.get_audio_metrics(outputs, batch)   # :364 (its images are dropped there: not built here)
+                            metrics_dict = dict(block_metrics[k])
                             if self.save_eval_audio_path is not None:                                          # :366-372
                                 d = os.path.join(self.save_eval_audio_path, str(step))
                                 os.makedirs(d, exist_ok=True)

@@ -183,3 +183,33 @@ def test_pipeline_trains_and_evaluates_from_a_raf_tree_on_disk(tmp_path):
     met, img = p.get_eval_image_metrics_and_images(6)
     audio_keys = [k for k in met if any(s in k for s in ("t60", "edt", "c50", "stft", "audio"))]
     assert audio_keys and all(np.isfinite(float(met[k])) for k in audio_keys), (met, audio_keys)
+
+
+def test_block_metric_chain_equals_the_per_item_chain(pipe):
+    """NeRAFAudioModel.get_audio_metrics_block (one batched Griffin-Lim for a block of RIRs, what get_average_eval_image_metrics
+    runs) against get_audio_metrics item by item, both with a generator seeded alike: same T60 / EDT / C50 / spectral errors."""
+    p, _ = pipe
+    am = p.audio_model
+    ev = p.audio_datamanager.eval_dataset
+    old = getattr(ev, "mode", None)
+    ev.mode = "eval_image"
+    try:
+        items = [ev[i] for i in range(len(ev))]
+    finally:
+        ev.mode = old
+    dev = am.aabb.device
+    was = am.training
+    am.eval()
+    try:
+        raws = am.get_outputs_for_rirs(*(torch.stack([it[k].to(dev).reshape(3) for it in items]) for k in ("mic_pose", "source_pose", "rot")))
+        g1 = torch.Generator(device=dev).manual_seed(11)
+        block = am.get_audio_metrics_block(raws, items, generator=g1)
+        g2 = torch.Generator(device=dev).manual_seed(11)
+        single = [am.get_audio_metrics(am.eval_outputs_from_raw(raws[k], it), it, generator=g2) for k, it in enumerate(items)]
+    finally:
+        am.train(was)
+    assert len(block) == len(single) == len(items) >= 2
+    for b, s in zip(block, single):
+        assert set(b) == set(s)
+        for k in s:
+            np.testing.assert_allclose(b[k], s[k], rtol=2e-3, atol=1e-6, err_msg=k)
