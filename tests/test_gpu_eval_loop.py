@@ -213,3 +213,31 @@ def test_block_metric_chain_equals_the_per_item_chain(pipe):
         assert set(b) == set(s)
         for k in s:
             np.testing.assert_allclose(b[k], s[k], rtol=2e-3, atol=1e-6, err_msg=k)
+
+
+def test_eval_loop_per_rir_cost_stays_far_below_the_round5_figure():
+    """get_average_eval_image_metrics over 64 RIRs incl. the metric chain: round 5's loop spent 94-143 ms per RIR on a 128-thread host
+    (thread wake-ups of 30 k-element torch CPU ops + per-RIR Griffin-Lim launches, profiles/r06_full_eval_loop.txt); now ~2 ms.  The
+    bound is 30 ms per RIR: an order of magnitude of slack for a slow box, still far below what the regression would read."""
+    import time
+    from neraf_amd import config as C
+    from neraf_amd.datamanagers import SyntheticAudioDataManager, SyntheticVisionDataManager
+    torch.manual_seed(0)
+    R = 64
+    m = C.make_method("RAF", "FurnishedRoom", datamanager=SyntheticVisionDataManager(2, 1, 96, 128, 1024),
+                      audio_datamanager=SyntheticAudioDataManager(4, R, batch_size=256))
+    m.config.pipeline.audio_model.grid_step = 1 / 64
+    m.config.pipeline.start_step_audio = 3
+    p = m.config.pipeline.setup(device="cuda:0", test_mode="val", world_size=1, local_rank=0, grad_scaler=None)
+    p.eval()
+    threads = torch.get_num_threads()
+    p.get_average_eval_image_metrics(step=10)                    # plans, graphs, FFT plans
+    torch.cuda.synchronize()
+    t0 = time.time()
+    met = p.get_average_eval_image_metrics(step=10)
+    torch.cuda.synchronize()
+    per_rir = (time.time() - t0) / R
+    print(f"eval loop: {per_rir * 1e3:.2f} ms per RIR incl. metrics (host threads {threads})")
+    assert torch.get_num_threads() == threads                    # the cap inside the metric chain is restored
+    assert {"audio_T60", "audio_EDT", "audio_C50", "fps_audio"} <= set(met) and np.isfinite(met["audio_T60"])
+    assert per_rir <= 0.030, per_rir
